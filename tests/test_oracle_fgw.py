@@ -1,0 +1,79 @@
+"""Pins the CPU oracle (oracle/fgw_oracle_impl.h) against the reference's own outputs:
+ - cfm_log.npz: the reference's only known-answer fixture (notebooks/data/cfm_log.pt);
+ - fgw_ref_*.npz: the reference's fgw_barycenters run in fp32/fp64 in the build container
+   (tests/golden/make_fgw_golden.py).
+The f64 oracle must match ref64 tightly (same algorithm, same control flow, same iteration counts); the f32
+oracle must match ref32 within the reference's own fp32 noise floor."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fgw
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fgw_ref_*.npz")))
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+
+
+def test_cfm_log_known_answer(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cfm_log.npz"))
+    # hyper-parameters that reproduce the stored answer: dimenet.py:235-260 (alpha=0.5, fixed_structure=True)
+    for dt, tol in ((np.float32, 1e-4), (np.float64, 1e-4)):
+        r = fgw.fgw_barycenter(g["Ys"], g["Cs"], g["ps"], g["lambdas"], g["Cs"][0], alpha=0.5, fixed_structure=True, dtype=dt)
+        assert r["outer"] == len(g["err_feature"]) == 5
+        assert np.abs(r["Y"] - g["F_bary"]).max() < tol          # stored vs re-run of the reference itself: 2.1e-5
+        assert np.array_equal(r["C"].astype(np.float32), g["C_bary"])      # structure fixed: C_bary == Cs[0]
+        np.testing.assert_allclose(r["err_feature"], g["err_feature"], rtol=2e-4)
+        assert rel(r["T"], g["T"]) < 2e-3
+
+
+def test_cfm_log_pins_glue(golden_dir):
+    """Ys[k] == normalize_tensor(node_feature[k] + 0.5, 0.1, 2.0) exactly (schnet_no_sum.py:59,66)."""
+    g = np.load(os.path.join(golden_dir, "cfm_log.npz"))
+    nf = g["node_feature"].reshape(10, 22, 3)
+    for k in range(10):
+        out = fgw.normalize_tensor(nf[k] + np.float32(0.5), 0.1, 2.0)
+        assert np.abs(out - g["Ys"][k]).max() <= 2.4e-7
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_oracle_f64_matches_ref64(path):
+    g = np.load(path)
+    r = fgw.fgw_barycenter(g["Ys"], g["Cs"], dtype=np.float64)
+    assert r["outer"] == len(g["r64_err_feature"])
+    assert np.array_equal(r["pgd"], g["r64_pgd"])
+    assert np.array_equal(r["sinkhorn"][..., : g["r64_sinkhorn"].shape[-1]], g["r64_sinkhorn"])
+    assert rel(r["Y"], g["r64_Y"]) < 1e-9
+    assert rel(r["C"], g["r64_C"]) < 1e-9
+    assert rel(r["T"], g["r64_T"]) < 1e-8
+    np.testing.assert_allclose(r["err_feature"], g["r64_err_feature"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(r["err_structure"], g["r64_err_structure"], rtol=1e-8, atol=1e-12)
+    # backward identity against the reference's autograd
+    dYs = fgw.fgw_barycenter_bwd(r["T"], g["r32_grad_w"].astype(np.float64), dtype=np.float64)
+    assert rel(dYs, g["r64_dYs"]) < 1e-6
+    # fgw_dist at the final barycenter (bregman.py:163-164)
+    import numpy as _np
+    K, N, d = g["Ys"].shape
+    for s in range(K):
+        Y = r["Y"]; Ys = g["Ys"][s].astype(_np.float64)
+        M = _np.maximum((Y * Y).sum(1)[:, None] + (Ys * Ys).sum(1)[None, :] - 2 * Y @ Ys.T, 0)
+        fd = fgw.fgw_dist(M, r["C"], g["Cs"][s], r["T"][s], alpha=0.1, dtype=_np.float64)
+        assert abs(fd - g["r64_fgw_dist"][s]) <= 1e-6 * abs(g["r64_fgw_dist"][s])
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_oracle_f32_within_reference_noise_floor(path):
+    """Appendix F protocol: err(oracle32, ref32) <= 1e-4 or err(oracle32, ref64) <= 3 * err(ref32, ref64)."""
+    g = np.load(path)
+    r = fgw.fgw_barycenter(g["Ys"], g["Cs"], dtype=np.float32)
+    assert r["outer"] == len(g["r32_err_feature"])
+    for key in ("Y", "C"):
+        yard = rel(g["r32_" + key], g["r64_" + key])
+        e32 = rel(r[key], g["r32_" + key]); e64 = rel(r[key], g["r64_" + key])
+        assert e32 <= 1e-4 or e64 <= 3 * yard + 1e-6, (key, e32, e64, yard)
+    ro, rr = r["Y"].sum(0), g["r64_Y"].sum(0)      # the readout the model consumes (schnet_no_sum.py:308)
+    assert rel(ro, rr) < 1e-4
