@@ -1,0 +1,108 @@
+"""ctypes binding of libconan_fgw_hip.so (include/conan_fgw_hip.h).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libconan_fgw_hip.so")
+_LIB = None
+
+c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
+
+
+class FgwParams(ctypes.Structure):
+    """Mirror of `conan_fgw_params` (include/conan_fgw_hip.h)."""
+    _fields_ = [("alpha", c_float), ("epsilon", c_float), ("max_iter", c_int), ("tol", c_float), ("inner_tol", c_float),
+                ("num_iter_max", c_int), ("stop_thr", c_float), ("fixed_structure", c_int), ("fixed_features", c_int),
+                ("warmstart", c_int)]
+
+
+# name -> (restype, argtypes); kept in the header's order.  tests/test_abi.py checks this table against the header.
+_P = c_void_p
+SIGNATURES = {
+    "conan_abi_version": (c_int, []),
+    "conan_graph_ptr_from_batch": (c_int, [_P, c_int, c_int, _P, _P]),
+    "conan_radius_graph_csr": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "conan_csr_transpose": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "conan_edge_index_i64": (c_int, [_P, _P, c_int, _P, _P]),
+    "conan_embedding_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "conan_embedding_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "conan_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_ssp_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "conan_linear_wgrad_ws": (c_ll, [c_int, c_int, c_int]),
+    "conan_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
+    "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "conan_segment_sum_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "conan_segment_sum_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "conan_fgw_densify": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "conan_fgw_densify_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P]),
+    "conan_fgw_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
+    "conan_fgw_barycenter_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(FgwParams),
+                                         _P, _P, _P, _P, _P, _P, _P]),
+    "conan_fgw_barycenter_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "conan_fgw_readout_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "conan_fgw_readout_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+}
+
+_ERR = {-1: "bad argument", -2: "HIP launch failure", -3: "unsupported configuration"}
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(
+                f"{_SO} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C conan-fgw_amd/csrc). There is no CPU fallback for this path.")
+        L = ctypes.CDLL(_SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.conan_abi_version() != 1:
+            raise RuntimeError("libconan_fgw_hip.so: ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("conan_fgw_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("conan_fgw_amd ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,557 @@
+// Batched Fused-Gromov-Wasserstein barycenter for gfx950.
+//
+// Reference algorithm: fgw_barycenters (conan_fgw/src/model/fgw/barycenter.py:7-225) -> fgw_projected
+// (bregman.py:70-167) -> sinkhorn_log (sinkhorn.py:318-450) with utils.py:39-95,154-171, called once per molecule from a
+// Python loop (schnet_no_sum.py:259-312).  Here every molecule of the batch is solved concurrently:
+//
+//   k_fgw_init                          C <- init_C (or Cs[b,0]),  Y <- init_Y (or 0)
+//   repeat max_iter times (fixed launch count, data-dependent early exit through a per-molecule `active` flag,
+//   no host synchronisation, hipGraph-capturable):
+//     k_fgw_coupling  grid B*K          one workgroup per (molecule, input graph): projected-gradient loop with
+//                                       log-domain Sinkhorn, matrices resident in LDS
+//     k_fgw_update    grid B            barycenter feature/structure update + stopping test
+//
+// Numerics ("FGW numerics" in DESIGN.md): I/O is fp32, the iteration state (C, Y, Sinkhorn potentials, cost matrices,
+// matmul accumulators) is fp64.  The reference's own fp32 run sits 1e-4..1e-3 away from its fp64 run because the
+// 5-iteration scheme amplifies rounding; computing on-chip in fp64 puts this kernel on the fp64
+// side of that yard-stick at negligible cost (the per-molecule matrices are tiny and MI355X runs fp64 FMA at half the
+// fp32 rate).  exp() is evaluated as 2^n * v_exp_f32(frac) with the range reduction done in fp64 (1 ulp of fp32).
+#include "common.h"
+
+namespace {
+
+constexpr int FGW_THREADS = 256;
+constexpr int FGW_WAVES = FGW_THREADS / 64;
+
+struct FgwDims {
+    int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
+};
+
+__device__ __forceinline__ double exp_acc(double x) {
+    // exp(x) = 2^(x*log2e); integer part applied with ldexp, fractional part on the fp32 transcendental unit.
+    if (x < -745.0) return 0.0;
+    const double t = x * 1.4426950408889634074;
+    const double n = rint(t);
+    const float f = (float)(t - n);
+    const float e = __builtin_amdgcn_exp2f(f);
+    return ldexp((double)e, (int)n);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// block-wide sum of one double per thread; result broadcast to every thread. red[] has FGW_WAVES+1 doubles.
+__device__ __forceinline__ double block_sum_d(double v, double *red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < FGW_WAVES; ++w) s += red[w];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ init
+__global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict__ init_C, const float *__restrict__ init_Y,
+                           FgwDims D, int max_iter, double *__restrict__ Cw, double *__restrict__ Yw, int *__restrict__ active,
+                           int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout) {
+    const int b = blockIdx.x;
+    const int NN = D.N * D.N, Nd = D.N * D.d;
+    const float *c0 = init_C ? init_C + (size_t)b * NN : Cs + (size_t)b * D.K * NN;   // init_C = Cs[0] (schnet_no_sum.py:303)
+    for (int t = threadIdx.x; t < NN; t += blockDim.x) { Cw[(size_t)b * NN + t] = (double)c0[t]; Cout[(size_t)b * NN + t] = c0[t]; }
+    for (int t = threadIdx.x; t < Nd; t += blockDim.x) {
+        float y = init_Y ? init_Y[(size_t)b * Nd + t] : 0.f;                            // barycenter.py:76-77
+        Yw[(size_t)b * Nd + t] = (double)y; Yout[(size_t)b * Nd + t] = y;
+    }
+    if (threadIdx.x == 0) { active[b] = 1; info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
+    for (int t = threadIdx.x; t < 2 * max_iter; t += blockDim.x) errs[(size_t)b * 2 * max_iter + t] = __builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------------ coupling solve
+// One workgroup per (molecule b, input graph s).  Matrices (pitch P): Tl fp32, Mr/Al/base fp64.
+// LDS_MODE: the four matrices live in LDS; otherwise in a per-workgroup global scratch (large N).
+template <bool LDS_MODE>
+__global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
+    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
+    FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    if (!active[b]) return;
+    const int N = D.N, P = D.P, d = D.d;
+    const int NN = N * N, NP = N * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- carve
+    double *vec = reinterpret_cast<double *>(smem);          // [6*N + 8] : u, v, loga, logb, r1/y2, r2/z2, red
+    double *u = vec, *v = vec + N, *loga = vec + 2 * N, *logb = vec + 3 * N, *ra = vec + 4 * N, *rb = vec + 5 * N;
+    double *red = vec + 6 * N;
+    char *mat = LDS_MODE ? smem + (size_t)(6 * N + 8) * 8 : scratch + (size_t)blockIdx.x * ((size_t)NP * 28);
+    double *Mr = reinterpret_cast<double *>(mat);
+    double *Al = Mr + NP;
+    double *base = Al + NP;
+    float *Tl = reinterpret_cast<float *>(base + NP);
+
+    const float *Z = Ys + ((size_t)b * D.K + s) * N * d;        // features of input graph s      [N,d]
+    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;          // structure of input graph s     [N,N]
+    const double *C1 = Cw + (size_t)b * NN;                     // current barycenter structure   [N,N]
+    const double *Y = Yw + (size_t)b * N * d;                   // current barycenter features    [N,d]
+    float *Tg = Tw + ((size_t)b * D.K + s) * NN;
+    const double alpha = (double)prm.alpha, eps = (double)prm.epsilon;
+
+    // ---- marginals: p (barycenter), q = ps[s]; uniform when not given (barycenter.py:50-51, schnet_no_sum.py:264-279)
+    for (int i = tid; i < N; i += FGW_THREADS) {
+        const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+        const double qi = ps ? (double)ps[((size_t)b * D.K + s) * N + i] : 1.0 / (double)N;
+        loga[i] = log(pi); logb[i] = log(qi);
+        u[i] = pi; v[i] = qi;                                  // temporarily hold p, q
+    }
+    __syncthreads();
+    // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
+    for (int t = tid; t < NN; t += FGW_THREADS) {
+        const int i = t / N, j = t - i * N;
+        Tl[i * P + j] = (outer > 0 && prm.warmstart) ? Tg[t] : (float)(u[i] * v[j]);
+    }
+    // ---- init_matrix (utils.py:39-43): constC[i][j] = sum_k C1[i,k]^2 p_k + sum_k q_k C2[j,k]^2 ; squared feature norms
+    double *y2a = Al, *z2a = Al + N;                            // Al is not live yet
+    for (int i = tid; i < N; i += FGW_THREADS) {
+        double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
+        for (int k = 0; k < N; ++k) {
+            const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
+            r1 += c1 * c1 * u[k];
+            r2 += v[k] * (c2 * c2);
+        }
+        for (int c = 0; c < d; ++c) {
+            const double yy = Y[i * d + c], zz = (double)Z[i * d + c];
+            y2 += yy * yy; z2 += zz * zz;
+        }
+        ra[i] = r1; rb[i] = r2; y2a[i] = y2; z2a[i] = z2;
+    }
+    __syncthreads();
+    // ---- base = alpha*2*constC + (1-alpha)*M,  M = clamp(|y_i|^2 + |z_j|^2 - 2 y_i.z_j, 0)   (utils.py:154-171, bregman.py:124-125)
+    for (int t = tid; t < NN; t += FGW_THREADS) {
+        const int i = t / N, j = t - i * N;
+        double dot = 0.0;
+        if (!y_zero) {                                          // Y == 0 on the first outer iteration unless init_Y is given
+            const double *yi = Y + (size_t)i * d;
+            const float *zj = Z + (size_t)j * d;
+            for (int c = 0; c < d; ++c) dot += yi[c] * (double)zj[c];
+        }
+        double m = -2.0 * dot;                                  // utils.py:159-161
+        m += y2a[i]; m += z2a[j];
+        m = m > 0.0 ? m : 0.0;                                  // :163
+        base[i * P + j] = 2.0 * alpha * (ra[i] + rb[j]) + (1.0 - alpha) * m;
+    }
+    __syncthreads();
+
+    // ---- projected gradient loop (bregman.py:119-157)
+    int cpt = 0, sk_total = 0;
+    double err = 1.0;
+    while (err > (double)prm.inner_tol && cpt < prm.max_iter) {
+        // A = C1 @ T
+        for (int t = tid; t < NN; t += FGW_THREADS) {
+            const int i = t / N, j = t - i * N;
+            double a = 0.0;
+            for (int k = 0; k < N; ++k) a += C1[i * N + k] * (double)Tl[k * P + j];
+            Al[i * P + j] = a;
+        }
+        __syncthreads();
+        // G = A @ (2 C2)^T ; tens = base - 2*alpha*G ; Mr = -tens/eps        (utils.py:48-64, bregman.py:124-125, sinkhorn.py:388)
+        for (int t = tid; t < NN; t += FGW_THREADS) {
+            const int i = t / N, j = t - i * N;
+            double g = 0.0;
+            for (int k = 0; k < N; ++k) g += Al[i * P + k] * (2.0 * (double)C2[j * N + k]);
+            const double tens = base[i * P + j] - 2.0 * alpha * g;
+            Mr[i * P + j] = -tens / eps;
+        }
+        for (int i = tid; i < N; i += FGW_THREADS) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
+        __syncthreads();
+        // ---- log-domain Sinkhorn (sinkhorn.py:413-433)
+        int ii = 0;
+        for (; ii < prm.num_iter_max; ++ii) {
+            // v_j = logb_j - logsumexp_i(Mr_ij + u_i): one wavefront per column, lanes over rows
+            for (int j = wave; j < N; j += FGW_WAVES) {
+                double mx = -1.0e300;
+                for (int i = lane; i < N; i += 64) { const double z = Mr[i * P + j] + u[i]; mx = z > mx ? z : mx; }
+                mx = wave_max_d(mx);
+                double sm = 0.0;
+                for (int i = lane; i < N; i += 64) sm += exp_acc(Mr[i * P + j] + u[i] - mx);
+                sm = wave_sum_d(sm);
+                if (lane == 0) v[j] = logb[j] - (log(sm) + mx);
+            }
+            __syncthreads();
+            // u_i = loga_i - logsumexp_j(Mr_ij + v_j): one wavefront per row, lanes over columns
+            for (int i = wave; i < N; i += FGW_WAVES) {
+                double mx = -1.0e300;
+                for (int j = lane; j < N; j += 64) { const double z = Mr[i * P + j] + v[j]; mx = z > mx ? z : mx; }
+                mx = wave_max_d(mx);
+                double sm = 0.0;
+                for (int j = lane; j < N; j += 64) sm += exp_acc(Mr[i * P + j] + v[j] - mx);
+                sm = wave_sum_d(sm);
+                if (lane == 0) u[i] = loga[i] - (log(sm) + mx);
+            }
+            __syncthreads();
+            if (ii % 10 == 0) {                                 // marginal violation, sinkhorn.py:418-433
+                double e2 = 0.0;
+                for (int j = wave; j < N; j += FGW_WAVES) {
+                    double sm = 0.0;
+                    for (int i = lane; i < N; i += 64) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
+                    sm = wave_sum_d(sm);
+                    const double df = sm - exp(logb[j]);
+                    if (lane == 0) e2 += df * df;
+                }
+                const double tot = block_sum_d(e2, red);
+                if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
+            }
+        }
+        sk_total += ii;
+        // ---- T = exp(Mr + u + v) (sinkhorn.py:450); err = ||T - Tprev||_F evaluated when cpt % 10 == 0 (bregman.py:144-147)
+        double e2 = 0.0;
+        for (int t = tid; t < NN; t += FGW_THREADS) {
+            const int i = t / N, j = t - i * N;
+            const float tn = (float)exp_acc(Mr[i * P + j] + u[i] + v[j]);
+            const double df = (double)tn - (double)Tl[i * P + j];
+            e2 += df * df;
+            Tl[i * P + j] = tn;
+        }
+        if (cpt % 10 == 0) err = sqrt(block_sum_d(e2, red));
+        else __syncthreads();
+        ++cpt;
+    }
+    __syncthreads();
+    for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
+}
+
+// ------------------------------------------------------------------------------------------------ barycenter update
+// One workgroup per molecule: Y <- sum_s lam_s diag(1/p) T_s Ys_s (utils.py:90-95), C <- sum_s lam_s T_s Cs_s T_s^T / (p p^T)
+// (utils.py:67-73), stopping test on ||Y-Yprev||_F and ||C-Cprev||_F (barycenter.py:186-192, :112).
+template <bool LDS_MODE>
+__global__ void __launch_bounds__(FGW_THREADS) k_fgw_update(
+    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ pb, const float *__restrict__ lambdas,
+    FgwDims D, conan_fgw_params prm, int outer, const float *__restrict__ Tw, double *__restrict__ Cw, double *__restrict__ Yw,
+    int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout,
+    char *__restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (!active[b]) return;
+    const int N = D.N, P = D.P, d = D.d, K = D.K;
+    const int NN = N * N, NP = N * P;
+    const int tid = threadIdx.x;
+    double *red = reinterpret_cast<double *>(smem);            // [8]
+    double *pinv = red + 8;                                    // [N]
+    char *mat = LDS_MODE ? smem + (size_t)(8 + N) * 8 : scratch + (size_t)b * ((size_t)NP * 16);
+    double *TC = reinterpret_cast<double *>(mat);              // [N,P]
+    double *Cacc = TC + NP;                                    // [N,P]
+    for (int i = tid; i < N; i += FGW_THREADS) pinv[i] = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
+    __syncthreads();
+
+    double ef2 = 0.0, es2 = 0.0;
+    if (!prm.fixed_features) {
+        double *Yb = Yw + (size_t)b * N * d;
+        for (int t = tid; t < N * d; t += FGW_THREADS) {
+            const int i = t / d, c = t - i * d;
+            double acc = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const float *Ts = Tw + ((size_t)b * K + s) * NN + (size_t)i * N;
+                const float *Z = Ys + ((size_t)b * K + s) * N * d + c;
+                double ts = 0.0;
+                for (int j = 0; j < N; ++j) ts += (double)Z[(size_t)j * d] * (double)Ts[j];
+                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                acc += lam * ts * pinv[i];
+            }
+            const double df = acc - Yb[t];
+            ef2 += df * df;
+            Yb[t] = acc;
+            Yout[(size_t)b * N * d + t] = (float)acc;
+        }
+    }
+    if (!prm.fixed_structure) {
+        for (int t = tid; t < NP; t += FGW_THREADS) Cacc[t] = 0.0;
+        for (int s = 0; s < K; ++s) {
+            const float *Ts = Tw + ((size_t)b * K + s) * NN;
+            const float *C2 = Cs + ((size_t)b * K + s) * NN;
+            __syncthreads();
+            for (int t = tid; t < NN; t += FGW_THREADS) {       // TC = T_s @ Cs_s
+                const int i = t / N, j = t - i * N;
+                double a = 0.0;
+                for (int k = 0; k < N; ++k) a += (double)Ts[i * N + k] * (double)C2[k * N + j];
+                TC[i * P + j] = a;
+            }
+            __syncthreads();
+            const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+            for (int t = tid; t < NN; t += FGW_THREADS) {       // Cacc += lam * TC @ T_s^T
+                const int i = t / N, j = t - i * N;
+                double a = 0.0;
+                for (int k = 0; k < N; ++k) a += TC[i * P + k] * (double)Ts[j * N + k];
+                Cacc[i * P + j] += lam * a;
+            }
+        }
+        __syncthreads();
+        double *Cb = Cw + (size_t)b * NN;
+        for (int t = tid; t < NN; t += FGW_THREADS) {
+            const int i = t / N, j = t - i * N;
+            const double cn = Cacc[i * P + j] * pinv[i] * pinv[j];     // / (p_i p_j)
+            const double df = cn - Cb[t];
+            es2 += df * df;
+            Cb[t] = cn;
+            Cout[(size_t)b * NN + t] = (float)cn;
+        }
+    }
+    const double ef = sqrt(block_sum_d(ef2, red));
+    const double es = sqrt(block_sum_d(es2, red));
+    if (tid == 0) {
+        errs[((size_t)b * 2 + 0) * prm.max_iter + outer] = (float)ef;
+        errs[((size_t)b * 2 + 1) * prm.max_iter + outer] = (float)es;
+        info[b * 4 + 0] = outer + 1;
+        // while (err_feature > tol or err_structure > tol) and cpt < max_iter        (barycenter.py:112)
+        active[b] = (ef > (double)prm.tol || es > (double)prm.tol) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dYs[b,s,j,c] = lam_s * sum_i T[b,s,i,j] * (1/p_i) * dY[b,i,c]
+__global__ void __launch_bounds__(256) k_fgw_bwd(const float *__restrict__ T, const float *__restrict__ dY, const float *__restrict__ pb,
+                                                 const float *__restrict__ lambdas, int K, int N, int d, float *__restrict__ dYs) {
+    const int b = blockIdx.x / K, s = blockIdx.x % K;
+    const float *Ts = T + ((size_t)b * K + s) * N * N;
+    const float *g = dY + (size_t)b * N * d;
+    const float lam = lambdas ? lambdas[s] : 1.0f / (float)K;
+    for (int t = threadIdx.x; t < N * d; t += 256) {
+        const int j = t / d, c = t - j * d;
+        float a = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const float pinv = pb ? 1.0f / pb[(size_t)b * N + i] : (float)N;
+            a += Ts[i * N + j] * pinv * g[i * d + c];
+        }
+        dYs[((size_t)b * K + s) * N * d + t] = lam * a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ glue: densify / normalise
+// One workgroup per conformer graph g.  feat[sumN,d] -> Ys[g,N,d] = a + (x + shift - min)*(b-a)/(max-min) with padded rows
+// x = 0 included in min/max (schnet_no_sum.py:59,66 / barycenter.py:393-399); Cs[g,src,tgt] += 1 per edge (to_dense_adj).
+__global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat, const int *__restrict__ gptr, const int *__restrict__ rowptr,
+                                                 const int *__restrict__ col, int N, int d, float shift, float a, float b,
+                                                 float *__restrict__ Ys, float *__restrict__ Cs, float *__restrict__ minmax) {
+    __shared__ float smn[4], smx[4];
+    const int g = blockIdx.x;
+    const int lo = gptr[g], n = gptr[g + 1] - lo;
+    const int tid = threadIdx.x;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int t = tid; t < n * d; t += 256) { const float v = feat[(size_t)lo * d + t] + shift; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    if (n < N) { const float v = 0.f + shift; mn = fminf(mn, v); mx = fmaxf(mx, v); }     // zero padding rows of to_dense_batch
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((tid & 63) == 0) { smn[tid >> 6] = mn; smx[tid >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    if (tid == 0) { minmax[g * 2] = mn; minmax[g * 2 + 1] = mx; }
+    const float scale = b - a, range = mx - mn;
+    float *Yg = Ys + (size_t)g * N * d;
+    for (int t = tid; t < N * d; t += 256) {
+        const float x = (t < n * d ? feat[(size_t)lo * d + t] : 0.f) + shift;
+        Yg[t] = a + __fdiv_rn((x - mn) * scale, range);                 // a + (t - min) * (b - a) / (max - min)
+    }
+    float *Cg = Cs + (size_t)g * N * N;
+    for (int t = tid; t < N * N; t += 256) Cg[t] = 0.f;
+    __syncthreads();
+    // edges of this graph: targets lo..lo+n-1 ; adj[src_local, tgt_local] += 1   (to_dense_adj accumulates)
+    for (int i = tid; i < n; i += 256) {
+        for (int e = rowptr[lo + i]; e < rowptr[lo + i + 1]; ++e) {
+            const int j = col[e] - lo;
+            Cg[j * N + i] += 1.0f;                  // distinct (src, tgt) per thread: no race
+        }
+    }
+}
+
+// Backward of the feature half: y = a + (x + shift - mn) * s / r, r = mx - mn, through min() and max() like autograd
+// (the gradient of a full-tensor min/max is split evenly among ties; padded entries absorb their share).
+__global__ void __launch_bounds__(256) k_densify_bwd(const float *__restrict__ feat, const float *__restrict__ dYs, const int *__restrict__ gptr,
+                                                     const float *__restrict__ minmax, int N, int d, float shift, float a, float b,
+                                                     float *__restrict__ dfeat) {
+    __shared__ float red[3][4];
+    const int g = blockIdx.x;
+    const int lo = gptr[g], n = gptr[g + 1] - lo;
+    const int tid = threadIdx.x;
+    const float mn = minmax[g * 2], mx = minmax[g * 2 + 1];
+    const float s = b - a, r = mx - mn;
+    const float *G = dYs + (size_t)g * N * d;
+    // S0 = sum g ; S1 = sum g*(x - mn) over the whole padded slab ; count ties of min and max
+    float s0 = 0.f, s1 = 0.f, cmin = 0.f, cmax = 0.f;
+    for (int t = tid; t < N * d; t += 256) {
+        const float x = (t < n * d ? feat[(size_t)lo * d + t] : 0.f) + shift;
+        const float gg = G[t];
+        s0 += gg; s1 += gg * (x - mn);
+        cmin += (x == mn) ? 1.f : 0.f; cmax += (x == mx) ? 1.f : 0.f;
+    }
+    float vals[4] = {s0, s1, cmin, cmax};
+    __shared__ float tot[4];
+    for (int q = 0; q < 4; ++q) {
+        float v = wave_sum(vals[q]);
+        if ((tid & 63) == 0) red[0][tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) tot[q] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        __syncthreads();
+    }
+    // dL/dmn = sum g * ( -s/r + (x-mn)*s/r^2 ) ; dL/dmx = sum g * ( -(x-mn)*s/r^2 )
+    const float dmn = -tot[0] * s / r + tot[1] * s / (r * r);
+    const float dmx = -tot[1] * s / (r * r);
+    for (int t = tid; t < n * d; t += 256) {
+        const float x = feat[(size_t)lo * d + t] + shift;
+        float gx = G[t] * s / r;
+        if (x == mn) gx += dmn / tot[2];
+        if (x == mx) gx += dmx / tot[3];
+        dfeat[(size_t)lo * d + t] = gx;
+    }
+}
+
+// F_bary readout (schnet_no_sum.py:308-312 ; visnet.py:233-248)
+__global__ void __launch_bounds__(64) k_readout_fwd(const float *__restrict__ Y, int K, int N, int d, int mode, float *__restrict__ out) {
+    const int b = blockIdx.x;
+    const float *Yb = Y + (size_t)b * N * d;
+    __shared__ int has_nan;
+    if (threadIdx.x == 0) has_nan = 0;
+    __syncthreads();
+    if (mode == 1) {
+        int bad = 0;
+        for (int t = threadIdx.x; t < N * d; t += 64) bad |= isnan(Yb[t]) ? 1 : 0;
+        if (bad) has_nan = 1;
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < d; c += 64) {
+        float sum = 0.f, sq = 0.f;
+        for (int i = 0; i < N; ++i) { const float y = has_nan ? 0.f : Yb[i * d + c]; sum += y; sq += y * y; }
+        float r = mode == 1 ? sum / sqrtf(sq) : sum;       // sum_i Y_ic / ||Y_:c||_2   (division by zero -> NaN, as the reference)
+        for (int k = 0; k < K; ++k) out[((size_t)b * K + k) * d + c] = r;
+    }
+}
+__global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y, const float *__restrict__ dout, int K, int N, int d, int mode,
+                                                    float *__restrict__ dY) {
+    const int b = blockIdx.x;
+    const float *Yb = Y + (size_t)b * N * d;
+    for (int c = threadIdx.x; c < d; c += 64) {
+        float g = 0.f;
+        for (int k = 0; k < K; ++k) g += dout[((size_t)b * K + k) * d + c];
+        if (mode == 0) {
+            for (int i = 0; i < N; ++i) dY[((size_t)b * N + i) * d + c] = g;
+        } else {
+            float sum = 0.f, sq = 0.f;
+            for (int i = 0; i < N; ++i) { const float y = Yb[i * d + c]; sum += y; sq += y * y; }
+            const float nrm = sqrtf(sq);
+            // d/dy_i [ sum / nrm ] = 1/nrm - sum * y_i / nrm^3
+            for (int i = 0; i < N; ++i) dY[((size_t)b * N + i) * d + c] = g * (1.0f / nrm - sum * Yb[i * d + c] / (nrm * nrm * nrm));
+        }
+    }
+}
+
+inline int pitch_of(int N) { return N | 1; }
+inline size_t coupling_lds(int N) { return (size_t)(6 * N + 8) * 8 + (size_t)N * pitch_of(N) * 28; }
+inline size_t update_lds(int N) { return (size_t)(8 + N) * 8 + (size_t)N * pitch_of(N) * 16; }
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+long long conan_fgw_workspace_bytes(int B, int K, int N, int d) {
+    if (B <= 0 || K <= 0 || N <= 0 || d <= 0) return 0;
+    const size_t NN = (size_t)N * N, NP = (size_t)N * pitch_of(N);
+    size_t bytes = 0;
+    bytes += (size_t)B * NN * 8;               // Cw
+    bytes += (size_t)B * N * d * 8;            // Yw
+    bytes += (size_t)B * 4 + 256;              // active
+    bytes += (size_t)B * K * NP * 28 + 256;    // coupling scratch (global mode)
+    bytes += (size_t)B * NP * 16 + 256;        // update scratch (global mode)
+    return (long long)bytes;
+}
+
+int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
+                             const float *init_C, const float *init_Y, int B, int K, int N, int d,
+                             const conan_fgw_params *params, float *Y, float *C, float *T, int *info, float *errs,
+                             void *workspace, void *stream) {
+    if (!Ys || !Cs || !params || !Y || !C || !T || !info || !errs || !workspace || B <= 0 || K <= 0 || N <= 0 || d <= 0)
+        return CONAN_E_BADARG;
+    if (params->max_iter <= 0 || params->num_iter_max <= 0) return CONAN_E_BADARG;
+    if (params->fixed_features && !init_Y) return CONAN_E_BADARG;      // barycenter.py:70-72
+    hipStream_t s = as_stream(stream);
+    FgwDims D{B, K, N, d, pitch_of(N)};
+    const size_t NN = (size_t)N * N, NP = (size_t)N * D.P;
+    char *w = static_cast<char *>(workspace);
+    double *Cw = reinterpret_cast<double *>(w); w += (size_t)B * NN * 8;
+    double *Yw = reinterpret_cast<double *>(w); w += (size_t)B * N * d * 8;
+    int *active = reinterpret_cast<int *>(w); w += (((size_t)B * 4 + 255) / 256) * 256;
+    char *sc_c = w; w += (((size_t)B * K * NP * 28 + 255) / 256) * 256;
+    char *sc_u = w;
+
+    k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
+    const size_t lc = coupling_lds(N), lu = update_lds(N);
+    const bool c_lds = lc <= LDS_LIMIT, u_lds = lu <= LDS_LIMIT;
+    if (c_lds && lc > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+    if (u_lds && lu > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lu);
+    const size_t vec_c = (size_t)(6 * N + 8) * 8, vec_u = (size_t)(8 + N) * 8;
+    for (int outer = 0; outer < params->max_iter; ++outer) {
+        if (c_lds)
+            k_fgw_coupling<true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info, sc_c);
+        else
+            k_fgw_coupling<false><<<B * K, FGW_THREADS, vec_c, s>>>(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info, sc_c);
+        if (u_lds)
+            k_fgw_update<true><<<B, FGW_THREADS, lu, s>>>(Ys, Cs, p, lambdas, D, *params, outer, T, Cw, Yw, active, info, errs, Y, C, sc_u);
+        else
+            k_fgw_update<false><<<B, FGW_THREADS, vec_u, s>>>(Ys, Cs, p, lambdas, D, *params, outer, T, Cw, Yw, active, info, errs, Y, C, sc_u);
+    }
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_fgw_barycenter_bwd(const float *T, const float *dY, const float *p, const float *lambdas, int B, int K,
+                             int N, int d, float *dYs, void *stream) {
+    if (!T || !dY || !dYs || B <= 0 || K <= 0 || N <= 0 || d <= 0) return CONAN_E_BADARG;
+    k_fgw_bwd<<<B * K, 256, 0, as_stream(stream)>>>(T, dY, p, lambdas, K, N, d, dYs);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_fgw_densify(const float *feat, const int *graph_ptr, const int *rowptr, const int *col, int num_graphs,
+                      int N, int d, float shift, float a, float b, float *Ys, float *Cs, float *minmax, void *stream) {
+    if (!feat || !graph_ptr || !rowptr || !col || !Ys || !Cs || !minmax || num_graphs <= 0 || N <= 0 || d <= 0) return CONAN_E_BADARG;
+    k_densify<<<num_graphs, 256, 0, as_stream(stream)>>>(feat, graph_ptr, rowptr, col, N, d, shift, a, b, Ys, Cs, minmax);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_fgw_densify_bwd(const float *feat, const float *dYs, const int *graph_ptr, const float *minmax,
+                          int num_graphs, int N, int d, float shift, float a, float b, float *dfeat, void *stream) {
+    if (!feat || !dYs || !graph_ptr || !minmax || !dfeat || num_graphs <= 0 || N <= 0 || d <= 0) return CONAN_E_BADARG;
+    k_densify_bwd<<<num_graphs, 256, 0, as_stream(stream)>>>(feat, dYs, graph_ptr, minmax, N, d, shift, a, b, dfeat);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_fgw_readout_fwd(const float *Y, int B, int K, int N, int d, int mode, float *out, void *stream) {
+    if (!Y || !out || B <= 0 || K <= 0 || N <= 0 || d <= 0 || mode < 0 || mode > 1) return CONAN_E_BADARG;
+    k_readout_fwd<<<B, 64, 0, as_stream(stream)>>>(Y, K, N, d, mode, out);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_fgw_readout_bwd(const float *Y, const float *dout, int B, int K, int N, int d, int mode, float *dY,
+                          void *stream) {
+    if (!Y || !dout || !dY || B <= 0 || K <= 0 || N <= 0 || d <= 0 || mode < 0 || mode > 1) return CONAN_E_BADARG;
+    k_readout_bwd<<<B, 64, 0, as_stream(stream)>>>(Y, dout, K, N, d, mode, dY);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+}  // extern "C"

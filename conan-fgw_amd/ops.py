@@ -1,0 +1,344 @@
+"""Operators of the ConAN hot path on MI355X: thin torch.autograd wrappers over the C-ABI (include/conan_fgw_hip.h).
+
+torch is used for device memory, streams and autograd bookkeeping only; every computation below is a HIP kernel of
+libconan_fgw_hip.so.  All ops require CUDA(ROCm) tensors and raise otherwise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from ._lib import FgwParams, call, lib, ptr, stream_ptr
+
+f32, i32, i64 = torch.float32, torch.int32, torch.int64
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ graphs
+class RadiusGraph:
+    """Device-resident neighbour lists of a batch of conformer graphs: CSR by target (+ lazily its by-source transpose).
+
+    Counterpart of what `RadiusInteractionGraph.forward` returns in the reference (schnet_no_sum.py:160,208,342), kept in
+    the layout the kernels consume.  `edge_index()` / `edge_weight()` export the reference's tensors (one host sync for E).
+    """
+
+    def __init__(self, pos: Tensor, graph_ptr: Tensor, num_graphs: int, cutoff: float, max_num_neighbors: int, loop: bool = False):
+        pos = _c(pos)
+        if pos.dtype != f32:
+            raise RuntimeError("pos must be float32")
+        n = pos.shape[0]
+        dev = pos.device
+        self.num_atoms, self.num_graphs, self.graph_ptr = n, num_graphs, graph_ptr
+        self.cutoff, self.cap, self.loop = float(cutoff), int(max_num_neighbors), bool(loop)
+        self.max_edges = max(1, n * self.cap)
+        self.rowptr = torch.empty(n + 1, dtype=i32, device=dev)
+        self.col = torch.empty(self.max_edges, dtype=i32, device=dev)
+        self.tgt = torch.empty(self.max_edges, dtype=i32, device=dev)
+        self.dist = torch.empty(self.max_edges, dtype=f32, device=dev)
+        self._deg = torch.empty(n + 1, dtype=i32, device=dev)
+        call("conan_radius_graph_csr", ptr(pos), ptr(graph_ptr, i32), n, num_graphs, self.cutoff, self.cap, int(self.loop),
+             ptr(self._deg), ptr(self.rowptr), ptr(self.col), ptr(self.tgt), ptr(self.dist), stream_ptr())
+        self.num_edges_dev = self.rowptr[n:]            # device-side edge count (1-element view)
+        self._num_edges: Optional[int] = None
+        self._t_rowptr = self._t_eid = None
+
+    @property
+    def num_edges(self) -> int:
+        if self._num_edges is None:
+            self._num_edges = int(self.num_edges_dev.item())     # host sync
+        return self._num_edges
+
+    def transpose(self):
+        if self._t_rowptr is None:
+            dev = self.rowptr.device
+            self._t_rowptr = torch.empty(self.num_atoms + 1, dtype=i32, device=dev)
+            self._t_eid = torch.empty(self.max_edges, dtype=i32, device=dev)
+            call("conan_csr_transpose", ptr(self.graph_ptr), self.num_graphs, self.num_atoms, ptr(self.rowptr), ptr(self.col),
+                 ptr(self._deg), ptr(self._t_rowptr), ptr(self._t_eid), stream_ptr())
+        return self._t_rowptr, self._t_eid
+
+    def edge_index(self) -> Tensor:
+        E = self.num_edges
+        ei = torch.empty(2, E, dtype=i64, device=self.rowptr.device)
+        call("conan_edge_index_i64", ptr(self.col), ptr(self.tgt), E, ptr(ei), stream_ptr())
+        return ei
+
+    def edge_weight(self) -> Tensor:
+        return self.dist[: self.num_edges]
+
+
+def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
+    batch = _c(batch)
+    out = torch.empty(num_graphs + 1, dtype=i32, device=batch.device)
+    call("conan_graph_ptr_from_batch", ptr(batch, i64), batch.shape[0], num_graphs, ptr(out), stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ linear / activation
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, residual, act, m_dev):
+        x, w = _c(x), _c(w)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=f32, device=x.device)
+        call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), ptr(_c(residual)) if residual is not None else None,
+             M, K, N, 0, act, ptr(m_dev), ptr(y), stream_ptr())
+        ctx.act, ctx.m_dev, ctx.has_b, ctx.has_res = act, m_dev, b is not None, residual is not None
+        ctx.save_for_backward(x, w, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        M, K = x.shape
+        N = w.shape[0]
+        md = ctx.m_dev
+        if ctx.act:
+            if ctx.has_res:
+                raise RuntimeError("act + residual backward is not defined for this op")
+            g = torch.empty_like(dy)
+            call("conan_ssp_bwd", ptr(dy), ptr(y), M, N, ptr(md), ptr(g), stream_ptr())
+        else:
+            g = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x) if md is None else torch.zeros_like(x)
+            call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            ws = torch.empty(int(lib().conan_linear_wgrad_ws(M, K, N)), dtype=f32, device=x.device)
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=f32, device=x.device) if ctx.has_b else None
+            call("conan_linear_wgrad", ptr(g), ptr(x), M, K, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
+        return dx, dw, db, (dy if ctx.has_res else None), None, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: bool = False, residual: Optional[Tensor] = None,
+           m_dev: Optional[Tensor] = None) -> Tensor:
+    """act(x @ weight.T + bias) (+ residual) with act = shifted softplus.  `m_dev`: device int32 row count (edge-level)."""
+    return _LinearFn.apply(x, weight, bias, residual, 1 if act else 0, m_dev)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, weight, padding_idx):
+        z, weight = _c(z), _c(weight)
+        out = torch.empty(z.shape[0], weight.shape[1], dtype=f32, device=weight.device)
+        call("conan_embedding_fwd", ptr(z, i64), ptr(weight, f32), z.shape[0], weight.shape[1], ptr(out), stream_ptr())
+        ctx.save_for_backward(z)
+        ctx.shape, ctx.padding_idx = weight.shape, padding_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (z,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.shape, dtype=f32, device=dout.device)
+        call("conan_embedding_bwd", ptr(z), ptr(_c(dout)), z.shape[0], ctx.shape[1], ctx.shape[0],
+             -1 if ctx.padding_idx is None else ctx.padding_idx, ptr(dw), stream_ptr())
+        return None, dw, None
+
+
+def embedding(z: Tensor, weight: Tensor, padding_idx: Optional[int] = 0) -> Tensor:
+    return _EmbeddingFn.apply(z, weight, padding_idx)
+
+
+# ------------------------------------------------------------------------------------------------ continuous filter pieces
+def rbf_expand(graph: RadiusGraph, offset: Tensor, coeff: float) -> Tensor:
+    """GaussianSmearing of every edge distance -> [max_edges, Gs] (rows >= E untouched).  No gradient (pos is an input)."""
+    Gs = offset.shape[0]
+    out = torch.empty(graph.max_edges, Gs, dtype=f32, device=offset.device)
+    call("conan_rbf_fwd", ptr(graph.dist), ptr(graph.num_edges_dev), graph.max_edges, ptr(_c(offset), f32), Gs, float(coeff),
+         ptr(out), stream_ptr())
+    return out
+
+
+class _CutoffScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_raw, graph):
+        out = torch.empty_like(w_raw)
+        call("conan_cutoff_scale", ptr(graph.dist), ptr(graph.num_edges_dev), graph.max_edges, w_raw.shape[1], graph.cutoff,
+             ptr(_c(w_raw)), ptr(out), stream_ptr())
+        ctx.graph = graph
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.graph
+        dout = _c(dout)
+        din = torch.empty_like(dout)
+        call("conan_cutoff_scale", ptr(g.dist), ptr(g.num_edges_dev), g.max_edges, dout.shape[1], g.cutoff, ptr(dout), ptr(din),
+             stream_ptr())
+        return din, None
+
+
+def cutoff_scale(w_raw: Tensor, graph: RadiusGraph) -> Tensor:
+    return _CutoffScaleFn.apply(w_raw, graph)
+
+
+class _CFConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, graph):
+        x, W = _c(x), _c(W)
+        out = torch.empty_like(x)
+        call("conan_cfconv_fwd", ptr(x, f32), ptr(W, f32), ptr(graph.rowptr), ptr(graph.col), graph.num_atoms, x.shape[1],
+             ptr(out), stream_ptr())
+        ctx.graph = graph
+        ctx.save_for_backward(x, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W = ctx.saved_tensors
+        g = ctx.graph
+        dout = _c(dout)
+        dx = dW = None
+        F = x.shape[1]
+        if ctx.needs_input_grad[0]:
+            t_rowptr, t_eid = g.transpose()
+            dx = torch.empty_like(x)
+            call("conan_cfconv_bwd_x", ptr(W), ptr(dout), ptr(t_rowptr), ptr(t_eid), ptr(g.tgt), g.num_atoms, F, ptr(dx),
+                 stream_ptr())
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F, ptr(dW),
+                 stream_ptr())
+        return dx, dW, None
+
+
+def cfconv(x: Tensor, W: Tensor, graph: RadiusGraph) -> Tensor:
+    """out[i] = sum_{j in N(i)} x[j] * W[(j->i)]   (CFConv.propagate)."""
+    return _CFConvFn.apply(x, W, graph)
+
+
+class _SegmentSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph_ptr, num_graphs):
+        x = _c(x)
+        out = torch.empty(num_graphs, x.shape[1], dtype=f32, device=x.device)
+        call("conan_segment_sum_fwd", ptr(x, f32), ptr(graph_ptr, i32), num_graphs, x.shape[1], ptr(out), stream_ptr())
+        ctx.save_for_backward(graph_ptr)
+        ctx.shape, ctx.G = x.shape, num_graphs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gp,) = ctx.saved_tensors
+        dx = torch.empty(ctx.shape, dtype=f32, device=dout.device)
+        call("conan_segment_sum_bwd", ptr(_c(dout)), ptr(gp), ctx.G, ctx.shape[1], ptr(dx), stream_ptr())
+        return dx, None, None
+
+
+def segment_sum(x: Tensor, graph_ptr: Tensor, num_graphs: int) -> Tensor:
+    """Sum readout per conformer graph (SumAggregation)."""
+    return _SegmentSumFn.apply(x, graph_ptr, num_graphs)
+
+
+# ------------------------------------------------------------------------------------------------ FGW barycenter
+class _DensifyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, graph, N, shift, a, b):
+        feat = _c(feat)
+        G, d = graph.num_graphs, feat.shape[1]
+        dev = feat.device
+        Ys = torch.empty(G, N, d, dtype=f32, device=dev)
+        Cs = torch.empty(G, N, N, dtype=f32, device=dev)
+        minmax = torch.empty(G, 2, dtype=f32, device=dev)
+        call("conan_fgw_densify", ptr(feat, f32), ptr(graph.graph_ptr), ptr(graph.rowptr), ptr(graph.col), G, N, d, shift, a, b,
+             ptr(Ys), ptr(Cs), ptr(minmax), stream_ptr())
+        ctx.save_for_backward(feat, minmax)
+        ctx.graph, ctx.args = graph, (N, shift, a, b)
+        ctx.mark_non_differentiable(Cs)
+        return Ys, Cs
+
+    @staticmethod
+    def backward(ctx, dYs, _dCs):
+        feat, minmax = ctx.saved_tensors
+        N, shift, a, b = ctx.args
+        g = ctx.graph
+        dfeat = torch.empty_like(feat)
+        call("conan_fgw_densify_bwd", ptr(feat), ptr(_c(dYs)), ptr(g.graph_ptr), ptr(minmax), g.num_graphs, N, feat.shape[1],
+             shift, a, b, ptr(dfeat), stream_ptr())
+        return dfeat, None, None, None, None, None
+
+
+def fgw_densify(feat: Tensor, graph: RadiusGraph, max_nodes: int, shift: float, a: float = 0.1, b: float = 2.0):
+    """to_dense_batch + shift + normalize_tensor per conformer slab, and to_dense_adj (schnet_no_sum.py:242-252)."""
+    return _DensifyFn.apply(feat, graph, max_nodes, float(shift), float(a), float(b))
+
+
+PROD_FGW = dict(alpha=0.1, epsilon=0.1, max_iter=5, tol=1e-2, inner_tol=1e-4, num_iter_max=5, stop_thr=1e-2,
+                fixed_structure=False, fixed_features=False, warmstart=True)       # schnet_no_sum.py:281-306
+
+
+class _FgwBarycenterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Ys, Cs, ps, p, lambdas, init_C, init_Y, params):
+        Ys, Cs = _c(Ys), _c(Cs)
+        B, K, N, d = Ys.shape
+        dev = Ys.device
+        prm = FgwParams(float(params["alpha"]), float(params["epsilon"]), int(params["max_iter"]), float(params["tol"]),
+                        float(params["inner_tol"]), int(params["num_iter_max"]), float(params["stop_thr"]),
+                        int(bool(params["fixed_structure"])), int(bool(params["fixed_features"])), int(bool(params["warmstart"])))
+        Y = torch.empty(B, N, d, dtype=f32, device=dev)
+        C = torch.empty(B, N, N, dtype=f32, device=dev)
+        T = torch.empty(B, K, N, N, dtype=f32, device=dev)
+        info = torch.empty(B, 4, dtype=i32, device=dev)
+        errs = torch.empty(B, 2, prm.max_iter, dtype=f32, device=dev)
+        ws = torch.empty(int(lib().conan_fgw_workspace_bytes(B, K, N, d)), dtype=torch.uint8, device=dev)
+        import ctypes
+        call("conan_fgw_barycenter_fwd", ptr(Ys, f32), ptr(Cs, f32), ptr(ps), ptr(p), ptr(lambdas), ptr(init_C), ptr(init_Y),
+             B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(info), ptr(errs), ptr(ws), stream_ptr())
+        ctx.save_for_backward(T, p, lambdas)
+        ctx.dims = (B, K, N, d)
+        ctx.mark_non_differentiable(C, T, info, errs)
+        return Y, C, T, info, errs
+
+    @staticmethod
+    def backward(ctx, dY, *_):
+        T, p, lambdas = ctx.saved_tensors
+        B, K, N, d = ctx.dims
+        dYs = torch.empty(B, K, N, d, dtype=f32, device=dY.device)
+        call("conan_fgw_barycenter_bwd", ptr(T), ptr(_c(dY)), ptr(p), ptr(lambdas), B, K, N, d, ptr(dYs), stream_ptr())
+        return dYs, None, None, None, None, None, None, None
+
+
+def fgw_barycenter_batched(Ys: Tensor, Cs: Tensor, ps: Optional[Tensor] = None, p: Optional[Tensor] = None,
+                           lambdas: Optional[Tensor] = None, init_C: Optional[Tensor] = None, init_Y: Optional[Tensor] = None,
+                           **params):
+    """B independent FGW barycenters.  Ys [B,K,N,d], Cs [B,K,N,N] -> Y [B,N,d], C [B,N,N], T [B,K,N,N], info [B,4], errs [B,2,max_iter].
+    Gradient flows to Ys only (through the final couplings as constants), like the reference."""
+    prm = dict(PROD_FGW)
+    prm.update(params)
+    opt = lambda t: _c(t) if t is not None else None
+    return _FgwBarycenterFn.apply(Ys, Cs, opt(ps), opt(p), opt(lambdas), opt(init_C), opt(init_Y), prm)
+
+
+class _ReadoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, K, mode):
+        Y = _c(Y)
+        B, N, d = Y.shape
+        out = torch.empty(B * K, d, dtype=f32, device=Y.device)
+        call("conan_fgw_readout_fwd", ptr(Y, f32), B, K, N, d, mode, ptr(out), stream_ptr())
+        ctx.save_for_backward(Y)
+        ctx.K, ctx.mode = K, mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (Y,) = ctx.saved_tensors
+        B, N, d = Y.shape
+        dY = torch.empty_like(Y)
+        call("conan_fgw_readout_bwd", ptr(Y), ptr(_c(dout)), B, ctx.K, N, d, ctx.mode, ptr(dY), stream_ptr())
+        return dY, None, None
+
+
+def fgw_readout(Y: Tensor, num_conformers: int, mode: int = 0) -> Tensor:
+    """[B,N,d] -> [B*K,d]: sum over barycenter nodes, repeated K times (schnet_no_sum.py:308-312); mode 1 = ViSNet variant."""
+    return _ReadoutFn.apply(Y, num_conformers, mode)

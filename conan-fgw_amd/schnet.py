@@ -1,0 +1,262 @@
+"""Drop-in `SchNetNoSum` for MI355X.
+
+Mirrors the reference's backbone class (conan_fgw/src/model/graph_embeddings/schnet_no_sum.py:90-354): same constructor
+arguments, same four methods (`forward`, `forward_3d_bary`, `_compute_barycenter`, `forward_w_barycenter`), same attribute
+names read by the Lightning heads (`hidden_channels`, schnet_based_models.py:95) and the same 49 `state_dict` keys
+(`embedding.weight`, `distance_expansion.offset`, `interactions.{i}.mlp/conv/lin.*`, `lin1`, `lin2`, `lin1_bary`,
+`lin2_bary`) so that stage-1 checkpoints load with `strict=True` (train_val.py:175-183).
+
+The torch.nn modules below are parameter containers only; every forward runs on the HIP kernels of
+libconan_fgw_hip.so through conan_fgw_amd.ops.  No CPU fallback: CPU tensors raise.
+
+Deviations from the reference, all documented in DESIGN.md:
+ * the radius graph is built once per `forward_w_barycenter` instead of twice (schnet_no_sum.py:208 and :342 give the
+   same result);
+ * `h_bary` is returned on the input's device (the reference allocates it on the device captured at construction,
+   usually the CPU, and the caller moves it back: schnet_no_sum.py:254-256, schnet_based_models.py:162-163);
+ * optional `num_graphs` / `max_nodes` hints avoid the host synchronisations the reference performs
+   (`len(batch.unique())`, :345; `to_dense_batch`, :242).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+from torch import Tensor
+from torch.nn import Embedding, Linear, ModuleList, Sequential
+
+from . import ops
+
+OptTensor = Optional[Tensor]
+
+
+class ShiftedSoftplus(torch.nn.Module):
+    """softplus(x) - ln 2.  Parameter-free marker module: the activation is fused into the epilogue of
+    `conan_linear_fwd`; it is kept so that `interactions.{i}.mlp` has the reference's Sequential indices (0, 2)."""
+
+    def __init__(self):
+        super().__init__()
+        self.shift = math.log(2.0)
+
+    def forward(self, x: Tensor) -> Tensor:  # pragma: no cover - not on the product path
+        raise RuntimeError("ShiftedSoftplus is fused into conan_linear_fwd on this backend")
+
+
+class GaussianSmearing(torch.nn.Module):
+    def __init__(self, start: float = 0.0, stop: float = 5.0, num_gaussians: int = 50):
+        super().__init__()
+        offset = torch.linspace(start, stop, num_gaussians)
+        self.coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
+        self.register_buffer("offset", offset)
+
+    def forward(self, graph: ops.RadiusGraph) -> Tensor:
+        return ops.rbf_expand(graph, self.offset, self.coeff)
+
+
+class RadiusInteractionGraph(torch.nn.Module):
+    """`(pos, batch) -> (edge_index, edge_weight)` like the reference's interaction graph; `.csr()` is the fast path."""
+
+    def __init__(self, cutoff: float = 10.0, max_num_neighbors: int = 32):
+        super().__init__()
+        self.cutoff = cutoff
+        self.max_num_neighbors = max_num_neighbors
+
+    def csr(self, pos: Tensor, graph_ptr: Tensor, num_graphs: int) -> ops.RadiusGraph:
+        return ops.RadiusGraph(pos, graph_ptr, num_graphs, self.cutoff, self.max_num_neighbors, loop=False)
+
+    def forward(self, pos: Tensor, batch: Tensor):
+        num_graphs = int(batch[-1].item()) + 1 if batch.numel() else 0
+        g = self.csr(pos, ops.graph_ptr_from_batch(batch, num_graphs), num_graphs)
+        return g.edge_index(), g.edge_weight()
+
+
+class CFConv(torch.nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, num_filters: int, nn: Sequential, cutoff: float):
+        super().__init__()
+        self.lin1 = Linear(in_channels, num_filters, bias=False)
+        self.lin2 = Linear(num_filters, out_channels)
+        self.nn = nn
+        self.cutoff = cutoff
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        torch.nn.init.xavier_uniform_(self.lin1.weight)
+        torch.nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+
+    def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf: Tensor) -> Tensor:
+        md = graph.num_edges_dev
+        h1 = ops.linear(rbf, self.nn[0].weight, self.nn[0].bias, act=True, m_dev=md)       # mlp[0] + ssp
+        w_raw = ops.linear(h1, self.nn[2].weight, self.nn[2].bias, m_dev=md)              # mlp[2]
+        W = ops.cutoff_scale(w_raw, graph)                                                # * C(d)
+        x = ops.linear(x, self.lin1.weight)                                               # lin1 (no bias)
+        x = ops.cfconv(x, W, graph)                                                       # propagate: gather * W, scatter-add
+        return x                                                                          # lin2 applied by the caller (fused with ssp)
+
+
+class InteractionBlock(torch.nn.Module):
+    def __init__(self, hidden_channels: int, num_gaussians: int, num_filters: int, cutoff: float):
+        super().__init__()
+        self.mlp = Sequential(Linear(num_gaussians, num_filters), ShiftedSoftplus(), Linear(num_filters, num_filters))
+        self.conv = CFConv(hidden_channels, hidden_channels, num_filters, self.mlp, cutoff)
+        self.act = ShiftedSoftplus()
+        self.lin = Linear(hidden_channels, hidden_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        torch.nn.init.xavier_uniform_(self.mlp[0].weight)
+        self.mlp[0].bias.data.fill_(0)
+        torch.nn.init.xavier_uniform_(self.mlp[2].weight)
+        self.mlp[2].bias.data.fill_(0)
+        self.conv.reset_parameters()
+        torch.nn.init.xavier_uniform_(self.lin.weight)
+        self.lin.bias.data.fill_(0)
+
+    def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf: Tensor) -> Tensor:
+        """Returns x + lin(ssp(conv(x)))  — the residual of schnet_no_sum.py:164 is fused into the last linear."""
+        m = self.conv(x, graph, rbf)
+        m = ops.linear(m, self.conv.lin2.weight, self.conv.lin2.bias, act=True)           # conv.lin2 + InteractionBlock.act
+        return ops.linear(m, self.lin.weight, self.lin.bias, residual=x)                  # lin, + x
+
+
+class SchNetNoSum(torch.nn.Module):
+    FEATURE_SHIFT = 0.5          # schnet_no_sum.py:59
+    READOUT_MODE = 0
+
+    def __init__(self, device, hidden_channels: int = 128, num_filters: int = 128, num_interactions: int = 6,
+                 num_gaussians: int = 50, cutoff: float = 10.0, interaction_graph: Optional[Callable] = None,
+                 max_num_neighbors: int = 32, readout: str = "add", dipole: bool = False, mean: Optional[float] = None,
+                 std: Optional[float] = None, atomref: OptTensor = None, use_covalent: bool = False, use_readout: bool = True):
+        super().__init__()
+        if interaction_graph is not None:
+            raise NotImplementedError("custom interaction_graph callables are not supported; the radius graph is a HIP kernel")
+        if use_covalent:
+            raise NotImplementedError("use_covalent=True (ESAN-only branch, schnet_no_sum.py:132-142) is out of scope")
+        if dipole or atomref is not None:
+            raise NotImplementedError("dipole / atomref are not used by ConAN (common.py:524-529)")
+        if readout not in ("add", "sum"):
+            raise NotImplementedError("only the sum readout is used by ConAN")
+        self.device = device
+        self.hidden_channels = hidden_channels
+        self.num_filters = num_filters
+        self.num_interactions = num_interactions
+        self.num_gaussians = num_gaussians
+        self.cutoff = cutoff
+        self.use_readout = use_readout
+        self.use_covalent = use_covalent
+        self.mean, self.std, self.scale = mean, std, None
+        self.embedding = Embedding(100, hidden_channels, padding_idx=0)
+        self.interaction_graph = RadiusInteractionGraph(cutoff, max_num_neighbors)
+        self.distance_expansion = GaussianSmearing(0.0, cutoff, num_gaussians)
+        self.interactions = ModuleList([InteractionBlock(hidden_channels, num_gaussians, num_filters, cutoff)
+                                        for _ in range(num_interactions)])
+        self.lin1 = Linear(hidden_channels, hidden_channels // 2)
+        self.act = ShiftedSoftplus()
+        self.register_buffer("initial_atomref", None)
+        self.atomref = None
+        # PyG SchNet.reset_parameters for the inherited layers ...
+        torch.nn.init.xavier_uniform_(self.lin1.weight)
+        self.lin1.bias.data.fill_(0)
+        # ... ConAN's own layers keep torch's default Linear init (schnet_no_sum.py:126-130)
+        self.lin1_bary = Linear(hidden_channels, hidden_channels // 2)
+        self.lin2_bary = Linear(hidden_channels // 2, hidden_channels // 2)
+        self.lin2 = Linear(hidden_channels // 2, hidden_channels // 2)
+
+    # ---------------------------------------------------------------------------------------------- helpers
+    def _graphs(self, z: Tensor, pos: Tensor, batch: OptTensor, num_graphs: Optional[int]):
+        if not z.is_cuda:
+            raise RuntimeError("SchNetNoSum (MI355X) runs on the GPU only: move the inputs to the device; there is no CPU fallback")
+        batch = torch.zeros_like(z) if batch is None else batch            # schnet_no_sum.py:157
+        if num_graphs is None:
+            num_graphs = int(batch[-1].item()) + 1                         # host sync; pass num_graphs= to avoid it
+        gptr = ops.graph_ptr_from_batch(batch, num_graphs)
+        graph = self.interaction_graph.csr(pos, gptr, num_graphs)
+        return batch, gptr, graph, num_graphs
+
+    def _trunk(self, z: Tensor, graph: ops.RadiusGraph) -> Tensor:
+        """embedding -> interactions with residual (schnet_no_sum.py:159-164 == :207-212)."""
+        h = ops.embedding(z, self.embedding.weight, self.embedding.padding_idx)
+        rbf = self.distance_expansion(graph)
+        for interaction in self.interactions:
+            h = interaction(h, graph, rbf)
+        return h
+
+    def _head(self, h: Tensor, lin1: Linear, lin2: Linear) -> Tensor:
+        h = ops.linear(h, lin1.weight, lin1.bias)
+        return ops.linear(h, lin2.weight, lin2.bias, act=True)
+
+    # ---------------------------------------------------------------------------------------------- reference API
+    def forward(self, z: Tensor, pos: Tensor, batch: OptTensor = None, data_batch=None, num_graphs: Optional[int] = None) -> Tensor:
+        """Stage-1 path (schnet_no_sum.py:144-188): per-conformer embedding [G, hidden/2] (or per-atom if use_readout=False)."""
+        batch, gptr, graph, G = self._graphs(z, pos, batch, num_graphs)
+        h = self._head(self._trunk(z, graph), self.lin1, self.lin2)        # :176-178
+        return ops.segment_sum(h, gptr, G) if self.use_readout else h      # :182-186
+
+    def forward_3d_bary(self, z: Tensor, pos: Tensor, batch: OptTensor = None, data_batch=None, num_graphs: Optional[int] = None,
+                        _graph=None):
+        """Two per-atom embeddings from the shared trunk (schnet_no_sum.py:190-232)."""
+        if _graph is None:
+            _, _, graph, _ = self._graphs(z, pos, batch, num_graphs)
+        else:
+            graph = _graph
+        h_shared = self._trunk(z, graph)
+        h = self._head(h_shared, self.lin1, self.lin2)                     # :225-227
+        h_bary = self._head(h_shared, self.lin1_bary, self.lin2_bary)      # :229-231
+        return h, h_bary
+
+    def _compute_barycenter(self, node_feature: Tensor, edge_index, batch: Tensor, batch_size: int, num_conformers: int,
+                            max_nodes: Optional[int] = None):
+        """schnet_no_sum.py:234-315.  `edge_index` may be the reference's int64 [2,E] tensor or an ops.RadiusGraph."""
+        K = num_conformers
+        G = batch_size * K
+        if isinstance(edge_index, ops.RadiusGraph):
+            graph = edge_index
+        else:
+            graph = _graph_from_edge_index(edge_index, batch, G)
+        if max_nodes is None:
+            gp = graph.graph_ptr
+            max_nodes = int((gp[1:] - gp[:-1]).max().item())                # host sync (to_dense_batch does the same, :242)
+        Ys, Cs = ops.fgw_densify(node_feature, graph, max_nodes, self.FEATURE_SHIFT)       # :242-252 with :41-87
+        N, d = max_nodes, node_feature.shape[1]
+        Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), Cs.view(batch_size, K, N, N))   # :259-306
+        self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs, Ys=Ys, Cs=Cs)
+        F_bary_batch = ops.fgw_readout(Y, K, self.READOUT_MODE)                            # :308-312
+        node_out = ops.segment_sum(node_feature, graph.graph_ptr, G)                       # :314
+        return node_out, F_bary_batch
+
+    def forward_w_barycenter(self, z: Tensor, pos: Tensor, num_conformers: int, batch: OptTensor = None, data_batch=None,
+                             max_iter: int = 100, epsilon: float = 0.1, num_graphs: Optional[int] = None,
+                             max_nodes: Optional[int] = None):
+        """schnet_no_sum.py:317-354.  `max_iter` / `epsilon` are accepted and ignored exactly like the reference
+        (the FGW hyper-parameters are the literals of :281-306)."""
+        batch, gptr, graph, G = self._graphs(z, pos, batch, num_graphs)
+        h_3d, h_bary = self.forward_3d_bary(z, pos, batch, _graph=graph)                   # :341
+        batch_size = G // num_conformers                                                  # :345
+        _, h_bary = self._compute_barycenter(h_bary, graph, batch, batch_size, num_conformers, max_nodes=max_nodes)   # :346-352
+        h_3d = ops.segment_sum(h_3d, gptr, G)                                              # :353
+        return h_3d, h_bary
+
+
+def _graph_from_edge_index(edge_index: Tensor, batch: Tensor, num_graphs: int) -> ops.RadiusGraph:
+    """Compatibility path for callers that hand `_compute_barycenter` the reference's int64 edge_index: rebuild the
+    CSR-by-target view with torch index ops (host-side plumbing, not the hot path)."""
+    g = object.__new__(ops.RadiusGraph)
+    n = batch.shape[0]
+    src, tgt = edge_index[0], edge_index[1]
+    order = torch.argsort(tgt * n + src)
+    src, tgt = src[order], tgt[order]
+    deg = torch.bincount(tgt, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=batch.device)
+    rowptr[1:] = deg.cumsum(0).to(torch.int32)
+    g.num_atoms, g.num_graphs = n, num_graphs
+    g.graph_ptr = ops.graph_ptr_from_batch(batch, num_graphs)
+    g.rowptr, g.col, g.tgt = rowptr, src.to(torch.int32).contiguous(), tgt.to(torch.int32).contiguous()
+    g.dist = None
+    g.max_edges = max(1, int(src.shape[0]))
+    g.num_edges_dev = rowptr[n:]
+    g._num_edges = int(src.shape[0])
+    g._t_rowptr = g._t_eid = None
+    g._deg = torch.empty(n + 1, dtype=torch.int32, device=batch.device)
+    g.cutoff = g.cap = g.loop = None
+    return g

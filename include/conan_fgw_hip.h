@@ -1,0 +1,172 @@
+/*
+ * conan_fgw_hip.h — C ABI of libconan_fgw_hip.so: the MI355X (gfx950) hot path of ConAN-FGW.
+ *
+ * The reference (duyhominhnguyen/conan-fgw) is 100 % Python and has no FFI of its own; its boundary for this path is
+ * the Python model API (EquivModelsHolder.get_model -> SchNetNoSum / ViSNet, conan_fgw/src/model/common.py:469-546).
+ * Each entry point below replaces one piece of third-party native code or one Python hot loop that the reference
+ * reaches from that API; the replaced call site is cited as file:line relative to the reference root.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer on the current HIP device unless marked (host);
+ *  - no entry point allocates, frees, synchronises the host or reads results back: all are stream-ordered and
+ *    hipGraph-capturable; workspaces are caller-provided;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - return value: 0 = launched, <0 = error (CONAN_E_*), nothing launched on a bad argument;
+ *  - float = IEEE fp32; indices are int32 on the device (edge counts < 2^31), the Python host converts to/from the
+ *    reference's int64 tensors at the API edge.
+ *  - graphs: `graph_ptr[G+1]` = first atom of every conformer graph (atoms of a graph are contiguous, as produced by
+ *    the reference's collate_fn, conan_fgw/src/data/datasets.py:170-199).
+ *  - edges: CSR by TARGET atom: edges of target i are rowptr[i] .. rowptr[i+1]-1, `col[e]` = source atom (global id),
+ *    sources ascending inside a row, `tgt[e]` = i.  Same orientation as PyG flow source_to_target
+ *    (edge_index[0] = col, edge_index[1] = tgt).
+ */
+#ifndef CONAN_FGW_HIP_H
+#define CONAN_FGW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONAN_OK 0
+#define CONAN_E_BADARG (-1)
+#define CONAN_E_LAUNCH (-2)
+#define CONAN_E_UNSUPPORTED (-3)
+
+/* Library / device probe.  Returns the ABI version (1). */
+int conan_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------- graph construction */
+
+/* graph_ptr[G+1] from the sorted per-atom graph id vector the reference passes around (`batch`,
+ * schnet_no_sum.py:157,205,338).  Empty graphs are allowed. */
+int conan_graph_ptr_from_batch(const int64_t *batch, int num_atoms, int num_graphs, int *graph_ptr, void *stream);
+
+/* Fixed-radius neighbour search: replaces torch_cluster.radius_graph as reached through
+ * RadiusInteractionGraph.forward (schnet_no_sum.py:160,208,342; visnet.py:276; torch_geometric_visnet.py:331-337).
+ * Edge (j -> i) iff same graph, (loop or j != i), d2 < r*r strictly with d2 = fl(fl(dx*dx + dy*dy) + dz*dz) (no FMA),
+ * and j is among the `cap` smallest-index qualifying sources of i.
+ * Outputs: rowptr[num_atoms+1]; col/tgt/dist sized for cap*num_atoms entries (only rowptr[num_atoms] are written);
+ * dist[e] = sqrt(d2) = the reference's edge_weight.  `deg_ws[num_atoms+1]` is scratch. */
+int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms, int num_graphs, float r, int cap,
+                           int loop, int *deg_ws, int *rowptr, int *col, int *tgt, float *dist, void *stream);
+
+/* CSR by SOURCE of the same edge set (needed by the backward of the message passing): t_rowptr[num_atoms+1],
+ * t_eid[e'] = edge id (position in the by-target CSR), ascending inside each source row. */
+int conan_csr_transpose(const int *graph_ptr, int num_graphs, int num_atoms, const int *rowptr, const int *col,
+                        int *deg_ws, int *t_rowptr, int *t_eid, void *stream);
+
+/* edge_index[2, E] int64 in the reference's layout from the CSR (E = capacity of the output rows = host-known edge
+ * count).  Row 0 = source, row 1 = target. */
+int conan_edge_index_i64(const int *col, const int *tgt, int num_edges, int64_t *edge_index, void *stream);
+
+/* ---------------------------------------------------------------------------------------------- SchNet trunk */
+
+/* out[a, :] = weight[z[a], :]  (torch.nn.Embedding(100, H, padding_idx=0); schnet_no_sum.py:159,207). */
+int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, int hidden, float *out, void *stream);
+/* dweight[z[a], :] += dout[a, :] for z[a] != padding_idx; dweight[num_embeddings, hidden] must be zeroed by the caller. */
+int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int hidden, int num_embeddings,
+                        int padding_idx, float *dweight, void *stream);
+
+/* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]) on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
+ * W is torch.nn.Linear's [N,K] when w_kn == 0, or a [K,N] matrix when w_kn == 1 (used by the backward: dx = g @ W).
+ * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2).  m_dev (nullable): device int holding the real row count
+ * (<= M) for edge-level calls whose row count is only known on the device; rows >= *m_dev are not touched.
+ * Replaces the aten addmm + softplus of CFConv.lin1/lin2, InteractionBlock.mlp/.lin and the heads
+ * (PyG SchNet, reached from schnet_no_sum.py:163-164,176-178,211-212,225-231). */
+int conan_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N,
+                     int w_kn, int act, const int *m_dev, float *y, void *stream);
+
+/* g[rows,width] = dy * ssp'(v) computed from the layer OUTPUT y (ssp'(v) = sigmoid(v) = 1 - 0.5*exp(-y)). In place allowed. */
+int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream);
+/* dW[N,K] = g^T @ x and dbias[N] = column sums of g (dbias nullable), deterministic two-stage reduction (no float
+ * atomics); ws holds conan_linear_wgrad_ws(M,K,N) floats. */
+long long conan_linear_wgrad_ws(int M, int K, int N);
+int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias,
+                       float *ws, void *stream);
+
+/* rbf[e,k] = exp(coeff * (dist[e] - offset[k])^2): GaussianSmearing (PyG; schnet_no_sum.py:161,209).  `offset` is the
+ * module's buffer (distance_expansion.offset), coeff = -0.5/(offset[1]-offset[0])^2.  num_edges_dev (nullable) = device
+ * int with the edge count (rowptr[num_atoms]); at most max_edges rows are written. */
+int conan_rbf_fwd(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int num_gaussians,
+                  float coeff, float *rbf, void *stream);
+/* out[e,:] = in[e,:] * 0.5*(cos(dist[e]*pi/cutoff)+1): CFConv's cosine cutoff (PyG; schnet_no_sum.py:163-164).
+ * Also its own backward (the factor does not depend on trainable parameters).  In place allowed. */
+int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edges, int width, float cutoff,
+                       const float *in, float *out, void *stream);
+
+/* CFConv message + aggregation (the HBM-bound kernel of the path): out[i,:] = sum_{e in row i} x[col[e],:] * W[e,:].
+ * Replaces index_select + mul + scatter-add inside CFConv.propagate (PyG; schnet_no_sum.py:163-164,211-212).
+ * CSR segment sum, one wavefront per target, no atomics. */
+int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const int *col, int num_atoms, int num_filters,
+                     float *out, void *stream);
+/* Backward: dx[j,:] = sum_{e: col[e]==j} W[e,:]*dout[tgt[e],:] (via the by-source CSR), dW[e,:] = x[col[e],:]*dout[tgt[e],:]. */
+int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt,
+                       int num_atoms, int num_filters, float *dx, void *stream);
+int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_dev, int max_edges, const int *col,
+                       const int *tgt, int num_filters, float *dW, void *stream);
+
+/* Sum readout per conformer graph: out[g,:] = sum_{a in graph g} x[a,:]  (SumAggregation; schnet_no_sum.py:183,353). */
+int conan_segment_sum_fwd(const float *x, const int *graph_ptr, int num_graphs, int width, float *out, void *stream);
+/* dx[a,:] = dout[graph(a),:] */
+int conan_segment_sum_bwd(const float *dout, const int *graph_ptr, int num_graphs, int width, float *dx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------- FGW barycenter */
+
+/* Glue of _compute_barycenter (schnet_no_sum.py:242-252 with :41-87; visnet.py:168-176 with :32-79):
+ * to_dense_batch + shift + normalize_tensor(.,a,b) per conformer slab (min/max over the WHOLE padded [N,d] slab,
+ * barycenter.py:393-399) and to_dense_adj.  Ys[G,N,d], Cs[G,N,N] (Cs[g, src, tgt] = multiplicity of edge src->tgt),
+ * minmax[G,2] saved for the backward. */
+int conan_fgw_densify(const float *feat, const int *graph_ptr, const int *rowptr, const int *col, int num_graphs,
+                      int N, int d, float shift, float a, float b, float *Ys, float *Cs, float *minmax, void *stream);
+/* Backward of the feature half of conan_fgw_densify (autograd through +shift, min(), max() and the affine map). */
+int conan_fgw_densify_bwd(const float *feat, const float *dYs, const int *graph_ptr, const float *minmax,
+                          int num_graphs, int N, int d, float shift, float a, float b, float *dfeat, void *stream);
+
+typedef struct conan_fgw_params {
+    float alpha;            /* trade-off structure/features          (schnet_no_sum.py:289: 0.1) */
+    float epsilon;          /* entropic regularisation                (:294: 0.1) */
+    int max_iter;           /* outer AND inner PGD iteration cap       (:297: 5; barycenter.py:134 passes it on) */
+    float tol;              /* outer stop on ||Y-Yprev||, ||C-Cprev||  (:298: 1e-2) */
+    float inner_tol;        /* PGD stop on ||T-Tprev||                 (barycenter.py:135: 1e-4) */
+    int num_iter_max;       /* Sinkhorn iteration cap                  (:299: 5) */
+    float stop_thr;         /* Sinkhorn marginal-violation threshold   (:300: 1e-2) */
+    int fixed_structure;    /* keep C = init_C                         (:291) */
+    int fixed_features;     /* keep Y = init_Y                         (:292) */
+    int warmstart;          /* warmstartT: start each coupling solve from the previous outer iteration's T (:285) */
+} conan_fgw_params;
+
+/* Workspace size in BYTES for conan_fgw_barycenter_fwd. */
+long long conan_fgw_workspace_bytes(int B, int K, int N, int d);
+
+/* Batched fgw_barycenters (barycenter.py:7-225 -> bregman.py:70-167 -> sinkhorn.py:318-450 -> utils.py), one
+ * independent problem per molecule, all K input graphs of a molecule padded to the same N nodes (the production glue
+ * always does; schnet_no_sum.py:281-306).  Replaces the Python loop over molecules (schnet_no_sum.py:259-312).
+ * Ys[B,K,N,d], Cs[B,K,N,N], ps[B,K,N] or NULL (uniform), p[B,N] or NULL (uniform), lambdas[K] or NULL (1/K),
+ * init_C[B,N,N] or NULL (= Cs[b,0], schnet_no_sum.py:303), init_Y[B,N,d] or NULL (zeros).
+ * Outputs: Y[B,N,d], C[B,N,N], T[B,K,N,N] (final couplings, saved for the backward),
+ * info[B,4] int32 = {outer iterations, total PGD iterations, total Sinkhorn iterations, flags},
+ * errs[B,2,max_iter] fp32 = err_feature / err_structure per outer iteration (NaN where not executed).
+ * Internal arithmetic is fp64 (DESIGN.md section "FGW numerics"); I/O is fp32. */
+int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
+                             const float *init_C, const float *init_Y, int B, int K, int N, int d,
+                             const conan_fgw_params *params /* (host) */, float *Y, float *C, float *T, int *info,
+                             float *errs, void *workspace, void *stream);
+
+/* dYs[b,s,j,:] = lambdas[s] * sum_i T[b,s,i,j] * (1/p[b,i]) * dY[b,i,:]  — the whole backward of the block given the
+ * saved couplings (the reference solves them under torch.no_grad(), barycenter.py:120). */
+int conan_fgw_barycenter_bwd(const float *T, const float *dY, const float *p, const float *lambdas, int B, int K,
+                             int N, int d, float *dYs, void *stream);
+
+/* F_bary readout of _compute_barycenter: out[b*K + k, :] = sum_i post(Y[b])[i, :] for k < K
+ * (schnet_no_sum.py:308-312).  mode 0 = SchNet (post = identity); mode 1 = ViSNet (NaN guard -> zeros, then column
+ * L2 normalisation over the N rows, visnet.py:233-242). */
+int conan_fgw_readout_fwd(const float *Y, int B, int K, int N, int d, int mode, float *out, void *stream);
+int conan_fgw_readout_bwd(const float *Y, const float *dout, int B, int K, int N, int d, int mode, float *dY,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONAN_FGW_HIP_H */

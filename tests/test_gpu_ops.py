@@ -1,0 +1,117 @@
+"""GPU parity of the SchNet trunk kernels against the oracle (oracle/pyg_semantics.py, run on the CPU in fp64)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel
+from conan_fgw_amd import ops
+from conan_fgw_amd.synthetic import make_batch
+from oracle import pyg_semantics as ps
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+TOL = 2e-6        # fp32 kernels vs fp64 oracle, relative Frobenius
+
+
+def _ssp(x):
+    return F.softplus(x) - math.log(2.0)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 50, 128), (63, 128, 128), (64, 128, 64), (1000, 64, 64), (257, 50, 32), (3210, 128, 128), (130, 10, 256)])
+@pytest.mark.parametrize("act", [False, True])
+def test_linear_fwd_bwd(M, K, N, act):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * 0.2; b = torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, act=act)
+    y.backward(gy.to(dev))
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    r = F.linear(x64, w64, b64)
+    r = _ssp(r) if act else r
+    r.backward(gy.double())
+    assert rel(y.detach().cpu(), r.detach()) < TOL
+    assert rel(xd.grad.cpu(), x64.grad) < TOL
+    assert rel(wd.grad.cpu(), w64.grad) < 5e-6
+    assert rel(bd.grad.cpu(), b64.grad) < 5e-6
+
+
+def test_linear_residual_nobias_and_device_row_count():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(500, 128, generator=g); w = torch.randn(128, 128, generator=g) * 0.1; res = torch.randn(500, 128, generator=g)
+    y = ops.linear(x.to(dev), w.to(dev), None, residual=res.to(dev))
+    assert rel(y.cpu(), F.linear(x.double(), w.double()) + res.double()) < TOL
+    m_dev = torch.tensor([321], dtype=torch.int32, device=dev)
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev).requires_grad_(True)
+    y = ops.linear(xd, wd, None, act=True, m_dev=m_dev)
+    assert rel(y[:321].detach().cpu(), _ssp(F.linear(x[:321].double(), w.double()))) < TOL
+    gy = torch.randn(500, 128, generator=g)
+    y.backward(gy.to(dev))
+    x64 = x[:321].double().requires_grad_(True); w64 = w.double().requires_grad_(True)
+    _ssp(F.linear(x64, w64)).backward(gy[:321].double())
+    assert rel(wd.grad.cpu(), w64.grad) < 5e-6                       # rows >= m_dev must not contribute
+    assert rel(xd.grad[:321].cpu(), x64.grad) < TOL and float(xd.grad[321:].abs().max()) == 0.0
+
+
+def _edges(b, cutoff=10.0, cap=32):
+    pos = torch.from_numpy(b.pos).to(dev); batch = torch.from_numpy(b.batch).to(dev)
+    gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
+    return ops.RadiusGraph(pos, gp, b.num_graphs, cutoff, cap)
+
+
+@pytest.mark.parametrize("F_", [128, 64, 256, 32])
+def test_cfconv_fwd_bwd(F_):
+    b = make_batch("esol", 6, 5, seed=5, box=14.0)
+    g = _edges(b)
+    E = g.num_edges
+    gen = torch.Generator().manual_seed(F_)
+    x = torch.randn(len(b.z), F_, generator=gen); W = torch.randn(E, F_, generator=gen); gy = torch.randn(len(b.z), F_, generator=gen)
+    Wfull = torch.zeros(g.max_edges, F_); Wfull[:E] = W
+    xd = x.to(dev).requires_grad_(True); Wd = Wfull.to(dev).requires_grad_(True)
+    out = ops.cfconv(xd, Wd, g)
+    out.backward(gy.to(dev))
+    ei = g.edge_index().cpu()
+    x64 = x.double().requires_grad_(True); W64 = W.double().requires_grad_(True)
+    ref = ps.scatter(x64[ei[0]] * W64, ei[1], dim=0, dim_size=len(b.z))
+    ref.backward(gy.double())
+    assert rel(out.detach().cpu(), ref.detach()) < TOL
+    assert rel(xd.grad.cpu(), x64.grad) < TOL
+    assert rel(Wd.grad[:E].cpu(), W64.grad) < TOL
+
+
+def test_rbf_cutoff_embedding_segment_sum():
+    b = make_batch("esol", 4, 5, seed=9, box=14.0)
+    g = _edges(b)
+    E = g.num_edges
+    gs = ps.GaussianSmearing(0.0, 10.0, 50)
+    rbf = ops.rbf_expand(g, gs.offset.to(dev), gs.coeff)[:E].cpu()
+    d = g.edge_weight().cpu()
+    assert rel(rbf, gs(d.double())) < TOL
+    Wr = torch.randn(g.max_edges, 128)
+    Wd = Wr.to(dev).requires_grad_(True)
+    out = ops.cutoff_scale(Wd, g)
+    C = 0.5 * (torch.cos(d.double() * math.pi / 10.0) + 1.0)
+    assert rel(out[:E].detach().cpu(), Wr[:E].double() * C[:, None]) < TOL
+    out.backward(torch.ones_like(out))
+    assert rel(Wd.grad[:E].cpu(), C[:, None].expand(-1, 128)) < TOL
+    # embedding with padding row
+    emb = torch.nn.Embedding(100, 64, padding_idx=0)
+    z = torch.from_numpy(b.z); z[0] = 0
+    wd = emb.weight.detach().to(dev).requires_grad_(True)
+    o = ops.embedding(z.to(dev), wd, 0)
+    assert torch.equal(o.detach().cpu(), emb(z).detach())
+    gy = torch.randn(len(z), 64)
+    o.backward(gy.to(dev)); emb(z).backward(gy)
+    assert rel(wd.grad.cpu(), emb.weight.grad) < TOL and float(wd.grad[0].abs().max()) == 0.0
+    # sum readout
+    gp = g.graph_ptr
+    xs = torch.randn(len(z), 64)
+    xd = xs.to(dev).requires_grad_(True)
+    o = ops.segment_sum(xd, gp, b.num_graphs)
+    assert rel(o.detach().cpu(), ps.scatter(xs.double(), torch.from_numpy(b.batch), 0, b.num_graphs)) < TOL
+    gg = torch.randn(b.num_graphs, 64)
+    o.backward(gg.to(dev))
+    assert torch.equal(xd.grad.cpu(), gg[torch.from_numpy(b.batch)])

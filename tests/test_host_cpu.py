@@ -1,0 +1,67 @@
+"""Host-side logic that needs no GPU: module surface, error behaviour, synthetic data, no-CPU-fallback guarantees."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_files, golden_state_dict
+from conan_fgw_amd import fgw as pfgw
+from conan_fgw_amd.schnet import SchNetNoSum
+from conan_fgw_amd.synthetic import CONFIGS, make_batch, make_config
+
+
+def test_state_dict_matches_reference_class():
+    g = np.load(golden_files("schnet_ref_b4_k5_h128")[0])
+    m = SchNetNoSum(torch.device("cpu"), hidden_channels=128, num_filters=128, num_interactions=3)
+    sd = golden_state_dict(g)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)                     # train_val.py:182-183 loads stage-1 checkpoints strictly
+    for k, v in m.state_dict().items():
+        assert v.shape == sd[k].shape
+    assert sum(p.numel() for p in m.parameters()) == 254976
+    assert m.interactions[0].mlp[0].weight is m.interactions[0].conv.nn[0].weight     # PyG registers the filter MLP twice
+    assert m.hidden_channels == 128                        # read by schnet_based_models.py:95
+
+
+def test_no_cpu_fallback():
+    m = SchNetNoSum(torch.device("cpu"), hidden_channels=32, num_filters=32, num_interactions=1)
+    z = torch.ones(4, dtype=torch.long); pos = torch.rand(4, 3)
+    for fn in (lambda: m(z, pos), lambda: m.forward_3d_bary(z, pos), lambda: m.forward_w_barycenter(z, pos, 1)):
+        with pytest.raises(RuntimeError, match="GPU only"):
+            fn()
+
+
+def test_unsupported_constructor_options():
+    with pytest.raises(NotImplementedError):
+        SchNetNoSum(torch.device("cpu"), use_covalent=True)
+    with pytest.raises(NotImplementedError):
+        SchNetNoSum(torch.device("cpu"), interaction_graph=lambda p, b: None)
+
+
+def test_fgw_barycenters_error_behaviour():
+    Ys = [torch.zeros(3, 2)]; Cs = [torch.zeros(3, 3)]
+    with pytest.raises(ValueError, match="loss_fun"):
+        pfgw.fgw_barycenters(3, Ys, Cs, loss_fun="nope")
+    with pytest.raises(ValueError, match="stop_criterion"):
+        pfgw.fgw_barycenters(3, Ys, Cs, stop_criterion="nope")
+    with pytest.raises(ValueError, match="solver"):
+        pfgw.fgw_barycenters(3, Ys, Cs, solver="nope")
+    with pytest.raises(ValueError, match="fixed"):
+        pfgw.fgw_barycenters(3, Ys, Cs, fixed_structure=True)
+    with pytest.raises(NotImplementedError):
+        pfgw.fgw_barycenters(3, Ys, Cs, loss_fun="kl_loss", init_C=Cs[0])
+
+
+def test_synthetic_batches_are_deterministic_and_shaped():
+    a, b = make_batch("esol", 8, 5, seed=3), make_batch("esol", 8, 5, seed=3)
+    assert np.array_equal(a.pos, b.pos) and np.array_equal(a.z, b.z)
+    assert a.num_graphs == 40 and a.batch.max() == 39 and np.all(np.diff(a.batch) >= 0)
+    assert a.z.min() >= 1
+    gp = a.graph_ptr
+    for m in range(8):                                     # K conformers share n and z, differ in pos
+        n = a.atoms_per_molecule[m]
+        zs = [a.z[gp[m * 5 + k]:gp[m * 5 + k + 1]] for k in range(5)]
+        assert all(len(q) == n and np.array_equal(q, zs[0]) for q in zs)
+    assert 6 <= a.atoms_per_molecule.min() and a.atoms_per_molecule.max() <= 33
+    for name in CONFIGS:
+        c = make_config(name, num_molecules=2)
+        assert c.num_conformers == CONFIGS[name][2]
