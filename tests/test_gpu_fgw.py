@@ -84,9 +84,7 @@ def test_cfm_log_known_answer(golden_dir):
 
 
 def test_batched_equals_single_and_is_deterministic():
-    gs = [np.load(p) for p in CASES if "k5_n20p4" in p or "k5_n24_d64_r5" in p]
-    # same K, N? pad-free batching needs equal shapes: use one case twice plus a permuted copy
-    g = gs[0]
+    g = [np.load(p) for p in CASES if "k5_n24_d64_r5" in p][0]      # sparse adjacency: the K structures differ
     Ys = np.stack([g["Ys"], g["Ys"][::-1].copy(), g["Ys"]]); Cs = np.stack([g["Cs"], g["Cs"][::-1].copy(), g["Cs"]]).astype(np.float32)
     Y, C, T, info, errs = _run(Ys, Cs)
     Y1, C1, T1, *_ = _run(g["Ys"], g["Cs"])
