@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the ConAN hot path on MI355X:  molecules/s (K=5 conformers).
+
+One "step" = one training step of the stage-2 hot path on one batch of synthetic ESOL-shaped conformers resident in HBM:
+SchNetNoSum.forward_w_barycenter (radius graph, 3 interaction blocks, two heads, FGW barycenter over the K conformers)
++ conformer-aggregation head + MSE loss, backward through all of it, one flat gradient all-reduce (RCCL) and Adam.
+Workload at every N: BASELINE.json configs[1] per GPU (ESOL + SchNet-128, K=5, batch=256) => weak scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around the CFConv gather/segment-sum kernel
+(the HBM-bound kernel BASELINE.json's target is quoted on); `cpu_baseline` times the CPU oracle on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["train", "fwd"], default="train")
+    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
+    ap.add_argument("--conformers", type=int, default=5)
+    ap.add_argument("--shape", default="esol")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cfconv_algorithmic_bytes(E, n_atoms, F):
+    """E*(4F gather x_j + 4F W_ij) + 8*(E + n+1) CSR + n*4F store (fp32, W materialised)."""
+    return E * 8 * F + 8 * (E + n_atoms + 1) + n_atoms * 4 * F
+
+
+def cpu_baseline(args, mode):
+    """CPU oracle ("port": oracle/schnet.py + the C FGW restatement) on the host cores, bounded sample."""
+    from conan_fgw_amd.synthetic import make_batch
+    from oracle.schnet import SchNetNoSumOracle
+    nb = 8
+    b = make_batch(args.shape, nb, args.conformers, seed=4321)
+    torch.manual_seed(5)
+    m = SchNetNoSumOracle(128, 128, 3)
+    w3, wb, wo = torch.nn.Linear(64, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 1)
+    z, pos, batch = torch.from_numpy(b.z), torch.from_numpy(b.pos), torch.from_numpy(b.batch)
+    y = torch.from_numpy(b.y)[:, None]
+
+    def step():
+        h3, hb = m.forward_w_barycenter(z, pos, args.conformers, batch)
+        pred = wo((w3(h3) + 0.2 * wb(hb)).view(nb, args.conformers, -1).mean(1))
+        if mode == "train":
+            loss = torch.nn.functional.mse_loss(pred, y)
+            loss.backward()
+    step()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        step(); n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(nb * n / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32, "
+                      f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; FGW = scalar C restatement"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from conan_fgw_amd import ops
+    from conan_fgw_amd.head import ConformerAggregationHead
+    from conan_fgw_amd.parallel import FlatGradients
+    from conan_fgw_amd.schnet import SchNetNoSum
+    from conan_fgw_amd.synthetic import make_batch
+
+    K = args.conformers
+    b = make_batch(args.shape, args.batch, K, seed=1236 + 1000 * rank)            # cfg2 seed (1234 + 2) on rank 0
+    z, pos, batch = (torch.from_numpy(a).to(dev) for a in (b.z, b.pos, b.batch))
+    y = torch.from_numpy(b.y).to(dev)[:, None]
+    torch.manual_seed(5)                                                          # train_val.py:223
+    model = SchNetNoSum(dev, hidden_channels=128, num_filters=128, num_interactions=3).to(dev)   # common.py:524-529
+    head = ConformerAggregationHead(64, 0.2).to(dev)
+    params = list(model.parameters()) + list(head.parameters())
+    flat = FlatGradients(params)
+    opt = torch.optim.Adam(flat.params, lr=1e-4)
+
+    # live per-kernel timing of the CFConv forward kernel with HIP events on the launch stream
+    ev = []
+    orig_call = ops.call
+
+    def timed_call(name, *a):
+        if name == "conan_cfconv_fwd" and timed_call.on:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); orig_call(name, *a); e.record(); ev.append((s, e))
+        else:
+            orig_call(name, *a)
+    timed_call.on = False
+    ops.call = timed_call
+
+    def step():
+        if args.mode == "train":
+            flat.zero()
+            h3, hb = model.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+            pred = head(h3, hb, K)
+            loss = torch.nn.functional.mse_loss(pred, y)
+            loss.backward()
+            flat.all_reduce_mean()
+            opt.step()
+        else:
+            with torch.no_grad():
+                h3, hb = model.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+                head(h3, hb, K)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timed_call.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timed_call.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # edge statistics of this rank's batch (device graph of the last step is rebuilt here only for reporting)
+    gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
+    E = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32).num_edges
+    n_atoms = int(z.shape[0])
+    kdur_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+    alg = cfconv_algorithmic_bytes(E, n_atoms, 128)
+    achieved = alg / (kdur_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        mol = args.batch * world * args.steps
+        out = {
+            "metric": "molecules/s (K=5 conformers)", "value": round(mol / dt, 1), "unit": "molecules/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.shape.upper()}-shaped + SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), "
+                                   f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
+                                   + ("(fwd + bwd + flat-gradient all-reduce + Adam)" if args.mode == "train" else "(forward_w_barycenter + head)"),
+                       "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "max_nodes": b.max_nodes,
+                       "mode": args.mode, "parallelism": f"dp{world}", "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
+            "roofline": {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kdur_ms, 5),
+                         "launches_timed": len(ev)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.mode)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,49 +16,9 @@
 // 5-iteration scheme amplifies rounding; computing on-chip in fp64 puts this kernel on the fp64
 // side of that yard-stick at negligible cost (the per-molecule matrices are tiny and MI355X runs fp64 FMA at half the
 // fp32 rate).  exp() is evaluated as 2^n * v_exp_f32(frac) with the range reduction done in fp64 (1 ulp of fp32).
-#include "common.h"
+#include "fgw_common.h"
 
 namespace {
-
-constexpr int FGW_THREADS = 256;
-constexpr int FGW_WAVES = FGW_THREADS / 64;
-
-struct FgwDims {
-    int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
-};
-
-__device__ __forceinline__ double exp_acc(double x) {
-    // exp(x) = 2^(x*log2e); integer part applied with ldexp, fractional part on the fp32 transcendental unit.
-    if (x < -745.0) return 0.0;
-    const double t = x * 1.4426950408889634074;
-    const double n = rint(t);
-    const float f = (float)(t - n);
-    const float e = __builtin_amdgcn_exp2f(f);
-    return ldexp((double)e, (int)n);
-}
-
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
-    return v;
-}
-
-// block-wide sum of one double per thread; result broadcast to every thread. red[] has FGW_WAVES+1 doubles.
-__device__ __forceinline__ double block_sum_d(double v, double *red) {
-    v = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < FGW_WAVES; ++w) s += red[w];
-    return s;
-}
 
 // ------------------------------------------------------------------------------------------------ init
 __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict__ init_C, const float *__restrict__ init_Y,
@@ -472,6 +432,7 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d) {
     bytes += (size_t)B * 4 + 256;              // active
     bytes += (size_t)B * K * NP * 28 + 256;    // coupling scratch (global mode)
     bytes += (size_t)B * NP * 16 + 256;        // update scratch (global mode)
+    bytes += conan_fgw_small_part_bytes(B, K, N, d);   // per-graph update contributions (register-resident path)
     return (long long)bytes;
 }
 
@@ -491,7 +452,10 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     double *Yw = reinterpret_cast<double *>(w); w += (size_t)B * N * d * 8;
     int *active = reinterpret_cast<int *>(w); w += (((size_t)B * 4 + 255) / 256) * 256;
     char *sc_c = w; w += (((size_t)B * K * NP * 28 + 255) / 256) * 256;
-    char *sc_u = w;
+    char *sc_u = w; w += (((size_t)B * NP * 16 + 255) / 256) * 256;
+    double *Ypart = reinterpret_cast<double *>(w);
+    double *Cpart = Ypart + (size_t)B * K * N * d;
+    const bool small = conan_fgw_small_supported(N);
 
     k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
     const size_t lc = coupling_lds(N), lu = update_lds(N);
@@ -502,6 +466,12 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lu);
     const size_t vec_c = (size_t)(6 * N + 8) * 8, vec_u = (size_t)(8 + N) * 8;
     for (int outer = 0; outer < params->max_iter; ++outer) {
+        if (small) {
+            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info,
+                                     Ypart, Cpart, s);
+            conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, s);
+            continue;
+        }
         if (c_lds)
             k_fgw_coupling<true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info, sc_c);
         else

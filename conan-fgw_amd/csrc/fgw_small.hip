@@ -1,0 +1,353 @@
+// FGW coupling solve for N <= 64 barycenter nodes (every ESOL/FreeSolv-shaped batch): register-resident Sinkhorn.
+//
+// Same algorithm and citations as fgw.hip (bregman.py:70-167, sinkhorn.py:318-450, utils.py:39-95).  What changes is the
+// mapping to the CU.  A 256-thread workgroup (4 wavefronts) owns one (molecule, input graph) problem:
+//
+//   lane  <-> column j (layout A)  /  lane <-> row i (layout B),      wavefront w <-> index residue (w + 4r), r < R
+//
+// Every thread keeps its R entries of the N x N cost matrix Mr in registers in BOTH layouts, so that the column
+// log-sum-exp (reduce over rows) and the row log-sum-exp (reduce over columns) are each a serial loop over registers
+// followed by a 4-way combine through LDS: no cross-lane shuffles of fp64 values, two barriers per half-iteration.
+// The two N^3 products of the gradient use the same mapping with T, C1 (fp64), C2 resident in LDS, one operand
+// broadcast per FMA.  At the end the workgroup also forms its contribution to the barycenter update
+// (T_s @ Ys_s and T_s @ Cs_s @ T_s^T) while T is still in LDS; the update kernel is then a K-term elementwise sum.
+#include "fgw_common.h"
+
+namespace {
+
+template <int R>
+__global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
+    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
+    FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
+    double *__restrict__ Cpart) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    if (!active[b]) return;
+    const int N = D.N, P = D.P, d = D.d;
+    const int NN = N * N, NP = N * P;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool lane_ok = lane < N;
+
+    // ---- LDS carve (doubles first)
+    double *Al = reinterpret_cast<double *>(smem);            // [N,P]  A = C1 @ T ; later aliased by Mr and by T @ C2
+    double *C1l = Al + NP;                                     // [N,P]
+    double *pm = C1l + NP;                                     // [4][64] partial max
+    double *psum = pm + 256;                                   // [4][64] partial sums
+    double *us = psum + 256;                                   // [4][64] per-wave copy of u (indexed by i)
+    double *vs = us + 256;                                     // [4][64] per-wave copy of v (indexed by j)
+    double *pq = vs + 256;                                     // [2][64] p, q
+    double *red = pq + 128;                                    // [8]
+    float *Tl = reinterpret_cast<float *>(red + 8);            // [N,P]
+    float *C2l = Tl + NP;                                      // [N,P]
+
+    const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
+    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
+    const double *C1 = Cw + (size_t)b * NN;
+    const double *Y = Yw + (size_t)b * N * d;
+    float *Tg = Tw + ((size_t)b * D.K + s) * NN;
+    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
+
+    // ---- stage p, q, C1, C2, T0
+    if (tid < 64) {
+        pq[tid] = tid < N ? (pb ? (double)pb[(size_t)b * N + tid] : 1.0 / (double)N) : 1.0;
+        pq[64 + tid] = tid < N ? (ps ? (double)ps[((size_t)b * D.K + s) * N + tid] : 1.0 / (double)N) : 1.0;
+    }
+    for (int t = tid; t < NN; t += FGW_THREADS) {
+        const int i = t / N, j = t - i * N;
+        C1l[i * P + j] = C1[t];
+        C2l[i * P + j] = C2[t];
+    }
+    __syncthreads();
+    const double loga = log(pq[lane]), logb = log(pq[64 + lane]);      // lane <-> i for loga, lane <-> j for logb
+    const double qj = pq[64 + lane];
+    for (int t = tid; t < NN; t += FGW_THREADS) {
+        const int i = t / N, j = t - i * N;
+        Tl[i * P + j] = (outer > 0 && prm.warmstart) ? Tg[t] : (float)(pq[i] * pq[64 + j]);     // bregman.py:98-101
+    }
+
+    // ---- base_A[r] = 2*alpha*constC[i_r][j] + (1-alpha)*M[i_r][j], j = lane           (utils.py:39-43,154-171)
+    double baseA[R];
+    {
+        // column parts (depend on j = lane): r2_j = sum_k q_k C2[j,k]^2 ; z2_j = |z_j|^2
+        double r2 = 0.0, z2 = 0.0;
+        if (lane_ok) {
+            for (int k = 0; k < N; ++k) { const double c2 = (double)C2l[lane * P + k]; r2 += pq[64 + k] * (c2 * c2); }
+            const float *zj = Z + (size_t)lane * d;
+            for (int c = 0; c < d; ++c) { const double zz = (double)zj[c]; z2 += zz * zz; }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = w + 4 * r;
+            double val = 0.0;
+            if (i < N && lane_ok) {
+                double r1 = 0.0, y2 = 0.0, dot = 0.0;
+                for (int k = 0; k < N; ++k) { const double c1 = C1l[i * P + k]; r1 += c1 * c1 * pq[k]; }
+                if (!y_zero) {
+                    const double *yi = Y + (size_t)i * d;
+                    const float *zj = Z + (size_t)lane * d;
+                    for (int c = 0; c < d; ++c) { const double yy = yi[c]; y2 += yy * yy; dot += yy * (double)zj[c]; }
+                }
+                double m = -2.0 * dot; m += y2; m += z2;
+                m = m > 0.0 ? m : 0.0;
+                val = 2.0 * alpha * (r1 + r2) + (1.0 - alpha) * m;
+            }
+            baseA[r] = val;
+        }
+    }
+    __syncthreads();
+
+    int cpt = 0, sk_total = 0;
+    double err = 1.0;
+    while (err > (double)prm.inner_tol && cpt < prm.max_iter) {          // bregman.py:119
+        // ---- A = C1 @ T : thread (w, j) computes rows i_r
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        if (lane_ok) {
+            for (int k = 0; k < N; ++k) {
+                const double t = (double)Tl[k * P + lane];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += C1l[i * P + k] * t; }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Al[i * P + lane] = acc[r]; }
+        }
+        __syncthreads();
+        // ---- G = A @ (2 C2)^T ; Mr = -(base - 2 alpha G)/eps  -> registers (layout A)
+        double mA[R], mB[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        if (lane_ok) {
+            for (int k = 0; k < N; ++k) {
+                const double c = 2.0 * (double)C2l[lane * P + k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += Al[i * P + k] * c; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) mA[r] = -(baseA[r] - 2.0 * alpha * acc[r]) * inv_eps;
+        __syncthreads();                                               // everyone done reading Al
+        if (lane_ok) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Al[i * P + lane] = mA[r]; }     // Mr aliases Al
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int j = w + 4 * r; mB[r] = (lane_ok && j < N) ? Al[lane * P + j] : 0.0; }   // layout B: lane <-> i
+
+        // ---- log-domain Sinkhorn (sinkhorn.py:393-433); u, v in registers (u_l: i = lane, v_l: j = lane)
+        double u_l = 0.0, v_l = 0.0;
+        us[w * 64 + lane] = 0.0;
+        int ii = 0;
+        for (; ii < prm.num_iter_max; ++ii) {
+            // v_j = logb_j - logsumexp_i(Mr_ij + u_i)          layout A, serial over my rows, 4-way combine
+            double z[R];
+            double mx = -1.0e300;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; z[r] = (i < N) ? mA[r] + us[w * 64 + i] : -1.0e300; mx = z[r] > mx ? z[r] : mx; }
+            pm[w * 64 + lane] = mx;
+            __syncthreads();
+            mx = fmax(fmax(pm[lane], pm[64 + lane]), fmax(pm[128 + lane], pm[192 + lane]));
+            double sm = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) sm += exp_acc(z[r] - mx); }
+            psum[w * 64 + lane] = sm;
+            __syncthreads();
+            sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
+            v_l = logb - (log(sm) + mx);
+            vs[w * 64 + lane] = v_l;                                   // private per-wave copy: read back by this wave only
+            // u_i = loga_i - logsumexp_j(Mr_ij + v_j)          layout B
+            mx = -1.0e300;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int j = w + 4 * r; z[r] = (j < N) ? mB[r] + vs[w * 64 + j] : -1.0e300; mx = z[r] > mx ? z[r] : mx; }
+            pm[w * 64 + lane] = mx;
+            __syncthreads();
+            mx = fmax(fmax(pm[lane], pm[64 + lane]), fmax(pm[128 + lane], pm[192 + lane]));
+            sm = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int j = w + 4 * r; if (j < N) sm += exp_acc(z[r] - mx); }
+            psum[w * 64 + lane] = sm;
+            __syncthreads();
+            sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
+            u_l = loga - (log(sm) + mx);
+            us[w * 64 + lane] = u_l;
+            if (ii % 10 == 0) {                                        // marginal violation (sinkhorn.py:418-433)
+                double cs = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) cs += exp_acc(mA[r] + us[w * 64 + i] + v_l); }
+                __syncthreads();                                       // previous psum fully consumed
+                psum[w * 64 + lane] = cs;
+                __syncthreads();
+                cs = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
+                double df = lane_ok ? cs - qj : 0.0;
+                df = wave_sum_d(df * df);
+                if (sqrt(df) < (double)prm.stop_thr) { ++ii; break; }
+            }
+        }
+        sk_total += ii;
+        // ---- T = exp(Mr + u + v) (sinkhorn.py:450); err = ||T - Tprev||_F when cpt % 10 == 0 (bregman.py:144-147)
+        double e2 = 0.0;
+        __syncthreads();
+        if (lane_ok) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = w + 4 * r;
+                if (i < N) {
+                    const float tn = (float)exp_acc(mA[r] + us[w * 64 + i] + v_l);
+                    const double df = (double)tn - (double)Tl[i * P + lane];
+                    e2 += df * df;
+                    Tl[i * P + lane] = tn;
+                }
+            }
+        }
+        if (cpt % 10 == 0) err = sqrt(block_sum_d(e2, red));
+        else __syncthreads();
+        ++cpt;
+    }
+    __syncthreads();
+    for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
+
+    // ---- contributions to the barycenter update while T is resident
+    if (!prm.fixed_features) {                                          // Ypart[i][c] = sum_j T[i][j] Z[j][c]   (utils.py:90-95)
+        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        for (int c0 = 0; c0 < d; c0 += 64) {
+            const int c = c0 + lane;
+            double acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = 0.0;
+            if (c < d) {
+                for (int j = 0; j < N; ++j) {
+                    const double zz = (double)Z[(size_t)j * d + c];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += (double)Tl[i * P + j] * zz; }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Yp[(size_t)i * d + c] = acc[r]; }
+            }
+        }
+    }
+    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T                 (utils.py:67-73)
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        if (lane_ok) {
+            for (int k = 0; k < N; ++k) {
+                const double c = (double)C2l[k * P + lane];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += (double)Tl[i * P + k] * c; }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Al[i * P + lane] = acc[r]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        if (lane_ok) {
+            for (int k = 0; k < N; ++k) {
+                const double t = (double)Tl[lane * P + k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += Al[i * P + k] * t; }
+            }
+            double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Cp[i * N + lane] = acc[r]; }
+        }
+    }
+}
+
+// Barycenter update from the per-graph contributions: elementwise, one workgroup per molecule.
+__global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
+    const float *__restrict__ pb, const float *__restrict__ lambdas, FgwDims D, conan_fgw_params prm, int outer,
+    const double *__restrict__ Ypart, const double *__restrict__ Cpart, double *__restrict__ Cw, double *__restrict__ Yw,
+    int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout) {
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    if (!active[b]) return;
+    const int N = D.N, d = D.d, K = D.K, NN = N * N, Nd = N * d;
+    const int tid = threadIdx.x;
+    double ef2 = 0.0, es2 = 0.0;
+    if (!prm.fixed_features) {
+        double *Yb = Yw + (size_t)b * Nd;
+        for (int t = tid; t < Nd; t += FGW_THREADS) {
+            const int i = t / d;
+            const double pinv = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
+            double acc = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                acc += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;              // utils.py:94
+            }
+            const double df = acc - Yb[t];
+            ef2 += df * df;
+            Yb[t] = acc;
+            Yout[(size_t)b * Nd + t] = (float)acc;
+        }
+    }
+    if (!prm.fixed_structure) {
+        double *Cb = Cw + (size_t)b * NN;
+        for (int t = tid; t < NN; t += FGW_THREADS) {
+            const int i = t / N, j = t - i * N;
+            const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+            const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
+            double acc = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                acc += lam * Cpart[((size_t)b * K + s) * NN + t];                     // utils.py:70
+            }
+            const double cn = acc / (pi * pj);                                         // :72-73
+            const double df = cn - Cb[t];
+            es2 += df * df;
+            Cb[t] = cn;
+            Cout[(size_t)b * NN + t] = (float)cn;
+        }
+    }
+    const double ef = sqrt(block_sum_d(ef2, red));
+    const double es = sqrt(block_sum_d(es2, red));
+    if (tid == 0) {
+        errs[((size_t)b * 2 + 0) * prm.max_iter + outer] = (float)ef;
+        errs[((size_t)b * 2 + 1) * prm.max_iter + outer] = (float)es;
+        info[b * 4 + 0] = outer + 1;
+        active[b] = (ef > (double)prm.tol || es > (double)prm.tol) ? 1 : 0;           // barycenter.py:112
+    }
+}
+
+inline size_t small_lds(int N) {
+    const size_t NP = (size_t)N * (N | 1);
+    return NP * 8 * 2 + (256 * 4 + 128 + 8) * 8 + NP * 4 * 2;
+}
+
+}  // namespace
+
+bool conan_fgw_small_supported(int N) { return N <= 64; }
+
+size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
+    return ((size_t)B * K * N * d + (size_t)B * K * N * N) * 8 + 512;
+}
+
+void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
+                              conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
+                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, hipStream_t s) {
+    const size_t lds = small_lds(D.N);
+    const int R = (D.N + 3) / 4;
+    const int grid = D.B * D.K;
+#define LAUNCH(RR)                                                                                                              \
+    do {                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR>),                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+        k_fgw_coupling_small<RR><<<grid, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw,     \
+                                                                info, Ypart, Cpart);                                            \
+    } while (0)
+    if (R <= 6) LAUNCH(6);
+    else if (R <= 9) LAUNCH(9);
+    else if (R <= 12) LAUNCH(12);
+    else LAUNCH(16);
+#undef LAUNCH
+}
+
+void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
+                            const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
+                            float *errs, float *Yout, float *Cout, hipStream_t s) {
+    k_fgw_update_parts<<<D.B, FGW_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout);
+}

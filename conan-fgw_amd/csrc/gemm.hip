@@ -98,67 +98,108 @@ __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict_
 }
 
 // ---- weight gradient: dW[N,K] = g^T @ x, reduction over the M rows ---------------------------------------------
-// Stage 1: each workgroup owns a contiguous slice of rows and one 64x64 tile of dW, accumulates it on MFMA
-// (A = g^T: lane -> n, B = x: lane -> k, both read row-wise from the staged tiles) and writes a partial slab.
-// Stage 2: slabs are summed in a fixed order => bitwise reproducible (no float atomics).
-constexpr int WG_ROWS = 64;    // rows staged per step
-constexpr int WG_SLICES_MAX = 64;
+// Stage 1: the rows are cut into slices; one workgroup per (slice, 128x128 tile of dW) streams its rows ONCE through LDS
+// in 32-row chunks and accumulates the whole tile on MFMA (A = g^T: lane -> n, B = x: lane -> k; both fragments are
+// plain row-wise reads of the staged chunk, conflict-free without padding).  4 wavefronts as 2x2, 64x64 each.
+// Stage 2: the per-slice slabs are summed in a fixed order => bitwise reproducible, no float atomics.
+constexpr int WG_CHUNK = 32;       // rows per staged chunk
+constexpr int WG_TILE = 128;
+constexpr int WG_SLICES_MAX = 512;
 
 __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
                                                        int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
                                                        const int *__restrict__ m_dev) {
     if (m_dev) M = min(M, *m_dev);
-    __shared__ float gs[WG_ROWS * 65];
-    __shared__ float xs[WG_ROWS * 65];
+    __shared__ __attribute__((aligned(16))) float gs[WG_CHUNK * WG_TILE];
+    __shared__ __attribute__((aligned(16))) float xs[WG_CHUNK * WG_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;          // 2x2 waves over the 64(n) x 64(k) tile
-    const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.y * WG_TILE, k0 = blockIdx.z * WG_TILE;
     const int slice = blockIdx.x;
     const int r_begin = slice * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
-    f32x16 acc;
+    const bool vec_ok = ((N & 3) == 0) && ((K & 3) == 0);
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;       // thread t < 64 accumulates the bias gradient of column n0 + t (only for blockIdx.z == 0)
-    for (int r0 = r_begin; r0 < r_end; r0 += WG_ROWS) {
-        for (int t = tid; t < WG_ROWS * 64; t += 256) {
-            int r = t >> 6, c = t & 63;
-            int gr = r0 + r;
-            bool ok = gr < r_end;
-            gs[r * 65 + c] = (ok && n0 + c < N) ? g[(size_t)gr * N + n0 + c] : 0.f;
-            xs[r * 65 + c] = (ok && k0 + c < K) ? x[(size_t)gr * K + k0 + c] : 0.f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum = 0.f;       // thread t < 128 accumulates the bias gradient of column n0 + t (blockIdx.z == 0 only)
+    const bool wave_active = (n0 + wm * 64 < N) && (k0 + wn * 64 < K);
+    for (int r0 = r_begin; r0 < r_end; r0 += WG_CHUNK) {
+        // stage 32 x 128 of g and of x (float4 per thread, 4 passes each)
+        for (int t = tid; t < WG_CHUNK * (WG_TILE / 4); t += 256) {
+            const int r = t >> 5, c4 = (t & 31) * 4;
+            const int gr = r0 + r;
+            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
+            if (gr < r_end) {
+                if (vec_ok) {
+                    if (n0 + c4 < N) gv = *reinterpret_cast<const float4 *>(g + (size_t)gr * N + n0 + c4);
+                    if (k0 + c4 < K) xv = *reinterpret_cast<const float4 *>(x + (size_t)gr * K + k0 + c4);
+                } else {
+                    float tg[4] = {0, 0, 0, 0}, tx[4] = {0, 0, 0, 0};
+                    for (int q = 0; q < 4; ++q) {
+                        if (n0 + c4 + q < N) tg[q] = g[(size_t)gr * N + n0 + c4 + q];
+                        if (k0 + c4 + q < K) tx[q] = x[(size_t)gr * K + k0 + c4 + q];
+                    }
+                    gv = make_float4(tg[0], tg[1], tg[2], tg[3]); xv = make_float4(tx[0], tx[1], tx[2], tx[3]);
+                }
+            }
+            *reinterpret_cast<float4 *>(&gs[r * WG_TILE + c4]) = gv;
+            *reinterpret_cast<float4 *>(&xs[r * WG_TILE + c4]) = xv;
         }
         __syncthreads();
-        if (blockIdx.z == 0 && tid < 64) {
+        if (blockIdx.z == 0 && tid < WG_TILE) {
             float s = 0.f;
-            for (int r = 0; r < WG_ROWS; ++r) s += gs[r * 65 + tid];
+#pragma unroll 8
+            for (int r = 0; r < WG_CHUNK; ++r) s += gs[r * WG_TILE + tid];
             bsum += s;
         }
-        const int kh = lane >> 5;
-#pragma unroll 8
-        for (int m = 0; m < WG_ROWS; m += 2) {
-            float a = gs[(m + kh) * 65 + wm * 32 + (lane & 31)];     // A[n][m] = g[m][n]
-            float b = xs[(m + kh) * 65 + wn * 32 + (lane & 31)];     // B[m][k] = x[m][k]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        if (wave_active) {
+            const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll 4
+            for (int m = 0; m < WG_CHUNK; m += 2) {
+                const float a0 = gs[(m + kh) * WG_TILE + wm * 64 + l31];
+                const float a1 = gs[(m + kh) * WG_TILE + wm * 64 + 32 + l31];
+                const float b0 = xs[(m + kh) * WG_TILE + wn * 64 + l31];
+                const float b1 = xs[(m + kh) * WG_TILE + wn * 64 + 32 + l31];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
     float *slab = slabs + (size_t)slice * N * K;
+    if (wave_active) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        int k = k0 + wn * 32 + (lane & 31);
-        if (n < N && k < K) slab[(size_t)n * K + k] = acc[r];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int k = k0 + wn * 64 + b * 32 + (lane & 31);
+                    if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
+                }
     }
-    if (blockIdx.z == 0 && tid < 64 && n0 + tid < N) bias_slabs[(size_t)slice * N + n0 + tid] = bsum;
+    if (blockIdx.z == 0 && tid < WG_TILE && n0 + tid < N) bias_slabs[(size_t)slice * N + n0 + tid] = bsum;
 }
 
 __global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int slices, int NK, int N,
                                float *__restrict__ dW, float *__restrict__ dbias) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < NK) {
-        float s = 0.f;
-        for (int sl = 0; sl < slices; ++sl) s += slabs[(size_t)sl * NK + i];
-        dW[i] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sl = 0;
+        for (; sl + 3 < slices; sl += 4) {
+            s0 += slabs[(size_t)sl * NK + i]; s1 += slabs[(size_t)(sl + 1) * NK + i];
+            s2 += slabs[(size_t)(sl + 2) * NK + i]; s3 += slabs[(size_t)(sl + 3) * NK + i];
+        }
+        for (; sl < slices; ++sl) s0 += slabs[(size_t)sl * NK + i];
+        dW[i] = (s0 + s1) + (s2 + s3);
     }
     if (dbias && i < N) {
         float s = 0.f;
@@ -168,7 +209,7 @@ __global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__r
 }
 
 static int wgrad_slices(int M) {
-    int s = (M + 4095) / 4096;
+    int s = (M + 127) / 128;           // >= 128 rows per slice
     if (s < 1) s = 1;
     if (s > WG_SLICES_MAX) s = WG_SLICES_MAX;
     return s;
@@ -215,9 +256,9 @@ int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, cons
     hipStream_t s = as_stream(stream);
     const int slices = wgrad_slices(M);
     int rows = (M + slices - 1) / slices;
-    rows = ((rows + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
+    rows = ((rows + WG_CHUNK - 1) / WG_CHUNK) * WG_CHUNK;
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * N * K;
-    dim3 grid(slices, (N + 63) / 64, (K + 63) / 64);
+    dim3 grid(slices, (N + WG_TILE - 1) / WG_TILE, (K + WG_TILE - 1) / WG_TILE);
     k_wgrad_partial<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
     const int NK = N * K;
     k_wgrad_reduce<<<(NK + 255) / 256, 256, 0, s>>>(slabs, bias_slabs, slices, NK, N, dW, dbias);

@@ -13,18 +13,33 @@ __global__ void k_embedding_fwd(const int64_t *__restrict__ z, const float *__re
     }
 }
 
-// Deterministic embedding gradient: one workgroup per embedding row r, fixed-order sum over the atoms with z == r.
-// (num_embeddings = 100 rows, a handful of them populated; the scan over z is L2-resident.)
-__global__ void __launch_bounds__(256) k_embedding_bwd(const int64_t *__restrict__ z, const float *__restrict__ dout, int n, int H,
-                                                       int padding_idx, float *__restrict__ dweight) {
-    const int r = blockIdx.x;
-    if (r == padding_idx) return;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
-        float s = 0.f;
-        for (int a = 0; a < n; ++a)
-            if (z[a] == r) s += dout[(size_t)a * H + c];
-        dweight[(size_t)r * H + c] = s;
-    }
+// Deterministic embedding gradient, two stages.  Stage 1: one workgroup per (chunk of 256 atoms, 128-column tile) keeps a
+// [num_embeddings x 128] partial table in LDS; thread c owns column c, walks the chunk's atoms in order and adds
+// dout[a][c] into row z[a] (no atomics, fixed order).  Stage 2 sums the per-chunk tables in chunk order.
+constexpr int EMB_CHUNK = 256;
+constexpr int EMB_ROWS_MAX = 100;     // torch.nn.Embedding(100, H): atomic numbers
+__global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__restrict__ z, const float *__restrict__ dout, int n, int H,
+                                                              int rows, float *__restrict__ slabs) {
+    __shared__ float acc[EMB_ROWS_MAX * 128];
+    __shared__ int zs[EMB_CHUNK];
+    const int chunk = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
+    const int a0 = chunk * EMB_CHUNK, a1 = min(n, a0 + EMB_CHUNK);
+    for (int t = threadIdx.x; t < rows * 128; t += 128) acc[t] = 0.f;
+    for (int t = threadIdx.x; t < a1 - a0; t += 128) zs[t] = (int)z[a0 + t];
+    __syncthreads();
+    if (c < H)
+        for (int a = a0; a < a1; ++a) acc[zs[a - a0] * 128 + threadIdx.x] += dout[(size_t)a * H + c];
+    __syncthreads();
+    if (c < H)
+        for (int r = 0; r < rows; ++r) slabs[((size_t)chunk * rows + r) * H + c] = acc[r * 128 + threadIdx.x];
+}
+__global__ void k_embedding_bwd_reduce(const float *__restrict__ slabs, int chunks, int rows, int H, int padding_idx,
+                                       float *__restrict__ dweight) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * H) return;
+    float s = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) s += slabs[(size_t)ch * rows * H + i];
+    dweight[i] = (i / H == padding_idx) ? 0.f : s;
 }
 
 __global__ void __launch_bounds__(64) k_segment_sum(const float *__restrict__ x, const int *__restrict__ gptr, int W,
@@ -63,10 +78,22 @@ int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, in
     return CONAN_OK;
 }
 
+long long conan_embedding_bwd_ws(int num_atoms, int hidden, int num_embeddings) {
+    return (long long)((num_atoms + EMB_CHUNK - 1) / EMB_CHUNK) * num_embeddings * hidden;
+}
+
 int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int hidden, int num_embeddings,
-                        int padding_idx, float *dweight, void *stream) {
-    if (!z || !dout || !dweight || num_atoms < 0 || hidden <= 0 || num_embeddings <= 0) return CONAN_E_BADARG;
-    k_embedding_bwd<<<num_embeddings, 256, 0, as_stream(stream)>>>(z, dout, num_atoms, hidden, padding_idx, dweight);
+                        int padding_idx, float *dweight, float *ws, void *stream) {
+    if (!z || !dout || !dweight || !ws || num_atoms < 0 || hidden <= 0 || num_embeddings <= 0) return CONAN_E_BADARG;
+    if (num_embeddings > EMB_ROWS_MAX) return CONAN_E_UNSUPPORTED;
+    const int chunks = (num_atoms + EMB_CHUNK - 1) / EMB_CHUNK;
+    hipStream_t s = as_stream(stream);
+    if (chunks > 0) {
+        dim3 grid(chunks, (hidden + 127) / 128);
+        k_embedding_bwd_partial<<<grid, 128, 0, s>>>(z, dout, num_atoms, hidden, num_embeddings, ws);
+    }
+    const int total = num_embeddings * hidden;
+    k_embedding_bwd_reduce<<<(total + 255) / 256, 256, 0, s>>>(ws, chunks, num_embeddings, hidden, padding_idx, dweight);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -138,9 +138,10 @@ class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (z,) = ctx.saved_tensors
-        dw = torch.zeros(ctx.shape, dtype=f32, device=dout.device)
+        dw = torch.empty(ctx.shape, dtype=f32, device=dout.device)
+        ws = torch.empty(int(lib().conan_embedding_bwd_ws(z.shape[0], ctx.shape[1], ctx.shape[0])), dtype=f32, device=dout.device)
         call("conan_embedding_bwd", ptr(z), ptr(_c(dout)), z.shape[0], ctx.shape[1], ctx.shape[0],
-             -1 if ctx.padding_idx is None else ctx.padding_idx, ptr(dw), stream_ptr())
+             -1 if ctx.padding_idx is None else ctx.padding_idx, ptr(dw), ptr(ws), stream_ptr())
         return None, dw, None
 
 

@@ -65,9 +65,11 @@ int conan_edge_index_i64(const int *col, const int *tgt, int num_edges, int64_t 
 
 /* out[a, :] = weight[z[a], :]  (torch.nn.Embedding(100, H, padding_idx=0); schnet_no_sum.py:159,207). */
 int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, int hidden, float *out, void *stream);
-/* dweight[z[a], :] += dout[a, :] for z[a] != padding_idx; dweight[num_embeddings, hidden] must be zeroed by the caller. */
+/* dweight[r, :] = sum_{a: z[a]==r} dout[a, :] (row padding_idx = 0), deterministic two-stage reduction;
+ * ws holds conan_embedding_bwd_ws(...) floats; num_embeddings <= 100. */
+long long conan_embedding_bwd_ws(int num_atoms, int hidden, int num_embeddings);
 int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int hidden, int num_embeddings,
-                        int padding_idx, float *dweight, void *stream);
+                        int padding_idx, float *dweight, float *ws, void *stream);
 
 /* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]) on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
  * W is torch.nn.Linear's [N,K] when w_kn == 0, or a [K,N] matrix when w_kn == 1 (used by the backward: dx = g @ W).
