@@ -455,7 +455,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     char *sc_u = w; w += (((size_t)B * NP * 16 + 255) / 256) * 256;
     double *Ypart = reinterpret_cast<double *>(w);
     double *Cpart = Ypart + (size_t)B * K * N * d;
-    const bool small = conan_fgw_small_supported(N);
+    const bool small = conan_fgw_small_supported(N, d);
 
     k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
     const size_t lc = coupling_lds(N), lu = update_lds(N);

@@ -44,7 +44,7 @@ __device__ __forceinline__ double block_sum_d(double v, double *red) {
 
 
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
-bool conan_fgw_small_supported(int N);
+bool conan_fgw_small_supported(int N, int d);
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,

@@ -15,6 +15,49 @@
 
 namespace {
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// exp(x) for x <= 0 in the log-sum-exp loops: x is a difference formed in fp64, so converting it to fp32 keeps a relative
+// precision of 2^-24 in the exponent; terms below e^-80 cannot change an fp64 sum whose largest term is 1.
+__device__ __forceinline__ double exp_lse(double x) {
+    const float f = (float)x;
+    return (double)__builtin_amdgcn_exp2f(f * 1.44269504088896340736f);
+}
+
+// D[M x Nn] = X[M x Kd] @ W[Kd x Nn] with fp64 MFMA (v_mfma_f64_16x16x4_f64) on the 16-aligned core and plain FMA loops on
+// the ragged border rows/columns (no padding of the problem).  X(i,k), W(k,j) are element readers, st(i,j,v) the writer.
+// Fragment layout: A lane l -> X[i0 + (l&15)][k0 + (l>>4)], B lane l -> W[k0 + (l>>4)][j0 + (l&15)],
+// D reg q lane l -> row i0 + (l>>4) + 4q, col j0 + (l&15).   Workgroup-collective; no barrier inside.
+template <class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Mq = M >> 4, Nq = Nn >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < Mq * Nq; t += FGW_WAVES) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kd; k0 += 4) {
+            const int k = k0 + lk;
+            const double a = k < Kd ? X(i0 + li, k) : 0.0;
+            const double b = k < Kd ? W(k, j0 + li) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st(i0 + lk + 4 * q, j0 + li, acc[q]);
+    }
+    // border: rows >= 16*Mq (all columns), then columns >= 16*Nq for the core rows
+    const int Mc = Mq << 4, Nc = Nq << 4;
+    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
+    for (int t = tid; t < nb1 + nb2; t += FGW_THREADS) {
+        int i, j;
+        if (t < nb1) { i = Mc + t / Nn; j = t % Nn; }
+        else { const int q = t - nb1; i = q / (Nn - Nc); j = Nc + q % (Nn - Nc); }
+        double a = 0.0;
+        for (int k = 0; k < Kd; ++k) a += X(i, k) * W(k, j);
+        st(i, j, a);
+    }
+}
+
 template <int R>
 __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
@@ -24,15 +67,17 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
-    const int N = D.N, P = D.P, d = D.d;
+    const int N = D.N, P = D.P, d = D.d, ZP = d + 1;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool lane_ok = lane < N;
 
     // ---- LDS carve (doubles first)
-    double *Al = reinterpret_cast<double *>(smem);            // [N,P]  A = C1 @ T ; later aliased by Mr and by T @ C2
-    double *C1l = Al + NP;                                     // [N,P]
-    double *pm = C1l + NP;                                     // [4][64] partial max
+    double *Al = reinterpret_cast<double *>(smem);            // [N,P]  A = C1 @ T ; dot(Y,Z) ; T @ C2
+    double *Gl = Al + NP;                                      // [N,P]  G = A @ (2 C2)^T
+    double *C1l = Gl + NP;                                     // [N,P]
+    double *Yl = C1l + NP;                                     // [N,d]
+    double *pm = Yl + (size_t)N * d;                           // [4][64] partial max
     double *psum = pm + 256;                                   // [4][64] partial sums
     double *us = psum + 256;                                   // [4][64] per-wave copy of u (indexed by i)
     double *vs = us + 256;                                     // [4][64] per-wave copy of v (indexed by j)
@@ -40,6 +85,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     double *red = pq + 128;                                    // [8]
     float *Tl = reinterpret_cast<float *>(red + 8);            // [N,P]
     float *C2l = Tl + NP;                                      // [N,P]
+    float *Zl = C2l + NP;                                      // [N,d+1]
 
     const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
     const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
@@ -48,7 +94,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     float *Tg = Tw + ((size_t)b * D.K + s) * NN;
     const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
 
-    // ---- stage p, q, C1, C2, T0
+    // ---- stage p, q, C1, C2, Y, Z (coalesced)
     if (tid < 64) {
         pq[tid] = tid < N ? (pb ? (double)pb[(size_t)b * N + tid] : 1.0 / (double)N) : 1.0;
         pq[64 + tid] = tid < N ? (ps ? (double)ps[((size_t)b * D.K + s) * N + tid] : 1.0 / (double)N) : 1.0;
@@ -58,6 +104,11 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
         C1l[i * P + j] = C1[t];
         C2l[i * P + j] = C2[t];
     }
+    for (int t = tid; t < N * d; t += FGW_THREADS) {
+        const int i = t / d, c = t - i * d;
+        Yl[t] = y_zero ? 0.0 : Y[t];
+        Zl[i * ZP + c] = Z[t];
+    }
     __syncthreads();
     const double loga = log(pq[lane]), logb = log(pq[64 + lane]);      // lane <-> i for loga, lane <-> j for logb
     const double qj = pq[64 + lane];
@@ -65,76 +116,62 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
         const int i = t / N, j = t - i * N;
         Tl[i * P + j] = (outer > 0 && prm.warmstart) ? Tg[t] : (float)(pq[i] * pq[64 + j]);     // bregman.py:98-101
     }
-
-    // ---- base_A[r] = 2*alpha*constC[i_r][j] + (1-alpha)*M[i_r][j], j = lane           (utils.py:39-43,154-171)
-    double baseA[R];
-    {
-        // column parts (depend on j = lane): r2_j = sum_k q_k C2[j,k]^2 ; z2_j = |z_j|^2
-        double r2 = 0.0, z2 = 0.0;
-        if (lane_ok) {
-            for (int k = 0; k < N; ++k) { const double c2 = (double)C2l[lane * P + k]; r2 += pq[64 + k] * (c2 * c2); }
-            const float *zj = Z + (size_t)lane * d;
-            for (int c = 0; c < d; ++c) { const double zz = (double)zj[c]; z2 += zz * zz; }
+    // ---- per-index vectors: r1_i = sum_k C1[i,k]^2 p_k, r2_j = sum_k q_k C2[j,k]^2, |y_i|^2, |z_j|^2  -> pm / psum scratch
+    if (tid < N) {
+        double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
+        for (int k = 0; k < N; ++k) {
+            const double c1 = C1l[tid * P + k], c2 = (double)C2l[tid * P + k];
+            r1 += c1 * c1 * pq[k]; r2 += pq[64 + k] * (c2 * c2);
         }
+        for (int c = 0; c < d; ++c) { const double yy = Yl[tid * d + c], zz = (double)Zl[tid * ZP + c]; y2 += yy * yy; z2 += zz * zz; }
+        pm[tid] = r1; pm[64 + tid] = r2; psum[tid] = y2; psum[64 + tid] = z2;
+    }
+    // ---- dot(Y_i, Z_j) on MFMA -> Al
+    if (!y_zero)
+        mm_f64(N, N, d, [&](int i, int k) { return Yl[i * d + k]; }, [&](int k, int j) { return (double)Zl[j * ZP + k]; },
+               [&](int i, int j, double v) { Al[i * P + j] = v; });
+    __syncthreads();
+    // ---- base = 2*alpha*constC + (1-alpha)*M in both register layouts            (utils.py:39-43,154-171, bregman.py:124-125)
+    double baseA[R], baseB[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = w + 4 * r;
-            double val = 0.0;
-            if (i < N && lane_ok) {
-                double r1 = 0.0, y2 = 0.0, dot = 0.0;
-                for (int k = 0; k < N; ++k) { const double c1 = C1l[i * P + k]; r1 += c1 * c1 * pq[k]; }
-                if (!y_zero) {
-                    const double *yi = Y + (size_t)i * d;
-                    const float *zj = Z + (size_t)lane * d;
-                    for (int c = 0; c < d; ++c) { const double yy = yi[c]; y2 += yy * yy; dot += yy * (double)zj[c]; }
-                }
-                double m = -2.0 * dot; m += y2; m += z2;
+    for (int r = 0; r < R; ++r) {
+        const int q = w + 4 * r;                               // row index in layout A, column index in layout B
+        double va = 0.0, vb = 0.0;
+        if (q < N && lane_ok) {
+            {   // layout A: (i, j) = (q, lane)
+                double m = -2.0 * (y_zero ? 0.0 : Al[q * P + lane]); m += psum[q]; m += psum[64 + lane];
                 m = m > 0.0 ? m : 0.0;
-                val = 2.0 * alpha * (r1 + r2) + (1.0 - alpha) * m;
+                va = 2.0 * alpha * (pm[q] + pm[64 + lane]) + (1.0 - alpha) * m;
             }
-            baseA[r] = val;
+            {   // layout B: (i, j) = (lane, q)
+                double m = -2.0 * (y_zero ? 0.0 : Al[lane * P + q]); m += psum[lane]; m += psum[64 + q];
+                m = m > 0.0 ? m : 0.0;
+                vb = 2.0 * alpha * (pm[lane] + pm[64 + q]) + (1.0 - alpha) * m;
+            }
         }
+        baseA[r] = va; baseB[r] = vb;
     }
     __syncthreads();
 
     int cpt = 0, sk_total = 0;
     double err = 1.0;
     while (err > (double)prm.inner_tol && cpt < prm.max_iter) {          // bregman.py:119
-        // ---- A = C1 @ T : thread (w, j) computes rows i_r
-        double acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.0;
-        if (lane_ok) {
-            for (int k = 0; k < N; ++k) {
-                const double t = (double)Tl[k * P + lane];
-#pragma unroll
-                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += C1l[i * P + k] * t; }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Al[i * P + lane] = acc[r]; }
-        }
+        // ---- A = C1 @ T ; G = A @ (2 C2)^T                                (utils.py:48-64)
+        mm_f64(N, N, N, [&](int i, int k) { return C1l[i * P + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
+               [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        // ---- G = A @ (2 C2)^T ; Mr = -(base - 2 alpha G)/eps  -> registers (layout A)
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return 2.0 * (double)C2l[j * P + k]; },
+               [&](int i, int j, double v) { Gl[i * P + j] = v; });
+        __syncthreads();
+        // ---- Mr = -(base - 2 alpha G)/eps in both layouts (sinkhorn.py:388)
         double mA[R], mB[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.0;
-        if (lane_ok) {
-            for (int k = 0; k < N; ++k) {
-                const double c = 2.0 * (double)C2l[lane * P + k];
-#pragma unroll
-                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += Al[i * P + k] * c; }
-            }
+        for (int r = 0; r < R; ++r) {
+            const int q = w + 4 * r;
+            const bool ok = q < N && lane_ok;
+            mA[r] = ok ? -(baseA[r] - 2.0 * alpha * Gl[q * P + lane]) * inv_eps : 0.0;
+            mB[r] = ok ? -(baseB[r] - 2.0 * alpha * Gl[lane * P + q]) * inv_eps : 0.0;
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) mA[r] = -(baseA[r] - 2.0 * alpha * acc[r]) * inv_eps;
-        __syncthreads();                                               // everyone done reading Al
-        if (lane_ok) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Al[i * P + lane] = mA[r]; }     // Mr aliases Al
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) { const int j = w + 4 * r; mB[r] = (lane_ok && j < N) ? Al[lane * P + j] : 0.0; }   // layout B: lane <-> i
 
         // ---- log-domain Sinkhorn (sinkhorn.py:393-433); u, v in registers (u_l: i = lane, v_l: j = lane)
         double u_l = 0.0, v_l = 0.0;
@@ -151,7 +188,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
             mx = fmax(fmax(pm[lane], pm[64 + lane]), fmax(pm[128 + lane], pm[192 + lane]));
             double sm = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) sm += exp_acc(z[r] - mx); }
+            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) sm += exp_lse(z[r] - mx); }
             psum[w * 64 + lane] = sm;
             __syncthreads();
             sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
@@ -166,7 +203,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
             mx = fmax(fmax(pm[lane], pm[64 + lane]), fmax(pm[128 + lane], pm[192 + lane]));
             sm = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int j = w + 4 * r; if (j < N) sm += exp_acc(z[r] - mx); }
+            for (int r = 0; r < R; ++r) { const int j = w + 4 * r; if (j < N) sm += exp_lse(z[r] - mx); }
             psum[w * 64 + lane] = sm;
             __syncthreads();
             sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
@@ -188,7 +225,6 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
         sk_total += ii;
         // ---- T = exp(Mr + u + v) (sinkhorn.py:450); err = ||T - Tprev||_F when cpt % 10 == 0 (bregman.py:144-147)
         double e2 = 0.0;
-        __syncthreads();
         if (lane_ok) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -210,50 +246,18 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
 
     // ---- contributions to the barycenter update while T is resident
-    if (!prm.fixed_features) {                                          // Ypart[i][c] = sum_j T[i][j] Z[j][c]   (utils.py:90-95)
+    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        for (int c0 = 0; c0 < d; c0 += 64) {
-            const int c = c0 + lane;
-            double acc[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = 0.0;
-            if (c < d) {
-                for (int j = 0; j < N; ++j) {
-                    const double zz = (double)Z[(size_t)j * d + c];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += (double)Tl[i * P + j] * zz; }
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Yp[(size_t)i * d + c] = acc[r]; }
-            }
-        }
+        mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Zl[k * ZP + c]; },
+               [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
-    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T                 (utils.py:67-73)
-        double acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.0;
-        if (lane_ok) {
-            for (int k = 0; k < N; ++k) {
-                const double c = (double)C2l[k * P + lane];
-#pragma unroll
-                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += (double)Tl[i * P + k] * c; }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Al[i * P + lane] = acc[r]; }
-        }
+    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
+        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int j) { return (double)C2l[k * P + j]; },
+               [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.0;
-        if (lane_ok) {
-            for (int k = 0; k < N; ++k) {
-                const double t = (double)Tl[lane * P + k];
-#pragma unroll
-                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) acc[r] += Al[i * P + k] * t; }
-            }
-            double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-#pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) Cp[i * N + lane] = acc[r]; }
-        }
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
+               [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
 }
 
@@ -312,14 +316,14 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
     }
 }
 
-inline size_t small_lds(int N) {
+inline size_t small_lds(int N, int d) {
     const size_t NP = (size_t)N * (N | 1);
-    return NP * 8 * 2 + (256 * 4 + 128 + 8) * 8 + NP * 4 * 2;
+    return NP * 8 * 3 + (size_t)N * d * 8 + (256 * 4 + 128 + 8) * 8 + NP * 4 * 2 + (size_t)N * (d + 1) * 4;
 }
 
 }  // namespace
 
-bool conan_fgw_small_supported(int N) { return N <= 64; }
+bool conan_fgw_small_supported(int N, int d) { return N <= 64 && small_lds(N, d) <= 160 * 1024; }
 
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
     return ((size_t)B * K * N * d + (size_t)B * K * N * N) * 8 + 512;
@@ -328,7 +332,7 @@ size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
                               const int *active, float *Tw, int *info, double *Ypart, double *Cpart, hipStream_t s) {
-    const size_t lds = small_lds(D.N);
+    const size_t lds = small_lds(D.N, D.d);
     const int R = (D.N + 3) / 4;
     const int grid = D.B * D.K;
 #define LAUNCH(RR)                                                                                                              \
