@@ -38,6 +38,8 @@ SIGNATURES = {
     "conan_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "conan_filter_fused_supported": (c_int, [c_int, c_int]),
+    "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P]),

@@ -1,0 +1,211 @@
+// Fused continuous-filter generator of SchNet's CFConv for gfx950:
+//
+//     W[e,:] = ( mlp2( ssp( mlp0( rbf(d_e) ) ) ) ) * 0.5*(cos(d_e*pi/cutoff)+1)
+//
+// (GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff of PyG; reached from
+// conan_fgw/src/model/graph_embeddings/schnet_no_sum.py:161-164,209-212).  One kernel, no [E,Gs] / [E,F] intermediates
+// in HBM: per edge the only traffic is 4 B in (d_e) and 4F B out (W[e,:]).
+//
+// MI355X mapping.  Everything is computed TRANSPOSED so that the edge index lives on the MFMA column (= lane) and the
+// filter channel on the MFMA row: a wavefront owns a tile of 32 edges and keeps H1^T[F][32] and W^T[F][32] in
+// accumulators (2 * F/32 * 16 registers).
+//   GEMM1^T  H1^T = W1 . rbf^T : the B operand (rbf_k(d_e), lane = e) is evaluated in registers, never stored;
+//   GEMM2^T  W^T  = W2 . H1    : the B operand IS the accumulator of GEMM1 (after bias + ssp), register r of lane-half h
+//                                being row 32mb + (r&3) + 8(r>>2) + 4h, so the k order of the A fragments is permuted to
+//                                match: no LDS round trip, no cross-lane traffic between the two GEMMs.
+// The A operands (the two weight matrices, <= 98 KB) are staged once per workgroup in LDS and read with conflict-free
+// ds_read_b128 (4 k-steps per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
+// v_mfma_f32_32x32x2_f32 back to back (exact fp32).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GP = 56;        // gaussians padded to a multiple of 8 (zero weights beyond num_gaussians)
+constexpr int W1P = 60;       // LDS pitch of W1 rows  (60 = 4*15: 16 consecutive rows hit 16 distinct 16-B slots)
+constexpr int FF_THREADS = 512;
+
+template <int F>
+__global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
+    const float *__restrict__ dist, const int *__restrict__ num_edges_dev, int max_edges, const float *__restrict__ offset,
+    int Gs, float coeff, float cutoff, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out) {
+    constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
+    constexpr int W2P = F + 4;            // LDS pitch of W2 rows
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *W1L = lds;                     // [F][W1P]
+    float *W2L = W1L + F * W1P;           // [F][W2P]
+    float *B1L = W2L + F * W2P;           // [F]
+    float *B2L = B1L + F;                 // [F]
+    float *OFL = B2L + F;                 // [GP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = num_edges_dev ? min(*num_edges_dev, max_edges) : max_edges;
+    const int tiles = (E + 31) >> 5;
+    if ((int)blockIdx.x * (FF_THREADS / 64) >= tiles) return;
+
+    for (int t = tid; t < F * W1P; t += FF_THREADS) {
+        const int f = t / W1P, k = t - f * W1P;
+        W1L[t] = k < Gs ? w1[(size_t)f * Gs + k] : 0.f;
+    }
+    for (int t = tid; t < F * W2P; t += FF_THREADS) {
+        const int f2 = t / W2P, f = t - f2 * W2P;
+        W2L[t] = f < F ? w2[(size_t)f2 * F + f] : 0.f;
+    }
+    for (int t = tid; t < F; t += FF_THREADS) { B1L[t] = b1[t]; B2L[t] = b2[t]; }
+    for (int t = tid; t < GP; t += FF_THREADS) OFL[t] = t < Gs ? offset[t] : 0.f;
+    __syncthreads();
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_stride = gridDim.x * (FF_THREADS / 64);
+    for (int tile = blockIdx.x * (FF_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
+        const int e = (tile << 5) + l31;
+        const bool valid = e < E;
+        const float d = valid ? dist[e] : 0.f;
+
+        // ---------------- GEMM1^T: acc1[mb] = W1[32mb.., :] . rbf^T
+        f32x16 acc1[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mb][r] = 0.f;
+        {
+            // software pipeline: the A fragments of group g+1 are requested before the MFMAs of group g issue;
+            // sched_barrier keeps the compiler from hoisting every LDS read to the top (register blow-up).
+            float4 a_cur[MB], a_nxt[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a_cur[mb] = *reinterpret_cast<const float4 *>(&W1L[(32 * mb + l31) * W1P + 4 * h]);
+#pragma unroll
+            for (int g = 0; g < GP / 8; ++g) {
+                const int kb = 8 * g + 4 * h;                    // this lane-half's 4 k indices of the group
+                if (g + 1 < GP / 8) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = *reinterpret_cast<const float4 *>(&W1L[(32 * mb + l31) * W1P + kb + 8]);
+                }
+                const float4 of = *reinterpret_cast<const float4 *>(&OFL[kb]);
+                float rb[4];
+                { float t0 = d - of.x; rb[0] = expf(coeff * (t0 * t0)); }
+                { float t0 = d - of.y; rb[1] = expf(coeff * (t0 * t0)); }
+                { float t0 = d - of.z; rb[2] = expf(coeff * (t0 * t0)); }
+                { float t0 = d - of.w; rb[3] = expf(coeff * (t0 * t0)); }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].x, rb[0], acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].y, rb[1], acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].z, rb[2], acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].w, rb[3], acc1[mb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
+            }
+        }
+        // bias + shifted softplus on the accumulators: register r of half h is channel 32mb + (r&3) + 8(r>>2) + 4h
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4 *>(&B1L[32 * mb + 8 * q + 4 * h]);
+                acc1[mb][4 * q + 0] = ssp_f(acc1[mb][4 * q + 0] + bb.x);
+                acc1[mb][4 * q + 1] = ssp_f(acc1[mb][4 * q + 1] + bb.y);
+                acc1[mb][4 * q + 2] = ssp_f(acc1[mb][4 * q + 2] + bb.z);
+                acc1[mb][4 * q + 3] = ssp_f(acc1[mb][4 * q + 3] + bb.w);
+            }
+        if (h1_out && valid) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(h1_out + (size_t)e * F + 32 * mb + 8 * q + 4 * h) =
+                        make_float4(acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]);
+        }
+
+        // ---------------- GEMM2^T in groups of NG output row-blocks (bounds the live accumulators: 16*(MB + NG) registers)
+        const float C = 0.5f * (cosf(__fdiv_rn(d * 3.14159265358979323846f, cutoff)) + 1.0f);
+        constexpr int NG = MB >= 4 ? 2 : MB;
+#pragma unroll
+        for (int n0 = 0; n0 < MB; n0 += NG) {
+            f32x16 acc2[NG];
+#pragma unroll
+            for (int nb = 0; nb < NG; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+            {
+                float4 a_cur[NG], a_nxt[NG];
+#pragma unroll
+                for (int nb = 0; nb < NG; ++nb) a_cur[nb] = *reinterpret_cast<const float4 *>(&W2L[(32 * (n0 + nb) + l31) * W2P + 4 * h]);
+#pragma unroll
+                for (int mq = 0; mq < 4 * MB; ++mq) {
+                    const int mb = mq >> 2, q = mq & 3;
+                    const int kb = 32 * mb + 8 * q + 4 * h;      // channels held by registers 4q..4q+3 of this half
+                    if (mq + 1 < 4 * MB) {
+#pragma unroll
+                        for (int nb = 0; nb < NG; ++nb) a_nxt[nb] = *reinterpret_cast<const float4 *>(&W2L[(32 * (n0 + nb) + l31) * W2P + kb + 8]);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NG; ++nb) {
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].x, acc1[mb][4 * q + 0], acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].y, acc1[mb][4 * q + 1], acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].z, acc1[mb][4 * q + 2], acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].w, acc1[mb][4 * q + 3], acc2[nb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < NG; ++nb) a_cur[nb] = a_nxt[nb];
+                }
+            }
+            // epilogue: + b2, * C(d), store W[e, 32nb + 8q + 4h .. +3]
+            if (valid) {
+#pragma unroll
+                for (int nb = 0; nb < NG; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bb = *reinterpret_cast<const float4 *>(&B2L[32 * (n0 + nb) + 8 * q + 4 * h]);
+                        float4 o;
+                        o.x = (acc2[nb][4 * q + 0] + bb.x) * C;
+                        o.y = (acc2[nb][4 * q + 1] + bb.y) * C;
+                        o.z = (acc2[nb][4 * q + 2] + bb.z) * C;
+                        o.w = (acc2[nb][4 * q + 3] + bb.w) * C;
+                        *reinterpret_cast<float4 *>(Wout + (size_t)e * F + 32 * (n0 + nb) + 8 * q + 4 * h) = o;
+                    }
+            }
+        }
+    }
+}
+
+template <int F>
+int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
+           float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
+           hipStream_t s) {
+    const size_t lds = ((size_t)F * W1P + (size_t)F * (F + 4) + 2 * F + GP) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (max_edges + 31) / 32;
+    int grid = (tiles + 7) / 8;
+    if (grid > 256) grid = 256;                           // one persistent 8-wave workgroup per CU
+    k_filter_fused<F><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1);
+    return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int conan_filter_fused_supported(int num_gaussians, int num_filters) {
+    return (num_gaussians >= 2 && num_gaussians <= GP && (num_filters == 32 || num_filters == 64 || num_filters == 128)) ? 1 : 0;
+}
+
+int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int num_gaussians,
+                     float coeff, float cutoff, int num_filters, const float *w1, const float *b1, const float *w2,
+                     const float *b2, float *W, float *h1_out, void *stream) {
+    if (!dist || !offset || !w1 || !b1 || !w2 || !b2 || !W || max_edges < 0) return CONAN_E_BADARG;
+    if (!conan_filter_fused_supported(num_gaussians, num_filters)) return CONAN_E_UNSUPPORTED;
+    if (max_edges == 0) return CONAN_OK;
+    hipStream_t s = as_stream(stream);
+    switch (num_filters) {
+        case 32: return launch<32>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s);
+        case 64: return launch<64>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s);
+        default: return launch<128>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s);
+    }
+}
+
+}  // extern "C"

@@ -89,6 +89,124 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
     }
 }
 
+// ---- weight-resident variant for K <= 128, N <= 128 (every layer of SchNet-128) ------------------------------------
+// Persistent workgroups: W^T is staged into LDS once ([K][N+1], <= 66 KB) and reused for every 128-row tile the workgroup
+// processes; only x streams.  x chunks (128 rows x 32 k) are prefetched global->registers while the previous chunk is
+// multiplied, then written to the other LDS buffer (one barrier per chunk).  4 wavefronts as 2x2, 64 rows x 32*NBW cols
+// each => 2*NBW accumulators of 32x32.
+constexpr int RM = 128;            // rows per tile
+template <int NBW>
+__global__ void __launch_bounds__(256) k_linear_res(const float *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, const float *__restrict__ residual,
+                                                    int M, int K, int N, int w_kn, int act, float *__restrict__ y,
+                                                    const int *__restrict__ m_dev) {
+    constexpr int BN = 64 * NBW;
+    constexpr int WP = BN + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (m_dev) M = min(M, *m_dev);
+    const int tiles = (M + RM - 1) / RM;
+    if ((int)blockIdx.x >= tiles) return;
+    const int Kp = (K + BK - 1) / BK * BK;                // K rounded up to the chunk size (zero filled)
+    float *ws = lds;                                      // [Kp][WP]
+    float *xs = lds + Kp * WP;                            // [2][RM][XP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    // stage W^T once
+    if (w_kn) {
+        for (int t = tid; t < Kp * BN; t += 256) {
+            const int k = t / BN, n = t % BN;
+            ws[k * WP + n] = (k < K && n < N) ? w[(size_t)k * N + n] : 0.f;
+        }
+    } else {
+        for (int t = tid; t < Kp * BN; t += 256) {
+            const int n = t / Kp, k = t % Kp;
+            ws[k * WP + n] = (k < K && n < N) ? w[(size_t)n * K + k] : 0.f;
+        }
+    }
+    const int chunks = Kp / BK;
+    // each thread prefetches 4 float4 per chunk: rows (tid>>3) + 32*q, columns (tid&7)*4 .. +3
+    const int pr = tid >> 3, pc = (tid & 7) * 4;
+    const bool vec_ok = (K & 3) == 0;
+    float4 pre[4];
+    auto fetch = [&](int row0, int kc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gr = row0 + pr + 32 * q, gk = kc * BK + pc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < M) {
+                if (vec_ok) { if (gk < K) v = *reinterpret_cast<const float4 *>(x + (size_t)gr * K + gk); }
+                else {
+                    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) if (gk + e < K) t4[e] = x[(size_t)gr * K + gk + e];
+                    v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                }
+            }
+            pre[q] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+        float *dst = xs + buf * (RM * XP);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float *p = dst + (pr + 32 * q) * XP + pc;
+            p[0] = pre[q].x; p[1] = pre[q].y; p[2] = pre[q].z; p[3] = pre[q].w;
+        }
+    };
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int row0 = tile * RM;
+        f32x16 acc[2][NBW];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        fetch(row0, 0);
+        __syncthreads();                                   // previous tile's readers of xs are done (and ws is staged)
+        stash(0);
+        __syncthreads();
+        for (int kc = 0; kc < chunks; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < chunks) fetch(row0, kc + 1);
+            const float *xb = xs + buf * (RM * XP);
+            const float *wb = ws + (kc * BK) * WP;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = xb[(wm * 64 + l31) * XP + kk + kh];
+                const float a1 = xb[(wm * 64 + 32 + l31) * XP + kk + kh];
+#pragma unroll
+                for (int b = 0; b < NBW; ++b) {
+                    const float bv = wb[(kk + kh) * WP + wn * 32 * NBW + b * 32 + l31];
+                    acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][b], 0, 0, 0);
+                    acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < chunks) {
+                stash(buf ^ 1);                            // the other buffer was last read one barrier ago
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            const int gc = wn * 32 * NBW + b * 32 + l31;
+            if (gc >= N) continue;
+            const float bv = bias ? bias[gc] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gr = row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (gr >= M) continue;
+                    float v = acc[a][b][r] + bv;
+                    if (act == 1) v = ssp_f(v);
+                    if (residual) v += residual[(size_t)gr * N + gc];
+                    y[(size_t)gr * N + gc] = v;
+                }
+        }
+    }
+}
+
 __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict__ y, long long n, int width,
                           const int *__restrict__ m_dev, float *__restrict__ g) {
     if (m_dev) n = min(n, (long long)(*m_dev) * width);
@@ -188,25 +306,30 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__
     if (blockIdx.z == 0 && tid < WG_TILE && n0 + tid < N) bias_slabs[(size_t)slice * N + n0 + tid] = bsum;
 }
 
-__global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int slices, int NK, int N,
-                               float *__restrict__ dW, float *__restrict__ dbias) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// slabs [slices][NK] (+ bias_slabs [slices][N]) -> out[g][NK] (+ bout[g][N]) for slice group g = blockIdx.y; fixed order.
+__global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int slices, int per_group,
+                               int NK, int N, float *__restrict__ out, float *__restrict__ bout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    const int s0 = g * per_group, s1 = min(slices, s0 + per_group);
     if (i < NK) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int sl = 0;
-        for (; sl + 3 < slices; sl += 4) {
-            s0 += slabs[(size_t)sl * NK + i]; s1 += slabs[(size_t)(sl + 1) * NK + i];
-            s2 += slabs[(size_t)(sl + 2) * NK + i]; s3 += slabs[(size_t)(sl + 3) * NK + i];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int sl = s0;
+        for (; sl + 3 < s1; sl += 4) {
+            a0 += slabs[(size_t)sl * NK + i]; a1 += slabs[(size_t)(sl + 1) * NK + i];
+            a2 += slabs[(size_t)(sl + 2) * NK + i]; a3 += slabs[(size_t)(sl + 3) * NK + i];
         }
-        for (; sl < slices; ++sl) s0 += slabs[(size_t)sl * NK + i];
-        dW[i] = (s0 + s1) + (s2 + s3);
+        for (; sl < s1; ++sl) a0 += slabs[(size_t)sl * NK + i];
+        out[(size_t)g * NK + i] = (a0 + a1) + (a2 + a3);
     }
-    if (dbias && i < N) {
-        float s = 0.f;
-        for (int sl = 0; sl < slices; ++sl) s += bias_slabs[(size_t)sl * N + i];
-        dbias[i] = s;
+    if (bout && i < N) {
+        float a = 0.f;
+        for (int sl = s0; sl < s1; ++sl) a += bias_slabs[(size_t)sl * N + i];
+        bout[(size_t)g * N + i] = a;
     }
 }
+
+constexpr int WG_GROUPS = 16;
 
 static int wgrad_slices(int M) {
     int s = (M + 127) / 128;           // >= 128 rows per slice
@@ -224,6 +347,22 @@ int conan_linear_fwd(const float *x, const float *w, const float *bias, const fl
     if (!x || !w || !y || M < 0 || K <= 0 || N <= 0 || act < 0 || act > 1) return CONAN_E_BADARG;
     if (M == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
+    if (K <= 128 && N <= 128) {
+        const int Kp = (K + BK - 1) / BK * BK;
+        const int tiles = (M + RM - 1) / RM;
+        const int grid = tiles < 512 ? tiles : 512;        // persistent: <= 2 workgroups per CU
+        if (N > 64) {
+            const size_t lds = ((size_t)Kp * 129 + 2 * RM * XP) * 4;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_res<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k_linear_res<2><<<grid, 256, lds, s>>>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev);
+        } else {
+            const size_t lds = ((size_t)Kp * 65 + 2 * RM * XP) * 4;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_res<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k_linear_res<1><<<grid, 256, lds, s>>>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev);
+        }
+        CONAN_LAUNCH_CHECK();
+        return CONAN_OK;
+    }
     if (N > 64) {
         dim3 grid((M + BM - 1) / BM, (N + 127) / 128);
         k_linear<2><<<grid, 256, 0, s>>>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev);
@@ -247,7 +386,7 @@ int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const in
 }
 
 long long conan_linear_wgrad_ws(int M, int K, int N) {
-    return (long long)wgrad_slices(M) * ((long long)N * K + N);
+    return (long long)(wgrad_slices(M) + WG_GROUPS) * ((long long)N * K + N);
 }
 
 int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias,
@@ -261,7 +400,14 @@ int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, cons
     dim3 grid(slices, (N + WG_TILE - 1) / WG_TILE, (K + WG_TILE - 1) / WG_TILE);
     k_wgrad_partial<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
     const int NK = N * K;
-    k_wgrad_reduce<<<(NK + 255) / 256, 256, 0, s>>>(slabs, bias_slabs, slices, NK, N, dW, dbias);
+    if (slices > 2 * WG_GROUPS) {                    // two-level, both levels in a fixed order
+        float *mid = bias_slabs + (size_t)slices * N, *bmid = mid + (size_t)WG_GROUPS * NK;
+        const int per = (slices + WG_GROUPS - 1) / WG_GROUPS;
+        k_wgrad_reduce<<<dim3((NK + 255) / 256, WG_GROUPS), 256, 0, s>>>(slabs, bias_slabs, slices, per, NK, N, mid, dbias ? bmid : nullptr);
+        k_wgrad_reduce<<<dim3((NK + 255) / 256, 1), 256, 0, s>>>(mid, bmid, WG_GROUPS, WG_GROUPS, NK, N, dW, dbias);
+    } else {
+        k_wgrad_reduce<<<dim3((NK + 255) / 256, 1), 256, 0, s>>>(slabs, bias_slabs, slices, slices, NK, N, dW, dbias);
+    }
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

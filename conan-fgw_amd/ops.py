@@ -182,6 +182,54 @@ def cutoff_scale(w_raw: Tensor, graph: RadiusGraph) -> Tensor:
     return _CutoffScaleFn.apply(w_raw, graph)
 
 
+class _FilterFn(torch.autograd.Function):
+    """Fused filter generator (conan_filter_fwd).  Backward is composed from the edge-level GEMM kernels:
+    g = dW * C ; dw2 = g^T h1 ; dh1 = g w2 ; gpre = dh1 * ssp'(h1) ; dw1 = gpre^T rbf  (rbf is recomputed)."""
+
+    @staticmethod
+    def forward(ctx, graph, offset, coeff, w1, b1, w2, b2):
+        F, Gs = w1.shape
+        dev = w1.device
+        need_grad = any(ctx.needs_input_grad[3:])
+        W = torch.empty(graph.max_edges, F, dtype=f32, device=dev)
+        h1 = torch.empty(graph.max_edges, F, dtype=f32, device=dev) if need_grad else None
+        call("conan_filter_fwd", ptr(graph.dist), ptr(graph.num_edges_dev), graph.max_edges, ptr(_c(offset), f32), Gs, float(coeff),
+             graph.cutoff, F, ptr(_c(w1), f32), ptr(_c(b1), f32), ptr(_c(w2), f32), ptr(_c(b2), f32), ptr(W), ptr(h1), stream_ptr())
+        ctx.graph, ctx.coeff = graph, float(coeff)
+        ctx.save_for_backward(offset, w1, w2, h1)
+        return W
+
+    @staticmethod
+    def backward(ctx, dW):
+        offset, w1, w2, h1 = ctx.saved_tensors
+        g_, md = ctx.graph, ctx.graph.num_edges_dev
+        F, Gs = w1.shape
+        ME = g_.max_edges
+        dev = dW.device
+        dW = _c(dW)
+        g = torch.empty_like(dW)
+        call("conan_cutoff_scale", ptr(g_.dist), ptr(md), ME, F, g_.cutoff, ptr(dW), ptr(g), stream_ptr())
+        ws = torch.empty(int(max(lib().conan_linear_wgrad_ws(ME, F, F), lib().conan_linear_wgrad_ws(ME, Gs, F))), dtype=f32, device=dev)
+        dw2, db2 = torch.empty_like(w2), torch.empty(F, dtype=f32, device=dev)
+        call("conan_linear_wgrad", ptr(g), ptr(h1), ME, F, F, ptr(md), ptr(dw2), ptr(db2), ptr(ws), stream_ptr())
+        dh1 = torch.empty_like(dW)
+        call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, None, ME, F, F, 1, 0, ptr(md), ptr(dh1), stream_ptr())
+        call("conan_ssp_bwd", ptr(dh1), ptr(h1), ME, F, ptr(md), ptr(dh1), stream_ptr())
+        rbf = rbf_expand(g_, offset, ctx.coeff)
+        dw1, db1 = torch.empty_like(w1), torch.empty(F, dtype=f32, device=dev)
+        call("conan_linear_wgrad", ptr(dh1), ptr(rbf), ME, Gs, F, ptr(md), ptr(dw1), ptr(db1), ptr(ws), stream_ptr())
+        return None, None, None, dw1, db1, dw2, db2
+
+
+def filter_fused_supported(num_gaussians: int, num_filters: int) -> bool:
+    return bool(lib().conan_filter_fused_supported(int(num_gaussians), int(num_filters)))
+
+
+def filter_generate(graph: "RadiusGraph", offset: Tensor, coeff: float, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """W[e,:] = mlp(rbf(d_e)) * C(d_e) for every edge -> [max_edges, F] (rows >= E untouched)."""
+    return _FilterFn.apply(graph, offset, coeff, w1, b1, w2, b2)
+
+
 class _CFConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, graph):

@@ -85,11 +85,15 @@ class CFConv(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
 
-    def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf: Tensor) -> Tensor:
-        md = graph.num_edges_dev
-        h1 = ops.linear(rbf, self.nn[0].weight, self.nn[0].bias, act=True, m_dev=md)       # mlp[0] + ssp
-        w_raw = ops.linear(h1, self.nn[2].weight, self.nn[2].bias, m_dev=md)              # mlp[2]
-        W = ops.cutoff_scale(w_raw, graph)                                                # * C(d)
+    def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf) -> Tensor:
+        if isinstance(rbf, Tensor):                                                       # generic path: any (Gs, F)
+            md = graph.num_edges_dev
+            h1 = ops.linear(rbf, self.nn[0].weight, self.nn[0].bias, act=True, m_dev=md)   # mlp[0] + ssp
+            w_raw = ops.linear(h1, self.nn[2].weight, self.nn[2].bias, m_dev=md)          # mlp[2]
+            W = ops.cutoff_scale(w_raw, graph)                                            # * C(d)
+        else:                                                                             # fused: rbf -> mlp -> * C(d) in one kernel
+            offset, coeff = rbf
+            W = ops.filter_generate(graph, offset, coeff, self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias)
         x = ops.linear(x, self.lin1.weight)                                               # lin1 (no bias)
         x = ops.cfconv(x, W, graph)                                                       # propagate: gather * W, scatter-add
         return x                                                                          # lin2 applied by the caller (fused with ssp)
@@ -145,6 +149,7 @@ class SchNetNoSum(torch.nn.Module):
         self.cutoff = cutoff
         self.use_readout = use_readout
         self.use_covalent = use_covalent
+        self.fused_filter = True            # False: compose the filter from rbf / linear / cutoff kernels (any shape)
         self.mean, self.std, self.scale = mean, std, None
         self.embedding = Embedding(100, hidden_channels, padding_idx=0)
         self.interaction_graph = RadiusInteractionGraph(cutoff, max_num_neighbors)
@@ -177,7 +182,10 @@ class SchNetNoSum(torch.nn.Module):
     def _trunk(self, z: Tensor, graph: ops.RadiusGraph) -> Tensor:
         """embedding -> interactions with residual (schnet_no_sum.py:159-164 == :207-212)."""
         h = ops.embedding(z, self.embedding.weight, self.embedding.padding_idx)
-        rbf = self.distance_expansion(graph)
+        if self.fused_filter and ops.filter_fused_supported(self.num_gaussians, self.num_filters):
+            rbf = (self.distance_expansion.offset, self.distance_expansion.coeff)          # expanded inside the fused kernel
+        else:
+            rbf = self.distance_expansion(graph)
         for interaction in self.interactions:
             h = interaction(h, graph, rbf)
         return h

@@ -98,6 +98,18 @@ int conan_rbf_fwd(const float *dist, const int *num_edges_dev, int max_edges, co
 int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edges, int width, float cutoff,
                        const float *in, float *out, void *stream);
 
+/* Fused continuous-filter generator: for every edge e
+ *   W[e,:] = ( mlp2( ssp( mlp0( rbf(dist[e]) ) ) ) ) * 0.5*(cos(dist[e]*pi/cutoff)+1)
+ * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel with both GEMMs on fp32 MFMA and
+ * every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
+ * are the torch Linear parameters of interactions.{i}.mlp.{0,2}.  h1_out (nullable) receives ssp(mlp0(rbf)) [E,F] for the
+ * backward.  Supported shapes: conan_filter_fused_supported(Gs, F) (Gs <= 56, F in {32,64,128}); otherwise
+ * CONAN_E_UNSUPPORTED and the caller composes conan_rbf_fwd / conan_linear_fwd / conan_cutoff_scale. */
+int conan_filter_fused_supported(int num_gaussians, int num_filters);
+int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int num_gaussians,
+                     float coeff, float cutoff, int num_filters, const float *w1, const float *b1, const float *w2,
+                     const float *b2, float *W, float *h1_out, void *stream);
+
 /* CFConv message + aggregation (the HBM-bound kernel of the path): out[i,:] = sum_{e in row i} x[col[e],:] * W[e,:].
  * Replaces index_select + mul + scatter-add inside CFConv.propagate (PyG; schnet_no_sum.py:163-164,211-212).
  * CSR segment sum, one wavefront per target, no atomics. */

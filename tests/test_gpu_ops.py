@@ -115,3 +115,36 @@ def test_rbf_cutoff_embedding_segment_sum():
     gg = torch.randn(b.num_graphs, 64)
     o.backward(gg.to(dev))
     assert torch.equal(xd.grad.cpu(), gg[torch.from_numpy(b.batch)])
+
+
+@pytest.mark.parametrize("F_,Gs", [(128, 50), (64, 50), (32, 50), (128, 10)])
+def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
+    """conan_filter_fwd (rbf -> mlp -> cosine cutoff in registers) vs the oracle's GaussianSmearing + mlp + C(d)."""
+    assert ops.filter_fused_supported(Gs, F_)
+    b = make_batch("esol", 5, 5, seed=13, box=14.0)
+    g = _edges(b)
+    E = g.num_edges
+    torch.manual_seed(F_ + Gs)
+    gs = ps.GaussianSmearing(0.0, 10.0, Gs)
+    mlp = torch.nn.Sequential(torch.nn.Linear(Gs, F_), ps.ShiftedSoftplus(), torch.nn.Linear(F_, F_))
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    prm = [p.detach().to(dev).requires_grad_(True) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
+    W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm)
+    d = g.edge_weight().cpu().double()
+    m64 = mlp.double()
+    C = 0.5 * (torch.cos(d * math.pi / 10.0) + 1.0)
+    ref = m64(gs(d)) * C[:, None]
+    assert rel(W[:E].detach().cpu(), ref.detach()) < TOL
+    gy = torch.randn(E, F_)
+    gfull = torch.zeros(g.max_edges, F_); gfull[:E] = gy
+    W.backward(gfull.to(dev))
+    ref.backward(gy.double())
+    for got, want in zip(prm, (m64[0].weight, m64[0].bias, m64[2].weight, m64[2].bias)):
+        assert rel(got.grad.cpu(), want.grad) < 1e-5
+    # and the composed (generic) path gives the same filters
+    rbf = ops.rbf_expand(g, gs.offset.to(dev), gs.coeff)
+    h1 = ops.linear(rbf, prm[0].detach(), prm[1].detach(), act=True, m_dev=g.num_edges_dev)
+    W2 = ops.cutoff_scale(ops.linear(h1, prm[2].detach(), prm[3].detach(), m_dev=g.num_edges_dev), g)
+    assert rel(W[:E].detach().cpu(), W2[:E].cpu()) < 1e-6
