@@ -17,6 +17,7 @@
 // ds_read_b128 (4 k-steps per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
 // v_mfma_f32_32x32x2_f32 back to back (exact fp32).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,7 +31,7 @@ template <int F>
 __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     const float *__restrict__ dist, const int *__restrict__ num_edges_dev, int max_edges, const float *__restrict__ offset,
     int Gs, float coeff, float cutoff, const float *__restrict__ w1, const float *__restrict__ b1,
-    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out) {
+    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out, int dbg) {
     constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
     constexpr int W2P = F + 4;            // LDS pitch of W2 rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -84,10 +85,10 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 }
                 const float4 of = *reinterpret_cast<const float4 *>(&OFL[kb]);
                 float rb[4];
-                { float t0 = d - of.x; rb[0] = expf(coeff * (t0 * t0)); }
-                { float t0 = d - of.y; rb[1] = expf(coeff * (t0 * t0)); }
-                { float t0 = d - of.z; rb[2] = expf(coeff * (t0 * t0)); }
-                { float t0 = d - of.w; rb[3] = expf(coeff * (t0 * t0)); }
+                { float t0 = d - of.x; rb[0] = exp_neg_f(coeff * (t0 * t0)); }
+                { float t0 = d - of.y; rb[1] = exp_neg_f(coeff * (t0 * t0)); }
+                { float t0 = d - of.z; rb[2] = exp_neg_f(coeff * (t0 * t0)); }
+                { float t0 = d - of.w; rb[3] = exp_neg_f(coeff * (t0 * t0)); }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].x, rb[0], acc1[mb], 0, 0, 0);
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&B1L[32 * mb + 8 * q + 4 * h]);
+                if (dbg & 2) continue;
                 acc1[mb][4 * q + 0] = ssp_f(acc1[mb][4 * q + 0] + bb.x);
                 acc1[mb][4 * q + 1] = ssp_f(acc1[mb][4 * q + 1] + bb.y);
                 acc1[mb][4 * q + 2] = ssp_f(acc1[mb][4 * q + 2] + bb.z);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 }
             }
             // epilogue: + b2, * C(d), store W[e, 32nb + 8q + 4h .. +3]
-            if (valid) {
+            if (valid && !(dbg & 1)) {
 #pragma unroll
                 for (int nb = 0; nb < NG; ++nb)
 #pragma unroll
@@ -182,7 +184,8 @@ int launch(const float *dist, const int *num_edges_dev, int max_edges, const flo
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;
     if (grid > 256) grid = 256;                           // one persistent 8-wave workgroup per CU
-    k_filter_fused<F><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1);
+    static int dbg = getenv("CONAN_FILTER_DEBUG") ? atoi(getenv("CONAN_FILTER_DEBUG")) : 0;
+    k_filter_fused<F><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, dbg);
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
