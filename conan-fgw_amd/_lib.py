@@ -42,7 +42,7 @@ SIGNATURES = {
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
-    "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_float, _P, _P]),
     "conan_segment_sum_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_segment_sum_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_fgw_densify": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),

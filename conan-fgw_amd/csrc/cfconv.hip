@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_x(const float *__restrict__ 
 __global__ void __launch_bounds__(256) k_cfconv_bwd_w(const float *__restrict__ x, const float *__restrict__ dout,
                                                       const int *__restrict__ num_edges_dev, int max_edges,
                                                       const int *__restrict__ col, const int *__restrict__ tgt, int F,
-                                                      float *__restrict__ dW) {
+                                                      const float *__restrict__ dist, float cutoff, float *__restrict__ dW) {
     const int E = num_edges_dev ? min(*num_edges_dev, max_edges) : max_edges;
     const int F4 = F >> 2;
     const long long n4 = (long long)E * F4;
@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_w(const float *__restrict__ 
         const int e = (int)(i / F4), c = (int)(i - (long long)e * F4);
         const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)col[e] * F)[c];
         const float4 g = reinterpret_cast<const float4 *>(dout + (size_t)tgt[e] * F)[c];
-        reinterpret_cast<float4 *>(dW)[i] = make_float4(xv.x * g.x, xv.y * g.y, xv.z * g.z, xv.w * g.w);
+        const float cc = dist ? 0.5f * (cosf(__fdiv_rn(dist[e] * 3.14159265358979323846f, cutoff)) + 1.0f) : 1.0f;
+        reinterpret_cast<float4 *>(dW)[i] = make_float4(xv.x * g.x * cc, xv.y * g.y * cc, xv.z * g.z * cc, xv.w * g.w * cc);
     }
 }
 
@@ -147,10 +148,10 @@ int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, c
 }
 
 int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_dev, int max_edges, const int *col,
-                       const int *tgt, int num_filters, float *dW, void *stream) {
+                       const int *tgt, int num_filters, const float *dist, float cutoff, float *dW, void *stream) {
     if (!x || !dout || !col || !tgt || !dW || max_edges < 0 || num_filters <= 0 || (num_filters & 3)) return CONAN_E_BADARG;
     if (max_edges == 0) return CONAN_OK;
-    k_cfconv_bwd_w<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_edges_dev, max_edges, col, tgt, num_filters, dW);
+    k_cfconv_bwd_w<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_edges_dev, max_edges, col, tgt, num_filters, dist, cutoff, dW);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -183,8 +183,9 @@ def cutoff_scale(w_raw: Tensor, graph: RadiusGraph) -> Tensor:
 
 
 class _FilterFn(torch.autograd.Function):
-    """Fused filter generator (conan_filter_fwd).  Backward is composed from the edge-level GEMM kernels:
-    g = dW * C ; dw2 = g^T h1 ; dh1 = g w2 ; gpre = dh1 * ssp'(h1) ; dw1 = gpre^T rbf  (rbf is recomputed)."""
+    """Fused filter generator (conan_filter_fwd).  Its output must be consumed by `cfconv(..., pre_cutoff_grad=True)`:
+    the incoming gradient g is then w.r.t. the un-scaled filter.  Backward is composed from the edge-level GEMM kernels:
+    dw2 = g^T h1 ; gpre = (g w2) * ssp'(h1) (fused epilogue) ; dw1 = gpre^T rbf  (rbf is recomputed)."""
 
     @staticmethod
     def forward(ctx, graph, offset, coeff, w1, b1, w2, b2):
@@ -206,15 +207,12 @@ class _FilterFn(torch.autograd.Function):
         F, Gs = w1.shape
         ME = g_.max_edges
         dev = dW.device
-        dW = _c(dW)
-        g = torch.empty_like(dW)
-        call("conan_cutoff_scale", ptr(g_.dist), ptr(md), ME, F, g_.cutoff, ptr(dW), ptr(g), stream_ptr())
+        g = _c(dW)                                   # already multiplied by C(d): cfconv(..., pre_cutoff_grad=True)
         ws = torch.empty(int(max(lib().conan_linear_wgrad_ws(ME, F, F), lib().conan_linear_wgrad_ws(ME, Gs, F))), dtype=f32, device=dev)
         dw2, db2 = torch.empty_like(w2), torch.empty(F, dtype=f32, device=dev)
         call("conan_linear_wgrad", ptr(g), ptr(h1), ME, F, F, ptr(md), ptr(dw2), ptr(db2), ptr(ws), stream_ptr())
-        dh1 = torch.empty_like(dW)
-        call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, None, ME, F, F, 1, 0, ptr(md), ptr(dh1), stream_ptr())
-        call("conan_ssp_bwd", ptr(dh1), ptr(h1), ME, F, ptr(md), ptr(dh1), stream_ptr())
+        dh1 = torch.empty_like(g)
+        call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
         rbf = rbf_expand(g_, offset, ctx.coeff)
         dw1, db1 = torch.empty_like(w1), torch.empty(F, dtype=f32, device=dev)
         call("conan_linear_wgrad", ptr(dh1), ptr(rbf), ME, Gs, F, ptr(md), ptr(dw1), ptr(db1), ptr(ws), stream_ptr())
@@ -232,12 +230,12 @@ def filter_generate(graph: "RadiusGraph", offset: Tensor, coeff: float, w1: Tens
 
 class _CFConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, graph):
+    def forward(ctx, x, W, graph, pre_cutoff_grad=False):
         x, W = _c(x), _c(W)
         out = torch.empty_like(x)
         call("conan_cfconv_fwd", ptr(x, f32), ptr(W, f32), ptr(graph.rowptr), ptr(graph.col), graph.num_atoms, x.shape[1],
              ptr(out), stream_ptr())
-        ctx.graph = graph
+        ctx.graph, ctx.pre = graph, pre_cutoff_grad
         ctx.save_for_backward(x, W)
         return out
 
@@ -255,14 +253,16 @@ class _CFConvFn(torch.autograd.Function):
                  stream_ptr())
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
-            call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F, ptr(dW),
-                 stream_ptr())
-        return dx, dW, None
+            call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F,
+                 ptr(g.dist) if ctx.pre else None, float(g.cutoff or 0.0), ptr(dW), stream_ptr())
+        return dx, dW, None, None
 
 
-def cfconv(x: Tensor, W: Tensor, graph: RadiusGraph) -> Tensor:
-    """out[i] = sum_{j in N(i)} x[j] * W[(j->i)]   (CFConv.propagate)."""
-    return _CFConvFn.apply(x, W, graph)
+def cfconv(x: Tensor, W: Tensor, graph: RadiusGraph, pre_cutoff_grad: bool = False) -> Tensor:
+    """out[i] = sum_{j in N(i)} x[j] * W[(j->i)]   (CFConv.propagate).
+    pre_cutoff_grad=True: the gradient returned for W is already multiplied by the cosine cutoff C(d_e), i.e. it is the
+    gradient w.r.t. the un-scaled filter (used with `filter_generate`, whose backward then skips its own scaling pass)."""
+    return _CFConvFn.apply(x, W, graph, pre_cutoff_grad)
 
 
 class _SegmentSumFn(torch.autograd.Function):

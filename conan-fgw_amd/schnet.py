@@ -95,7 +95,7 @@ class CFConv(torch.nn.Module):
             offset, coeff = rbf
             W = ops.filter_generate(graph, offset, coeff, self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias)
         x = ops.linear(x, self.lin1.weight)                                               # lin1 (no bias)
-        x = ops.cfconv(x, W, graph)                                                       # propagate: gather * W, scatter-add
+        x = ops.cfconv(x, W, graph, pre_cutoff_grad=not isinstance(rbf, Tensor))          # propagate: gather * W, scatter-add
         return x                                                                          # lin2 applied by the caller (fused with ssp)
 
 

@@ -73,7 +73,9 @@ int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int 
 
 /* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]) on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
  * W is torch.nn.Linear's [N,K] when w_kn == 0, or a [K,N] matrix when w_kn == 1 (used by the backward: dx = g @ W).
- * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2).  m_dev (nullable): device int holding the real row count
+ * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2), 2 = multiply by ssp'(.) evaluated from `residual`, which
+ * then holds the saved OUTPUT o of an ssp layer (ssp' = 1 - 0.5*exp(-o)) instead of being added: the fused backward
+ * dpre = (g @ W) * ssp'(pre).  m_dev (nullable): device int holding the real row count
  * (<= M) for edge-level calls whose row count is only known on the device; rows >= *m_dev are not touched.
  * Replaces the aten addmm + softplus of CFConv.lin1/lin2, InteractionBlock.mlp/.lin and the heads
  * (PyG SchNet, reached from schnet_no_sum.py:163-164,176-178,211-212,225-231). */
@@ -118,8 +120,10 @@ int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const in
 /* Backward: dx[j,:] = sum_{e: col[e]==j} W[e,:]*dout[tgt[e],:] (via the by-source CSR), dW[e,:] = x[col[e],:]*dout[tgt[e],:]. */
 int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt,
                        int num_atoms, int num_filters, float *dx, void *stream);
+/* dist (nullable) + cutoff: additionally multiply row e by 0.5*(cos(dist[e]*pi/cutoff)+1), i.e. return the gradient with
+ * respect to the filter BEFORE the cosine cutoff. */
 int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_dev, int max_edges, const int *col,
-                       const int *tgt, int num_filters, float *dW, void *stream);
+                       const int *tgt, int num_filters, const float *dist, float cutoff, float *dW, void *stream);
 
 /* Sum readout per conformer graph: out[g,:] = sum_{a in graph g} x[a,:]  (SumAggregation; schnet_no_sum.py:183,353). */
 int conan_segment_sum_fwd(const float *x, const int *graph_ptr, int num_graphs, int width, float *out, void *stream);

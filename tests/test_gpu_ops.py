@@ -131,15 +131,15 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
         for p in mlp.parameters():
             p.add_(0.1 * torch.randn_like(p))
     prm = [p.detach().to(dev).requires_grad_(True) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
-    W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm)
+    W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm)  # NB: backward expects a pre-cutoff gradient
     d = g.edge_weight().cpu().double()
     m64 = mlp.double()
     C = 0.5 * (torch.cos(d * math.pi / 10.0) + 1.0)
     ref = m64(gs(d)) * C[:, None]
     assert rel(W[:E].detach().cpu(), ref.detach()) < TOL
     gy = torch.randn(E, F_)
-    gfull = torch.zeros(g.max_edges, F_); gfull[:E] = gy
-    W.backward(gfull.to(dev))
+    gfull = torch.zeros(g.max_edges, F_); gfull[:E] = gy * C[:, None].float()      # the op consumes the PRE-cutoff gradient
+    W.backward(gfull.to(dev))                                                      # (what cfconv(..., pre_cutoff_grad=True) hands it)
     ref.backward(gy.double())
     for got, want in zip(prm, (m64[0].weight, m64[0].bias, m64[2].weight, m64[2].bias)):
         assert rel(got.grad.cpu(), want.grad) < 1e-5
