@@ -128,5 +128,64 @@ def main():
               "rel(h3d32,64)=%.2e rel(hbary32,64)=%.2e" % (rel(rec["r32_h_3d"], rec["r64_h_3d"]), rel(rec["r32_h_bary"], rec["r64_h_bary"])))
 
 
+def main_visnet():
+    """Same procedure for the ViSNet wrapper (visnet.py) over the vendored torch_geometric_visnet.py."""
+    install_standin()
+    import conan_fgw.src.model.graph_embeddings.visnet as ref_mod
+    from conan_fgw_amd.synthetic import make_batch
+    orig_fgw = ref_mod.fgw_barycenters
+
+    def fgw_cast(**kw):
+        dt = kw["Ys"][0].dtype
+        kw["Cs"] = [c.to(dt) for c in kw["Cs"]]
+        kw["ps"] = [q.to(dt) for q in kw["ps"]]
+        kw["lambdas"] = kw["lambdas"].to(dt)
+        kw["init_C"] = kw["init_C"].to(dt)
+        return orig_fgw(**kw)
+
+    ref_mod.fgw_barycenters = fgw_cast
+    cases = [("b2_k3_h32", "bace", 2, 3, 201, 32, None), ("b3_k5_h64", "esol", 3, 5, 202, 64, 6.0)]
+    for name, shape, B, K, seed, H, box in cases:
+        torch.manual_seed(5)
+        model = ref_mod.ViSNet(torch.device("cpu"), hidden_channels=H)            # common.py:542-546
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+        b = make_batch(shape, B, K, seed=seed, box=box)
+        z, pos, batch = torch.from_numpy(b.z), torch.from_numpy(b.pos), torch.from_numpy(b.batch)
+        rec = dict(z=b.z, pos=b.pos, batch=b.batch, K=np.int64(K), B=np.int64(B), hidden=np.int64(H))
+        for k, v in model.state_dict().items():
+            rec["sd:" + k] = v.numpy()
+        for tag, dt in (("r32", torch.float32), ("r64", torch.float64)):
+            m = model.double() if dt == torch.float64 else model.float()
+            p = pos.to(dt)
+            # the vendored ViSNet allocates with torch.zeros(...) (torch_geometric_visnet.py:342,868): its fp64 run needs the
+            # process-wide default dtype switched; no reference code is modified
+            torch.set_default_dtype(dt)
+            with torch.no_grad():
+                xs, vs = m.representation_model(z, p, batch)
+                out = m(z, p, batch)
+                h, hb = m.forward_3d_bary(z, p, batch)
+                h3d, hbary = m.forward_w_barycenter(z=z, pos=p, num_conformers=K, batch=batch)
+                ei, ew = m.interaction_graph(p, batch)
+                ei_loop, ew_loop, _ = m.representation_model.distance(p, batch)
+            f = (lambda a: a.detach().numpy().astype(np.float32)) if tag == "r32" else (lambda a: a.detach().numpy())
+            rec.update({f"{tag}_x": f(xs), f"{tag}_vec": f(vs), f"{tag}_forward": f(out), f"{tag}_h": f(h), f"{tag}_h_bary_nodes": f(hb),
+                        f"{tag}_h_3d": f(h3d), f"{tag}_h_bary": f(hbary)})
+            if tag == "r32":
+                rec["edge_index"], rec["edge_index_loop"] = ei.numpy(), ei_loop.numpy()
+        torch.set_default_dtype(torch.float32)
+        model.float()
+        np.savez_compressed(os.path.join(HERE, f"visnet_ref_{name}.npz"), **rec)
+        rel = lambda a, c: float(np.linalg.norm(a - c) / np.linalg.norm(c))
+        print("visnet", name, "atoms", len(b.z), "E_loop", rec["edge_index_loop"].shape[1], "params", sum(p.numel() for p in model.parameters()),
+              "rel(x32,64)=%.2e rel(h3d)=%.2e rel(hbary)=%.2e" % (rel(rec["r32_x"], rec["r64_x"]), rel(rec["r32_h_3d"], rec["r64_h_3d"]), rel(rec["r32_h_bary"], rec["r64_h_bary"])))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "visnet":
+        main_visnet()
+    else:
+        main()
+        main_visnet()
