@@ -45,6 +45,21 @@ SIGNATURES = {
     "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_float, _P, _P]),
     "conan_segment_sum_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_segment_sum_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "conan_visnet_edge_unit": (c_int, [_P, _P, _P, _P, c_int, _P, _P]),
+    "conan_visnet_expnormal": (c_int, [_P, _P, c_int, _P, _P, c_int, c_float, c_float, _P, _P]),
+    "conan_visnet_neighbor_scale": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "conan_concat2": (c_int, [_P, c_int, _P, c_int, c_ll, _P, _P]),
+    "conan_visnet_edge_embed": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_layernorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),
+    "conan_scale_channels": (c_int, [_P, _P, c_ll, c_int, _P, _P]),
+    "conan_visnet_vecdot": (c_int, [_P, c_int, c_int, _P, _P]),
+    "conan_visnet_attn_message": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_vec_aggregate": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_visnet_node_update": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_edge_update": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_spatial_norm": (c_int, [_P, c_int, c_int, _P, _P]),
+    "conan_visnet_gate": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_prior": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_fgw_densify": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
     "conan_fgw_densify_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P]),
     "conan_fgw_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),

@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
             if (gr >= M) continue;
             float v = acc[b][r] + bv;
             if (act == 1) v = ssp_f(v);
+            if (act == 3) v = v / (1.0f + __expf(-v));          // SiLU
             if (act == 2) v *= 1.0f - 0.5f * __expf(-residual[(size_t)gr * N + gc]);      // * ssp'(pre) from the saved output
             else if (residual) v += residual[(size_t)gr * N + gc];
             y[(size_t)gr * N + gc] = v;
@@ -201,6 +202,7 @@ __global__ void __launch_bounds__(256) k_linear_res(const float *__restrict__ x,
                     if (gr >= M) continue;
                     float v = acc[a][b][r] + bv;
                     if (act == 1) v = ssp_f(v);
+                    if (act == 3) v = v / (1.0f + __expf(-v));      // SiLU
                     if (act == 2) v *= 1.0f - 0.5f * __expf(-residual[(size_t)gr * N + gc]);   // * ssp'(pre) from the saved output
                     else if (residual) v += residual[(size_t)gr * N + gc];
                     y[(size_t)gr * N + gc] = v;
@@ -346,7 +348,7 @@ extern "C" {
 
 int conan_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N,
                      int w_kn, int act, const int *m_dev, float *y, void *stream) {
-    if (!x || !w || !y || M < 0 || K <= 0 || N <= 0 || act < 0 || act > 2 || (act == 2 && !residual)) return CONAN_E_BADARG;
+    if (!x || !w || !y || M < 0 || K <= 0 || N <= 0 || act < 0 || act > 3 || (act == 2 && !residual)) return CONAN_E_BADARG;
     if (M == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
     if (K <= 128 && N <= 128) {

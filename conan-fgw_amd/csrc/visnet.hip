@@ -1,0 +1,336 @@
+// ViSNet (vector-scalar interactive message passing) forward kernels for gfx950: everything of
+// conan_fgw/src/model/graph_embeddings/torch_geometric_visnet.py that is not a plain Linear layer
+// (those run on conan_linear_fwd).  Layouts: x [n,H]; vec [n,3,H]; edges = CSR by target INCLUDING self loops
+// (Distance(add_self_loops=True), :331-347); f_ij [E,H]; d_ij [E,3] unit vectors (0 for loops); r_ij [E] (0 for loops).
+// All kernels are HBM/L2-streaming gathers; node-side projections were hoisted out of the edge loops
+// (w_trg_proj / w_src_proj commute with the gather, :657-658), so the only edge-level GEMMs left are dk/dv/s/f_proj.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float cos_cutoff(float d, float cutoff) {      // CosineCutoff, :33-46
+    return d < cutoff ? 0.5f * (cosf(__fdiv_rn(d * 3.14159265358979323846f, cutoff)) + 1.0f) : 0.0f;
+}
+
+// d_ij = (pos[src]-pos[tgt]) / |.| for src != tgt, 0 for self loops   (:340-347, :864-866; Sphere(lmax=1) is the identity)
+__global__ void k_edge_unit(const float *__restrict__ pos, const int *__restrict__ col, const int *__restrict__ tgt,
+                            const int *__restrict__ ne_dev, int max_edges, float *__restrict__ dvec) {
+    const int E = min(*ne_dev, max_edges);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const int j = col[e], i = tgt[e];
+        float dx = pos[j * 3] - pos[i * 3], dy = pos[j * 3 + 1] - pos[i * 3 + 1], dz = pos[j * 3 + 2] - pos[i * 3 + 2];
+        if (i != j) { const float nrm = sqrtf(dx * dx + dy * dy + dz * dz); dx /= nrm; dy /= nrm; dz /= nrm; }
+        else { dx = dy = dz = 0.f; }
+        dvec[e * 3] = dx; dvec[e * 3 + 1] = dy; dvec[e * 3 + 2] = dz;
+    }
+}
+
+// ExpNormalSmearing (:100-111): cutoff(d) * exp(-beta_k * (exp(-alpha d) - mu_k)^2)
+__global__ void k_expnormal(const float *__restrict__ dist, const int *__restrict__ ne_dev, int max_edges, const float *__restrict__ means,
+                            const float *__restrict__ betas, int R, float alpha, float cutoff, float *__restrict__ out) {
+    const int E = min(*ne_dev, max_edges);
+    const long long n = (long long)E * R, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int e = (int)(t / R), k = (int)(t - (long long)e * R);
+        const float d = dist[e];
+        const float u = expf(alpha * (-d)) - means[k];
+        out[t] = cos_cutoff(d, cutoff) * expf(-betas[k] * (u * u));
+    }
+}
+
+// W[e,:] *= C(r_e) * [src != tgt]      (NeighborEmbedding, :408-415: loops removed, cosine cutoff)
+__global__ void k_ne_scale(float *__restrict__ W, const float *__restrict__ dist, const int *__restrict__ col, const int *__restrict__ tgt,
+                           const int *__restrict__ ne_dev, int max_edges, int H, float cutoff) {
+    const int E = min(*ne_dev, max_edges);
+    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int e = (int)(t / H);
+        W[t] *= (col[e] != tgt[e]) ? cos_cutoff(dist[e], cutoff) : 0.0f;
+    }
+}
+
+__global__ void k_concat2(const float *__restrict__ a, int Ha, const float *__restrict__ b, int Hb, long long rows, float *__restrict__ out) {
+    const int Ho = Ha + Hb;
+    const long long n = rows * Ho, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const long long r = t / Ho; const int c = (int)(t - r * Ho);
+        out[t] = c < Ha ? a[r * Ha + c] : b[r * Hb + (c - Ha)];
+    }
+}
+
+// f_ij = (x_i + x_j) * p_e    (EdgeEmbedding, :463-465)
+__global__ void k_edge_embed(const float *__restrict__ x, const float *__restrict__ p, const int *__restrict__ col, const int *__restrict__ tgt,
+                             const int *__restrict__ ne_dev, int max_edges, int H, float *__restrict__ f) {
+    const int E = min(*ne_dev, max_edges);
+    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int e = (int)(t / H), c = (int)(t - (long long)e * H);
+        f[t] = (x[(size_t)tgt[e] * H + c] + x[(size_t)col[e] * H + c]) * p[t];
+    }
+}
+
+// torch.nn.LayerNorm over the last dim (biased variance), one wavefront per row
+__global__ void __launch_bounds__(256) k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   int rows, int H, float eps, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) s += x[(size_t)r * H + c];
+        const float mean = wave_sum(s) / (float)H;
+        float v = 0.f;
+        for (int c = lane; c < H; c += 64) { const float d = x[(size_t)r * H + c] - mean; v += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
+        for (int c = lane; c < H; c += 64) out[(size_t)r * H + c] = (x[(size_t)r * H + c] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+__global__ void k_scale_channels(const float *__restrict__ v, const float *__restrict__ w, long long rows, int H, float *__restrict__ out) {
+    const long long n = rows * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = v[t] * w[t % H];
+}
+
+// vec_dot[a,c] = sum_sp vp[a,sp,c] * vp[a,sp,H+c]   with vp = vec_proj(vec) [n,3,3H]    (:606-607)
+__global__ void k_vecdot(const float *__restrict__ vp, int n, int H, float *__restrict__ out) {
+    const long long tot = (long long)n * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / H), c = (int)(t - (long long)a * H);
+        float s = 0.f;
+        for (int sp = 0; sp < 3; ++sp) { const float *row = vp + ((size_t)a * 3 + sp) * 3 * H; s += row[c] * row[H + c]; }
+        out[t] = s;
+    }
+}
+
+// Attention message + scalar aggregation (ViS_MP.message first half + aggregate, :632-645, :671):
+// attn_h = SiLU(sum_{c in head h} q_i k_j dk_e) * C(r_e);  vmsg_e = v_j * dv_e * attn_h;  xagg_i = sum_e vmsg_e.
+// One wavefront per target; lane l owns CPL consecutive channels; a head spans LPH lanes (xor-shuffle reduction).
+template <int CPL>
+__global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                  const float *__restrict__ dk, const float *__restrict__ dv, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col, const float *__restrict__ dist, float cutoff, int n, int H,
+                                                  int lph, float *__restrict__ vmsg, float *__restrict__ xagg) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int c0 = lane * CPL;
+    const bool on = c0 < H;
+    for (int i = wave; i < n; i += nw) {
+        float qi[CPL], acc[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) { qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f; acc[u] = 0.f; }
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const int j = col[e];
+            float part = 0.f, dvv[CPL], vj[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                const float kj = on ? k[(size_t)j * H + c0 + u] : 0.f;
+                const float dke = on ? dk[(size_t)e * H + c0 + u] : 0.f;
+                dvv[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
+                vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f;
+                part += qi[u] * kj * dke;
+            }
+            for (int o = 1; o < lph; o <<= 1) part += __shfl_xor(part, o, 64);
+            const float attn = silu_f(part) * cos_cutoff(dist[e], cutoff);
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                const float m = vj[u] * dvv[u] * attn;
+                if (on) vmsg[(size_t)e * H + c0 + u] = m;
+                acc[u] += m;
+            }
+        }
+        if (on)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) xagg[(size_t)i * H + c0 + u] = acc[u];
+    }
+}
+
+// Vector message + aggregation (:646-653, :672): vagg_i[sp] = sum_e vec_j[sp]*s1_e + s2_e*d_e[sp],  s = [s1|s2] in [E,2H]
+__global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__ vec, const float *__restrict__ s, const float *__restrict__ dvec,
+                                                       const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H,
+                                                       float *__restrict__ vagg) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < n; i += nw) {
+        for (int c = lane; c < H; c += 64) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                const int j = col[e];
+                const float s1 = s[(size_t)e * 2 * H + c], s2 = s[(size_t)e * 2 * H + H + c];
+                const float *vj = vec + (size_t)j * 3 * H;
+                a0 += vj[c] * s1 + s2 * dvec[e * 3];
+                a1 += vj[H + c] * s1 + s2 * dvec[e * 3 + 1];
+                a2 += vj[2 * H + c] * s1 + s2 * dvec[e * 3 + 2];
+            }
+            float *o = vagg + (size_t)i * 3 * H;
+            o[c] = a0; o[H + c] = a1; o[2 * H + c] = a2;
+        }
+    }
+}
+
+// Node update (:623-625, :873-881): x' = x + vec_dot*o2 + o3 ;  vec'[sp] = vec[sp] + vec3[sp]*o1 + vagg[sp]
+// o = o_proj(xagg) [n,3H] = [o1|o2|o3];  vec3 = vp[:, :, 2H:3H]
+__global__ void k_node_update(const float *__restrict__ x, const float *__restrict__ vec, const float *__restrict__ vdot, const float *__restrict__ o,
+                              const float *__restrict__ vp, const float *__restrict__ vagg, int n, int H, float *__restrict__ xo, float *__restrict__ veco) {
+    const long long tot = (long long)n * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / H), c = (int)(t - (long long)a * H);
+        const float o1 = o[(size_t)a * 3 * H + c], o2 = o[(size_t)a * 3 * H + H + c], o3 = o[(size_t)a * 3 * H + 2 * H + c];
+        xo[t] = x[t] + (vdot[t] * o2 + o3);
+        for (int sp = 0; sp < 3; ++sp) {
+            const size_t idx = ((size_t)a * 3 + sp) * H + c;
+            veco[idx] = vec[idx] + (vp[((size_t)a * 3 + sp) * 3 * H + 2 * H + c] * o1 + vagg[idx]);
+        }
+    }
+}
+
+// Edge update (:655-661): w1 = rej(wt[tgt], d), w2 = rej(ws[src], -d), f' = f + SiLU(f_proj(f)) * sum_sp w1*w2
+// wt = w_trg_proj(vec), ws = w_src_proj(vec) are node-level [n,3,H]; t = SiLU(f_proj(f_ij)) [E,H]
+__global__ void k_edge_update(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t, const float *__restrict__ dvec,
+                              const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H,
+                              const float *__restrict__ f, float *__restrict__ fo) {
+    const int E = min(*ne_dev, max_edges);
+    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+        const int e = (int)(q / H), c = (int)(q - (long long)e * H);
+        const float d0 = dvec[e * 3], d1 = dvec[e * 3 + 1], d2 = dvec[e * 3 + 2];
+        const float *a = wt + (size_t)tgt[e] * 3 * H, *b = ws + (size_t)col[e] * 3 * H;
+        const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c], b0 = b[c], b1 = b[H + c], b2 = b[2 * H + c];
+        const float pa = a0 * d0 + a1 * d1 + a2 * d2;                 // vec . d
+        const float pb = b0 * (-d0) + b1 * (-d1) + b2 * (-d2);        // vec . (-d)
+        const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
+        const float w20 = b0 - pb * (-d0), w21 = b1 - pb * (-d1), w22 = b2 - pb * (-d2);
+        fo[q] = f[q] + t[q] * (w10 * w20 + w11 * w21 + w12 * w22);
+    }
+}
+
+// |v|_2 over the spatial axis: [n,3,H] -> [n,H]      (GatedEquivariantBlock, :943)
+__global__ void k_spatial_norm(const float *__restrict__ v, int n, int H, float *__restrict__ out) {
+    const long long tot = (long long)n * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / H), c = (int)(t - (long long)a * H);
+        const float v0 = v[((size_t)a * 3) * H + c], v1 = v[((size_t)a * 3 + 1) * H + c], v2 = v[((size_t)a * 3 + 2) * H + c];
+        out[t] = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+    }
+}
+
+// u [n,2*O] = [x|gate] -> x_out = act ? SiLU(x) : x ;  v_out[sp] = gate * v2[sp]        (:950-959)
+__global__ void k_gate(const float *__restrict__ u, const float *__restrict__ v2, int n, int O, int act, float *__restrict__ xo, float *__restrict__ vo) {
+    const long long tot = (long long)n * O, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / O), c = (int)(t - (long long)a * O);
+        const float xv = u[(size_t)a * 2 * O + c], g = u[(size_t)a * 2 * O + O + c];
+        xo[t] = act ? silu_f(xv) : xv;
+        for (int sp = 0; sp < 3; ++sp) vo[((size_t)a * 3 + sp) * O + c] = g * v2[((size_t)a * 3 + sp) * O + c];
+    }
+}
+
+// out = x * std + atomref[z]     (visnet.py:148-156; Atomref :1051-1058)
+__global__ void k_prior(const float *__restrict__ x, const int64_t *__restrict__ z, const float *__restrict__ atomref, const float *__restrict__ stdp,
+                        int n, int O, float *__restrict__ out) {
+    const long long tot = (long long)n * O, stride = (long long)gridDim.x * blockDim.x;
+    const float sd = *stdp;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) out[t] = x[t] * sd + atomref[z[t / O]];
+}
+
+inline int nblk(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+}  // namespace
+
+#define VN_CHECK(cond) if (!(cond)) return CONAN_E_BADARG
+extern "C" {
+
+int conan_visnet_edge_unit(const float *pos, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, float *dvec, void *stream) {
+    VN_CHECK(pos && col && tgt && num_edges_dev && dvec && max_edges >= 0);
+    k_edge_unit<<<nblk(max_edges), 256, 0, as_stream(stream)>>>(pos, col, tgt, num_edges_dev, max_edges, dvec);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_expnormal(const float *dist, const int *num_edges_dev, int max_edges, const float *means, const float *betas, int num_rbf,
+                           float alpha, float cutoff, float *out, void *stream) {
+    VN_CHECK(dist && num_edges_dev && means && betas && out && num_rbf > 0);
+    k_expnormal<<<nblk((long long)max_edges * num_rbf), 256, 0, as_stream(stream)>>>(dist, num_edges_dev, max_edges, means, betas, num_rbf, alpha, cutoff, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_neighbor_scale(float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
+                                float cutoff, void *stream) {
+    VN_CHECK(W && dist && col && tgt && num_edges_dev && H > 0);
+    k_ne_scale<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows, float *out, void *stream) {
+    VN_CHECK(a && b && out && Ha > 0 && Hb > 0 && rows >= 0);
+    k_concat2<<<nblk(rows * (Ha + Hb)), 256, 0, as_stream(stream)>>>(a, Ha, b, Hb, rows, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_edge_embed(const float *x, const float *p, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
+                            float *f, void *stream) {
+    VN_CHECK(x && p && col && tgt && num_edges_dev && f && H > 0);
+    k_edge_embed<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_layernorm_fwd(const float *x, const float *gamma, const float *beta, int rows, int H, float eps, float *out, void *stream) {
+    VN_CHECK(x && gamma && beta && out && rows >= 0 && H > 0);
+    if (rows == 0) return CONAN_OK;
+    k_layernorm<<<nblk((long long)rows * 64), 256, 0, as_stream(stream)>>>(x, gamma, beta, rows, H, eps, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_scale_channels(const float *v, const float *w, long long rows, int H, float *out, void *stream) {
+    VN_CHECK(v && w && out && rows >= 0 && H > 0);
+    k_scale_channels<<<nblk(rows * H), 256, 0, as_stream(stream)>>>(v, w, rows, H, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_vecdot(const float *vp, int n, int H, float *out, void *stream) {
+    VN_CHECK(vp && out && n >= 0 && H > 0);
+    k_vecdot<<<nblk((long long)n * H), 256, 0, as_stream(stream)>>>(vp, n, H, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_attn_message(const float *q, const float *k, const float *v, const float *dk, const float *dv, const int *rowptr,
+                              const int *col, const float *dist, float cutoff, int n, int H, int num_heads, float *vmsg, float *xagg,
+                              void *stream) {
+    VN_CHECK(q && k && v && dk && dv && rowptr && col && dist && vmsg && xagg && n >= 0 && H > 0 && num_heads > 0 && H % num_heads == 0);
+    const int hd = H / num_heads;
+    const int cpl = H > 64 ? (H + 63) / 64 : 1;
+    if (H > 128 || (H > 64 && H != 128) || hd % cpl != 0) return CONAN_E_UNSUPPORTED;
+    const int lph = hd / cpl;
+    if (lph & (lph - 1)) return CONAN_E_UNSUPPORTED;
+    if (n == 0) return CONAN_OK;
+    if (cpl == 2) k_attn_msg<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, vmsg, xagg);
+    else k_attn_msg<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, vmsg, xagg);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_vec_aggregate(const float *vec, const float *s, const float *dvec, const int *rowptr, const int *col, int n, int H,
+                               float *vagg, void *stream) {
+    VN_CHECK(vec && s && dvec && rowptr && col && vagg && n >= 0 && H > 0);
+    if (n == 0) return CONAN_OK;
+    k_vec_aggregate<<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, vagg);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_node_update(const float *x, const float *vec, const float *vdot, const float *o, const float *vp, const float *vagg, int n,
+                             int H, float *x_out, float *vec_out, void *stream) {
+    VN_CHECK(x && vec && vdot && o && vp && vagg && x_out && vec_out && n >= 0 && H > 0);
+    k_node_update<<<nblk((long long)n * H), 256, 0, as_stream(stream)>>>(x, vec, vdot, o, vp, vagg, n, H, x_out, vec_out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_edge_update(const float *wt, const float *ws, const float *t, const float *dvec, const int *col, const int *tgt,
+                             const int *num_edges_dev, int max_edges, int H, const float *f, float *f_out, void *stream) {
+    VN_CHECK(wt && ws && t && dvec && col && tgt && num_edges_dev && f && f_out && H > 0);
+    k_edge_update<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, f, f_out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_spatial_norm(const float *v, int n, int H, float *out, void *stream) {
+    VN_CHECK(v && out && n >= 0 && H > 0);
+    k_spatial_norm<<<nblk((long long)n * H), 256, 0, as_stream(stream)>>>(v, n, H, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_gate(const float *u, const float *v2, int n, int out_channels, int scalar_activation, float *x_out, float *v_out, void *stream) {
+    VN_CHECK(u && v2 && x_out && v_out && n >= 0 && out_channels > 0);
+    k_gate<<<nblk((long long)n * out_channels), 256, 0, as_stream(stream)>>>(u, v2, n, out_channels, scalar_activation, x_out, v_out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_prior(const float *x, const int64_t *z, const float *atomref, const float *std_dev, int n, int out_channels, float *out,
+                       void *stream) {
+    VN_CHECK(x && z && atomref && std_dev && out && n >= 0 && out_channels > 0);
+    k_prior<<<nblk((long long)n * out_channels), 256, 0, as_stream(stream)>>>(x, z, atomref, std_dev, n, out_channels, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+
+}  // extern "C"

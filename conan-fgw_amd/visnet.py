@@ -1,0 +1,302 @@
+"""Drop-in ConAN `ViSNet` backbone for MI355X — forward path.
+
+Mirrors the reference's wrapper class (conan_fgw/src/model/graph_embeddings/visnet.py:82-288) and the vendored ViSNet it
+subclasses (torch_geometric_visnet.py:1061-1229) with the only configuration ConAN instantiates (common.py:542-546:
+lmax=1, 8 heads, 6 layers, 32 non-trainable RBFs, cutoff 5 A, vertex=False, vecnorm_type=None): same constructor
+`ViSNet(device, hidden_channels, cutoff=5.0)`, same methods, same parameter / buffer names, so the reference's
+`state_dict` loads with strict=True.  The nn modules are parameter containers; compute runs on libconan_fgw_hip.so.
+
+Round-1 scope: INFERENCE (forward) only — outputs carry no autograd graph; the ViSNet backward kernels are the next
+row of the build (the SchNet path has the full backward).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.nn import Embedding, LayerNorm, Linear
+
+from . import ops
+from ._lib import call, ptr, stream_ptr
+
+f32 = torch.float32
+
+
+def _lin(x: Tensor, m: Linear, act: int = 0, m_dev: Optional[Tensor] = None) -> Tensor:
+    x = x if x.is_contiguous() else x.contiguous()
+    M, K = x.shape
+    N = m.weight.shape[0]
+    y = torch.empty(M, N, dtype=f32, device=x.device)
+    call("conan_linear_fwd", ptr(x, f32), ptr(m.weight.detach().contiguous()), ptr(m.bias.detach()) if m.bias is not None else None, None,
+         M, K, N, 0, act, ptr(m_dev), ptr(y), stream_ptr())
+    return y
+
+
+SILU = 3
+
+
+class ExpNormalSmearing(torch.nn.Module):
+    def __init__(self, cutoff: float = 5.0, num_rbf: int = 32):
+        super().__init__()
+        self.cutoff, self.num_rbf, self.alpha = cutoff, num_rbf, 5.0 / cutoff
+        start = torch.exp(torch.tensor(-cutoff))
+        self.register_buffer("means", torch.linspace(start, 1, num_rbf))
+        self.register_buffer("betas", torch.tensor([(2 / num_rbf * (1 - start)) ** -2] * num_rbf))
+
+
+class VecLayerNorm(torch.nn.Module):
+    def __init__(self, hidden: int):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(hidden))
+
+
+class NeighborEmbedding(torch.nn.Module):
+    def __init__(self, hidden: int, num_rbf: int, cutoff: float, max_z: int = 100):
+        super().__init__()
+        self.embedding = Embedding(max_z, hidden)
+        self.distance_proj = Linear(num_rbf, hidden)
+        self.combine = Linear(hidden * 2, hidden)
+        torch.nn.init.xavier_uniform_(self.distance_proj.weight); self.distance_proj.bias.data.zero_()
+        torch.nn.init.xavier_uniform_(self.combine.weight); self.combine.bias.data.zero_()
+
+
+class EdgeEmbedding(torch.nn.Module):
+    def __init__(self, num_rbf: int, hidden: int):
+        super().__init__()
+        self.edge_proj = Linear(num_rbf, hidden)
+        torch.nn.init.xavier_uniform_(self.edge_proj.weight); self.edge_proj.bias.data.zero_()
+
+
+class ViS_MP(torch.nn.Module):
+    def __init__(self, num_heads: int, hidden: int, cutoff: float, last_layer: bool = False):
+        super().__init__()
+        self.num_heads, self.hidden_channels, self.last_layer, self.cutoff = num_heads, hidden, last_layer, cutoff
+        self.layernorm = LayerNorm(hidden)
+        self.vec_layernorm = VecLayerNorm(hidden)
+        self.vec_proj = Linear(hidden, hidden * 3, False)
+        self.q_proj, self.k_proj, self.v_proj = Linear(hidden, hidden), Linear(hidden, hidden), Linear(hidden, hidden)
+        self.dk_proj, self.dv_proj = Linear(hidden, hidden), Linear(hidden, hidden)
+        self.s_proj = Linear(hidden, hidden * 2)
+        if not last_layer:
+            self.f_proj = Linear(hidden, hidden)
+            self.w_src_proj = Linear(hidden, hidden, False)
+            self.w_trg_proj = Linear(hidden, hidden, False)
+        self.o_proj = Linear(hidden, hidden * 3)
+        for m in self.modules():
+            if isinstance(m, Linear):
+                torch.nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+
+class ViSNetBlock(torch.nn.Module):
+    def __init__(self, num_heads=8, num_layers=6, hidden_channels=128, num_rbf=32, max_z=100, cutoff=5.0, max_num_neighbors=32):
+        super().__init__()
+        self.num_heads, self.hidden_channels, self.cutoff, self.max_num_neighbors = num_heads, hidden_channels, cutoff, max_num_neighbors
+        self.embedding = Embedding(max_z, hidden_channels)
+        self.distance_expansion = ExpNormalSmearing(cutoff, num_rbf)
+        self.neighbor_embedding = NeighborEmbedding(hidden_channels, num_rbf, cutoff, max_z)
+        self.edge_embedding = EdgeEmbedding(num_rbf, hidden_channels)
+        self.vis_mp_layers = torch.nn.ModuleList([ViS_MP(num_heads, hidden_channels, cutoff, last_layer=(i == num_layers - 1))
+                                                  for i in range(num_layers)])
+        self.out_norm = LayerNorm(hidden_channels)
+        self.vec_out_norm = VecLayerNorm(hidden_channels)
+
+    @torch.no_grad()
+    def forward(self, z: Tensor, pos: Tensor, graph_ptr: Tensor, num_graphs: int):
+        """torch_geometric_visnet.py:843-886."""
+        H, dev, n, s = self.hidden_channels, z.device, z.shape[0], stream_ptr()
+        g = ops.RadiusGraph(pos, graph_ptr, num_graphs, self.cutoff, self.max_num_neighbors, loop=True)      # Distance, :331-347
+        md, ME = g.num_edges_dev, g.max_edges
+        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
+        dvec = new(ME, 3)
+        call("conan_visnet_edge_unit", ptr(pos.contiguous(), f32), ptr(g.col), ptr(g.tgt), ptr(md), ME, ptr(dvec), s)
+        de = self.distance_expansion
+        rbf = new(ME, de.num_rbf)
+        call("conan_visnet_expnormal", ptr(g.dist), ptr(md), ME, ptr(de.means), ptr(de.betas), de.num_rbf, de.alpha, de.cutoff, ptr(rbf), s)
+        x = ops.embedding(z, self.embedding.weight.detach(), None)
+        # NeighborEmbedding, :387-420
+        ne = self.neighbor_embedding
+        W = _lin(rbf, ne.distance_proj, 0, md)
+        call("conan_visnet_neighbor_scale", ptr(W), ptr(g.dist), ptr(g.col), ptr(g.tgt), ptr(md), ME, H, ne_cutoff(self), s)
+        xn = ops.cfconv(ops.embedding(z, ne.embedding.weight.detach(), None), W, g)
+        cat = new(n, 2 * H)
+        call("conan_concat2", ptr(x), H, ptr(xn), H, n, ptr(cat), s)
+        x = _lin(cat, ne.combine)
+        vec = torch.zeros(n, 3, H, dtype=f32, device=dev)                                                    # :868-870
+        # EdgeEmbedding, :463-465
+        p = _lin(rbf, self.edge_embedding.edge_proj, 0, md)
+        f = new(ME, H)
+        call("conan_visnet_edge_embed", ptr(x), ptr(p), ptr(g.col), ptr(g.tgt), ptr(md), ME, H, ptr(f), s)
+        for layer in self.vis_mp_layers:
+            x, vec, f = self._vis_mp(layer, x, vec, f, g, dvec)
+        xo = new(n, H)
+        call("conan_layernorm_fwd", ptr(x), ptr(self.out_norm.weight.detach()), ptr(self.out_norm.bias.detach()), n, H, self.out_norm.eps, ptr(xo), s)
+        vo = new(n, 3, H)
+        call("conan_scale_channels", ptr(vec), ptr(self.vec_out_norm.weight), 3 * n, H, ptr(vo), s)
+        return xo, vo
+
+    def _vis_mp(self, L: ViS_MP, x, vec, f, g, dvec):
+        """ViS_MP.forward / message / aggregate / edge_update, torch_geometric_visnet.py:579-673."""
+        H, n, dev, s = self.hidden_channels, x.shape[0], x.device, stream_ptr()
+        md, ME = g.num_edges_dev, g.max_edges
+        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
+        xl = new(n, H)
+        call("conan_layernorm_fwd", ptr(x), ptr(L.layernorm.weight.detach()), ptr(L.layernorm.bias.detach()), n, H, L.layernorm.eps, ptr(xl), s)
+        vl = new(n, 3, H)
+        call("conan_scale_channels", ptr(vec), ptr(L.vec_layernorm.weight), 3 * n, H, ptr(vl), s)
+        q, k, v = _lin(xl, L.q_proj), _lin(xl, L.k_proj), _lin(xl, L.v_proj)
+        dk, dv = _lin(f, L.dk_proj, SILU, md), _lin(f, L.dv_proj, SILU, md)
+        vp = _lin(vl.view(3 * n, H), L.vec_proj)                                   # [3n, 3H] = [vec1|vec2|vec3]
+        vdot = new(n, H)
+        call("conan_visnet_vecdot", ptr(vp), n, H, ptr(vdot), s)
+        vmsg, xagg = new(ME, H), new(n, H)
+        call("conan_visnet_attn_message", ptr(q), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(g.rowptr), ptr(g.col), ptr(g.dist), L.cutoff, n, H,
+             L.num_heads, ptr(vmsg), ptr(xagg), s)
+        sact = _lin(vmsg, L.s_proj, SILU, md)                                      # [E, 2H] = [s1|s2]
+        vagg = new(n, 3, H)
+        call("conan_visnet_vec_aggregate", ptr(vl), ptr(sact), ptr(dvec), ptr(g.rowptr), ptr(g.col), n, H, ptr(vagg), s)
+        o = _lin(xagg, L.o_proj)
+        xo, veco = new(n, H), new(n, 3, H)
+        call("conan_visnet_node_update", ptr(x), ptr(vec), ptr(vdot), ptr(o), ptr(vp), ptr(vagg), n, H, ptr(xo), ptr(veco), s)
+        if L.last_layer:
+            return xo, veco, f
+        wt, ws = _lin(vl.view(3 * n, H), L.w_trg_proj), _lin(vl.view(3 * n, H), L.w_src_proj)      # node-level: Linear commutes with the gather
+        t = _lin(f, L.f_proj, SILU, md)
+        fo = new(ME, H)
+        call("conan_visnet_edge_update", ptr(wt), ptr(ws), ptr(t), ptr(dvec), ptr(g.col), ptr(g.tgt), ptr(md), ME, H, ptr(f), ptr(fo), s)
+        return xo, veco, fo
+
+
+def ne_cutoff(block: ViSNetBlock) -> float:
+    return float(block.cutoff)
+
+
+class GatedEquivariantBlock(torch.nn.Module):
+    def __init__(self, hidden: int, out: int, scalar_activation: bool = False):
+        super().__init__()
+        self.hidden, self.out_channels, self.scalar_activation = hidden, out, scalar_activation
+        self.vec1_proj = Linear(hidden, hidden, bias=False)
+        self.vec2_proj = Linear(hidden, out, bias=False)
+        self.update_net = torch.nn.Sequential(Linear(hidden * 2, hidden), torch.nn.SiLU(), Linear(hidden, out * 2))
+        for m in (self.vec1_proj, self.vec2_proj, self.update_net[0], self.update_net[2]):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                m.bias.data.zero_()
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, v: Tensor):
+        """torch_geometric_visnet.py:942-960."""
+        n, Hh, O, dev, s = x.shape[0], self.hidden, self.out_channels, x.device, stream_ptr()
+        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
+        v1 = _lin(v.view(3 * n, Hh), self.vec1_proj)
+        v1n = new(n, Hh)
+        call("conan_visnet_spatial_norm", ptr(v1), n, Hh, ptr(v1n), s)
+        v2 = _lin(v.view(3 * n, Hh), self.vec2_proj)                               # [3n, O]
+        cat = new(n, 2 * Hh)
+        call("conan_concat2", ptr(x), Hh, ptr(v1n), Hh, n, ptr(cat), s)
+        u = _lin(_lin(cat, self.update_net[0], SILU), self.update_net[2])          # [n, 2*O]
+        xo, vo = new(n, O), new(n, 3, O)
+        call("conan_visnet_gate", ptr(u), ptr(v2), n, O, int(self.scalar_activation), ptr(xo), ptr(vo), s)
+        return xo, vo
+
+
+class EquivariantScalar(torch.nn.Module):
+    def __init__(self, hidden: int, out: int):
+        super().__init__()
+        self.output_network = torch.nn.ModuleList([GatedEquivariantBlock(hidden, hidden // 2, True), GatedEquivariantBlock(hidden // 2, out, False)])
+
+    def pre_reduce(self, x: Tensor, v: Tensor) -> Tensor:
+        for layer in self.output_network:
+            x, v = layer(x, v)
+        return x                                                                    # "+ v.sum() * 0" (:1014) is an autograd anchor only
+
+
+class Atomref(torch.nn.Module):
+    def __init__(self, max_z: int = 100):
+        super().__init__()
+        self.register_buffer("initial_atomref", torch.zeros(max_z, 1))
+        self.atomref = Embedding(max_z, 1)
+        self.atomref.weight.data.copy_(self.initial_atomref)
+
+
+class ViSNet(torch.nn.Module):
+    FEATURE_SHIFT = 1.0          # visnet.py:50
+    READOUT_MODE = 1             # NaN guard + column L2 normalisation, visnet.py:233-242
+
+    def __init__(self, device, hidden_channels: int, cutoff: float = 5.0):
+        super().__init__()
+        self.device = device
+        self.hidden_channels = hidden_channels
+        self.cutoff = cutoff
+        self.derivative = False
+        self.reduce_op = "sum"
+        self.representation_model = ViSNetBlock(hidden_channels=hidden_channels)    # keeps ViSNet's default cutoff 5.0 (visnet.py:84-86)
+        self.output_model = EquivariantScalar(hidden_channels, hidden_channels // 2)
+        self.prior_model = Atomref()
+        self.output_model_bary = EquivariantScalar(hidden_channels, hidden_channels // 2)
+        self.prior_model_bary = Atomref()
+        self.register_buffer("mean", torch.tensor(0.0))
+        self.register_buffer("std", torch.tensor(1.0))
+        from .schnet import RadiusInteractionGraph
+        self.interaction_graph = RadiusInteractionGraph(cutoff, max_num_neighbors=32)   # FGW adjacency, no self loops (visnet.py:90)
+
+    # ---------------------------------------------------------------------------------------------- helpers
+    def _prep(self, z: Tensor, batch: Optional[Tensor], num_graphs: Optional[int]):
+        if not z.is_cuda:
+            raise RuntimeError("ViSNet (MI355X) runs on the GPU only: move the inputs to the device; there is no CPU fallback")
+        batch = torch.zeros_like(z) if batch is None else batch
+        if num_graphs is None:
+            num_graphs = int(batch[-1].item()) + 1
+        return batch, ops.graph_ptr_from_batch(batch, num_graphs), num_graphs
+
+    @torch.no_grad()
+    def _head(self, xs, vs, z, output_model, prior):
+        x = output_model.pre_reduce(xs, vs)
+        out = torch.empty_like(x)
+        call("conan_visnet_prior", ptr(x), ptr(z.contiguous(), torch.int64), ptr(prior.atomref.weight.detach().contiguous()), ptr(self.std),
+             x.shape[0], x.shape[1], ptr(out), stream_ptr())
+        return out
+
+    # ---------------------------------------------------------------------------------------------- reference API
+    @torch.no_grad()
+    def forward(self, z: Tensor, pos: Tensor, batch: Tensor, num_graphs: Optional[int] = None) -> Tensor:
+        """visnet.py:93-122: per-conformer sum of the scalar head."""
+        batch, gp, G = self._prep(z, batch, num_graphs)
+        xs, vs = self.representation_model(z, pos, gp, G)
+        return ops.segment_sum(self._head(xs, vs, z, self.output_model, self.prior_model), gp, G)
+
+    @torch.no_grad()
+    def forward_3d_bary(self, z: Tensor, pos: Tensor, batch: Tensor, num_graphs: Optional[int] = None):
+        """visnet.py:124-158: two per-atom heads from the shared representation."""
+        batch, gp, G = self._prep(z, batch, num_graphs)
+        xs, vs = self.representation_model(z, pos, gp, G)
+        return self._head(xs, vs, z, self.output_model, self.prior_model), self._head(xs, vs, z, self.output_model_bary, self.prior_model_bary)
+
+    @torch.no_grad()
+    def _compute_barycenter(self, node_feature: Tensor, edge_index, batch: Tensor, batch_size: int, num_conformers: int,
+                            max_nodes: Optional[int] = None):
+        """visnet.py:160-249 (shift +1.0, NaN guard, column normalisation)."""
+        from .schnet import _graph_from_edge_index
+        K, G = num_conformers, batch_size * num_conformers
+        graph = edge_index if isinstance(edge_index, ops.RadiusGraph) else _graph_from_edge_index(edge_index, batch, G)
+        if max_nodes is None:
+            gp = graph.graph_ptr
+            max_nodes = int((gp[1:] - gp[:-1]).max().item())
+        Ys, Cs = ops.fgw_densify(node_feature, graph, max_nodes, self.FEATURE_SHIFT)
+        N, d = max_nodes, node_feature.shape[1]
+        Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), Cs.view(batch_size, K, N, N))
+        self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs)
+        return ops.segment_sum(node_feature, graph.graph_ptr, G), ops.fgw_readout(Y, K, self.READOUT_MODE)
+
+    @torch.no_grad()
+    def forward_w_barycenter(self, z: Tensor, pos: Tensor, num_conformers: int, batch: Optional[Tensor] = None, data_batch=None,
+                             max_iter: int = 100, epsilon: float = 0.1, num_graphs: Optional[int] = None, max_nodes: Optional[int] = None):
+        """visnet.py:251-288."""
+        batch, gp, G = self._prep(z, batch, num_graphs)
+        h_3d, h_bary = self.forward_3d_bary(z, pos, batch, num_graphs=G)
+        graph = self.interaction_graph.csr(pos, gp, G)                              # visnet.py:276
+        _, h_bary = self._compute_barycenter(h_bary, graph, batch, G // num_conformers, num_conformers, max_nodes=max_nodes)
+        return ops.segment_sum(h_3d, gp, G), h_bary

@@ -73,7 +73,7 @@ int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int 
 
 /* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]) on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
  * W is torch.nn.Linear's [N,K] when w_kn == 0, or a [K,N] matrix when w_kn == 1 (used by the backward: dx = g @ W).
- * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2), 2 = multiply by ssp'(.) evaluated from `residual`, which
+ * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2), 3 = SiLU, 2 = multiply by ssp'(.) evaluated from `residual`, which
  * then holds the saved OUTPUT o of an ssp layer (ssp' = 1 - 0.5*exp(-o)) instead of being added: the fused backward
  * dpre = (g @ W) * ssp'(pre).  m_dev (nullable): device int holding the real row count
  * (<= M) for edge-level calls whose row count is only known on the device; rows >= *m_dev are not touched.
@@ -129,6 +129,56 @@ int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_d
 int conan_segment_sum_fwd(const float *x, const int *graph_ptr, int num_graphs, int width, float *out, void *stream);
 /* dx[a,:] = dout[graph(a),:] */
 int conan_segment_sum_bwd(const float *dout, const int *graph_ptr, int num_graphs, int width, float *dx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------- ViSNet (forward)
+ * Everything of the vendored ViSNet (conan_fgw/src/model/graph_embeddings/torch_geometric_visnet.py) that is not a plain
+ * Linear layer; Linear layers run on conan_linear_fwd (act 3 = SiLU).  Edges: CSR by target INCLUDING self loops
+ * (Distance(add_self_loops=True), :331-347 => conan_radius_graph_csr(..., loop=1)); vec tensors are [n,3,H]. */
+
+/* d_ij[e,3] = (pos[src]-pos[tgt])/|.|, 0 for self loops (:340-347, :864-866; Sphere(lmax=1) = identity, :132-189). */
+int conan_visnet_edge_unit(const float *pos, const int *col, const int *tgt, const int *num_edges_dev, int max_edges,
+                           float *dvec, void *stream);
+/* ExpNormalSmearing (:100-111): out[e,k] = C(d_e) * exp(-betas[k] * (exp(-alpha d_e) - means[k])^2), C = 0 for d >= cutoff. */
+int conan_visnet_expnormal(const float *dist, const int *num_edges_dev, int max_edges, const float *means,
+                           const float *betas, int num_rbf, float alpha, float cutoff, float *out, void *stream);
+/* NeighborEmbedding (:408-415): W[e,:] *= C(d_e) for src != tgt, 0 for self loops (in place). */
+int conan_visnet_neighbor_scale(float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev,
+                                int max_edges, int H, float cutoff, void *stream);
+/* out[r,:] = [a[r,:Ha] | b[r,:Hb]]   (torch.cat(dim=1), :419, :945). */
+int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows, float *out, void *stream);
+/* EdgeEmbedding (:463-465): f[e,:] = (x[tgt] + x[src]) * p[e,:]. */
+int conan_visnet_edge_embed(const float *x, const float *p, const int *col, const int *tgt, const int *num_edges_dev,
+                            int max_edges, int H, float *f, void *stream);
+/* torch.nn.LayerNorm over the last dimension (:583, :883). */
+int conan_layernorm_fwd(const float *x, const float *gamma, const float *beta, int rows, int H, float eps, float *out,
+                        void *stream);
+/* out[r,c] = v[r,c] * w[c]   (VecLayerNorm with norm_type=None, :262-268). */
+int conan_scale_channels(const float *v, const float *w, long long rows, int H, float *out, void *stream);
+/* vec_dot[a,c] = sum_sp vp[a,sp,c] * vp[a,sp,H+c], vp = vec_proj(vec) [n,3,3H] (:605-607). */
+int conan_visnet_vecdot(const float *vp, int n, int H, float *out, void *stream);
+/* ViS_MP.message (scalar half) + aggregate (:632-645, :671): attn_h = SiLU(sum_{c in head} q_i k_j dk_e) * C(r_e);
+ * vmsg[e,:] = v_j * dv_e * attn_h;  xagg[i,:] = sum_{e in row i} vmsg[e,:].  H <= 64 or H == 128. */
+int conan_visnet_attn_message(const float *q, const float *k, const float *v, const float *dk, const float *dv,
+                              const int *rowptr, const int *col, const float *dist, float cutoff, int n, int H,
+                              int num_heads, float *vmsg, float *xagg, void *stream);
+/* ViS_MP.message (vector half) + aggregate (:646-653, :672): vagg[i,sp,:] = sum_e vec[src,sp,:]*s1_e + s2_e*d_e[sp], s=[s1|s2]. */
+int conan_visnet_vec_aggregate(const float *vec, const float *s, const float *dvec, const int *rowptr, const int *col,
+                               int n, int H, float *vagg, void *stream);
+/* Residual node update (:621-625, :873-881): x' = x + vec_dot*o2 + o3; vec' = vec + vec3*o1 + vagg; o=[o1|o2|o3], vec3=vp[:,:,2H:]. */
+int conan_visnet_node_update(const float *x, const float *vec, const float *vdot, const float *o, const float *vp,
+                             const float *vagg, int n, int H, float *x_out, float *vec_out, void *stream);
+/* ViS_MP.edge_update (:655-661) with the node-side projections hoisted: wt = w_trg_proj(vec), ws = w_src_proj(vec) [n,3,H],
+ * t = SiLU(f_proj(f)) [E,H]:  f'[e] = f[e] + t[e] * sum_sp rej(wt[tgt],d)[sp] * rej(ws[src],-d)[sp]. */
+int conan_visnet_edge_update(const float *wt, const float *ws, const float *t, const float *dvec, const int *col,
+                             const int *tgt, const int *num_edges_dev, int max_edges, int H, const float *f, float *f_out,
+                             void *stream);
+/* GatedEquivariantBlock pieces (:942-960): |v|_2 over the spatial axis; gated split of update_net's output. */
+int conan_visnet_spatial_norm(const float *v, int n, int H, float *out, void *stream);
+int conan_visnet_gate(const float *u, const float *v2, int n, int out_channels, int scalar_activation, float *x_out,
+                      float *v_out, void *stream);
+/* x * std + atomref[z]   (visnet.py:147-156; Atomref :1051-1058; std is a device scalar). */
+int conan_visnet_prior(const float *x, const int64_t *z, const float *atomref, const float *std_dev, int n,
+                       int out_channels, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------- FGW barycenter */
 

@@ -65,3 +65,15 @@ def test_synthetic_batches_are_deterministic_and_shaped():
     for name in CONFIGS:
         c = make_config(name, num_molecules=2)
         assert c.num_conformers == CONFIGS[name][2]
+
+
+def test_visnet_state_dict_matches_reference_class():
+    from conan_fgw_amd.visnet import ViSNet
+    g = np.load(golden_files("visnet_ref_b2_k3_h32")[0])
+    m = ViSNet(torch.device("cpu"), hidden_channels=32)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd:")}
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in ViSNet(torch.device("cpu"), hidden_channels=128).parameters()) == 1798472
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.ones(3, dtype=torch.long), torch.rand(3, 3), torch.zeros(3, dtype=torch.long))
