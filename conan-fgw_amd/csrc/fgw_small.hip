@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
             psum[w * 64 + lane] = sm;
             __syncthreads();
             sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
-            v_l = logb - (log(sm) + mx);
+            v_l = logb - (log_acc(sm) + mx);
             vs[w * 64 + lane] = v_l;                                   // private per-wave copy: read back by this wave only
             // u_i = loga_i - logsumexp_j(Mr_ij + v_j)          layout B
             mx = -1.0e300;
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
             psum[w * 64 + lane] = sm;
             __syncthreads();
             sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
-            u_l = loga - (log(sm) + mx);
+            u_l = loga - (log_acc(sm) + mx);
             us[w * 64 + lane] = u_l;
             if (ii % 10 == 0) {                                        // marginal violation (sinkhorn.py:418-433)
                 double cs = 0.0;

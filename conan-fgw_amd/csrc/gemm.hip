@@ -114,16 +114,32 @@ __global__ void __launch_bounds__(256) k_linear_res(const float *__restrict__ x,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
-    // stage W^T once
-    if (w_kn) {
-        for (int t = tid; t < Kp * BN; t += 256) {
-            const int k = t / BN, n = t % BN;
-            ws[k * WP + n] = (k < K && n < N) ? w[(size_t)k * N + n] : 0.f;
-        }
-    } else {
-        for (int t = tid; t < Kp * BN; t += 256) {
-            const int n = t / Kp, k = t % Kp;
-            ws[k * WP + n] = (k < K && n < N) ? w[(size_t)n * K + k] : 0.f;
+    // stage W^T once: 8 independent global loads in flight per thread before the LDS writes (the loop is latency-bound
+    // otherwise: one L2 round trip per element, which dominates node-level calls that process a single tile)
+    {
+        const int total = Kp * BN;
+        for (int t0 = tid; t0 < total; t0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256;
+                float val = 0.f;
+                if (t < total) {
+                    int k, n;
+                    if (w_kn) { k = t / BN; n = t - k * BN; if (k < K && n < N) val = w[(size_t)k * N + n]; }
+                    else { n = t / Kp; k = t - n * Kp; if (k < K && n < N) val = w[(size_t)n * K + k]; }
+                }
+                v[u] = val;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256;
+                if (t < total) {
+                    int k, n;
+                    if (w_kn) { k = t / BN; n = t - k * BN; } else { n = t / Kp; k = t - n * Kp; }
+                    ws[k * WP + n] = v[u];
+                }
+            }
         }
     }
     const int chunks = Kp / BK;
@@ -189,6 +205,22 @@ __global__ void __launch_bounds__(256) k_linear_res(const float *__restrict__ x,
                 __syncthreads();
             }
         }
+        // epilogue.  The residual / saved-output operand is fetched for the whole fragment FIRST (independent loads in
+        // flight together); interleaving each load with its store serialises 32*NBW HBM round trips per thread.
+        f32x16 rv[2][NBW];
+        if (residual) {
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                const int gc = wn * 32 * NBW + b * 32 + l31;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int gr = row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        rv[a][b][r] = (gc < N && gr < M) ? residual[(size_t)gr * N + gc] : 0.f;
+                    }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
             const int gc = wn * 32 * NBW + b * 32 + l31;
@@ -203,8 +235,8 @@ __global__ void __launch_bounds__(256) k_linear_res(const float *__restrict__ x,
                     float v = acc[a][b][r] + bv;
                     if (act == 1) v = ssp_f(v);
                     if (act == 3) v = v / (1.0f + __expf(-v));      // SiLU
-                    if (act == 2) v *= 1.0f - 0.5f * __expf(-residual[(size_t)gr * N + gc]);   // * ssp'(pre) from the saved output
-                    else if (residual) v += residual[(size_t)gr * N + gc];
+                    if (act == 2) v *= 1.0f - 0.5f * __expf(-rv[a][b][r]);   // * ssp'(pre) from the saved output
+                    else if (residual) v += rv[a][b][r];
                     y[(size_t)gr * N + gc] = v;
                 }
         }
@@ -249,9 +281,12 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum = 0.f;       // thread t < 128 accumulates the bias gradient of column n0 + t (blockIdx.z == 0 only)
     const bool wave_active = (n0 + wm * 64 < N) && (k0 + wn * 64 < K);
-    for (int r0 = r_begin; r0 < r_end; r0 += WG_CHUNK) {
-        // stage 32 x 128 of g and of x (float4 per thread, 4 passes each)
-        for (int t = tid; t < WG_CHUNK * (WG_TILE / 4); t += 256) {
+    // software pipeline: the next 32-row chunk is fetched into registers while the current one is multiplied
+    float4 pg[4], px[4];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + u * 256;
             const int r = t >> 5, c4 = (t & 31) * 4;
             const int gr = r0 + r;
             float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
@@ -268,10 +303,21 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__
                     gv = make_float4(tg[0], tg[1], tg[2], tg[3]); xv = make_float4(tx[0], tx[1], tx[2], tx[3]);
                 }
             }
-            *reinterpret_cast<float4 *>(&gs[r * WG_TILE + c4]) = gv;
-            *reinterpret_cast<float4 *>(&xs[r * WG_TILE + c4]) = xv;
+            pg[u] = gv; px[u] = xv;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += WG_CHUNK) {
+        __syncthreads();                                   // previous chunk fully consumed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + u * 256;
+            const int r = t >> 5, c4 = (t & 31) * 4;
+            *reinterpret_cast<float4 *>(&gs[r * WG_TILE + c4]) = pg[u];
+            *reinterpret_cast<float4 *>(&xs[r * WG_TILE + c4]) = px[u];
         }
         __syncthreads();
+        if (r0 + WG_CHUNK < r_end) fetch(r0 + WG_CHUNK);
         if (blockIdx.z == 0 && tid < WG_TILE) {
             float s = 0.f;
 #pragma unroll 8
@@ -292,7 +338,6 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
-        __syncthreads();
     }
     float *slab = slabs + (size_t)slice * N * K;
     if (wave_active) {
