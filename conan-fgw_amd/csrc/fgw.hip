@@ -98,15 +98,14 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     }
     __syncthreads();
     // ---- base = alpha*2*constC + (1-alpha)*M,  M = clamp(|y_i|^2 + |z_j|^2 - 2 y_i.z_j, 0)   (utils.py:154-171, bregman.py:124-125)
+    // dot(Y_i, Z_j) on fp64 MFMA straight from global memory (L2-resident), then the elementwise assembly
+    if (!y_zero)
+        mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
+               [&](int i, int j, double v) { base[i * P + j] = v; });
+    __syncthreads();
     for (int t = tid; t < NN; t += FGW_THREADS) {
         const int i = t / N, j = t - i * N;
-        double dot = 0.0;
-        if (!y_zero) {                                          // Y == 0 on the first outer iteration unless init_Y is given
-            const double *yi = Y + (size_t)i * d;
-            const float *zj = Z + (size_t)j * d;
-            for (int c = 0; c < d; ++c) dot += yi[c] * (double)zj[c];
-        }
-        double m = -2.0 * dot;                                  // utils.py:159-161
+        double m = -2.0 * (y_zero ? 0.0 : base[i * P + j]);    // utils.py:159-161
         m += y2a[i]; m += z2a[j];
         m = m > 0.0 ? m : 0.0;                                  // :163
         base[i * P + j] = 2.0 * alpha * (ra[i] + rb[j]) + (1.0 - alpha) * m;
@@ -117,22 +116,13 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     int cpt = 0, sk_total = 0;
     double err = 1.0;
     while (err > (double)prm.inner_tol && cpt < prm.max_iter) {
-        // A = C1 @ T
-        for (int t = tid; t < NN; t += FGW_THREADS) {
-            const int i = t / N, j = t - i * N;
-            double a = 0.0;
-            for (int k = 0; k < N; ++k) a += C1[i * N + k] * (double)Tl[k * P + j];
-            Al[i * P + j] = a;
-        }
+        // A = C1 @ T ; G = A @ (2 C2)^T on fp64 MFMA ; tens = base - 2*alpha*G ; Mr = -tens/eps
+        // (utils.py:48-64, bregman.py:124-125, sinkhorn.py:388)
+        mm_f64(N, N, N, [&](int i, int k) { return C1[i * N + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
+               [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        // G = A @ (2 C2)^T ; tens = base - 2*alpha*G ; Mr = -tens/eps        (utils.py:48-64, bregman.py:124-125, sinkhorn.py:388)
-        for (int t = tid; t < NN; t += FGW_THREADS) {
-            const int i = t / N, j = t - i * N;
-            double g = 0.0;
-            for (int k = 0; k < N; ++k) g += Al[i * P + k] * (2.0 * (double)C2[j * N + k]);
-            const double tens = base[i * P + j] - 2.0 * alpha * g;
-            Mr[i * P + j] = -tens / eps;
-        }
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return 2.0 * (double)C2[j * N + k]; },
+               [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
         for (int i = tid; i < N; i += FGW_THREADS) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
         __syncthreads();
         // ---- log-domain Sinkhorn (sinkhorn.py:413-433)
@@ -241,20 +231,12 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update(
             const float *Ts = Tw + ((size_t)b * K + s) * NN;
             const float *C2 = Cs + ((size_t)b * K + s) * NN;
             __syncthreads();
-            for (int t = tid; t < NN; t += FGW_THREADS) {       // TC = T_s @ Cs_s
-                const int i = t / N, j = t - i * N;
-                double a = 0.0;
-                for (int k = 0; k < N; ++k) a += (double)Ts[i * N + k] * (double)C2[k * N + j];
-                TC[i * P + j] = a;
-            }
+            mm_f64(N, N, N, [&](int i, int k) { return (double)Ts[i * N + k]; }, [&](int k, int j) { return (double)C2[k * N + j]; },
+                   [&](int i, int j, double v) { TC[i * P + j] = v; });                 // TC = T_s @ Cs_s
             __syncthreads();
             const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
-            for (int t = tid; t < NN; t += FGW_THREADS) {       // Cacc += lam * TC @ T_s^T
-                const int i = t / N, j = t - i * N;
-                double a = 0.0;
-                for (int k = 0; k < N; ++k) a += TC[i * P + k] * (double)Ts[j * N + k];
-                Cacc[i * P + j] += lam * a;
-            }
+            mm_f64(N, N, N, [&](int i, int k) { return TC[i * P + k]; }, [&](int k, int j) { return (double)Ts[j * N + k]; },
+                   [&](int i, int j, double v) { Cacc[i * P + j] += lam * v; });         // Cacc += lam * TC @ T_s^T
         }
         __syncthreads();
         double *Cb = Cw + (size_t)b * NN;

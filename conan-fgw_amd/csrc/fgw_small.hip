@@ -15,49 +15,6 @@
 
 namespace {
 
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// exp(x) for x <= 0 in the log-sum-exp loops: x is a difference formed in fp64, so converting it to fp32 keeps a relative
-// precision of 2^-24 in the exponent; terms below e^-80 cannot change an fp64 sum whose largest term is 1.
-__device__ __forceinline__ double exp_lse(double x) {
-    const float f = (float)x;
-    return (double)__builtin_amdgcn_exp2f(f * 1.44269504088896340736f);
-}
-
-// D[M x Nn] = X[M x Kd] @ W[Kd x Nn] with fp64 MFMA (v_mfma_f64_16x16x4_f64) on the 16-aligned core and plain FMA loops on
-// the ragged border rows/columns (no padding of the problem).  X(i,k), W(k,j) are element readers, st(i,j,v) the writer.
-// Fragment layout: A lane l -> X[i0 + (l&15)][k0 + (l>>4)], B lane l -> W[k0 + (l>>4)][j0 + (l&15)],
-// D reg q lane l -> row i0 + (l>>4) + 4q, col j0 + (l&15).   Workgroup-collective; no barrier inside.
-template <class FX, class FW, class FS>
-__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Mq = M >> 4, Nq = Nn >> 4;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int t = wave; t < Mq * Nq; t += FGW_WAVES) {
-        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < Kd; k0 += 4) {
-            const int k = k0 + lk;
-            const double a = k < Kd ? X(i0 + li, k) : 0.0;
-            const double b = k < Kd ? W(k, j0 + li) : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) st(i0 + lk + 4 * q, j0 + li, acc[q]);
-    }
-    // border: rows >= 16*Mq (all columns), then columns >= 16*Nq for the core rows
-    const int Mc = Mq << 4, Nc = Nq << 4;
-    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
-    for (int t = tid; t < nb1 + nb2; t += FGW_THREADS) {
-        int i, j;
-        if (t < nb1) { i = Mc + t / Nn; j = t % Nn; }
-        else { const int q = t - nb1; i = q / (Nn - Nc); j = Nc + q % (Nn - Nc); }
-        double a = 0.0;
-        for (int k = 0; k < Kd; ++k) a += X(i, k) * W(k, j);
-        st(i, j, a);
-    }
-}
-
 template <int R>
 __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
