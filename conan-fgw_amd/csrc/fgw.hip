@@ -43,7 +43,8 @@ template <bool LDS_MODE>
 __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
-    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch) {
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch, int mr_lds,
+    double *__restrict__ Ypart, double *__restrict__ Cpart) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
@@ -55,9 +56,12 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     double *vec = reinterpret_cast<double *>(smem);          // [6*N + 8] : u, v, loga, logb, r1/y2, r2/z2, red
     double *u = vec, *v = vec + N, *loga = vec + 2 * N, *logb = vec + 3 * N, *ra = vec + 4 * N, *rb = vec + 5 * N;
     double *red = vec + 6 * N;
-    char *mat = LDS_MODE ? smem + (size_t)(6 * N + 8) * 8 : scratch + (size_t)blockIdx.x * ((size_t)NP * 28);
-    double *Mr = reinterpret_cast<double *>(mat);
-    double *Al = Mr + NP;
+    // LDS_MODE: all four matrices in LDS.  Otherwise only the Sinkhorn cost Mr (read 2x per Sinkhorn iteration, once by
+    // rows and once by columns) stays in LDS when it fits (mr_lds); A, base and T live in an L2-resident global scratch.
+    char *gs = scratch + (size_t)blockIdx.x * ((size_t)NP * 28);
+    char *ls = smem + (size_t)(6 * N + 8) * 8;
+    double *Mr = reinterpret_cast<double *>((LDS_MODE || mr_lds) ? ls : gs);
+    double *Al = LDS_MODE ? Mr + NP : reinterpret_cast<double *>(gs) + NP;
     double *base = Al + NP;
     float *Tl = reinterpret_cast<float *>(base + NP);
 
@@ -180,83 +184,19 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     __syncthreads();
     for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
-}
-
-// ------------------------------------------------------------------------------------------------ barycenter update
-// One workgroup per molecule: Y <- sum_s lam_s diag(1/p) T_s Ys_s (utils.py:90-95), C <- sum_s lam_s T_s Cs_s T_s^T / (p p^T)
-// (utils.py:67-73), stopping test on ||Y-Yprev||_F and ||C-Cprev||_F (barycenter.py:186-192, :112).
-template <bool LDS_MODE>
-__global__ void __launch_bounds__(FGW_THREADS) k_fgw_update(
-    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ pb, const float *__restrict__ lambdas,
-    FgwDims D, conan_fgw_params prm, int outer, const float *__restrict__ Tw, double *__restrict__ Cw, double *__restrict__ Yw,
-    int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout,
-    char *__restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x;
-    if (!active[b]) return;
-    const int N = D.N, P = D.P, d = D.d, K = D.K;
-    const int NN = N * N, NP = N * P;
-    const int tid = threadIdx.x;
-    double *red = reinterpret_cast<double *>(smem);            // [8]
-    double *pinv = red + 8;                                    // [N]
-    char *mat = LDS_MODE ? smem + (size_t)(8 + N) * 8 : scratch + (size_t)b * ((size_t)NP * 16);
-    double *TC = reinterpret_cast<double *>(mat);              // [N,P]
-    double *Cacc = TC + NP;                                    // [N,P]
-    for (int i = tid; i < N; i += FGW_THREADS) pinv[i] = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
-    __syncthreads();
-
-    double ef2 = 0.0, es2 = 0.0;
-    if (!prm.fixed_features) {
-        double *Yb = Yw + (size_t)b * N * d;
-        for (int t = tid; t < N * d; t += FGW_THREADS) {
-            const int i = t / d, c = t - i * d;
-            double acc = 0.0;
-            for (int s = 0; s < K; ++s) {
-                const float *Ts = Tw + ((size_t)b * K + s) * NN + (size_t)i * N;
-                const float *Z = Ys + ((size_t)b * K + s) * N * d + c;
-                double ts = 0.0;
-                for (int j = 0; j < N; ++j) ts += (double)Z[(size_t)j * d] * (double)Ts[j];
-                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
-                acc += lam * ts * pinv[i];
-            }
-            const double df = acc - Yb[t];
-            ef2 += df * df;
-            Yb[t] = acc;
-            Yout[(size_t)b * N * d + t] = (float)acc;
-        }
+    // ---- contributions to the barycenter update (summed over s by k_fgw_update_parts)
+    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
+        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
+               [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
-    if (!prm.fixed_structure) {
-        for (int t = tid; t < NP; t += FGW_THREADS) Cacc[t] = 0.0;
-        for (int s = 0; s < K; ++s) {
-            const float *Ts = Tw + ((size_t)b * K + s) * NN;
-            const float *C2 = Cs + ((size_t)b * K + s) * NN;
-            __syncthreads();
-            mm_f64(N, N, N, [&](int i, int k) { return (double)Ts[i * N + k]; }, [&](int k, int j) { return (double)C2[k * N + j]; },
-                   [&](int i, int j, double v) { TC[i * P + j] = v; });                 // TC = T_s @ Cs_s
-            __syncthreads();
-            const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
-            mm_f64(N, N, N, [&](int i, int k) { return TC[i * P + k]; }, [&](int k, int j) { return (double)Ts[j * N + k]; },
-                   [&](int i, int j, double v) { Cacc[i * P + j] += lam * v; });         // Cacc += lam * TC @ T_s^T
-        }
+    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
+        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int j) { return (double)C2[k * N + j]; },
+               [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        double *Cb = Cw + (size_t)b * NN;
-        for (int t = tid; t < NN; t += FGW_THREADS) {
-            const int i = t / N, j = t - i * N;
-            const double cn = Cacc[i * P + j] * pinv[i] * pinv[j];     // / (p_i p_j)
-            const double df = cn - Cb[t];
-            es2 += df * df;
-            Cb[t] = cn;
-            Cout[(size_t)b * NN + t] = (float)cn;
-        }
-    }
-    const double ef = sqrt(block_sum_d(ef2, red));
-    const double es = sqrt(block_sum_d(es2, red));
-    if (tid == 0) {
-        errs[((size_t)b * 2 + 0) * prm.max_iter + outer] = (float)ef;
-        errs[((size_t)b * 2 + 1) * prm.max_iter + outer] = (float)es;
-        info[b * 4 + 0] = outer + 1;
-        // while (err_feature > tol or err_structure > tol) and cpt < max_iter        (barycenter.py:112)
-        active[b] = (ef > (double)prm.tol || es > (double)prm.tol) ? 1 : 0;
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
+               [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
 }
 
@@ -398,7 +338,6 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
 
 inline int pitch_of(int N) { return N | 1; }
 inline size_t coupling_lds(int N) { return (size_t)(6 * N + 8) * 8 + (size_t)N * pitch_of(N) * 28; }
-inline size_t update_lds(int N) { return (size_t)(8 + N) * 8 + (size_t)N * pitch_of(N) * 16; }
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 }  // namespace
@@ -434,34 +373,32 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     double *Yw = reinterpret_cast<double *>(w); w += (size_t)B * N * d * 8;
     int *active = reinterpret_cast<int *>(w); w += (((size_t)B * 4 + 255) / 256) * 256;
     char *sc_c = w; w += (((size_t)B * K * NP * 28 + 255) / 256) * 256;
-    char *sc_u = w; w += (((size_t)B * NP * 16 + 255) / 256) * 256;
+    w += (((size_t)B * NP * 16 + 255) / 256) * 256;        // (reserved)
     double *Ypart = reinterpret_cast<double *>(w);
     double *Cpart = Ypart + (size_t)B * K * N * d;
     const bool small = conan_fgw_small_supported(N, d);
 
     k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
-    const size_t lc = coupling_lds(N), lu = update_lds(N);
-    const bool c_lds = lc <= LDS_LIMIT, u_lds = lu <= LDS_LIMIT;
+    const size_t lc = coupling_lds(N);
+    const bool c_lds = lc <= LDS_LIMIT;
     if (c_lds && lc > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
-    if (u_lds && lu > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lu);
-    const size_t vec_c = (size_t)(6 * N + 8) * 8, vec_u = (size_t)(8 + N) * 8;
+    const size_t vec_c = (size_t)(6 * N + 8) * 8;
+    const size_t mr_bytes = NP * 8;
+    const int mr_lds = (!c_lds && vec_c + mr_bytes <= LDS_LIMIT) ? 1 : 0;
+    if (mr_lds)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(vec_c + mr_bytes));
     for (int outer = 0; outer < params->max_iter; ++outer) {
-        if (small) {
-            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info,
-                                     Ypart, Cpart, s);
-            conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, s);
-            continue;
-        }
-        if (c_lds)
-            k_fgw_coupling<true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info, sc_c);
+        const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
+        if (small)
+            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, s);
+        else if (c_lds)
+            k_fgw_coupling<true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
         else
-            k_fgw_coupling<false><<<B * K, FGW_THREADS, vec_c, s>>>(Ys, Cs, ps, p, D, *params, outer, (outer == 0 && !init_Y) ? 1 : 0, Cw, Yw, active, T, info, sc_c);
-        if (u_lds)
-            k_fgw_update<true><<<B, FGW_THREADS, lu, s>>>(Ys, Cs, p, lambdas, D, *params, outer, T, Cw, Yw, active, info, errs, Y, C, sc_u);
-        else
-            k_fgw_update<false><<<B, FGW_THREADS, vec_u, s>>>(Ys, Cs, p, lambdas, D, *params, outer, T, Cw, Yw, active, info, errs, Y, C, sc_u);
+            k_fgw_coupling<false><<<B * K, FGW_THREADS, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
+                                                                                               active, T, info, sc_c, mr_lds, Ypart, Cpart);
+        conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, s);
     }
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;

@@ -72,7 +72,15 @@ __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st)
     for (int t = wave; t < Mq * Nq; t += FGW_WAVES) {
         const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < Kd; k0 += 4) {
+        int k0 = 0;
+        for (; k0 + 16 <= Kd; k0 += 16) {                 // 4 k-steps per trip: 8 operand loads in flight before the MFMAs
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = X(i0 + li, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, j0 + li); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+        for (; k0 < Kd; k0 += 4) {
             const int k = k0 + lk;
             const double a = k < Kd ? X(i0 + li, k) : 0.0;
             const double b = k < Kd ? W(k, j0 + li) : 0.0;
