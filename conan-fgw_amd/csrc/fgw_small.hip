@@ -38,7 +38,9 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     double *psum = pm + 256;                                   // [4][64] partial sums
     double *us = psum + 256;                                   // [4][64] per-wave copy of u (indexed by i)
     double *vs = us + 256;                                     // [4][64] per-wave copy of v (indexed by j)
-    double *pq = vs + 256;                                     // [2][64] p, q
+    double *pm2 = vs + 256;                                    // [4][64] second partial buffers (row half-iteration)
+    double *psum2 = pm2 + 256;
+    double *pq = psum2 + 256;                                  // [2][64] p, q
     double *red = pq + 128;                                    // [8]
     float *Tl = reinterpret_cast<float *>(red + 8);            // [N,P]
     float *C2l = Tl + NP;                                      // [N,P]
@@ -135,36 +137,41 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
         us[w * 64 + lane] = 0.0;
         int ii = 0;
         for (; ii < prm.num_iter_max; ++ii) {
-            // v_j = logb_j - logsumexp_i(Mr_ij + u_i)          layout A, serial over my rows, 4-way combine
+            // v_j = logb_j - logsumexp_i(Mr_ij + u_i)          layout A: serial over my rows, then ONE 4-way combine of
+            // (partial max, partial sum) pairs: sum = sum_w s_w * exp(m_w - M)  => one barrier per half-iteration
             double z[R];
             double mx = -1.0e300;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const int i = w + 4 * r; z[r] = (i < N) ? mA[r] + us[w * 64 + i] : -1.0e300; mx = z[r] > mx ? z[r] : mx; }
-            pm[w * 64 + lane] = mx;
-            __syncthreads();
-            mx = fmax(fmax(pm[lane], pm[64 + lane]), fmax(pm[128 + lane], pm[192 + lane]));
             double sm = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) sm += exp_lse(z[r] - mx); }
-            psum[w * 64 + lane] = sm;
+            pm[w * 64 + lane] = mx; psum[w * 64 + lane] = sm;
             __syncthreads();
-            sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
-            v_l = logb - (log_acc(sm) + mx);
+            {
+                const double m0 = pm[lane], m1 = pm[64 + lane], m2 = pm[128 + lane], m3 = pm[192 + lane];
+                const double M = fmax(fmax(m0, m1), fmax(m2, m3));
+                sm = ((psum[lane] * exp_lse(m0 - M) + psum[64 + lane] * exp_lse(m1 - M)) + psum[128 + lane] * exp_lse(m2 - M)) +
+                     psum[192 + lane] * exp_lse(m3 - M);
+                v_l = logb - (log_acc(sm) + M);
+            }
             vs[w * 64 + lane] = v_l;                                   // private per-wave copy: read back by this wave only
-            // u_i = loga_i - logsumexp_j(Mr_ij + v_j)          layout B
+            // u_i = loga_i - logsumexp_j(Mr_ij + v_j)          layout B (pm2/psum2: second buffer => no extra barrier)
             mx = -1.0e300;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const int j = w + 4 * r; z[r] = (j < N) ? mB[r] + vs[w * 64 + j] : -1.0e300; mx = z[r] > mx ? z[r] : mx; }
-            pm[w * 64 + lane] = mx;
-            __syncthreads();
-            mx = fmax(fmax(pm[lane], pm[64 + lane]), fmax(pm[128 + lane], pm[192 + lane]));
             sm = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const int j = w + 4 * r; if (j < N) sm += exp_lse(z[r] - mx); }
-            psum[w * 64 + lane] = sm;
+            pm2[w * 64 + lane] = mx; psum2[w * 64 + lane] = sm;
             __syncthreads();
-            sm = ((psum[lane] + psum[64 + lane]) + psum[128 + lane]) + psum[192 + lane];
-            u_l = loga - (log_acc(sm) + mx);
+            {
+                const double m0 = pm2[lane], m1 = pm2[64 + lane], m2 = pm2[128 + lane], m3 = pm2[192 + lane];
+                const double M = fmax(fmax(m0, m1), fmax(m2, m3));
+                sm = ((psum2[lane] * exp_lse(m0 - M) + psum2[64 + lane] * exp_lse(m1 - M)) + psum2[128 + lane] * exp_lse(m2 - M)) +
+                     psum2[192 + lane] * exp_lse(m3 - M);
+                u_l = loga - (log_acc(sm) + M);
+            }
             us[w * 64 + lane] = u_l;
             if (ii % 10 == 0) {                                        // marginal violation (sinkhorn.py:418-433)
                 double cs = 0.0;
@@ -275,7 +282,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
 
 inline size_t small_lds(int N, int d) {
     const size_t NP = (size_t)N * (N | 1);
-    return NP * 8 * 3 + (size_t)N * d * 8 + (256 * 4 + 128 + 8) * 8 + NP * 4 * 2 + (size_t)N * (d + 1) * 4;
+    return NP * 8 * 3 + (size_t)N * d * 8 + (256 * 6 + 128 + 8) * 8 + NP * 4 * 2 + (size_t)N * (d + 1) * 4;
 }
 
 }  // namespace
