@@ -154,6 +154,15 @@ def main():
     E = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32).num_edges
     n_atoms = int(z.shape[0])
     kdur_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+    # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately and
+    # committed under profiles/; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE) -- only valid for the default workload
+    traffic = None
+    try:
+        if args.shape == "esol" and args.batch == 256 and K == 5:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]["k_cfconv_fwd<1>"]
+            traffic = int(pm["traffic_bytes_corrected"])
+    except Exception:
+        traffic = None
     alg = cfconv_algorithmic_bytes(E, n_atoms, 128)
     achieved = alg / (kdur_ms * 1e-3) / 1e9
 
@@ -170,7 +179,8 @@ def main():
                        "mode": args.mode, "parallelism": f"dp{world}", "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
             "roofline": {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kdur_ms, 5),
+                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_hbm.json (separate rocprofv3 --pmc passes)" if traffic else None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kdur_ms, 5),
                          "launches_timed": len(ev)},
         }
         if not args.no_cpu_baseline:
