@@ -143,24 +143,15 @@ __global__ void __launch_bounds__(256) k_linear_res(const float *__restrict__ x,
         }
     }
     const int chunks = Kp / BK;
-    // each thread prefetches 4 float4 per chunk: rows (tid>>3) + 32*q, columns (tid&7)*4 .. +3
+    // each thread prefetches 4 float4 per chunk: rows (tid>>3) + 32*q, columns (tid&7)*4 .. +3.  Branch-free: K is a
+    // multiple of 32 on this path and rows past M are clamped to M-1 (their results are masked at the store).
     const int pr = tid >> 3, pc = (tid & 7) * 4;
-    const bool vec_ok = (K & 3) == 0;
     float4 pre[4];
     auto fetch = [&](int row0, int kc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int gr = row0 + pr + 32 * q, gk = kc * BK + pc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr < M) {
-                if (vec_ok) { if (gk < K) v = *reinterpret_cast<const float4 *>(x + (size_t)gr * K + gk); }
-                else {
-                    float t4[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int e = 0; e < 4; ++e) if (gk + e < K) t4[e] = x[(size_t)gr * K + gk + e];
-                    v = make_float4(t4[0], t4[1], t4[2], t4[3]);
-                }
-            }
-            pre[q] = v;
+            const int gr = min(row0 + pr + 32 * q, M - 1);
+            pre[q] = *reinterpret_cast<const float4 *>(x + (size_t)gr * K + kc * BK + pc);
         }
     };
     auto stash = [&](int buf) {
@@ -389,6 +380,9 @@ static int wgrad_slices(int M) {
 
 }  // namespace
 
+int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
+                       int act, float *y, const int *m_dev, hipStream_t s, int *rc);      // gemm_t.hip
+
 extern "C" {
 
 int conan_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N,
@@ -396,7 +390,11 @@ int conan_linear_fwd(const float *x, const float *w, const float *bias, const fl
     if (!x || !w || !y || M < 0 || K <= 0 || N <= 0 || act < 0 || act > 3 || (act == 2 && !residual)) return CONAN_E_BADARG;
     if (M == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
-    if (K <= 128 && N <= 128) {
+    {
+        int rc = CONAN_OK;
+        if (conan_linear_t_try(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, &rc)) return rc;   // K, N in {64,128}
+    }
+    if (K <= 128 && N <= 128 && (K % BK) == 0) {
         const int Kp = (K + BK - 1) / BK * BK;
         const int tiles = (M + RM - 1) / RM;
         const int grid = tiles < 512 ? tiles : 512;        // persistent: <= 2 workgroups per CU

@@ -1,0 +1,127 @@
+// Register-streamed linear layer for gfx950:  y = act(x @ W^T + b) (+ residual)  for K, N in {64, 128}.
+//
+// Same transposed mapping as the fused filter kernel (filter_fused.hip): the ROW index of x lives on the MFMA column
+// (= lane), the output feature on the MFMA row.  A wavefront owns 32 rows of x; lane (m, h) reads its own row straight
+// from global memory as K/8 float4 (the two lane-halves split each group of 8 k's), which are exactly the B operands of
+// v_mfma_f32_32x32x2_f32 — x never touches LDS, there is no barrier after the weights are staged, and every wavefront
+// keeps K/8 independent 16-B loads in flight.  W ([N][K+4] in LDS, <= 68 KB) is read as conflict-free ds_read_b128 A
+// fragments, software-pipelined one group ahead.  The accumulators (D layout: row = feature, column = x row) are
+// stored / combined with `residual` as float4 per lane.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int LT_THREADS = 512;
+
+template <int K, int N>
+__global__ void __launch_bounds__(LT_THREADS) k_linear_t(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, const float *__restrict__ residual,
+                                                         int M, int w_kn, int act, float *__restrict__ y,
+                                                         const int *__restrict__ m_dev) {
+    constexpr int NB = N / 32;            // output row blocks
+    constexpr int G = K / 8;              // k groups (8 k's per group: 4 per lane-half)
+    constexpr int WP = K + 4;             // LDS pitch of a W row (16 consecutive rows -> 16 distinct 16-B slots)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *WL = lds;                      // [N][WP]
+    float *BL = WL + N * WP;              // [N]
+    if (m_dev) M = min(M, *m_dev);
+    const int tiles = (M + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x * (LT_THREADS / 64) >= tiles) return;
+    // stage W as [n][k] (torch Linear layout when w_kn == 0; transposed on the fly when W is [K][N])
+    for (int t = tid; t < N * K; t += LT_THREADS) {
+        const int n = t / K, k = t - n * K;
+        WL[n * WP + k] = w_kn ? w[(size_t)k * N + n] : w[t];
+    }
+    for (int t = tid; t < N; t += LT_THREADS) BL[t] = bias ? bias[t] : 0.f;
+    __syncthreads();
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_stride = gridDim.x * (LT_THREADS / 64);
+    for (int tile = blockIdx.x * (LT_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
+        const int m = (tile << 5) + l31;
+        const bool valid = m < M;
+        const float *xr = x + (size_t)(valid ? m : M - 1) * K + 4 * h;
+        float4 xb[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) xb[g] = *reinterpret_cast<const float4 *>(xr + 8 * g);     // all loads in flight at once
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        float4 a_cur[NB], a_nxt[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) a_cur[nb] = *reinterpret_cast<const float4 *>(&WL[(32 * nb + l31) * WP + 4 * h]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) a_nxt[nb] = *reinterpret_cast<const float4 *>(&WL[(32 * nb + l31) * WP + 8 * (g + 1) + 4 * h]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].x, xb[g].x, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].y, xb[g].y, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].z, xb[g].z, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].w, xb[g].w, acc[nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a_cur[nb] = a_nxt[nb];
+        }
+        if (!valid) continue;
+        // epilogue: registers 4q..4q+3 of block nb, half h = features 32nb + 8q + 4h .. +3 of row m
+        float *yr = y + (size_t)m * N + 4 * h;
+        const float *rr = residual ? residual + (size_t)m * N + 4 * h : nullptr;
+        float4 rv[NB][4];
+        if (rr) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
+                float v[4] = {acc[nb][4 * q] + bb.x, acc[nb][4 * q + 1] + bb.y, acc[nb][4 * q + 2] + bb.z, acc[nb][4 * q + 3] + bb.w};
+                const float r4[4] = {rr ? rv[nb][q].x : 0.f, rr ? rv[nb][q].y : 0.f, rr ? rv[nb][q].z : 0.f, rr ? rv[nb][q].w : 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (act == 1) v[u] = ssp_f(v[u]);
+                    else if (act == 3) v[u] = v[u] / (1.0f + __expf(-v[u]));
+                    if (act == 2) v[u] *= 1.0f - 0.5f * __expf(-r4[u]);
+                    else if (rr) v[u] += r4[u];
+                }
+                *reinterpret_cast<float4 *>(yr + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+}
+
+template <int K, int N>
+int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
+             const int *m_dev, hipStream_t s) {
+    const size_t lds = ((size_t)N * (K + 4) + N) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t<K, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (M + 31) / 32;
+    int grid = (tiles + 7) / 8;
+    if (grid > 256) grid = 256;
+    k_linear_t<K, N><<<grid, LT_THREADS, lds, s>>>(x, w, bias, residual, M, w_kn, act, y, m_dev);
+    return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+}
+
+}  // namespace
+
+// Returns 1 and launches when (K, N) is one of the register-streamed shapes, 0 otherwise (caller falls back).
+int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
+                       int act, float *y, const int *m_dev, hipStream_t s, int *rc) {
+    if (M < 1) return 0;
+    if (K == 128 && N == 128) { *rc = launch_t<128, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
+    if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
+    if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
+    if (K == 64 && N == 128) { *rc = launch_t<64, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
+    return 0;
+}
