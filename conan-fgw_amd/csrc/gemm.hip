@@ -243,26 +243,28 @@ __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict_
 }
 
 // ---- weight gradient: dW[N,K] = g^T @ x, reduction over the M rows ---------------------------------------------
-// Stage 1: the rows are cut into slices; one workgroup per (slice, 128x128 tile of dW) streams its rows ONCE through LDS
-// in 32-row chunks and accumulates the whole tile on MFMA (A = g^T: lane -> n, B = x: lane -> k; both fragments are
-// plain row-wise reads of the staged chunk, conflict-free without padding).  4 wavefronts as 2x2, 64x64 each.
+// Stage 1: the rows are cut into slices, one workgroup per (slice, 128x128 tile of dW), partial slabs written per slice.
 // Stage 2: the per-slice slabs are summed in a fixed order => bitwise reproducible, no float atomics.
-constexpr int WG_CHUNK = 32;       // rows per staged chunk
+// Operands come straight from global memory in their natural layout: for a pair of rows (m, m+1) lane (l31, h) loads
+// g[m+h][n0 + l31] (A: lane -> n) and x[m+h][k0 + l31] (B: lane -> k) — each half-wavefront reads one contiguous 128-B
+// segment, no LDS, no barrier; WG_U row pairs are requested before their MFMAs issue (4*WG_U dword loads per lane in
+// flight).  4 wavefronts as 2x2 over the 128x128 tile (64x64 each = 2x2 accumulators); duplicates between the waves of a
+// workgroup hit L1/L2, HBM sees every row of g and x once.
 constexpr int WG_TILE = 128;
 constexpr int WG_SLICES_MAX = 512;
+constexpr int WG_U = 8;            // row pairs in flight
 
 __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
                                                        int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
                                                        const int *__restrict__ m_dev) {
     if (m_dev) M = min(M, *m_dev);
-    __shared__ __attribute__((aligned(16))) float gs[WG_CHUNK * WG_TILE];
-    __shared__ __attribute__((aligned(16))) float xs[WG_CHUNK * WG_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.y * WG_TILE, k0 = blockIdx.z * WG_TILE;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * WG_TILE + wm * 64, k0 = blockIdx.z * WG_TILE + wn * 64;
     const int slice = blockIdx.x;
     const int r_begin = slice * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
-    const bool vec_ok = ((N & 3) == 0) && ((K & 3) == 0);
+    const bool wave_active = (n0 < N) && (k0 < K);
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -270,80 +272,61 @@ __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum = 0.f;       // thread t < 128 accumulates the bias gradient of column n0 + t (blockIdx.z == 0 only)
-    const bool wave_active = (n0 + wm * 64 < N) && (k0 + wn * 64 < K);
-    // software pipeline: the next 32-row chunk is fetched into registers while the current one is multiplied
-    float4 pg[4], px[4];
-    auto fetch = [&](int r0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = tid + u * 256;
-            const int r = t >> 5, c4 = (t & 31) * 4;
-            const int gr = r0 + r;
-            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
-            if (gr < r_end) {
-                if (vec_ok) {
-                    if (n0 + c4 < N) gv = *reinterpret_cast<const float4 *>(g + (size_t)gr * N + n0 + c4);
-                    if (k0 + c4 < K) xv = *reinterpret_cast<const float4 *>(x + (size_t)gr * K + k0 + c4);
-                } else {
-                    float tg[4] = {0, 0, 0, 0}, tx[4] = {0, 0, 0, 0};
-                    for (int q = 0; q < 4; ++q) {
-                        if (n0 + c4 + q < N) tg[q] = g[(size_t)gr * N + n0 + c4 + q];
-                        if (k0 + c4 + q < K) tx[q] = x[(size_t)gr * K + k0 + c4 + q];
-                    }
-                    gv = make_float4(tg[0], tg[1], tg[2], tg[3]); xv = make_float4(tx[0], tx[1], tx[2], tx[3]);
-                }
-            }
-            pg[u] = gv; px[u] = xv;
-        }
-    };
-    if (r_begin < r_end) fetch(r_begin);
-    for (int r0 = r_begin; r0 < r_end; r0 += WG_CHUNK) {
-        __syncthreads();                                   // previous chunk fully consumed
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = tid + u * 256;
-            const int r = t >> 5, c4 = (t & 31) * 4;
-            *reinterpret_cast<float4 *>(&gs[r * WG_TILE + c4]) = pg[u];
-            *reinterpret_cast<float4 *>(&xs[r * WG_TILE + c4]) = px[u];
-        }
-        __syncthreads();
-        if (r0 + WG_CHUNK < r_end) fetch(r0 + WG_CHUNK);
-        if (blockIdx.z == 0 && tid < WG_TILE) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < WG_CHUNK; ++r) s += gs[r * WG_TILE + tid];
-            bsum += s;
-        }
-        if (wave_active) {
-            const int kh = lane >> 5, l31 = lane & 31;
-#pragma unroll 4
-            for (int m = 0; m < WG_CHUNK; m += 2) {
-                const float a0 = gs[(m + kh) * WG_TILE + wm * 64 + l31];
-                const float a1 = gs[(m + kh) * WG_TILE + wm * 64 + 32 + l31];
-                const float b0 = xs[(m + kh) * WG_TILE + wn * 64 + l31];
-                const float b1 = xs[(m + kh) * WG_TILE + wn * 64 + 32 + l31];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        }
-    }
-    float *slab = slabs + (size_t)slice * N * K;
+    float bs0 = 0.f, bs1 = 0.f;          // bias gradient partials of columns n0 + l31, n0 + 32 + l31 (rows of parity h)
+    const bool na0 = n0 + l31 < N, na1 = n0 + 32 + l31 < N, ka0 = k0 + l31 < K, ka1 = k0 + 32 + l31 < K;
     if (wave_active) {
+        const float *gp = g + n0 + l31, *xp = x + k0 + l31;
+        int m = r_begin;
+        for (; m + 2 * WG_U <= r_end; m += 2 * WG_U) {
+            float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                const size_t row = (size_t)(m + 2 * u + h);
+                a0[u] = na0 ? gp[row * N] : 0.f;
+                a1[u] = na1 ? gp[row * N + 32] : 0.f;
+                b0[u] = ka0 ? xp[row * K] : 0.f;
+                b1[u] = ka1 ? xp[row * K + 32] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+                bs0 += a0[u]; bs1 += a1[u];
+            }
+        }
+        for (; m < r_end; m += 2) {          // ragged tail: rows past r_end contribute zeros
+            const int row = m + h;
+            const bool ok = row < r_end;
+            const float a0 = (ok && na0) ? gp[(size_t)row * N] : 0.f, a1 = (ok && na1) ? gp[(size_t)row * N + 32] : 0.f;
+            const float b0 = (ok && ka0) ? xp[(size_t)row * K] : 0.f, b1 = (ok && ka1) ? xp[(size_t)row * K + 32] : 0.f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            bs0 += a0; bs1 += a1;
+        }
+        float *slab = slabs + (size_t)slice * N * K;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int k = k0 + wn * 64 + b * 32 + (lane & 31);
+                    const int n = n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int k = k0 + b * 32 + l31;
                     if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
                 }
     }
-    if (blockIdx.z == 0 && tid < WG_TILE && n0 + tid < N) bias_slabs[(size_t)slice * N + n0 + tid] = bsum;
+    // bias gradient: the wn == 0 waves of the blockIdx.z == 0 column own it; combine the two row parities
+    if (blockIdx.z == 0 && wn == 0 && n0 < N) {
+        bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
+        if (h == 0) {
+            if (na0) bias_slabs[(size_t)slice * N + n0 + l31] = bs0;
+            if (na1) bias_slabs[(size_t)slice * N + n0 + 32 + l31] = bs1;
+        }
+    }
 }
 
 // slabs [slices][NK] (+ bias_slabs [slices][N]) -> out[g][NK] (+ bout[g][N]) for slice group g = blockIdx.y; fixed order.
@@ -442,7 +425,7 @@ int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, cons
     hipStream_t s = as_stream(stream);
     const int slices = wgrad_slices(M);
     int rows = (M + slices - 1) / slices;
-    rows = ((rows + WG_CHUNK - 1) / WG_CHUNK) * WG_CHUNK;
+    rows = ((rows + 2 * WG_U - 1) / (2 * WG_U)) * (2 * WG_U);
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * N * K;
     dim3 grid(slices, (N + WG_TILE - 1) / WG_TILE, (K + WG_TILE - 1) / WG_TILE);
     k_wgrad_partial<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
