@@ -60,12 +60,49 @@ __device__ __forceinline__ double exp_lse(double x) {
     return (double)__builtin_amdgcn_exp2f(f * 1.44269504088896340736f);
 }
 
-// D[M x Nn] = X[M x Kd] @ W[Kd x Nn] with fp64 MFMA (v_mfma_f64_16x16x4_f64) on the 16-aligned core and plain FMA loops on
-// the ragged border rows/columns (no padding of the problem).  X(i,k), W(k,j) are element readers, st(i,j,v) the writer.
-// Fragment layout: A lane l -> X[i0 + (l&15)][k0 + (l>>4)], B lane l -> W[k0 + (l>>4)][j0 + (l&15)],
-// D reg q lane l -> row i0 + (l>>4) + 4q, col j0 + (l&15).   Workgroup-collective; no barrier inside.
+// D[M x Nn] = X[M x Kd] @ W[Kd x Nn] with fp64 MFMA (v_mfma_f64_16x16x4_f64).  The problem is covered by ceil(M/16) x
+// ceil(Nn/16) tiles; out-of-range operand elements are read as 0 and out-of-range results are not stored, so ragged
+// sizes (N = 33) need no separate border code (a VALU border loop serialises on the one wavefront that owns it).
+// X(i,k), W(k,j) are element readers, st(i,j,v) the writer.  Fragment layout: A lane l -> X[i0 + (l&15)][k0 + (l>>4)],
+// B lane l -> W[k0 + (l>>4)][j0 + (l&15)], D reg q lane l -> row i0 + (l>>4) + 4q, col j0 + (l&15).
+// Workgroup-collective (tiles are dealt round-robin to the wavefronts); no barrier inside.
 template <class FX, class FW, class FS>
-__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
+__device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS st) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < Mq * Nq; t += FGW_WAVES) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool ra = ia < M, cb = jb < Nn;
+        const int ic = ra ? ia : M - 1, jc = cb ? jb : Nn - 1;          // clamped: loads stay in range, values masked
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        int k0 = 0;
+        for (; k0 + 16 <= Kd; k0 += 16) {                 // 4 k-steps per trip: 8 operand loads in flight before the MFMAs
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = X(ic, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, jc); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
+        }
+        for (; k0 < Kd; k0 += 4) {
+            const int k = k0 + lk;
+            const bool kin = k < Kd;
+            const int kc = kin ? k : Kd - 1;
+            const double a = X(ic, kc), b = W(kc, jc);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + lk + 4 * q;
+            if (i < M && cb) st(i, jb, acc[q]);
+        }
+    }
+}
+
+// Variant for thin ragged borders: MFMA on the 16-aligned core, plain FMA loops for the few border rows/columns.
+template <class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W, FS st) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mq = M >> 4, Nq = Nn >> 4;
     const int li = lane & 15, lk = lane >> 4;
@@ -73,7 +110,7 @@ __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st)
         const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         int k0 = 0;
-        for (; k0 + 16 <= Kd; k0 += 16) {                 // 4 k-steps per trip: 8 operand loads in flight before the MFMAs
+        for (; k0 + 16 <= Kd; k0 += 16) {
             double a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { a[u] = X(i0 + li, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, j0 + li); }
@@ -89,7 +126,6 @@ __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st)
 #pragma unroll
         for (int q = 0; q < 4; ++q) st(i0 + lk + 4 * q, j0 + li, acc[q]);
     }
-    // border: rows >= 16*Mq (all columns), then columns >= 16*Nq for the core rows
     const int Mc = Mq << 4, Nc = Nq << 4;
     const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
     for (int t = tid; t < nb1 + nb2; t += FGW_THREADS) {
@@ -102,6 +138,15 @@ __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st)
     }
 }
 
+// Dispatch (workgroup-uniform): a border of at most one pass of the 256 threads (e.g. N = 33: 65 outputs) is cheaper on
+// the FMA path than the extra mostly-empty tiles; anything thicker goes to the padded-tile path.
+template <class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
+    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
+    const int border = (M - Mc) * Nn + Mc * (Nn - Nc);
+    if (border <= FGW_THREADS / 2 && Mc > 0 && Nc > 0) mm_f64_border(M, Nn, Kd, X, W, st);
+    else mm_f64_pad(M, Nn, Kd, X, W, st);
+}
 
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
 bool conan_fgw_small_supported(int N, int d);
