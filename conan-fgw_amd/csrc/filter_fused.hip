@@ -22,22 +22,40 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Exact 3-way bf16 split of 8 fp32 values: v = p1 + p2 + p3 up to 2^-24 |v| (each part is a round-to-nearest bf16 of the
+// running remainder, the remainders are exact in fp32).  With the six products p1q1, p1q2, p2q1, p1q3, p2q2, p3q1 a
+// bf16 MFMA chain reproduces the fp32 product to ~2^-24 relative (fp32 class, full fp32 exponent range) at 6 x 32 cycles
+// per 32x32x16 block instead of 8 x 64 cycles on the fp32 MFMA (2.7x).
+__device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h1 = (__bf16)v[j];
+        const float r1 = v[j] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
+    }
+}
 
 constexpr int GP = 56;        // gaussians padded to a multiple of 8 (zero weights beyond num_gaussians)
 constexpr int W1P = 60;       // LDS pitch of W1 rows  (60 = 4*15: 16 consecutive rows hit 16 distinct 16-B slots)
 constexpr int FF_THREADS = 512;
 
-template <int F>
+template <int F, bool SPLIT>
 __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     const float *__restrict__ dist, const int *__restrict__ num_edges_dev, int max_edges, const float *__restrict__ offset,
     int Gs, float coeff, float cutoff, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out, int dbg) {
     constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
-    constexpr int W2P = F + 4;            // LDS pitch of W2 rows
+    constexpr int W2P = F + 4;            // LDS pitch of W2 rows (fp32 image)
+    constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (bf16 elements; 16-B slots stay distinct)
+    constexpr int W2WORDS = SPLIT ? (3 * F * W2S) / 2 : F * W2P;      // floats occupied by the W2 image(s)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *W1L = lds;                     // [F][W1P]
-    float *W2L = W1L + F * W1P;           // [F][W2P]
-    float *B1L = W2L + F * W2P;           // [F]
+    float *W2L = W1L + F * W1P;           // fp32 [F][W2P]  |  SPLIT: 3 x bf16 [F][W2S], columns permuted per 16-group
+    float *B1L = W2L + W2WORDS;           // [F]
     float *B2L = B1L + F;                 // [F]
     float *OFL = B2L + F;                 // [GP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,9 +67,27 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
         const int f = t / W1P, k = t - f * W1P;
         W1L[t] = k < Gs ? w1[(size_t)f * Gs + k] : 0.f;
     }
-    for (int t = tid; t < F * W2P; t += FF_THREADS) {
-        const int f2 = t / W2P, f = t - f2 * W2P;
-        W2L[t] = f < F ? w2[(size_t)f2 * F + f] : 0.f;
+    if (!SPLIT) {
+        for (int t = tid; t < F * W2P; t += FF_THREADS) {
+            const int f2 = t / W2P, f = t - f2 * W2P;
+            W2L[t] = f < F ? w2[(size_t)f2 * F + f] : 0.f;
+        }
+    } else {
+        // three bf16 images of W2; inside every group of 16 input channels the columns are stored in the order the B
+        // fragment (GEMM1's accumulator registers 8s..8s+7 of lane-half h) enumerates them: position 8h + j holds
+        // channel (j&3) + 8(j>>2) + 4h, so a lane reads its 8 k-values as one 16-byte access.
+        __bf16 *W2B = reinterpret_cast<__bf16 *>(W2L);
+        for (int t = tid; t < F * F; t += FF_THREADS) {
+            const int f2 = t / F, f = t - f2 * F;
+            const int kk = f & 15, hh = (kk >> 2) & 1, jj = (kk & 3) + 4 * (kk >> 3);
+            const int colp = (f & ~15) + 8 * hh + jj;
+            const float v = w2[t];
+            const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
+            const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
+            W2B[(0 * F + f2) * W2S + colp] = h1;
+            W2B[(1 * F + f2) * W2S + colp] = h2;
+            W2B[(2 * F + f2) * W2S + colp] = (__bf16)r2;
+        }
     }
     for (int t = tid; t < F; t += FF_THREADS) { B1L[t] = b1[t]; B2L[t] = b2[t]; }
     for (int t = tid; t < GP; t += FF_THREADS) OFL[t] = t < Gs ? offset[t] : 0.f;
@@ -132,7 +168,34 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             for (int nb = 0; nb < NG; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
-            {
+            if constexpr (SPLIT) {
+                const __bf16 *W2B = reinterpret_cast<const __bf16 *>(W2L);
+#pragma unroll
+                for (int ms = 0; ms < 2 * MB; ++ms) {
+                    const int mb = ms >> 1, sgrp = ms & 1;
+                    float hv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
+                    bf16x8 q1, q2, q3;
+                    split3(hv, q1, q2, q3);
+                    const int colp = 32 * mb + 16 * sgrp + 8 * h;
+#pragma unroll
+                    for (int nb = 0; nb < NG; ++nb) {
+                        const int row = 32 * (n0 + nb) + l31;
+                        const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&W2B[(0 * F + row) * W2S + colp]);
+                        const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&W2B[(1 * F + row) * W2S + colp]);
+                        const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&W2B[(2 * F + row) * W2S + colp]);
+                        // smallest terms first
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc2[nb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
                 float4 a_cur[NG], a_nxt[NG];
 #pragma unroll
                 for (int nb = 0; nb < NG; ++nb) a_cur[nb] = *reinterpret_cast<const float4 *>(&W2L[(32 * (n0 + nb) + l31) * W2P + 4 * h]);
@@ -175,17 +238,17 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     }
 }
 
-template <int F>
+template <int F, bool SPLIT>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    const size_t lds = ((size_t)F * W1P + (size_t)F * (F + 4) + 2 * F + GP) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = ((size_t)F * W1P + (SPLIT ? (size_t)(3 * F * (F + 8)) / 2 : (size_t)F * (F + 4)) + 2 * F + GP) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;
     if (grid > 256) grid = 256;                           // one persistent 8-wave workgroup per CU
     static int dbg = getenv("CONAN_FILTER_DEBUG") ? atoi(getenv("CONAN_FILTER_DEBUG")) : 0;
-    k_filter_fused<F><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, dbg);
+    k_filter_fused<F, SPLIT><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, dbg);
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
@@ -204,11 +267,17 @@ int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges,
     if (!conan_filter_fused_supported(num_gaussians, num_filters)) return CONAN_E_UNSUPPORTED;
     if (max_edges == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
+    // CONAN_FILTER_FP32=1 forces the plain fp32-MFMA second GEMM (default: exact 3-way bf16 split on the bf16 MFMA)
+    static const bool fp32_only = getenv("CONAN_FILTER_FP32") && atoi(getenv("CONAN_FILTER_FP32")) != 0;
+#define CONAN_FF(FV)                                                                                                                   \
+    return fp32_only ? launch<FV, false>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s) \
+                     : launch<FV, true>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s)
     switch (num_filters) {
-        case 32: return launch<32>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s);
-        case 64: return launch<64>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s);
-        default: return launch<128>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s);
+        case 32: CONAN_FF(32);
+        case 64: CONAN_FF(64);
+        default: CONAN_FF(128);
     }
+#undef CONAN_FF
 }
 
 }  // extern "C"

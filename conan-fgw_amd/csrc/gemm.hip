@@ -252,7 +252,7 @@ __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict_
 // workgroup hit L1/L2, HBM sees every row of g and x once.
 constexpr int WG_TILE = 128;
 constexpr int WG_SLICES_MAX = 512;
-constexpr int WG_U = 8;            // row pairs in flight
+constexpr int WG_U = 16;            // row pairs in flight
 
 __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
                                                        int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
