@@ -8,11 +8,120 @@
 // fragments, software-pipelined one group ahead.  The accumulators (D layout: row = feature, column = x row) are
 // stored / combined with `residual` as float4 per lane.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LT_THREADS = 512;
+
+// exact 3-way bf16 split (see filter_fused.hip): v = p1 + p2 + p3 up to 2^-24 |v|
+__device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h1 = (__bf16)v[j];
+        const float r1 = v[j] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
+    }
+}
+
+// SPLIT variant: both operands are split into three bf16 parts and the product is formed from the six significant
+// partial products on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, 2.7x the fp32 MFMA rate).  W's three images are
+// staged once per workgroup; x is split in registers after the global load.
+template <int K, int N>
+__global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restrict__ x, const float *__restrict__ w,
+                                                           const float *__restrict__ bias, const float *__restrict__ residual,
+                                                           int M, int w_kn, int act, float *__restrict__ y,
+                                                           const int *__restrict__ m_dev) {
+    constexpr int NB = N / 32;
+    constexpr int S = K / 16;             // MFMA k-steps
+    constexpr int WS = K + 8;             // LDS pitch (bf16 elements)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [3][N][WS]
+    float *BL = lds + (3 * N * WS) / 2;                         // [N]
+    if (m_dev) M = min(M, *m_dev);
+    const int tiles = (M + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x * (LT_THREADS / 64) >= tiles) return;
+    for (int t = tid; t < N * K; t += LT_THREADS) {
+        const int n = t / K, k = t - n * K;
+        const float v = w_kn ? w[(size_t)k * N + n] : w[t];
+        const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
+        const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
+        WB[(0 * N + n) * WS + k] = h1; WB[(1 * N + n) * WS + k] = h2; WB[(2 * N + n) * WS + k] = (__bf16)r2;
+    }
+    for (int t = tid; t < N; t += LT_THREADS) BL[t] = bias ? bias[t] : 0.f;
+    __syncthreads();
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_stride = gridDim.x * (LT_THREADS / 64);
+    for (int tile = blockIdx.x * (LT_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
+        const int m = (tile << 5) + l31;
+        const bool valid = m < M;
+        const float *xr = x + (size_t)(valid ? m : M - 1) * K + 8 * h;
+        float4 xa[S], xb[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                          // lane-half h owns k = 16s + 8h .. +7 of its row
+            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
+            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
+        }
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+            bf16x8 q1, q2, q3;
+            split3(xv, q1, q2, q3);
+            const int colp = 16 * s + 8 * h;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int row = 32 * nb + l31;
+                const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&WB[(0 * N + row) * WS + colp]);
+                const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&WB[(1 * N + row) * WS + colp]);
+                const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&WB[(2 * N + row) * WS + colp]);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc[nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!valid) continue;
+        float *yr = y + (size_t)m * N + 4 * h;
+        const float *rr = residual ? residual + (size_t)m * N + 4 * h : nullptr;
+        float4 rv[NB][4];
+        if (rr) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
+                float v[4] = {acc[nb][4 * q] + bb.x, acc[nb][4 * q + 1] + bb.y, acc[nb][4 * q + 2] + bb.z, acc[nb][4 * q + 3] + bb.w};
+                const float r4[4] = {rr ? rv[nb][q].x : 0.f, rr ? rv[nb][q].y : 0.f, rr ? rv[nb][q].z : 0.f, rr ? rv[nb][q].w : 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (act == 1) v[u] = ssp_f(v[u]);
+                    else if (act == 3) v[u] = v[u] / (1.0f + __expf(-v[u]));
+                    if (act == 2) v[u] *= 1.0f - 0.5f * __expf(-r4[u]);
+                    else if (rr) v[u] += r4[u];
+                }
+                *reinterpret_cast<float4 *>(yr + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+}
 
 template <int K, int N>
 __global__ void __launch_bounds__(LT_THREADS) k_linear_t(const float *__restrict__ x, const float *__restrict__ w,
@@ -104,6 +213,17 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t(const float *__restrict
 template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
              const int *m_dev, hipStream_t s) {
+    // CONAN_LINEAR_FP32=1 forces the plain fp32-MFMA kernel (default: exact 3-way bf16 split on the bf16 MFMA)
+    static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
+    if (!fp32_only) {
+        const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        const int tiles16 = (M + 31) / 32;
+        int grid16 = (tiles16 + 7) / 8;
+        if (grid16 > 256) grid16 = 256;
+        k_linear_t16<K, N><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, act, y, m_dev);
+        return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+    }
     const size_t lds = ((size_t)N * (K + 4) + N) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t<K, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (M + 31) / 32;
