@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
     ap.add_argument("--conformers", type=int, default=5)
     ap.add_argument("--shape", default="esol")
+    ap.add_argument("--model", choices=["schnet", "visnet"], default="schnet", help="backbone (BASELINE.json configs[3] = visnet + bace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -96,7 +97,11 @@ def main():
     z, pos, batch = (torch.from_numpy(a).to(dev) for a in (b.z, b.pos, b.batch))
     y = torch.from_numpy(b.y).to(dev)[:, None]
     torch.manual_seed(5)                                                          # train_val.py:223
-    model = SchNetNoSum(dev, hidden_channels=128, num_filters=128, num_interactions=3).to(dev)   # common.py:524-529
+    if args.model == "visnet":
+        from conan_fgw_amd.visnet import ViSNet
+        model = ViSNet(dev, hidden_channels=128).to(dev)                                              # common.py:542-546
+    else:
+        model = SchNetNoSum(dev, hidden_channels=128, num_filters=128, num_interactions=3).to(dev)   # common.py:524-529
     head = ConformerAggregationHead(64, 0.2).to(dev)
     params = list(model.parameters()) + list(head.parameters())
     flat = FlatGradients(params)
@@ -172,8 +177,8 @@ def main():
             "metric": "molecules/s (K=5 conformers)", "value": round(mol / dt, 1), "unit": "molecules/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.shape.upper()}-shaped + SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), "
-                                   f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
+            "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
+                                   + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
                                    + ("(fwd + bwd + flat-gradient all-reduce + Adam)" if args.mode == "train" else "(forward_w_barycenter + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "max_nodes": b.max_nodes,
                        "mode": args.mode, "parallelism": f"dp{world}", "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},

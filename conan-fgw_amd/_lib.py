@@ -60,6 +60,21 @@ SIGNATURES = {
     "conan_visnet_spatial_norm": (c_int, [_P, c_int, c_int, _P, _P]),
     "conan_visnet_gate": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_visnet_prior": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_silu_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    "conan_silu_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "conan_split2": (c_int, [_P, c_int, c_int, c_ll, _P, _P, _P]),
+    "conan_rowsum": (c_int, [_P, c_int, c_int, _P, _P]),
+    "conan_scale_scalar": (c_int, [_P, _P, c_ll, _P, _P]),
+    "conan_visnet_edge_embed_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_layernorm_bwd_ws": (c_ll, [c_int, c_int]),
+    "conan_layernorm_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
+    "conan_visnet_vecdot_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "conan_visnet_attn_message_bwd": (c_int, [_P] * 13 + [c_float, c_int, c_int, c_int] + [_P] * 6),
+    "conan_visnet_vec_aggregate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_node_update_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "conan_visnet_edge_update_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "conan_visnet_spatial_norm_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "conan_visnet_gate_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_fgw_densify": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
     "conan_fgw_densify_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P]),
     "conan_fgw_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),

@@ -1,0 +1,489 @@
+// ViSNet backward kernels for gfx950 (gradients of the kernels in visnet.hip; same layouts and citations).
+// Node-level gradients that receive contributions from many edges are accumulated WITHOUT atomics: one wavefront per
+// node walks the node's by-target CSR row (gradients flowing to the target side) or its by-source list
+// (t_rowptr / t_eid: gradients flowing to the source side) in a fixed order => bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f(v); }
+__device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f(v); return s * (1.0f + v * (1.0f - s)); }
+__device__ __forceinline__ float cos_cutoff(float d, float cutoff) {
+    return d < cutoff ? 0.5f * (cosf(__fdiv_rn(d * 3.14159265358979323846f, cutoff)) + 1.0f) : 0.0f;
+}
+inline int nblk(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+// ---------------------------------------------------------------------------------------------- SiLU
+__global__ void k_silu_fwd(const float *__restrict__ x, int rows, int width, const int *__restrict__ m_dev, float *__restrict__ y) {
+    long long n = (long long)(m_dev ? min(rows, *m_dev) : rows) * width;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) y[t] = silu_f(x[t]);
+}
+__global__ void k_silu_bwd(const float *__restrict__ x, const float *__restrict__ dy, int rows, int width, const int *__restrict__ m_dev,
+                           float *__restrict__ dx) {
+    long long n = (long long)(m_dev ? min(rows, *m_dev) : rows) * width;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) dx[t] = dy[t] * dsilu_f(x[t]);
+}
+
+__global__ void k_split2(const float *__restrict__ in, int Ha, int Hb, long long rows, float *__restrict__ a, float *__restrict__ b) {
+    const int Ho = Ha + Hb;
+    const long long n = rows * Ho, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const long long r = t / Ho; const int c = (int)(t - r * Ho);
+        if (c < Ha) a[r * Ha + c] = in[t]; else b[r * Hb + (c - Ha)] = in[t];
+    }
+}
+
+__global__ void k_rowsum(const float *__restrict__ x, int rows, int width, float *__restrict__ out) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < width; ++c) s += x[(size_t)r * width + c];
+        out[r] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- EdgeEmbedding backward
+// dp[e] = (x_i + x_j) * df[e]
+__global__ void k_edge_embed_bwd_p(const float *__restrict__ x, const float *__restrict__ df, const int *__restrict__ col, const int *__restrict__ tgt,
+                                   const int *__restrict__ ne_dev, int max_edges, int H, float *__restrict__ dp) {
+    const int E = min(*ne_dev, max_edges);
+    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int e = (int)(t / H), c = (int)(t - (long long)e * H);
+        dp[t] = (x[(size_t)tgt[e] * H + c] + x[(size_t)col[e] * H + c]) * df[t];
+    }
+}
+// dx[i] = sum_{e in row(i)} df[e]*p[e] + sum_{e in srclist(i)} df[e]*p[e]
+__global__ void __launch_bounds__(256) k_edge_embed_bwd_x(const float *__restrict__ p, const float *__restrict__ df, const int *__restrict__ rowptr,
+                                                          const int *__restrict__ t_rowptr, const int *__restrict__ t_eid, int n, int H,
+                                                          float *__restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < n; i += nw)
+        for (int c = lane; c < H; c += 64) {
+            float a = 0.f;
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) a += df[(size_t)e * H + c] * p[(size_t)e * H + c];
+            for (int s = t_rowptr[i]; s < t_rowptr[i + 1]; ++s) { const int e = t_eid[s]; a += df[(size_t)e * H + c] * p[(size_t)e * H + c]; }
+            dx[(size_t)i * H + c] = a;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm backward
+// dx per row (one wavefront per row); stats[r] = (mean, rstd) saved for the parameter-gradient pass
+__global__ void __launch_bounds__(256) k_layernorm_bwd_x(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ dy,
+                                                         int rows, int H, float eps, float *__restrict__ dx, float *__restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        const float *xr = x + (size_t)r * H, *gr = dy + (size_t)r * H;
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / (float)H;
+        float v = 0.f;
+        for (int c = lane; c < H; c += 64) { const float d = xr[c] - mean; v += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
+        float s1 = 0.f, s2 = 0.f;                        // mean(dxhat), mean(dxhat * xhat)
+        for (int c = lane; c < H; c += 64) { const float dxh = gr[c] * gamma[c], xh = (xr[c] - mean) * rstd; s1 += dxh; s2 += dxh * xh; }
+        s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+        for (int c = lane; c < H; c += 64) {
+            const float dxh = gr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+            dx[(size_t)r * H + c] = rstd * (dxh - s1 - xh * s2);
+        }
+        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    }
+}
+// per-chunk partial dgamma / dbeta (thread <-> column, rows of the chunk in order), then reduced in chunk order
+constexpr int LN_CHUNK = 256;
+__global__ void __launch_bounds__(128) k_layernorm_bwd_p(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ stats,
+                                                         int rows, int H, float *__restrict__ slabs) {
+    const int chunk = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
+    if (c >= H) return;
+    const int r0 = chunk * LN_CHUNK, r1 = min(rows, r0 + LN_CHUNK);
+    float dg = 0.f, db = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float g = dy[(size_t)r * H + c];
+        dg += g * (x[(size_t)r * H + c] - stats[2 * r]) * stats[2 * r + 1];
+        db += g;
+    }
+    slabs[((size_t)chunk * 2) * H + c] = dg;
+    slabs[((size_t)chunk * 2 + 1) * H + c] = db;
+}
+__global__ void k_layernorm_bwd_reduce(const float *__restrict__ slabs, int chunks, int H, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float a = 0.f, b = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) { a += slabs[((size_t)ch * 2) * H + c]; b += slabs[((size_t)ch * 2 + 1) * H + c]; }
+    dgamma[c] = a; dbeta[c] = b;
+}
+
+// ---------------------------------------------------------------------------------------------- vec_dot backward
+// dvp[a,sp,0:H] = dout * vp[a,sp,H:2H]; dvp[a,sp,H:2H] = dout * vp[a,sp,0:H]; dvp[a,sp,2H:3H] = 0
+__global__ void k_vecdot_bwd(const float *__restrict__ vp, const float *__restrict__ dout, int n, int H, float *__restrict__ dvp) {
+    const long long tot = (long long)n * 3 * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const long long row = t / H; const int c = (int)(t - row * H);          // row = a*3 + sp
+        const int a = (int)(row / 3);
+        const float g = dout[(size_t)a * H + c];
+        const float *vr = vp + (size_t)row * 3 * H;
+        float *dr = dvp + (size_t)row * 3 * H;
+        dr[c] = g * vr[H + c]; dr[H + c] = g * vr[c]; dr[2 * H + c] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- attention message backward
+// Shared per-edge recomputation: lane owns CPL channels of head (lane / lph)
+template <int CPL>
+__device__ __forceinline__ void attn_edge(const float *qi, const float *kj, const float *vj, const float *dke, const float *dve, const float *dm,
+                                          float cut, int lph, float &attn, float &da) {
+    float part = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) { part += qi[u] * kj[u] * dke[u]; t1 += dm[u] * vj[u] * dve[u]; }
+    for (int o = 1; o < lph; o <<= 1) { part += __shfl_xor(part, o, 64); t1 += __shfl_xor(t1, o, 64); }
+    const float sg = sigmoid_f(part);
+    attn = part * sg * cut;                                    // SiLU(a) * C
+    da = t1 * cut * (sg * (1.0f + part * (1.0f - sg)));        // d attn * C * SiLU'(a)
+}
+
+// target side: dq[i] (sum over row i), and the edge gradients d dk[e], d dv[e]
+template <int CPL>
+__global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                         const float *__restrict__ dk, const float *__restrict__ dv, const float *__restrict__ dvmsg,
+                                                         const float *__restrict__ dxagg, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                         const float *__restrict__ dist, float cutoff, int n, int H, int lph,
+                                                         float *__restrict__ dq, float *__restrict__ ddk, float *__restrict__ ddv) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int c0 = lane * CPL;
+    const bool on = c0 < H;
+    for (int i = wave; i < n; i += nw) {
+        float qi[CPL], gx[CPL], acc[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) { qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f; gx[u] = on ? dxagg[(size_t)i * H + c0 + u] : 0.f; acc[u] = 0.f; }
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const int j = col[e];
+            float kj[CPL], vj[CPL], dke[CPL], dve[CPL], dm[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                kj[u] = on ? k[(size_t)j * H + c0 + u] : 0.f; vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f;
+                dke[u] = on ? dk[(size_t)e * H + c0 + u] : 0.f; dve[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
+                dm[u] = on ? dvmsg[(size_t)e * H + c0 + u] + gx[u] : 0.f;
+            }
+            float attn, da;
+            attn_edge<CPL>(qi, kj, vj, dke, dve, dm, cos_cutoff(dist[e], cutoff), lph, attn, da);
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                if (on) { ddv[(size_t)e * H + c0 + u] = dm[u] * vj[u] * attn; ddk[(size_t)e * H + c0 + u] = da * qi[u] * kj[u]; }
+                acc[u] += da * kj[u] * dke[u];
+            }
+        }
+        if (on)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) dq[(size_t)i * H + c0 + u] = acc[u];
+    }
+}
+// source side: dk[j], dv[j] (sum over the by-source list of j)
+template <int CPL>
+__global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                         const float *__restrict__ dk, const float *__restrict__ dv, const float *__restrict__ dvmsg,
+                                                         const float *__restrict__ dxagg, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
+                                                         const int *__restrict__ tgt, const float *__restrict__ dist, float cutoff, int n, int H, int lph,
+                                                         float *__restrict__ dkn, float *__restrict__ dvn) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int c0 = lane * CPL;
+    const bool on = c0 < H;
+    for (int j = wave; j < n; j += nw) {
+        float kj[CPL], vj[CPL], ak[CPL], av[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) { kj[u] = on ? k[(size_t)j * H + c0 + u] : 0.f; vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f; ak[u] = 0.f; av[u] = 0.f; }
+        for (int s = t_rowptr[j]; s < t_rowptr[j + 1]; ++s) {
+            const int e = t_eid[s], i = tgt[e];
+            float qi[CPL], dke[CPL], dve[CPL], dm[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f;
+                dke[u] = on ? dk[(size_t)e * H + c0 + u] : 0.f; dve[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
+                dm[u] = on ? dvmsg[(size_t)e * H + c0 + u] + dxagg[(size_t)i * H + c0 + u] : 0.f;
+            }
+            float attn, da;
+            attn_edge<CPL>(qi, kj, vj, dke, dve, dm, cos_cutoff(dist[e], cutoff), lph, attn, da);
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { ak[u] += da * qi[u] * dke[u]; av[u] += dm[u] * dve[u] * attn; }
+        }
+        if (on)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { dkn[(size_t)j * H + c0 + u] = ak[u]; dvn[(size_t)j * H + c0 + u] = av[u]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- vector aggregate backward
+// ds[e] = [ sum_sp dvagg[tgt,sp]*vec[src,sp] | sum_sp dvagg[tgt,sp]*d_e[sp] ]
+__global__ void k_vec_aggregate_bwd_s(const float *__restrict__ vec, const float *__restrict__ dvagg, const float *__restrict__ dvec3,
+                                      const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges,
+                                      int H, float *__restrict__ ds) {
+    const int E = min(*ne_dev, max_edges);
+    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int e = (int)(t / H), c = (int)(t - (long long)e * H);
+        const float *g = dvagg + (size_t)tgt[e] * 3 * H, *vj = vec + (size_t)col[e] * 3 * H;
+        const float g0 = g[c], g1 = g[H + c], g2 = g[2 * H + c];
+        ds[(size_t)e * 2 * H + c] = g0 * vj[c] + g1 * vj[H + c] + g2 * vj[2 * H + c];
+        ds[(size_t)e * 2 * H + H + c] = g0 * dvec3[e * 3] + g1 * dvec3[e * 3 + 1] + g2 * dvec3[e * 3 + 2];
+    }
+}
+// dvec[j,sp] = sum_{e in srclist(j)} dvagg[tgt_e,sp] * s1_e
+__global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__restrict__ s, const float *__restrict__ dvagg, const int *__restrict__ t_rowptr,
+                                                             const int *__restrict__ t_eid, const int *__restrict__ tgt, int n, int H,
+                                                             float *__restrict__ dvec) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int j = wave; j < n; j += nw)
+        for (int c = lane; c < H; c += 64) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int q = t_rowptr[j]; q < t_rowptr[j + 1]; ++q) {
+                const int e = t_eid[q];
+                const float s1 = s[(size_t)e * 2 * H + c];
+                const float *g = dvagg + (size_t)tgt[e] * 3 * H;
+                a0 += g[c] * s1; a1 += g[H + c] * s1; a2 += g[2 * H + c] * s1;
+            }
+            float *o = dvec + (size_t)j * 3 * H;
+            o[c] = a0; o[H + c] = a1; o[2 * H + c] = a2;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- node update backward
+// forward: xo = x + vdot*o2 + o3 ; veco[sp] = vec[sp] + vec3[sp]*o1 + vagg[sp]      (dx = dxo, dvec = dveco, dvagg = dveco: aliases)
+// outputs: dvdot[n,H], do[n,3H] = [sum_sp dveco*vec3 | dxo*vdot | dxo], dvp[3n,3H] = [0 | 0 | dveco*o1]
+__global__ void k_node_update_bwd(const float *__restrict__ dxo, const float *__restrict__ dveco, const float *__restrict__ vdot, const float *__restrict__ o,
+                                  const float *__restrict__ vp, int n, int H, float *__restrict__ dvdot, float *__restrict__ dout_o, float *__restrict__ dvp) {
+    const long long tot = (long long)n * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / H), c = (int)(t - (long long)a * H);
+        const float gx = dxo[t];
+        const float o1 = o[(size_t)a * 3 * H + c], o2 = o[(size_t)a * 3 * H + H + c];
+        dvdot[t] = gx * o2;
+        float g1 = 0.f;
+        for (int sp = 0; sp < 3; ++sp) {
+            const size_t vi = ((size_t)a * 3 + sp) * H + c, pi = ((size_t)a * 3 + sp) * 3 * H;
+            const float gv = dveco[vi];
+            g1 += gv * vp[pi + 2 * H + c];
+            dvp[pi + c] = 0.f; dvp[pi + H + c] = 0.f; dvp[pi + 2 * H + c] = gv * o1;
+        }
+        dout_o[(size_t)a * 3 * H + c] = g1;
+        dout_o[(size_t)a * 3 * H + H + c] = gx * vdot[t];
+        dout_o[(size_t)a * 3 * H + 2 * H + c] = gx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- edge update backward
+// forward: fo = f + t * sum_sp w1*w2, w1 = a - (a.d)d, w2 = b - (b.d)d  (a = wt[tgt], b = ws[src]; the sign of d cancels)
+// target pass: dwt[i] = sum_{e in row(i)} P_d (g * w2), and dt[e] = dfo * (w1.w2)   with g = dfo * t, P_d u = u - (u.d)d
+__global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t,
+                                                           const float *__restrict__ dvec3, const float *__restrict__ dfo, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ col, int n, int H, float *__restrict__ dwt, float *__restrict__ dt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < n; i += nw)
+        for (int c = lane; c < H; c += 64) {
+            const float *a = wt + (size_t)i * 3 * H;
+            const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                const float d0 = dvec3[e * 3], d1 = dvec3[e * 3 + 1], d2 = dvec3[e * 3 + 2];
+                const float *b = ws + (size_t)col[e] * 3 * H;
+                const float b0 = b[c], b1 = b[H + c], b2 = b[2 * H + c];
+                const float pa = a0 * d0 + a1 * d1 + a2 * d2, pb = b0 * d0 + b1 * d1 + b2 * d2;
+                const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
+                const float w20 = b0 - pb * d0, w21 = b1 - pb * d1, w22 = b2 - pb * d2;
+                const float gf = dfo[(size_t)e * H + c];
+                dt[(size_t)e * H + c] = gf * (w10 * w20 + w11 * w21 + w12 * w22);
+                const float g = gf * t[(size_t)e * H + c];
+                const float u0 = g * w20, u1 = g * w21, u2 = g * w22;
+                const float pu = u0 * d0 + u1 * d1 + u2 * d2;
+                s0 += u0 - pu * d0; s1 += u1 - pu * d1; s2 += u2 - pu * d2;
+            }
+            float *o = dwt + (size_t)i * 3 * H;
+            o[c] = s0; o[H + c] = s1; o[2 * H + c] = s2;
+        }
+}
+// source pass: dws[j] = sum_{e in srclist(j)} P_d (g * w1)
+__global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restrict__ wt, const float *__restrict__ t, const float *__restrict__ dvec3,
+                                                           const float *__restrict__ dfo, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
+                                                           const int *__restrict__ tgt, int n, int H, float *__restrict__ dws) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int j = wave; j < n; j += nw)
+        for (int c = lane; c < H; c += 64) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int q = t_rowptr[j]; q < t_rowptr[j + 1]; ++q) {
+                const int e = t_eid[q];
+                const float d0 = dvec3[e * 3], d1 = dvec3[e * 3 + 1], d2 = dvec3[e * 3 + 2];
+                const float *a = wt + (size_t)tgt[e] * 3 * H;
+                const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c];
+                const float pa = a0 * d0 + a1 * d1 + a2 * d2;
+                const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
+                const float g = dfo[(size_t)e * H + c] * t[(size_t)e * H + c];
+                const float u0 = g * w10, u1 = g * w11, u2 = g * w12;
+                const float pu = u0 * d0 + u1 * d1 + u2 * d2;
+                s0 += u0 - pu * d0; s1 += u1 - pu * d1; s2 += u2 - pu * d2;
+            }
+            float *o = dws + (size_t)j * 3 * H;
+            o[c] = s0; o[H + c] = s1; o[2 * H + c] = s2;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- head pieces backward
+__global__ void k_spatial_norm_bwd(const float *__restrict__ v, const float *__restrict__ dout, int n, int H, float *__restrict__ dv) {
+    const long long tot = (long long)n * H, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / H), c = (int)(t - (long long)a * H);
+        const size_t i0 = ((size_t)a * 3) * H + c;
+        const float v0 = v[i0], v1 = v[i0 + H], v2 = v[i0 + 2 * H];
+        const float nrm = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+        const float s = nrm > 0.f ? dout[t] / nrm : 0.f;           // torch.norm backward: zero sub-gradient at the origin
+        dv[i0] = s * v0; dv[i0 + H] = s * v1; dv[i0 + 2 * H] = s * v2;
+    }
+}
+// du[n,2O] = [dxo * act'(xv) | sum_sp dvo*v2],  dv2[sp] = dvo[sp] * gate
+__global__ void k_gate_bwd(const float *__restrict__ u, const float *__restrict__ v2, const float *__restrict__ dxo, const float *__restrict__ dvo, int n, int O,
+                           int act, float *__restrict__ du, float *__restrict__ dv2) {
+    const long long tot = (long long)n * O, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const int a = (int)(t / O), c = (int)(t - (long long)a * O);
+        const float xv = u[(size_t)a * 2 * O + c], g = u[(size_t)a * 2 * O + O + c];
+        du[(size_t)a * 2 * O + c] = dxo[t] * (act ? dsilu_f(xv) : 1.0f);
+        float dg = 0.f;
+        for (int sp = 0; sp < 3; ++sp) {
+            const size_t i = ((size_t)a * 3 + sp) * O + c;
+            dg += dvo[i] * v2[i];
+            dv2[i] = dvo[i] * g;
+        }
+        du[(size_t)a * 2 * O + O + c] = dg;
+    }
+}
+__global__ void k_scale_scalar(const float *__restrict__ x, const float *__restrict__ sdev, long long n, float *__restrict__ out) {
+    const float s = *sdev;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = x[t] * s;
+}
+
+}  // namespace
+
+#define VB_CHECK(cond) if (!(cond)) return CONAN_E_BADARG
+extern "C" {
+
+int conan_silu_fwd(const float *x, int rows, int width, const int *m_dev, float *y, void *stream) {
+    VB_CHECK(x && y && rows >= 0 && width > 0);
+    k_silu_fwd<<<nblk((long long)rows * width), 256, 0, as_stream(stream)>>>(x, rows, width, m_dev, y);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_silu_bwd(const float *x, const float *dy, int rows, int width, const int *m_dev, float *dx, void *stream) {
+    VB_CHECK(x && dy && dx && rows >= 0 && width > 0);
+    k_silu_bwd<<<nblk((long long)rows * width), 256, 0, as_stream(stream)>>>(x, dy, rows, width, m_dev, dx);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_split2(const float *in, int Ha, int Hb, long long rows, float *a, float *b, void *stream) {
+    VB_CHECK(in && a && b && Ha > 0 && Hb > 0 && rows >= 0);
+    k_split2<<<nblk(rows * (Ha + Hb)), 256, 0, as_stream(stream)>>>(in, Ha, Hb, rows, a, b);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_rowsum(const float *x, int rows, int width, float *out, void *stream) {
+    VB_CHECK(x && out && rows >= 0 && width > 0);
+    k_rowsum<<<nblk(rows), 256, 0, as_stream(stream)>>>(x, rows, width, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_scale_scalar(const float *x, const float *scale_dev, long long count, float *out, void *stream) {
+    VB_CHECK(x && scale_dev && out && count >= 0);
+    k_scale_scalar<<<nblk(count), 256, 0, as_stream(stream)>>>(x, scale_dev, count, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_edge_embed_bwd(const float *x, const float *p, const float *df, const int *rowptr, const int *col, const int *tgt,
+                                const int *t_rowptr, const int *t_eid, const int *num_edges_dev, int max_edges, int n, int H, float *dp,
+                                float *dx, void *stream) {
+    VB_CHECK(x && p && df && rowptr && col && tgt && t_rowptr && t_eid && num_edges_dev && dp && dx && H > 0);
+    hipStream_t s = as_stream(stream);
+    k_edge_embed_bwd_p<<<nblk((long long)max_edges * H), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
+    k_edge_embed_bwd_x<<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+long long conan_layernorm_bwd_ws(int rows, int H) { return 2LL * rows + 2LL * ((rows + LN_CHUNK - 1) / LN_CHUNK) * H; }
+int conan_layernorm_bwd(const float *x, const float *gamma, const float *dy, int rows, int H, float eps, float *dx, float *dgamma,
+                        float *dbeta, float *ws, void *stream) {
+    VB_CHECK(x && gamma && dy && dx && dgamma && dbeta && ws && rows >= 0 && H > 0);
+    hipStream_t s = as_stream(stream);
+    float *stats = ws, *slabs = ws + 2 * (size_t)rows;
+    const int chunks = (rows + LN_CHUNK - 1) / LN_CHUNK;
+    if (rows > 0) {
+        k_layernorm_bwd_x<<<nblk((long long)rows * 64), 256, 0, s>>>(x, gamma, dy, rows, H, eps, dx, stats);
+        k_layernorm_bwd_p<<<dim3(chunks, (H + 127) / 128), 128, 0, s>>>(x, dy, stats, rows, H, slabs);
+    }
+    k_layernorm_bwd_reduce<<<(H + 255) / 256, 256, 0, s>>>(slabs, chunks, H, dgamma, dbeta);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_vecdot_bwd(const float *vp, const float *dout, int n, int H, float *dvp, void *stream) {
+    VB_CHECK(vp && dout && dvp && n >= 0 && H > 0);
+    k_vecdot_bwd<<<nblk((long long)n * 3 * H), 256, 0, as_stream(stream)>>>(vp, dout, n, H, dvp);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v, const float *dk, const float *dv, const float *dvmsg,
+                                  const float *dxagg, const int *rowptr, const int *col, const int *tgt, const int *t_rowptr,
+                                  const int *t_eid, const float *dist, float cutoff, int n, int H, int num_heads, float *dq, float *dkn,
+                                  float *dvn, float *ddk, float *ddv, void *stream) {
+    VB_CHECK(q && k && v && dk && dv && dvmsg && dxagg && rowptr && col && tgt && t_rowptr && t_eid && dist && dq && dkn && dvn && ddk && ddv);
+    VB_CHECK(n >= 0 && H > 0 && num_heads > 0 && H % num_heads == 0);
+    const int hd = H / num_heads, cpl = H > 64 ? (H + 63) / 64 : 1;
+    if (H > 128 || (H > 64 && H != 128) || hd % cpl != 0) return CONAN_E_UNSUPPORTED;
+    const int lph = hd / cpl;
+    if (lph & (lph - 1)) return CONAN_E_UNSUPPORTED;
+    if (n == 0) return CONAN_OK;
+    hipStream_t s = as_stream(stream);
+    const int g = nblk((long long)n * 64);
+    if (cpl == 2) {
+        k_attn_bwd_target<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, dq, ddk, ddv);
+        k_attn_bwd_source<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, dkn, dvn);
+    } else {
+        k_attn_bwd_target<1><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, dq, ddk, ddv);
+        k_attn_bwd_source<1><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, dkn, dvn);
+    }
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float *dvec3, const float *dvagg, const int *col, const int *tgt,
+                                   const int *t_rowptr, const int *t_eid, const int *num_edges_dev, int max_edges, int n, int H, float *ds,
+                                   float *dvec, void *stream) {
+    VB_CHECK(vec && s && dvec3 && dvagg && col && tgt && t_rowptr && t_eid && num_edges_dev && ds && dvec && H > 0);
+    hipStream_t st = as_stream(stream);
+    k_vec_aggregate_bwd_s<<<nblk((long long)max_edges * H), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, ds);
+    if (n > 0) k_vec_aggregate_bwd_v<<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, dvec);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp, int n, int H,
+                                 float *dvdot, float *dout_o, float *dvp, void *stream) {
+    VB_CHECK(dxo && dveco && vdot && o && vp && dvdot && dout_o && dvp && n >= 0 && H > 0);
+    k_node_update_bwd<<<nblk((long long)n * H), 256, 0, as_stream(stream)>>>(dxo, dveco, vdot, o, vp, n, H, dvdot, dout_o, dvp);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_edge_update_bwd(const float *wt, const float *ws, const float *t, const float *dvec3, const float *dfo, const int *rowptr,
+                                 const int *col, const int *tgt, const int *t_rowptr, const int *t_eid, int n, int H, float *dwt, float *dws,
+                                 float *dt, void *stream) {
+    VB_CHECK(wt && ws && t && dvec3 && dfo && rowptr && col && tgt && t_rowptr && t_eid && dwt && dws && dt && n >= 0 && H > 0);
+    if (n == 0) return CONAN_OK;
+    hipStream_t s = as_stream(stream);
+    k_edge_update_bwd_t<<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, dwt, dt);
+    k_edge_update_bwd_s<<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, dws);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_spatial_norm_bwd(const float *v, const float *dout, int n, int H, float *dv, void *stream) {
+    VB_CHECK(v && dout && dv && n >= 0 && H > 0);
+    k_spatial_norm_bwd<<<nblk((long long)n * H), 256, 0, as_stream(stream)>>>(v, dout, n, H, dv);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+int conan_visnet_gate_bwd(const float *u, const float *v2, const float *dxo, const float *dvo, int n, int out_channels, int scalar_activation,
+                          float *du, float *dv2, void *stream) {
+    VB_CHECK(u && v2 && dxo && dvo && du && dv2 && n >= 0 && out_channels > 0);
+    k_gate_bwd<<<nblk((long long)n * out_channels), 256, 0, as_stream(stream)>>>(u, v2, dxo, dvo, n, out_channels, scalar_activation, du, dv2);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
+
+}  // extern "C"

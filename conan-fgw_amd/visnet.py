@@ -1,4 +1,4 @@
-"""Drop-in ConAN `ViSNet` backbone for MI355X — forward path.
+"""Drop-in ConAN `ViSNet` backbone for MI355X.
 
 Mirrors the reference's wrapper class (conan_fgw/src/model/graph_embeddings/visnet.py:82-288) and the vendored ViSNet it
 subclasses (torch_geometric_visnet.py:1061-1229) with the only configuration ConAN instantiates (common.py:542-546:
@@ -6,8 +6,9 @@ lmax=1, 8 heads, 6 layers, 32 non-trainable RBFs, cutoff 5 A, vertex=False, vecn
 `ViSNet(device, hidden_channels, cutoff=5.0)`, same methods, same parameter / buffer names, so the reference's
 `state_dict` loads with strict=True.  The nn modules are parameter containers; compute runs on libconan_fgw_hip.so.
 
-Round-1 scope: INFERENCE (forward) only — outputs carry no autograd graph; the ViSNet backward kernels are the next
-row of the build (the SchNet path has the full backward).  No CPU fallback.
+Forward and backward run on HIP kernels (csrc/visnet.hip, csrc/visnet_bwd.hip) through the autograd wrappers of
+visnet_ops.py; gradients reach every trainable parameter exactly as in the reference (the RBF means/betas and the
+VecLayerNorm weights are non-trainable buffers there too).  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -19,22 +20,10 @@ from torch import Tensor
 from torch.nn import Embedding, LayerNorm, Linear
 
 from . import ops
+from . import visnet_ops as vo
 from ._lib import call, ptr, stream_ptr
 
 f32 = torch.float32
-
-
-def _lin(x: Tensor, m: Linear, act: int = 0, m_dev: Optional[Tensor] = None) -> Tensor:
-    x = x if x.is_contiguous() else x.contiguous()
-    M, K = x.shape
-    N = m.weight.shape[0]
-    y = torch.empty(M, N, dtype=f32, device=x.device)
-    call("conan_linear_fwd", ptr(x, f32), ptr(m.weight.detach().contiguous()), ptr(m.bias.detach()) if m.bias is not None else None, None,
-         M, K, N, 0, act, ptr(m_dev), ptr(y), stream_ptr())
-    return y
-
-
-SILU = 3
 
 
 class ExpNormalSmearing(torch.nn.Module):
@@ -104,70 +93,48 @@ class ViSNetBlock(torch.nn.Module):
         self.out_norm = LayerNorm(hidden_channels)
         self.vec_out_norm = VecLayerNorm(hidden_channels)
 
-    @torch.no_grad()
     def forward(self, z: Tensor, pos: Tensor, graph_ptr: Tensor, num_graphs: int):
         """torch_geometric_visnet.py:843-886."""
         H, dev, n, s = self.hidden_channels, z.device, z.shape[0], stream_ptr()
         g = ops.RadiusGraph(pos, graph_ptr, num_graphs, self.cutoff, self.max_num_neighbors, loop=True)      # Distance, :331-347
         md, ME = g.num_edges_dev, g.max_edges
-        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
-        dvec = new(ME, 3)
+        dvec = torch.empty(ME, 3, dtype=f32, device=dev)                                                     # geometry: no gradient (pos is an input)
         call("conan_visnet_edge_unit", ptr(pos.contiguous(), f32), ptr(g.col), ptr(g.tgt), ptr(md), ME, ptr(dvec), s)
         de = self.distance_expansion
-        rbf = new(ME, de.num_rbf)
+        rbf = torch.zeros(ME, de.num_rbf, dtype=f32, device=dev)
         call("conan_visnet_expnormal", ptr(g.dist), ptr(md), ME, ptr(de.means), ptr(de.betas), de.num_rbf, de.alpha, de.cutoff, ptr(rbf), s)
-        x = ops.embedding(z, self.embedding.weight.detach(), None)
+        x = ops.embedding(z, self.embedding.weight, None)
         # NeighborEmbedding, :387-420
         ne = self.neighbor_embedding
-        W = _lin(rbf, ne.distance_proj, 0, md)
-        call("conan_visnet_neighbor_scale", ptr(W), ptr(g.dist), ptr(g.col), ptr(g.tgt), ptr(md), ME, H, ne_cutoff(self), s)
-        xn = ops.cfconv(ops.embedding(z, ne.embedding.weight.detach(), None), W, g)
-        cat = new(n, 2 * H)
-        call("conan_concat2", ptr(x), H, ptr(xn), H, n, ptr(cat), s)
-        x = _lin(cat, ne.combine)
+        W = vo.neighbor_scale(vo.lin(rbf, ne.distance_proj, False, md), g, self.cutoff)
+        xn = ops.cfconv(ops.embedding(z, ne.embedding.weight, None), W, g)
+        x = vo.lin(vo.concat2(x, xn), ne.combine)
         vec = torch.zeros(n, 3, H, dtype=f32, device=dev)                                                    # :868-870
-        # EdgeEmbedding, :463-465
-        p = _lin(rbf, self.edge_embedding.edge_proj, 0, md)
-        f = new(ME, H)
-        call("conan_visnet_edge_embed", ptr(x), ptr(p), ptr(g.col), ptr(g.tgt), ptr(md), ME, H, ptr(f), s)
+        f = vo.edge_embed(x, vo.lin(rbf, self.edge_embedding.edge_proj, False, md), g)                       # EdgeEmbedding, :463-465
         for layer in self.vis_mp_layers:
             x, vec, f = self._vis_mp(layer, x, vec, f, g, dvec)
-        xo = new(n, H)
-        call("conan_layernorm_fwd", ptr(x), ptr(self.out_norm.weight.detach()), ptr(self.out_norm.bias.detach()), n, H, self.out_norm.eps, ptr(xo), s)
-        vo = new(n, 3, H)
-        call("conan_scale_channels", ptr(vec), ptr(self.vec_out_norm.weight), 3 * n, H, ptr(vo), s)
-        return xo, vo
+        return vo.layernorm(x, self.out_norm), vo.scale_channels(vec, self.vec_out_norm.weight)
 
     def _vis_mp(self, L: ViS_MP, x, vec, f, g, dvec):
         """ViS_MP.forward / message / aggregate / edge_update, torch_geometric_visnet.py:579-673."""
-        H, n, dev, s = self.hidden_channels, x.shape[0], x.device, stream_ptr()
-        md, ME = g.num_edges_dev, g.max_edges
-        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
-        xl = new(n, H)
-        call("conan_layernorm_fwd", ptr(x), ptr(L.layernorm.weight.detach()), ptr(L.layernorm.bias.detach()), n, H, L.layernorm.eps, ptr(xl), s)
-        vl = new(n, 3, H)
-        call("conan_scale_channels", ptr(vec), ptr(L.vec_layernorm.weight), 3 * n, H, ptr(vl), s)
-        q, k, v = _lin(xl, L.q_proj), _lin(xl, L.k_proj), _lin(xl, L.v_proj)
-        dk, dv = _lin(f, L.dk_proj, SILU, md), _lin(f, L.dv_proj, SILU, md)
-        vp = _lin(vl.view(3 * n, H), L.vec_proj)                                   # [3n, 3H] = [vec1|vec2|vec3]
-        vdot = new(n, H)
-        call("conan_visnet_vecdot", ptr(vp), n, H, ptr(vdot), s)
-        vmsg, xagg = new(ME, H), new(n, H)
-        call("conan_visnet_attn_message", ptr(q), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(g.rowptr), ptr(g.col), ptr(g.dist), L.cutoff, n, H,
-             L.num_heads, ptr(vmsg), ptr(xagg), s)
-        sact = _lin(vmsg, L.s_proj, SILU, md)                                      # [E, 2H] = [s1|s2]
-        vagg = new(n, 3, H)
-        call("conan_visnet_vec_aggregate", ptr(vl), ptr(sact), ptr(dvec), ptr(g.rowptr), ptr(g.col), n, H, ptr(vagg), s)
-        o = _lin(xagg, L.o_proj)
-        xo, veco = new(n, H), new(n, 3, H)
-        call("conan_visnet_node_update", ptr(x), ptr(vec), ptr(vdot), ptr(o), ptr(vp), ptr(vagg), n, H, ptr(xo), ptr(veco), s)
+        H, n = self.hidden_channels, x.shape[0]
+        md = g.num_edges_dev
+        xl = vo.layernorm(x, L.layernorm)
+        vl = vo.scale_channels(vec, L.vec_layernorm.weight)
+        q, k, v = vo.lin(xl, L.q_proj), vo.lin(xl, L.k_proj), vo.lin(xl, L.v_proj)
+        dk, dv = vo.lin(f, L.dk_proj, True, md), vo.lin(f, L.dv_proj, True, md)
+        vp = vo.lin(vl.view(3 * n, H), L.vec_proj)                                 # [3n, 3H] = [vec1|vec2|vec3]
+        vdot = vo.vecdot(vp, n, H)
+        vmsg, xagg = vo.attn_message(q, k, v, dk, dv, g, L.cutoff, L.num_heads)
+        sact = vo.lin(vmsg, L.s_proj, True, md)                                    # [E, 2H] = [s1|s2]
+        vagg = vo.vec_aggregate(vl, sact, dvec, g)
+        o = vo.lin(xagg, L.o_proj)
+        xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
         if L.last_layer:
             return xo, veco, f
-        wt, ws = _lin(vl.view(3 * n, H), L.w_trg_proj), _lin(vl.view(3 * n, H), L.w_src_proj)      # node-level: Linear commutes with the gather
-        t = _lin(f, L.f_proj, SILU, md)
-        fo = new(ME, H)
-        call("conan_visnet_edge_update", ptr(wt), ptr(ws), ptr(t), ptr(dvec), ptr(g.col), ptr(g.tgt), ptr(md), ME, H, ptr(f), ptr(fo), s)
-        return xo, veco, fo
+        wt, ws = vo.lin(vl.view(3 * n, H), L.w_trg_proj), vo.lin(vl.view(3 * n, H), L.w_src_proj)   # node-level: Linear commutes with the gather
+        t = vo.lin(f, L.f_proj, True, md)
+        return xo, veco, vo.edge_update(wt, ws, t, dvec, f, g)
 
 
 def ne_cutoff(block: ViSNetBlock) -> float:
@@ -186,21 +153,13 @@ class GatedEquivariantBlock(torch.nn.Module):
             if m.bias is not None:
                 m.bias.data.zero_()
 
-    @torch.no_grad()
     def forward(self, x: Tensor, v: Tensor):
         """torch_geometric_visnet.py:942-960."""
-        n, Hh, O, dev, s = x.shape[0], self.hidden, self.out_channels, x.device, stream_ptr()
-        new = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)
-        v1 = _lin(v.view(3 * n, Hh), self.vec1_proj)
-        v1n = new(n, Hh)
-        call("conan_visnet_spatial_norm", ptr(v1), n, Hh, ptr(v1n), s)
-        v2 = _lin(v.view(3 * n, Hh), self.vec2_proj)                               # [3n, O]
-        cat = new(n, 2 * Hh)
-        call("conan_concat2", ptr(x), Hh, ptr(v1n), Hh, n, ptr(cat), s)
-        u = _lin(_lin(cat, self.update_net[0], SILU), self.update_net[2])          # [n, 2*O]
-        xo, vo = new(n, O), new(n, 3, O)
-        call("conan_visnet_gate", ptr(u), ptr(v2), n, O, int(self.scalar_activation), ptr(xo), ptr(vo), s)
-        return xo, vo
+        n, Hh, O = x.shape[0], self.hidden, self.out_channels
+        v1n = vo.spatial_norm(vo.lin(v.reshape(3 * n, Hh), self.vec1_proj), n, Hh)
+        v2 = vo.lin(v.reshape(3 * n, Hh), self.vec2_proj)                            # [3n, O]
+        u = vo.lin(vo.lin(vo.concat2(x, v1n), self.update_net[0], True), self.update_net[2])     # [n, 2*O]
+        return vo.gate(u, v2, n, O, int(self.scalar_activation))
 
 
 class EquivariantScalar(torch.nn.Module):
@@ -252,30 +211,22 @@ class ViSNet(torch.nn.Module):
             num_graphs = int(batch[-1].item()) + 1
         return batch, ops.graph_ptr_from_batch(batch, num_graphs), num_graphs
 
-    @torch.no_grad()
     def _head(self, xs, vs, z, output_model, prior):
-        x = output_model.pre_reduce(xs, vs)
-        out = torch.empty_like(x)
-        call("conan_visnet_prior", ptr(x), ptr(z.contiguous(), torch.int64), ptr(prior.atomref.weight.detach().contiguous()), ptr(self.std),
-             x.shape[0], x.shape[1], ptr(out), stream_ptr())
-        return out
+        return vo.prior(output_model.pre_reduce(xs, vs), z, prior.atomref.weight, self.std)
 
     # ---------------------------------------------------------------------------------------------- reference API
-    @torch.no_grad()
     def forward(self, z: Tensor, pos: Tensor, batch: Tensor, num_graphs: Optional[int] = None) -> Tensor:
         """visnet.py:93-122: per-conformer sum of the scalar head."""
         batch, gp, G = self._prep(z, batch, num_graphs)
         xs, vs = self.representation_model(z, pos, gp, G)
         return ops.segment_sum(self._head(xs, vs, z, self.output_model, self.prior_model), gp, G)
 
-    @torch.no_grad()
     def forward_3d_bary(self, z: Tensor, pos: Tensor, batch: Tensor, num_graphs: Optional[int] = None):
         """visnet.py:124-158: two per-atom heads from the shared representation."""
         batch, gp, G = self._prep(z, batch, num_graphs)
         xs, vs = self.representation_model(z, pos, gp, G)
         return self._head(xs, vs, z, self.output_model, self.prior_model), self._head(xs, vs, z, self.output_model_bary, self.prior_model_bary)
 
-    @torch.no_grad()
     def _compute_barycenter(self, node_feature: Tensor, edge_index, batch: Tensor, batch_size: int, num_conformers: int,
                             max_nodes: Optional[int] = None):
         """visnet.py:160-249 (shift +1.0, NaN guard, column normalisation)."""
@@ -291,7 +242,6 @@ class ViSNet(torch.nn.Module):
         self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs)
         return ops.segment_sum(node_feature, graph.graph_ptr, G), ops.fgw_readout(Y, K, self.READOUT_MODE)
 
-    @torch.no_grad()
     def forward_w_barycenter(self, z: Tensor, pos: Tensor, num_conformers: int, batch: Optional[Tensor] = None, data_batch=None,
                              max_iter: int = 100, epsilon: float = 0.1, num_graphs: Optional[int] = None, max_nodes: Optional[int] = None):
         """visnet.py:251-288."""

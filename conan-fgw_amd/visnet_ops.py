@@ -1,0 +1,371 @@
+"""torch.autograd wrappers of the ViSNet kernels (csrc/visnet.hip, csrc/visnet_bwd.hip).  Plumbing only: every forward and
+backward below is a HIP kernel of libconan_fgw_hip.so."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import call, lib, ptr, stream_ptr
+
+f32 = torch.float32
+_c = ops._c
+
+
+def _new(like: Tensor, *shape):
+    return torch.empty(*shape, dtype=f32, device=like.device)
+
+
+class _Silu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m_dev):
+        x = _c(x)
+        y = torch.empty_like(x) if m_dev is None else torch.zeros_like(x)
+        call("conan_silu_fwd", ptr(x, f32), x.shape[0], x.shape[1], ptr(m_dev), ptr(y), stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.m_dev = m_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x) if ctx.m_dev is None else torch.zeros_like(x)
+        call("conan_silu_bwd", ptr(x), ptr(_c(dy)), x.shape[0], x.shape[1], ptr(ctx.m_dev), ptr(dx), stream_ptr())
+        return dx, None
+
+
+def silu(x, m_dev=None):
+    return _Silu.apply(x, m_dev)
+
+
+def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Tensor:
+    y = ops.linear(x, m.weight, m.bias, m_dev=m_dev)
+    return silu(y, m_dev) if act_silu else y
+
+
+class _NeighborScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, graph, cutoff):
+        out = W.clone()
+        call("conan_visnet_neighbor_scale", ptr(out), ptr(graph.dist), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev),
+             graph.max_edges, W.shape[1], float(cutoff), stream_ptr())
+        ctx.graph, ctx.cutoff = graph, float(cutoff)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.graph
+        d = _c(dout).clone()
+        call("conan_visnet_neighbor_scale", ptr(d), ptr(g.dist), ptr(g.col), ptr(g.tgt), ptr(g.num_edges_dev), g.max_edges, d.shape[1],
+             ctx.cutoff, stream_ptr())
+        return d, None, None
+
+
+def neighbor_scale(W, graph, cutoff):
+    return _NeighborScale.apply(W, graph, cutoff)
+
+
+class _Concat2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        out = _new(a, a.shape[0], a.shape[1] + b.shape[1])
+        call("conan_concat2", ptr(a, f32), a.shape[1], ptr(b, f32), b.shape[1], a.shape[0], ptr(out), stream_ptr())
+        ctx.dims = (a.shape[0], a.shape[1], b.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, Ha, Hb = ctx.dims
+        da, db = _new(dout, n, Ha), _new(dout, n, Hb)
+        call("conan_split2", ptr(_c(dout)), Ha, Hb, n, ptr(da), ptr(db), stream_ptr())
+        return da, db
+
+
+def concat2(a, b):
+    return _Concat2.apply(a, b)
+
+
+class _EdgeEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, graph):
+        x, p = _c(x), _c(p)
+        H = x.shape[1]
+        f = torch.zeros(graph.max_edges, H, dtype=f32, device=x.device)
+        call("conan_visnet_edge_embed", ptr(x, f32), ptr(p, f32), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev), graph.max_edges, H,
+             ptr(f), stream_ptr())
+        ctx.save_for_backward(x, p)
+        ctx.graph = graph
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        x, p = ctx.saved_tensors
+        g = ctx.graph
+        tr, te = g.transpose()
+        dp, dx = torch.zeros_like(p), torch.empty_like(x)
+        call("conan_visnet_edge_embed_bwd", ptr(x), ptr(p), ptr(_c(df)), ptr(g.rowptr), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
+             ptr(g.num_edges_dev), g.max_edges, x.shape[0], x.shape[1], ptr(dp), ptr(dx), stream_ptr())
+        return dx, dp, None
+
+
+def edge_embed(x, p, graph):
+    return _EdgeEmbed.apply(x, p, graph)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        out = torch.empty_like(x)
+        call("conan_layernorm_fwd", ptr(x, f32), ptr(_c(gamma)), ptr(_c(beta)), x.shape[0], x.shape[1], float(eps), ptr(out), stream_ptr())
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        n, H = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(int(lib().conan_layernorm_bwd_ws(n, H)), dtype=f32, device=x.device)
+        call("conan_layernorm_bwd", ptr(x), ptr(_c(gamma)), ptr(_c(dy)), n, H, ctx.eps, ptr(dx), ptr(dg), ptr(db), ptr(ws), stream_ptr())
+        return dx, dg, db, None
+
+
+def layernorm(x, m: torch.nn.LayerNorm):
+    return _LayerNorm.apply(x, m.weight, m.bias, m.eps)
+
+
+class _ScaleChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, w):
+        v = _c(v)
+        out = torch.empty_like(v)
+        H = v.shape[-1]
+        call("conan_scale_channels", ptr(v, f32), ptr(w, f32), v.numel() // H, H, ptr(out), stream_ptr())
+        ctx.save_for_backward(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w,) = ctx.saved_tensors
+        dout = _c(dout)
+        dv = torch.empty_like(dout)
+        H = dout.shape[-1]
+        call("conan_scale_channels", ptr(dout), ptr(w), dout.numel() // H, H, ptr(dv), stream_ptr())
+        return dv, None
+
+
+def scale_channels(v, w):
+    return _ScaleChannels.apply(v, w)
+
+
+class _VecDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vp, n, H):
+        vp = _c(vp)
+        out = _new(vp, n, H)
+        call("conan_visnet_vecdot", ptr(vp, f32), n, H, ptr(out), stream_ptr())
+        ctx.save_for_backward(vp)
+        ctx.dims = (n, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (vp,) = ctx.saved_tensors
+        n, H = ctx.dims
+        dvp = torch.empty_like(vp)
+        call("conan_visnet_vecdot_bwd", ptr(vp), ptr(_c(dout)), n, H, ptr(dvp), stream_ptr())
+        return dvp, None, None
+
+
+def vecdot(vp, n, H):
+    return _VecDot.apply(vp, n, H)
+
+
+class _AttnMessage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, dk, dv, graph, cutoff, heads):
+        q, k, v, dk, dv = (_c(t) for t in (q, k, v, dk, dv))
+        n, H = q.shape
+        vmsg = torch.zeros(graph.max_edges, H, dtype=f32, device=q.device)
+        xagg = _new(q, n, H)
+        call("conan_visnet_attn_message", ptr(q, f32), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(graph.rowptr), ptr(graph.col), ptr(graph.dist),
+             float(cutoff), n, H, heads, ptr(vmsg), ptr(xagg), stream_ptr())
+        ctx.save_for_backward(q, k, v, dk, dv)
+        ctx.graph, ctx.cutoff, ctx.heads = graph, float(cutoff), heads
+        return vmsg, xagg
+
+    @staticmethod
+    def backward(ctx, dvmsg, dxagg):
+        q, k, v, dk, dv = ctx.saved_tensors
+        g = ctx.graph
+        tr, te = g.transpose()
+        n, H = q.shape
+        dq, dkn, dvn = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ddk, ddv = torch.zeros_like(dk), torch.zeros_like(dv)
+        call("conan_visnet_attn_message_bwd", ptr(q), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(_c(dvmsg)), ptr(_c(dxagg)), ptr(g.rowptr), ptr(g.col),
+             ptr(g.tgt), ptr(tr), ptr(te), ptr(g.dist), ctx.cutoff, n, H, ctx.heads, ptr(dq), ptr(dkn), ptr(dvn), ptr(ddk), ptr(ddv), stream_ptr())
+        return dq, dkn, dvn, ddk, ddv, None, None, None
+
+
+def attn_message(q, k, v, dk, dv, graph, cutoff, heads):
+    return _AttnMessage.apply(q, k, v, dk, dv, graph, cutoff, heads)
+
+
+class _VecAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vec, s, dvec3, graph):
+        vec, s = _c(vec), _c(s)
+        n, _, H = vec.shape
+        vagg = torch.empty_like(vec)
+        call("conan_visnet_vec_aggregate", ptr(vec, f32), ptr(s, f32), ptr(dvec3), ptr(graph.rowptr), ptr(graph.col), n, H, ptr(vagg), stream_ptr())
+        ctx.save_for_backward(vec, s, dvec3)
+        ctx.graph = graph
+        return vagg
+
+    @staticmethod
+    def backward(ctx, dvagg):
+        vec, s, dvec3 = ctx.saved_tensors
+        g = ctx.graph
+        tr, te = g.transpose()
+        n, _, H = vec.shape
+        ds, dvec = torch.zeros_like(s), torch.empty_like(vec)
+        call("conan_visnet_vec_aggregate_bwd", ptr(vec), ptr(s), ptr(dvec3), ptr(_c(dvagg)), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
+             ptr(g.num_edges_dev), g.max_edges, n, H, ptr(ds), ptr(dvec), stream_ptr())
+        return dvec, ds, None, None
+
+
+def vec_aggregate(vec, s, dvec3, graph):
+    return _VecAggregate.apply(vec, s, dvec3, graph)
+
+
+class _NodeUpdate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, vec, vdot, o, vp, vagg):
+        x, vec, vdot, o, vp, vagg = (_c(t) for t in (x, vec, vdot, o, vp, vagg))
+        n, H = x.shape
+        xo, veco = torch.empty_like(x), torch.empty_like(vec)
+        call("conan_visnet_node_update", ptr(x, f32), ptr(vec), ptr(vdot), ptr(o), ptr(vp), ptr(vagg), n, H, ptr(xo), ptr(veco), stream_ptr())
+        ctx.save_for_backward(vdot, o, vp)
+        return xo, veco
+
+    @staticmethod
+    def backward(ctx, dxo, dveco):
+        vdot, o, vp = ctx.saved_tensors
+        n, H = vdot.shape
+        dxo, dveco = _c(dxo), _c(dveco)
+        dvdot, do, dvp = torch.empty_like(vdot), torch.empty_like(o), torch.empty_like(vp)
+        call("conan_visnet_node_update_bwd", ptr(dxo), ptr(dveco), ptr(vdot), ptr(o), ptr(vp), n, H, ptr(dvdot), ptr(do), ptr(dvp), stream_ptr())
+        return dxo, dveco, dvdot, do, dvp, dveco
+
+
+def node_update(x, vec, vdot, o, vp, vagg):
+    return _NodeUpdate.apply(x, vec, vdot, o, vp, vagg)
+
+
+class _EdgeUpdate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wt, ws, t, dvec3, f, graph):
+        wt, ws, t, f = (_c(a) for a in (wt, ws, t, f))
+        H = f.shape[1]
+        fo = torch.zeros_like(f)
+        call("conan_visnet_edge_update", ptr(wt, f32), ptr(ws), ptr(t), ptr(dvec3), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev),
+             graph.max_edges, H, ptr(f), ptr(fo), stream_ptr())
+        ctx.save_for_backward(wt, ws, t, dvec3)
+        ctx.graph = graph
+        return fo
+
+    @staticmethod
+    def backward(ctx, dfo):
+        wt, ws, t, dvec3 = ctx.saved_tensors
+        g = ctx.graph
+        tr, te = g.transpose()
+        n, H = wt.shape[0] // 3, t.shape[1]
+        dfo = _c(dfo)
+        dwt, dws, dt = torch.empty_like(wt), torch.empty_like(ws), torch.zeros_like(t)
+        call("conan_visnet_edge_update_bwd", ptr(wt), ptr(ws), ptr(t), ptr(dvec3), ptr(dfo), ptr(g.rowptr), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
+             n, H, ptr(dwt), ptr(dws), ptr(dt), stream_ptr())
+        return dwt, dws, dt, None, dfo, None
+
+
+def edge_update(wt, ws, t, dvec3, f, graph):
+    return _EdgeUpdate.apply(wt, ws, t, dvec3, f, graph)
+
+
+class _SpatialNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, n, H):
+        v = _c(v)
+        out = _new(v, n, H)
+        call("conan_visnet_spatial_norm", ptr(v, f32), n, H, ptr(out), stream_ptr())
+        ctx.save_for_backward(v)
+        ctx.dims = (n, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (v,) = ctx.saved_tensors
+        n, H = ctx.dims
+        dv = torch.empty_like(v)
+        call("conan_visnet_spatial_norm_bwd", ptr(v), ptr(_c(dout)), n, H, ptr(dv), stream_ptr())
+        return dv, None, None
+
+
+def spatial_norm(v, n, H):
+    return _SpatialNorm.apply(v, n, H)
+
+
+class _Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, v2, n, O, act):
+        u, v2 = _c(u), _c(v2)
+        xo, vo = _new(u, n, O), _new(u, n, 3, O)
+        call("conan_visnet_gate", ptr(u, f32), ptr(v2, f32), n, O, act, ptr(xo), ptr(vo), stream_ptr())
+        ctx.save_for_backward(u, v2)
+        ctx.dims = (n, O, act)
+        return xo, vo
+
+    @staticmethod
+    def backward(ctx, dxo, dvo):
+        u, v2 = ctx.saved_tensors
+        n, O, act = ctx.dims
+        du, dv2 = torch.empty_like(u), torch.empty_like(v2)
+        call("conan_visnet_gate_bwd", ptr(u), ptr(v2), ptr(_c(dxo)), ptr(_c(dvo)), n, O, act, ptr(du), ptr(dv2), stream_ptr())
+        return du, dv2, None, None, None
+
+
+def gate(u, v2, n, O, act):
+    return _Gate.apply(u, v2, n, O, act)
+
+
+class _Prior(torch.autograd.Function):
+    """out = x * std + atomref[z]   (std is a buffer: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, z, atomref_w, std):
+        x = _c(x)
+        out = torch.empty_like(x)
+        call("conan_visnet_prior", ptr(x, f32), ptr(_c(z), torch.int64), ptr(_c(atomref_w)), ptr(std), x.shape[0], x.shape[1], ptr(out), stream_ptr())
+        ctx.save_for_backward(z, std)
+        ctx.rows = atomref_w.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, std = ctx.saved_tensors
+        dout = _c(dout)
+        n, O = dout.shape
+        dx = torch.empty_like(dout)
+        call("conan_scale_scalar", ptr(dout), ptr(std), dout.numel(), ptr(dx), stream_ptr())
+        rs = _new(dout, n, 1)
+        call("conan_rowsum", ptr(dout), n, O, ptr(rs), stream_ptr())
+        dw = _new(dout, ctx.rows, 1)
+        ws = torch.empty(int(lib().conan_embedding_bwd_ws(n, 1, ctx.rows)), dtype=f32, device=dout.device)
+        call("conan_embedding_bwd", ptr(z), ptr(rs), n, 1, ctx.rows, -1, ptr(dw), ptr(ws), stream_ptr())
+        return dx, None, dw, None
+
+
+def prior(x, z, atomref_w, std):
+    return _Prior.apply(x, z, atomref_w, std)

@@ -180,6 +180,48 @@ int conan_visnet_gate(const float *u, const float *v2, int n, int out_channels, 
 int conan_visnet_prior(const float *x, const int64_t *z, const float *atomref, const float *std_dev, int n,
                        int out_channels, float *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------- ViSNet (backward)
+ * Gradients of the kernels above (autograd of torch_geometric_visnet.py).  Node-level gradients fed by many edges are
+ * accumulated without atomics: one wavefront per node walks its CSR row (target side) or its by-source list
+ * (t_rowptr / t_eid from conan_csr_transpose) in a fixed order. */
+int conan_silu_fwd(const float *x, int rows, int width, const int *m_dev, float *y, void *stream);
+int conan_silu_bwd(const float *x, const float *dy, int rows, int width, const int *m_dev, float *dx, void *stream);
+/* inverse of conan_concat2 (backward of torch.cat). */
+int conan_split2(const float *in, int Ha, int Hb, long long rows, float *a, float *b, void *stream);
+int conan_rowsum(const float *x, int rows, int width, float *out, void *stream);
+int conan_scale_scalar(const float *x, const float *scale_dev, long long count, float *out, void *stream);
+/* EdgeEmbedding: dp[e] = (x_i+x_j)*df[e]; dx[i] = sum over the edges incident to i (either side) of df*p. */
+int conan_visnet_edge_embed_bwd(const float *x, const float *p, const float *df, const int *rowptr, const int *col,
+                                const int *tgt, const int *t_rowptr, const int *t_eid, const int *num_edges_dev,
+                                int max_edges, int n, int H, float *dp, float *dx, void *stream);
+/* LayerNorm: dx, dgamma, dbeta (deterministic chunked reduction); ws holds conan_layernorm_bwd_ws(rows, H) floats. */
+long long conan_layernorm_bwd_ws(int rows, int H);
+int conan_layernorm_bwd(const float *x, const float *gamma, const float *dy, int rows, int H, float eps, float *dx,
+                        float *dgamma, float *dbeta, float *ws, void *stream);
+/* dvp [n,3,3H] = [dout*vec2 | dout*vec1 | 0]. */
+int conan_visnet_vecdot_bwd(const float *vp, const float *dout, int n, int H, float *dvp, void *stream);
+/* Attention message: given dvmsg [E,H] and dxagg [n,H] returns dq, dk, dv [n,H] and d(dk), d(dv) [E,H]. */
+int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v, const float *dk, const float *dv,
+                                  const float *dvmsg, const float *dxagg, const int *rowptr, const int *col,
+                                  const int *tgt, const int *t_rowptr, const int *t_eid, const float *dist, float cutoff,
+                                  int n, int H, int num_heads, float *dq, float *dkn, float *dvn, float *ddk, float *ddv,
+                                  void *stream);
+/* Vector aggregate: ds [E,2H], dvec [n,3,H] from dvagg [n,3,H]. */
+int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float *dvec3, const float *dvagg,
+                                   const int *col, const int *tgt, const int *t_rowptr, const int *t_eid,
+                                   const int *num_edges_dev, int max_edges, int n, int H, float *ds, float *dvec,
+                                   void *stream);
+/* Node update: dvdot [n,H], do [n,3H], dvp [n,3,3H] = [0|0|dvec_out*o1] (dx = dx_out, dvec = dvagg = dvec_out). */
+int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp,
+                                 int n, int H, float *dvdot, float *dout_o, float *dvp, void *stream);
+/* Edge update: dwt, dws [n,3,H] and dt [E,H] from df_out (df = df_out). */
+int conan_visnet_edge_update_bwd(const float *wt, const float *ws, const float *t, const float *dvec3, const float *dfo,
+                                 const int *rowptr, const int *col, const int *tgt, const int *t_rowptr, const int *t_eid,
+                                 int n, int H, float *dwt, float *dws, float *dt, void *stream);
+int conan_visnet_spatial_norm_bwd(const float *v, const float *dout, int n, int H, float *dv, void *stream);
+int conan_visnet_gate_bwd(const float *u, const float *v2, const float *dxo, const float *dvo, int n, int out_channels,
+                          int scalar_activation, float *du, float *dv2, void *stream);
+
 /* ---------------------------------------------------------------------------------------------- FGW barycenter */
 
 /* Glue of _compute_barycenter (schnet_no_sum.py:242-252 with :41-87; visnet.py:168-176 with :32-79):

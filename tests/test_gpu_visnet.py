@@ -26,16 +26,16 @@ def test_against_reference_visnet(path):
     z, pos, batch = (torch.from_numpy(g[k]).to(dev) for k in ("z", "pos", "batch"))
     gp = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(g["batch"]))]).astype(np.int32)).to(dev)
     xs, vs = m.representation_model(z, pos, gp, int(g["batch"].max()) + 1)
-    assert rel(xs.cpu().numpy(), g["r64_x"]) < 2e-5 and rel(vs.cpu().numpy(), g["r64_vec"]) < 2e-5
-    assert rel(m(z, pos, batch).cpu().numpy(), g["r64_forward"]) < 2e-5
+    assert rel(xs.detach().cpu().numpy(), g["r64_x"]) < 2e-5 and rel(vs.detach().cpu().numpy(), g["r64_vec"]) < 2e-5
+    assert rel(m(z, pos, batch).detach().cpu().numpy(), g["r64_forward"]) < 2e-5
     h, hb = m.forward_3d_bary(z, pos, batch)
-    assert rel(h.cpu().numpy(), g["r64_h"]) < 2e-5 and rel(hb.cpu().numpy(), g["r64_h_bary_nodes"]) < 2e-5
+    assert rel(h.detach().cpu().numpy(), g["r64_h"]) < 2e-5 and rel(hb.detach().cpu().numpy(), g["r64_h_bary_nodes"]) < 2e-5
     ei, _ = m.interaction_graph(pos, batch)
-    assert np.array_equal(ei.cpu().numpy(), g["edge_index"])
+    assert np.array_equal(ei.detach().cpu().numpy(), g["edge_index"])
     h3d, hbary = m.forward_w_barycenter(z, pos, K, batch)
-    assert rel(h3d.cpu().numpy(), g["r64_h_3d"]) < 2e-5
+    assert rel(h3d.detach().cpu().numpy(), g["r64_h_3d"]) < 2e-5
     for tag in ("r32", "r64"):
-        assert rel(hbary.cpu().numpy(), g[tag + "_h_bary"]) < 1e-4
+        assert rel(hbary.detach().cpu().numpy(), g[tag + "_h_bary"]) < 1e-4
 
 
 def test_production_width_vs_oracle_and_invariance():
@@ -52,11 +52,49 @@ def test_production_width_vs_oracle_and_invariance():
     h3d, hbary = m.forward_w_barycenter(z.to(dev), pos.to(dev), 5, batch.to(dev), num_graphs=b.num_graphs, max_nodes=b.max_nodes)
     with torch.no_grad():
         r3, rb = ref.forward_w_barycenter(z, pos.double(), 5, batch)
-    assert rel(h3d.cpu().numpy(), r3.numpy()) < 2e-5
-    assert rel(hbary.cpu().numpy(), rb.numpy()) < 1e-4
+    assert rel(h3d.detach().cpu().numpy(), r3.numpy()) < 2e-5
+    assert rel(hbary.detach().cpu().numpy(), rb.numpy()) < 1e-4
     # E(3) invariance of the scalar head under a random rotation + translation
     Q, _ = np.linalg.qr(np.random.RandomState(1).normal(size=(3, 3)))
     pos2 = (b.pos @ Q.T.astype(np.float32) + np.float32([1.5, -2.0, 0.7])).astype(np.float32)
     out1 = m(z.to(dev), pos.to(dev), batch.to(dev))
     out2 = m(z.to(dev), torch.from_numpy(pos2).to(dev), batch.to(dev))
-    assert rel(out2.cpu().numpy(), out1.cpu().numpy()) < 1e-4
+    assert rel(out2.detach().cpu().numpy(), out1.detach().cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("H,shape,B,K", [(32, "esol", 2, 3), (64, "bace", 2, 3), (128, "esol", 2, 5)])
+def test_backward_matches_oracle_autograd(H, shape, B, K):
+    """Gradients of every trainable ViSNet parameter (trunk, both heads, atomref priors) through forward_w_barycenter,
+    against torch autograd of the fp64 oracle (the oracle's FGW backward is the reference's: T held constant)."""
+    b = make_batch(shape, B, K, seed=55, box=7.0 if shape == "esol" else None)
+    torch.manual_seed(H)
+    m = ViSNet(dev, hidden_channels=H).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    ref = ViSNetOracle(H)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}, strict=True)
+    ref = ref.double()
+    z, pos, batch = torch.from_numpy(b.z), torch.from_numpy(b.pos), torch.from_numpy(b.batch)
+    g1 = torch.randn(b.num_graphs, H // 2, generator=torch.Generator().manual_seed(1))
+    g2 = torch.randn(b.num_graphs, H // 2, generator=torch.Generator().manual_seed(2))
+    h3, hb = m.forward_w_barycenter(z.to(dev), pos.to(dev), K, batch.to(dev))
+    ((h3 * g1.to(dev)).sum() + (hb * g2.to(dev)).sum()).backward()
+    r3, rb = ref.forward_w_barycenter(z, pos.double(), K, batch)
+    ((r3 * g1.double()).sum() + (rb * g2.double()).sum()).backward()
+    assert rel(h3.detach().cpu().numpy(), r3.detach().numpy()) < 2e-5
+    refp = dict(ref.named_parameters())
+    checked = 0
+    for name, p in m.named_parameters():
+        q = refp[name]
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        gn = float(q.grad.norm())
+        if gn == 0.0:
+            assert float(p.grad.abs().max()) < 1e-6, name
+            continue
+        assert rel(p.grad.detach().cpu().numpy(), q.grad.numpy()) < 2e-3, name
+        checked += 1
+    assert checked > 100
