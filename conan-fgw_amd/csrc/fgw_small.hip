@@ -16,7 +16,7 @@
 namespace {
 
 template <int R>
-__global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
+__global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_small(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
-    const int N = D.N, P = D.P, d = D.d, ZP = d + 1;
+    const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool lane_ok = lane < N;
@@ -33,8 +33,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     double *Al = reinterpret_cast<double *>(smem);            // [N,P]  A = C1 @ T ; dot(Y,Z) ; T @ C2
     double *Gl = Al + NP;                                      // [N,P]  G = A @ (2 C2)^T
     double *C1l = Gl + NP;                                     // [N,P]
-    double *Yl = C1l + NP;                                     // [N,d]
-    double *pm = Yl + (size_t)N * d;                           // [4][64] partial max
+    double *pm = C1l + NP;                                     // [4][64] partial max
     double *psum = pm + 256;                                   // [4][64] partial sums
     double *us = psum + 256;                                   // [4][64] per-wave copy of u (indexed by i)
     double *vs = us + 256;                                     // [4][64] per-wave copy of v (indexed by j)
@@ -44,7 +43,6 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     double *red = pq + 128;                                    // [8]
     float *Tl = reinterpret_cast<float *>(red + 8);            // [N,P]
     float *C2l = Tl + NP;                                      // [N,P]
-    float *Zl = C2l + NP;                                      // [N,d+1]
 
     const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
     const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
@@ -63,11 +61,6 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
         C1l[i * P + j] = C1[t];
         C2l[i * P + j] = C2[t];
     }
-    for (int t = tid; t < N * d; t += FGW_THREADS) {
-        const int i = t / d, c = t - i * d;
-        Yl[t] = y_zero ? 0.0 : Y[t];
-        Zl[i * ZP + c] = Z[t];
-    }
     __syncthreads();
     const double loga = log(pq[lane]), logb = log(pq[64 + lane]);      // lane <-> i for loga, lane <-> j for logb
     const double qj = pq[64 + lane];
@@ -82,12 +75,12 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
             const double c1 = C1l[tid * P + k], c2 = (double)C2l[tid * P + k];
             r1 += c1 * c1 * pq[k]; r2 += pq[64 + k] * (c2 * c2);
         }
-        for (int c = 0; c < d; ++c) { const double yy = Yl[tid * d + c], zz = (double)Zl[tid * ZP + c]; y2 += yy * yy; z2 += zz * zz; }
+        for (int c = 0; c < d; ++c) { const double yy = y_zero ? 0.0 : Y[(size_t)tid * d + c], zz = (double)Z[(size_t)tid * d + c]; y2 += yy * yy; z2 += zz * zz; }
         pm[tid] = r1; pm[64 + tid] = r2; psum[tid] = y2; psum[64 + tid] = z2;
     }
     // ---- dot(Y_i, Z_j) on MFMA -> Al
     if (!y_zero)
-        mm_f64(N, N, d, [&](int i, int k) { return Yl[i * d + k]; }, [&](int k, int j) { return (double)Zl[j * ZP + k]; },
+        mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
                [&](int i, int j, double v) { Al[i * P + j] = v; });
     __syncthreads();
     // ---- base = 2*alpha*constC + (1-alpha)*M in both register layouts            (utils.py:39-43,154-171, bregman.py:124-125)
@@ -212,7 +205,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling_small(
     // ---- contributions to the barycenter update while T is resident
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Zl[k * ZP + c]; },
+        mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
                [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
@@ -282,7 +275,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
 
 inline size_t small_lds(int N, int d) {
     const size_t NP = (size_t)N * (N | 1);
-    return NP * 8 * 3 + (size_t)N * d * 8 + (256 * 6 + 128 + 8) * 8 + NP * 4 * 2 + (size_t)N * (d + 1) * 4;
+    (void)d; return NP * 8 * 3 + (256 * 6 + 128 + 8) * 8 + NP * 4 * 2;
 }
 
 }  // namespace
