@@ -33,15 +33,19 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     double *Al = reinterpret_cast<double *>(smem);            // [N,P]  A = C1 @ T ; dot(Y,Z) ; T @ C2
     double *Gl = Al + NP;                                      // [N,P]  G = A @ (2 C2)^T
     double *C1l = Gl + NP;                                     // [N,P]
-    double *pm = C1l + NP;                                     // [4][64] partial max
-    double *psum = pm + 256;                                   // [4][64] partial sums
-    double *us = psum + 256;                                   // [4][64] per-wave copy of u (indexed by i)
-    double *vs = us + 256;                                     // [4][64] per-wave copy of v (indexed by j)
-    double *pm2 = vs + 256;                                    // [4][64] second partial buffers (row half-iteration)
-    double *psum2 = pm2 + 256;
-    double *pq = psum2 + 256;                                  // [2][64] p, q
+    // Sinkhorn scratch (6 x [4][64] doubles) aliases the two product buffers, which are dead while the Sinkhorn loop runs;
+    // for tiny problems (N*P < 768) it gets its own region behind the matrices.
+    double *pq = C1l + NP;                                     // [2][64] p, q
     double *red = pq + 128;                                    // [8]
-    float *Tl = reinterpret_cast<float *>(red + 8);            // [N,P]
+    const bool alias = NP >= 768;
+    double *own = red + 8;
+    double *pm = alias ? Gl : own;                             // [4][64] partial max
+    double *psum = pm + 256;                                   // [4][64] partial sums
+    double *pm2 = psum + 256;                                  // [4][64] second partial buffers (row half-iteration)
+    double *psum2 = alias ? Al : pm2 + 256;                    // [4][64]
+    double *us = psum2 + 256;                                  // [4][64] per-wave copy of u (indexed by i)
+    double *vs = us + 256;                                     // [4][64] per-wave copy of v (indexed by j)
+    float *Tl = reinterpret_cast<float *>(own + (alias ? 0 : 6 * 256));     // [N,P]
     float *C2l = Tl + NP;                                      // [N,P]
 
     const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
@@ -125,6 +129,7 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
             mB[r] = ok ? -(baseB[r] - 2.0 * alpha * Gl[lane * P + q]) * inv_eps : 0.0;
         }
 
+        __syncthreads();                                               // G fully consumed: its storage now holds the Sinkhorn scratch
         // ---- log-domain Sinkhorn (sinkhorn.py:393-433); u, v in registers (u_l: i = lane, v_l: j = lane)
         double u_l = 0.0, v_l = 0.0;
         us[w * 64 + lane] = 0.0;
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
 
 inline size_t small_lds(int N, int d) {
     const size_t NP = (size_t)N * (N | 1);
-    (void)d; return NP * 8 * 3 + (256 * 6 + 128 + 8) * 8 + NP * 4 * 2;
+    (void)d; return NP * 8 * 3 + ((NP >= 768 ? 0 : 256 * 6) + 128 + 8) * 8 + NP * 4 * 2;
 }
 
 }  // namespace
