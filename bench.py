@@ -79,12 +79,12 @@ def cpu_baseline(args, mode):
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")              # "nccl" is RCCL on ROCm: one rank per GPU over xGMI
 
     from conan_fgw_amd import ops
     from conan_fgw_amd.head import ConformerAggregationHead
@@ -154,6 +154,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # forward-only throughput of the same workload (outside the timed region; this rank's shard)
+    fwd_extra = None
+    if args.mode == "train":
+        def fwd_step():
+            with torch.no_grad():
+                h3, hb = model.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+                head(h3, hb, K)
+        for _ in range(2):
+            fwd_step()
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        nf = max(5, args.steps // 2)
+        for _ in range(nf):
+            fwd_step()
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - tf) / nf
+        fwd_extra = {"molecules_per_s_per_gpu": round(args.batch / tf, 1), "ms_per_step": round(1e3 * tf, 4)}
+
     # edge statistics of this rank's batch (device graph of the last step is rebuilt here only for reporting)
     gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
     E = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32).num_edges
@@ -188,7 +206,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kdur_ms, 5),
                          "launches_timed": len(ev)},
         }
-        if not args.no_cpu_baseline:
+        out["forward_only"] = fwd_extra
+        if not args.no_cpu_baseline and world == 1:      # CPU oracle timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, args.mode)
         print(json.dumps(out), flush=True)
     if world > 1:
