@@ -109,12 +109,14 @@ def main():
 
     # live per-kernel timing of the CFConv forward kernel with HIP events on the launch stream
     ev = []
+    ev_other = {"conan_filter_fwd": [], "conan_fgw_barycenter_fwd": []}
     orig_call = ops.call
 
     def timed_call(name, *a):
-        if name == "conan_cfconv_fwd" and timed_call.on:
+        if timed_call.on and (name == "conan_cfconv_fwd" or name in ev_other):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(); orig_call(name, *a); e.record(); ev.append((s, e))
+            s.record(); orig_call(name, *a); e.record()
+            (ev if name == "conan_cfconv_fwd" else ev_other[name]).append((s, e))
         else:
             orig_call(name, *a)
     timed_call.on = False
@@ -189,6 +191,18 @@ def main():
     alg = cfconv_algorithmic_bytes(E, n_atoms, 128)
     achieved = alg / (kdur_ms * 1e-3) / 1e9
 
+    other = []
+    if ev_other["conan_filter_fwd"]:
+        t_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_other["conan_filter_fwd"]]))
+        fl = E * 2.0 * (50 * 128 + 128 * 128)                       # E*(2*Gs*F + 2*F*F)
+        other.append({"kernel": "k_filter_fused (rbf -> filter MLP -> cosine cutoff)", "bound": "mfma", "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2),
+                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / (t_ms * 1e-3) / 1e12 / 157.3, 4), "avg_launch_ms": round(t_ms, 5),
+                      "note": "fp32-equivalent algorithmic FLOP vs the fp32 MFMA peak; the second GEMM runs as an exact 3-way bf16 split"})
+    if ev_other["conan_fgw_barycenter_fwd"]:
+        t_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_other["conan_fgw_barycenter_fwd"]]))
+        other.append({"kernel": "FGW barycenter, whole batched solve (init + 5 x (coupling + update))", "bound": "fp64 issue / latency",
+                      "avg_ms": round(t_ms, 4), "us_per_molecule": round(1e3 * t_ms / args.batch, 3),
+                      "algorithmic_bytes_per_molecule": 4 * (2 * K * b.max_nodes ** 2 + K * b.max_nodes * 64 + b.max_nodes * 64 + b.max_nodes ** 2)})
     if rank == 0:
         mol = args.batch * world * args.steps
         out = {
@@ -206,6 +220,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kdur_ms, 5),
                          "launches_timed": len(ev)},
         }
+        out["roofline_other"] = other
         out["forward_only"] = fwd_extra
         if not args.no_cpu_baseline and world == 1:      # CPU oracle timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, args.mode)
