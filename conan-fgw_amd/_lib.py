@@ -28,6 +28,7 @@ SIGNATURES = {
     "conan_graph_ptr_from_batch": (c_int, [_P, c_int, c_int, _P, _P]),
     "conan_radius_graph_csr": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "conan_csr_transpose": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "conan_edge_pairs": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_edge_index_i64": (c_int, [_P, _P, c_int, _P, _P]),
     "conan_embedding_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_embedding_bwd_ws": (c_ll, [c_int, c_int, c_int]),
@@ -40,8 +41,9 @@ SIGNATURES = {
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
-    "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_bwd_w_pairs": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_float, _P, _P]),
     "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_float, _P, _P]),
     "conan_segment_sum_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_segment_sum_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),

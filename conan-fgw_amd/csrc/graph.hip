@@ -90,6 +90,52 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_exclusive_scan(const int *__re
     if (t == SCAN_THREADS - 1) out[n] = part[SCAN_THREADS - 1];
 }
 
+// Multi-workgroup exclusive scan for long inputs (the pair flags: up to cap * num_atoms entries): per-block sums, a
+// single-workgroup scan of the (few hundred) block sums, then a per-block local scan with the block offset.
+constexpr int SB_THREADS = 256;
+constexpr int SB_ITEMS = 16;                 // 4096 elements per workgroup
+__global__ void __launch_bounds__(SB_THREADS) k_scan_block_sums(const int *__restrict__ in, int n, int *__restrict__ bsum) {
+    __shared__ int red[SB_THREADS / 64];
+    const int base = blockIdx.x * SB_THREADS * SB_ITEMS + threadIdx.x * SB_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int u = 0; u < SB_ITEMS; ++u) s += (base + u < n) ? in[base + u] : 0;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(SB_THREADS) k_scan_block_apply(const int *__restrict__ in, int n, const int *__restrict__ boff,
+                                                                 int nblocks, int *__restrict__ out) {
+    __shared__ int part[SB_THREADS];
+    const int t = threadIdx.x;
+    const int base = blockIdx.x * SB_THREADS * SB_ITEMS + t * SB_ITEMS;
+    int v[SB_ITEMS], s = 0;
+#pragma unroll
+    for (int u = 0; u < SB_ITEMS; ++u) { v[u] = (base + u < n) ? in[base + u] : 0; s += v[u]; }
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < SB_THREADS; o <<= 1) {
+        const int a = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += a;
+        __syncthreads();
+    }
+    int run = boff[blockIdx.x] + (t == 0 ? 0 : part[t - 1]);
+#pragma unroll
+    for (int u = 0; u < SB_ITEMS; ++u) { if (base + u < n) out[base + u] = run; run += v[u]; }
+    if (blockIdx.x == nblocks - 1 && t == SB_THREADS - 1) out[n] = boff[nblocks];      // grand total
+}
+// out[0..n], out[n] = total; ws holds 2 * (nblocks + 1) ints
+static void scan_large(const int *in, int n, int *out, int *ws, hipStream_t s) {
+    const int per = SB_THREADS * SB_ITEMS;
+    const int nblocks = (n + per - 1) / per;
+    int *bsum = ws, *boff = ws + nblocks + 1;
+    k_scan_block_sums<<<nblocks, SB_THREADS, 0, s>>>(in, n, bsum);
+    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(bsum, nblocks, boff);
+    k_scan_block_apply<<<nblocks, SB_THREADS, 0, s>>>(in, n, boff, nblocks, out);
+}
+
 // by-source transpose, one workgroup per graph; deterministic (ascending edge id inside each source row)
 template <int PASS>
 __global__ void __launch_bounds__(RG_THREADS) k_transpose(const int *__restrict__ gptr, const int *__restrict__ rowptr,
@@ -105,6 +151,48 @@ __global__ void __launch_bounds__(RG_THREADS) k_transpose(const int *__restrict_
         for (int e = e0; e < e1; ++e)
             if (col[e] == j) { if (PASS) t_eid[base + cnt] = e; ++cnt; }
         if (!PASS) deg[j] = cnt;
+    }
+}
+
+// ---- undirected pairs ----------------------------------------------------------------------------------------------
+// The continuous filter depends on the edge only through d_ij = d_ji, so both directions of a pair can share one filter
+// row.  An edge (s -> t) is the REPRESENTATIVE of its pair when s <= t, or when s > t and the reverse edge (t -> s) is not
+// in the graph (possible once the neighbour cap truncates rows).  Rows are sorted by source => binary search.
+__device__ __forceinline__ int find_edge(const int *__restrict__ rowptr, const int *__restrict__ col, int target, int source) {
+    int lo = rowptr[target], hi = rowptr[target + 1] - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = col[mid];
+        if (c == source) return mid;
+        if (c < source) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+__global__ void k_pair_flag(const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ tgt,
+                            const int *__restrict__ ne_dev, int max_edges, int *__restrict__ flag) {
+    const int E = min(*ne_dev, max_edges);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < max_edges; e += gridDim.x * blockDim.x) {
+        int f = 0;
+        if (e < E) {
+            const int s = col[e], t = tgt[e];
+            f = (s <= t) ? 1 : (find_edge(rowptr, col, s, t) < 0 ? 1 : 0);
+        }
+        flag[e] = f;
+    }
+}
+__global__ void k_pair_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ tgt, const float *__restrict__ dist,
+                            const int *__restrict__ ne_dev, int max_edges, const int *__restrict__ flag, const int *__restrict__ pidx,
+                            int *__restrict__ pid, int *__restrict__ pe0, int *__restrict__ pe1, float *__restrict__ pdist) {
+    const int E = min(*ne_dev, max_edges);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const int s = col[e], t = tgt[e];
+        const int rev = (s == t) ? -1 : find_edge(rowptr, col, s, t);      // the edge (t -> s) lives in row s
+        if (flag[e]) {
+            const int p = pidx[e];
+            pid[e] = p; pe0[p] = e; pe1[p] = rev; pdist[p] = dist[e];
+        } else {
+            pid[e] = pidx[rev];
+        }
     }
 }
 
@@ -151,6 +239,23 @@ int conan_csr_transpose(const int *graph_ptr, int num_graphs, int num_atoms, con
     k_transpose<0><<<num_graphs, RG_THREADS, 0, s>>>(graph_ptr, rowptr, col, deg_ws, nullptr, nullptr);
     k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_ws, num_atoms, t_rowptr);
     k_transpose<1><<<num_graphs, RG_THREADS, 0, s>>>(graph_ptr, rowptr, col, nullptr, t_rowptr, t_eid);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_edge_pairs(const int *rowptr, const int *col, const int *tgt, const float *dist, const int *num_edges_dev, int max_edges,
+                     int *flag_ws, int *pidx_ws, int *scan_ws, int *pid, int *pair_e0, int *pair_e1, float *pair_dist, void *stream) {
+    if (!rowptr || !col || !tgt || !dist || !num_edges_dev || !flag_ws || !pidx_ws || !scan_ws || !pid || !pair_e0 || !pair_e1 || !pair_dist ||
+        max_edges <= 0)
+        return CONAN_E_BADARG;
+    hipStream_t s = as_stream(stream);
+    int blocks = (max_edges + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    k_pair_flag<<<blocks, 256, 0, s>>>(rowptr, col, tgt, num_edges_dev, max_edges, flag_ws);
+    // pidx_ws[max_edges] = number of pairs; the block-sum scratch lives in the tail of pair_e1 (overwritten afterwards by
+    // k_pair_fill only for pair ids < number of pairs <= number of edges, and the scan is complete by then)
+    scan_large(flag_ws, max_edges, pidx_ws, scan_ws, s);
+    k_pair_fill<<<blocks, 256, 0, s>>>(rowptr, col, tgt, dist, num_edges_dev, max_edges, flag_ws, pidx_ws, pid, pair_e0, pair_e1, pair_dist);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -46,6 +46,7 @@ class RadiusGraph:
         self.num_edges_dev = self.rowptr[n:]            # device-side edge count (1-element view)
         self._num_edges: Optional[int] = None
         self._t_rowptr = self._t_eid = None
+        self.pid = None
 
     @property
     def num_edges(self) -> int:
@@ -61,6 +62,23 @@ class RadiusGraph:
             call("conan_csr_transpose", ptr(self.graph_ptr), self.num_graphs, self.num_atoms, ptr(self.rowptr), ptr(self.col),
                  ptr(self._deg), ptr(self._t_rowptr), ptr(self._t_eid), stream_ptr())
         return self._t_rowptr, self._t_eid
+
+    def pairs(self):
+        """Undirected pairs of the edge set (conan_edge_pairs): the continuous filter is evaluated once per pair.
+        Returns self; fills pid [max_edges], pair_e0/pair_e1/pair_dist [max_edges] and num_pairs_dev (device int)."""
+        if getattr(self, "pid", None) is None:
+            dev, ME = self.rowptr.device, self.max_edges
+            flag = torch.empty(ME + 1, dtype=i32, device=dev)
+            pidx = torch.empty(ME + 1, dtype=i32, device=dev)
+            scan_ws = torch.empty(2 * (ME // 4096 + 2), dtype=i32, device=dev)
+            self.pid = torch.empty(ME, dtype=i32, device=dev)
+            self.pair_e0 = torch.empty(ME, dtype=i32, device=dev)
+            self.pair_e1 = torch.empty(ME, dtype=i32, device=dev)
+            self.pair_dist = torch.empty(ME, dtype=f32, device=dev)
+            call("conan_edge_pairs", ptr(self.rowptr), ptr(self.col), ptr(self.tgt), ptr(self.dist), ptr(self.num_edges_dev), ME, ptr(flag),
+                 ptr(pidx), ptr(scan_ws), ptr(self.pid), ptr(self.pair_e0), ptr(self.pair_e1), ptr(self.pair_dist), stream_ptr())
+            self.num_pairs_dev = pidx[ME:]
+        return self
 
     def edge_index(self) -> Tensor:
         E = self.num_edges
@@ -188,22 +206,24 @@ class _FilterFn(torch.autograd.Function):
     dw2 = g^T h1 ; gpre = (g w2) * ssp'(h1) (fused epilogue) ; dw1 = gpre^T rbf  (rbf is recomputed)."""
 
     @staticmethod
-    def forward(ctx, graph, offset, coeff, w1, b1, w2, b2):
+    def forward(ctx, graph, offset, coeff, w1, b1, w2, b2, use_pairs):
         F, Gs = w1.shape
         dev = w1.device
-        need_grad = any(ctx.needs_input_grad[3:])
+        need_grad = any(ctx.needs_input_grad[3:7])
+        dist, cnt = (graph.pairs().pair_dist, graph.num_pairs_dev) if use_pairs else (graph.dist, graph.num_edges_dev)
         W = torch.empty(graph.max_edges, F, dtype=f32, device=dev)
         h1 = torch.empty(graph.max_edges, F, dtype=f32, device=dev) if need_grad else None
-        call("conan_filter_fwd", ptr(graph.dist), ptr(graph.num_edges_dev), graph.max_edges, ptr(_c(offset), f32), Gs, float(coeff),
+        call("conan_filter_fwd", ptr(dist), ptr(cnt), graph.max_edges, ptr(_c(offset), f32), Gs, float(coeff),
              graph.cutoff, F, ptr(_c(w1), f32), ptr(_c(b1), f32), ptr(_c(w2), f32), ptr(_c(b2), f32), ptr(W), ptr(h1), stream_ptr())
-        ctx.graph, ctx.coeff = graph, float(coeff)
+        ctx.graph, ctx.coeff, ctx.rows = graph, float(coeff), (dist, cnt)
         ctx.save_for_backward(offset, w1, w2, h1)
         return W
 
     @staticmethod
     def backward(ctx, dW):
         offset, w1, w2, h1 = ctx.saved_tensors
-        g_, md = ctx.graph, ctx.graph.num_edges_dev
+        g_ = ctx.graph
+        dist, md = ctx.rows                          # per-edge or per-pair distances and their device-side count
         F, Gs = w1.shape
         ME = g_.max_edges
         dev = dW.device
@@ -213,29 +233,33 @@ class _FilterFn(torch.autograd.Function):
         call("conan_linear_wgrad", ptr(g), ptr(h1), ME, F, F, ptr(md), ptr(dw2), ptr(db2), ptr(ws), stream_ptr())
         dh1 = torch.empty_like(g)
         call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
-        rbf = rbf_expand(g_, offset, ctx.coeff)
+        rbf = torch.empty(ME, Gs, dtype=f32, device=dev)
+        call("conan_rbf_fwd", ptr(dist), ptr(md), ME, ptr(_c(offset), f32), Gs, ctx.coeff, ptr(rbf), stream_ptr())
         dw1, db1 = torch.empty_like(w1), torch.empty(F, dtype=f32, device=dev)
         call("conan_linear_wgrad", ptr(dh1), ptr(rbf), ME, Gs, F, ptr(md), ptr(dw1), ptr(db1), ptr(ws), stream_ptr())
-        return None, None, None, dw1, db1, dw2, db2
+        return None, None, None, dw1, db1, dw2, db2, None
 
 
 def filter_fused_supported(num_gaussians: int, num_filters: int) -> bool:
     return bool(lib().conan_filter_fused_supported(int(num_gaussians), int(num_filters)))
 
 
-def filter_generate(graph: "RadiusGraph", offset: Tensor, coeff: float, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
-    """W[e,:] = mlp(rbf(d_e)) * C(d_e) for every edge -> [max_edges, F] (rows >= E untouched)."""
-    return _FilterFn.apply(graph, offset, coeff, w1, b1, w2, b2)
+def filter_generate(graph: "RadiusGraph", offset: Tensor, coeff: float, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
+                    use_pairs: bool = True) -> Tensor:
+    """Filter rows mlp(rbf(d)) * C(d) -> [max_edges, F].  use_pairs=True: ONE row per undirected pair (d_ij = d_ji), to be
+    consumed by `cfconv(..., pre_cutoff_grad=True, use_pairs=True)`; False: one row per directed edge."""
+    return _FilterFn.apply(graph, offset, coeff, w1, b1, w2, b2, use_pairs)
 
 
 class _CFConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, graph, pre_cutoff_grad=False):
+    def forward(ctx, x, W, graph, pre_cutoff_grad=False, use_pairs=False):
         x, W = _c(x), _c(W)
         out = torch.empty_like(x)
-        call("conan_cfconv_fwd", ptr(x, f32), ptr(W, f32), ptr(graph.rowptr), ptr(graph.col), graph.num_atoms, x.shape[1],
+        pid = graph.pairs().pid if use_pairs else None
+        call("conan_cfconv_fwd", ptr(x, f32), ptr(W, f32), ptr(graph.rowptr), ptr(graph.col), ptr(pid), graph.num_atoms, x.shape[1],
              ptr(out), stream_ptr())
-        ctx.graph, ctx.pre = graph, pre_cutoff_grad
+        ctx.graph, ctx.pre, ctx.pairs = graph, pre_cutoff_grad, use_pairs
         ctx.save_for_backward(x, W)
         return out
 
@@ -249,20 +273,26 @@ class _CFConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             t_rowptr, t_eid = g.transpose()
             dx = torch.empty_like(x)
-            call("conan_cfconv_bwd_x", ptr(W), ptr(dout), ptr(t_rowptr), ptr(t_eid), ptr(g.tgt), g.num_atoms, F, ptr(dx),
-                 stream_ptr())
+            call("conan_cfconv_bwd_x", ptr(W), ptr(dout), ptr(t_rowptr), ptr(t_eid), ptr(g.tgt), ptr(g.pid) if ctx.pairs else None,
+                 g.num_atoms, F, ptr(dx), stream_ptr())
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
-            call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F,
-                 ptr(g.dist) if ctx.pre else None, float(g.cutoff or 0.0), ptr(dW), stream_ptr())
-        return dx, dW, None, None
+            if ctx.pairs:
+                if not ctx.pre:
+                    raise RuntimeError("use_pairs requires pre_cutoff_grad=True (the pair gradient includes the cosine cutoff)")
+                call("conan_cfconv_bwd_w_pairs", ptr(x), ptr(dout), ptr(g.num_pairs_dev), g.max_edges, ptr(g.pair_e0), ptr(g.pair_e1), ptr(g.col),
+                     ptr(g.tgt), F, ptr(g.pair_dist), float(g.cutoff), ptr(dW), stream_ptr())
+            else:
+                call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F,
+                     ptr(g.dist) if ctx.pre else None, float(g.cutoff or 0.0), ptr(dW), stream_ptr())
+        return dx, dW, None, None, None
 
 
-def cfconv(x: Tensor, W: Tensor, graph: RadiusGraph, pre_cutoff_grad: bool = False) -> Tensor:
+def cfconv(x: Tensor, W: Tensor, graph: RadiusGraph, pre_cutoff_grad: bool = False, use_pairs: bool = False) -> Tensor:
     """out[i] = sum_{j in N(i)} x[j] * W[(j->i)]   (CFConv.propagate).
     pre_cutoff_grad=True: the gradient returned for W is already multiplied by the cosine cutoff C(d_e), i.e. it is the
     gradient w.r.t. the un-scaled filter (used with `filter_generate`, whose backward then skips its own scaling pass)."""
-    return _CFConvFn.apply(x, W, graph, pre_cutoff_grad)
+    return _CFConvFn.apply(x, W, graph, pre_cutoff_grad, use_pairs)
 
 
 class _SegmentSumFn(torch.autograd.Function):

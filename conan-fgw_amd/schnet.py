@@ -95,7 +95,8 @@ class CFConv(torch.nn.Module):
             offset, coeff = rbf
             W = ops.filter_generate(graph, offset, coeff, self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias)
         x = ops.linear(x, self.lin1.weight)                                               # lin1 (no bias)
-        x = ops.cfconv(x, W, graph, pre_cutoff_grad=not isinstance(rbf, Tensor))          # propagate: gather * W, scatter-add
+        fused = not isinstance(rbf, Tensor)            # fused path: one filter row per undirected pair (W_ij = W_ji)
+        x = ops.cfconv(x, W, graph, pre_cutoff_grad=fused, use_pairs=fused)               # propagate: gather * W, scatter-add
         return x                                                                          # lin2 applied by the caller (fused with ssp)
 
 
@@ -265,6 +266,7 @@ def _graph_from_edge_index(edge_index: Tensor, batch: Tensor, num_graphs: int) -
     g.num_edges_dev = rowptr[n:]
     g._num_edges = int(src.shape[0])
     g._t_rowptr = g._t_eid = None
+    g.pid = None
     g._deg = torch.empty(n + 1, dtype=torch.int32, device=batch.device)
     g.cutoff = g.cap = g.loop = None
     return g

@@ -57,6 +57,15 @@ int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms
 int conan_csr_transpose(const int *graph_ptr, int num_graphs, int num_atoms, const int *rowptr, const int *col,
                         int *deg_ws, int *t_rowptr, int *t_eid, void *stream);
 
+/* Undirected pairs of the edge set.  The continuous filter depends on an edge only through d_ij = d_ji, so both
+ * directions of a pair share one filter row: the filter network then runs on ~E/2 rows.  pid[e] = pair of edge e;
+ * pair p is represented by edge pair_e0[p] (source <= target, or a one-directional edge when the cap truncated its
+ * reverse) and pair_e1[p] = the reverse edge or -1; pair_dist[p] = its distance; the pair count is written to
+ * pidx_ws[max_edges] (device).  flag_ws, pidx_ws: int scratch of max_edges + 1 entries; scan_ws: 2*(max_edges/4096 + 2) ints. */
+int conan_edge_pairs(const int *rowptr, const int *col, const int *tgt, const float *dist, const int *num_edges_dev,
+                     int max_edges, int *flag_ws, int *pidx_ws, int *scan_ws, int *pid, int *pair_e0, int *pair_e1,
+                     float *pair_dist, void *stream);
+
 /* edge_index[2, E] int64 in the reference's layout from the CSR (E = capacity of the output rows = host-known edge
  * count).  Row 0 = source, row 1 = target. */
 int conan_edge_index_i64(const int *col, const int *tgt, int num_edges, int64_t *edge_index, void *stream);
@@ -114,12 +123,18 @@ int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges,
 
 /* CFConv message + aggregation (the HBM-bound kernel of the path): out[i,:] = sum_{e in row i} x[col[e],:] * W[e,:].
  * Replaces index_select + mul + scatter-add inside CFConv.propagate (PyG; schnet_no_sum.py:163-164,211-212).
- * CSR segment sum, one wavefront per target, no atomics. */
-int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const int *col, int num_atoms, int num_filters,
-                     float *out, void *stream);
+ * CSR segment sum, one wavefront per target, no atomics.  pid (nullable): row of W used by edge e (conan_edge_pairs);
+ * NULL = row e. */
+int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const int *col, const int *pid, int num_atoms,
+                     int num_filters, float *out, void *stream);
 /* Backward: dx[j,:] = sum_{e: col[e]==j} W[e,:]*dout[tgt[e],:] (via the by-source CSR), dW[e,:] = x[col[e],:]*dout[tgt[e],:]. */
 int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt,
-                       int num_atoms, int num_filters, float *dx, void *stream);
+                       const int *pid, int num_atoms, int num_filters, float *dx, void *stream);
+/* Pair-level filter gradient (before the cosine cutoff): dWp[p,:] = C(d_p) * sum over the (1 or 2) edges of pair p of
+ * x[src(e),:] * dout[tgt(e),:]. */
+int conan_cfconv_bwd_w_pairs(const float *x, const float *dout, const int *num_pairs_dev, int max_pairs, const int *pair_e0,
+                             const int *pair_e1, const int *col, const int *tgt, int num_filters, const float *pair_dist,
+                             float cutoff, float *dWp, void *stream);
 /* dist (nullable) + cutoff: additionally multiply row e by 0.5*(cos(dist[e]*pi/cutoff)+1), i.e. return the gradient with
  * respect to the filter BEFORE the cosine cutoff. */
 int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_dev, int max_edges, const int *col,

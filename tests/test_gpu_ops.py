@@ -131,7 +131,7 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
         for p in mlp.parameters():
             p.add_(0.1 * torch.randn_like(p))
     prm = [p.detach().to(dev).requires_grad_(True) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
-    W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm)  # NB: backward expects a pre-cutoff gradient
+    W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm, use_pairs=False)  # NB: backward expects a pre-cutoff gradient
     d = g.edge_weight().cpu().double()
     m64 = mlp.double()
     C = 0.5 * (torch.cos(d * math.pi / 10.0) + 1.0)
