@@ -43,9 +43,11 @@ def parse():
     return ap.parse_args()
 
 
-def cfconv_algorithmic_bytes(E, n_atoms, F):
-    """E*(4F gather x_j + 4F W_ij) + 8*(E + n+1) CSR + n*4F store (fp32, W materialised)."""
-    return E * 8 * F + 8 * (E + n_atoms + 1) + n_atoms * 4 * F
+def cfconv_algorithmic_bytes(E, P, n_atoms, F):
+    """SURVEY.md 8(d), W materialised: E*4F [gather x_j] + 4F per UNIQUE filter row + CSR + n*4F [store out].  The filter is
+    shared by the two directions of a pair (W_ij = W_ji), so the filter tensor has P ~ E/2 rows (P = E without sharing);
+    indices are int32 here: 4*(2E + n+1) for col + pid + rowptr."""
+    return E * 4 * F + P * 4 * F + 4 * (2 * E + n_atoms + 1) + n_atoms * 4 * F
 
 
 def cpu_baseline(args, mode):
@@ -176,7 +178,9 @@ def main():
 
     # edge statistics of this rank's batch (device graph of the last step is rebuilt here only for reporting)
     gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
-    E = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32).num_edges
+    _g = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32)
+    E = _g.num_edges
+    P = int(_g.pairs().num_pairs_dev.item()) if args.model == "schnet" else E
     n_atoms = int(z.shape[0])
     kdur_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
     # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately and
@@ -188,13 +192,13 @@ def main():
             traffic = int(pm["traffic_bytes_corrected"])
     except Exception:
         traffic = None
-    alg = cfconv_algorithmic_bytes(E, n_atoms, 128)
+    alg = cfconv_algorithmic_bytes(E, P, n_atoms, 128)
     achieved = alg / (kdur_ms * 1e-3) / 1e9
 
     other = []
     if ev_other["conan_filter_fwd"]:
         t_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_other["conan_filter_fwd"]]))
-        fl = E * 2.0 * (50 * 128 + 128 * 128)                       # E*(2*Gs*F + 2*F*F)
+        fl = P * 2.0 * (50 * 128 + 128 * 128)                       # (2*Gs*F + 2*F*F) per filter row; P rows (pairs)
         other.append({"kernel": "k_filter_fused (rbf -> filter MLP -> cosine cutoff)", "bound": "mfma", "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2),
                       "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / (t_ms * 1e-3) / 1e12 / 157.3, 4), "avg_launch_ms": round(t_ms, 5),
                       "note": "fp32-equivalent algorithmic FLOP vs the fp32 MFMA peak; the second GEMM runs as an exact 3-way bf16 split"})
@@ -212,7 +216,7 @@ def main():
             "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
                                    + ("(fwd + bwd + flat-gradient all-reduce + Adam)" if args.mode == "train" else "(forward_w_barycenter + head)"),
-                       "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "max_nodes": b.max_nodes,
+                       "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
                        "mode": args.mode, "parallelism": f"dp{world}", "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
             "roofline": {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
