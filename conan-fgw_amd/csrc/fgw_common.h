@@ -126,15 +126,26 @@ __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W,
 #pragma unroll
         for (int q = 0; q < 4; ++q) st(i0 + lk + 4 * q, j0 + li, acc[q]);
     }
+    // Border outputs: 4 lanes per output, each summing every 4th k, combined with two xor-shuffles.  This spreads the
+    // (few) border dot products over all wavefronts: with one thread per output the whole border lands on wavefront 0,
+    // which then holds every barrier of the caller (PMC: 58 % of the wave cycles were spent waiting).
     const int Mc = Mq << 4, Nc = Nq << 4;
-    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
-    for (int t = tid; t < nb1 + nb2; t += FGW_THREADS) {
-        int i, j;
-        if (t < nb1) { i = Mc + t / Nn; j = t % Nn; }
-        else { const int q = t - nb1; i = q / (Nn - Nc); j = Nc + q % (Nn - Nc); }
+    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc), nb = nb1 + nb2;
+    const int sub = tid & 3;
+    for (int t0 = 0; t0 < nb; t0 += FGW_THREADS / 4) {
+        const int t = t0 + (tid >> 2);
+        const bool on = t < nb;
+        int i = 0, j = 0;
+        if (on) {
+            if (t < nb1) { i = Mc + t / Nn; j = t % Nn; }
+            else { const int q = t - nb1; i = q / (Nn - Nc); j = Nc + q % (Nn - Nc); }
+        }
         double a = 0.0;
-        for (int k = 0; k < Kd; ++k) a += X(i, k) * W(k, j);
-        st(i, j, a);
+        if (on)
+            for (int k = sub; k < Kd; k += 4) a += X(i, k) * W(k, j);
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (on && sub == 0) st(i, j, a);
     }
 }
 
