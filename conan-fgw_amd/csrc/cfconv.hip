@@ -79,7 +79,42 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd_generic(const float *__restr
     }
 }
 
-// dx[j,:] = sum over edges e with source j of W[e,:] * dout[tgt[e],:]   (by-source CSR: t_rowptr / t_eid)
+// dx[j,:] = sum over edges e with source j of W[row(e),:] * dout[tgt[e],:]   (by-source CSR: t_rowptr / t_eid).
+// F = 128: same mapping as the forward — one half-wavefront (32 lanes x float4) per edge, two edges per step.
+__global__ void __launch_bounds__(256) k_cfconv_bwd_x128(const float *__restrict__ W, const float *__restrict__ dout,
+                                                         const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
+                                                         const int *__restrict__ tgt, int num_atoms, float *__restrict__ dx,
+                                                         const int *__restrict__ pid) {
+    constexpr int F = 128;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int j = wave; j < num_atoms; j += nwaves) {
+        const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = s0 + half;
+        for (; s + 2 < s1; s += 4) {
+            const int ea = t_eid[s], eb = t_eid[s + 2];
+            const float4 wa = reinterpret_cast<const float4 *>(W + (size_t)(pid ? pid[ea] : ea) * F)[l32];
+            const float4 wb = reinterpret_cast<const float4 *>(W + (size_t)(pid ? pid[eb] : eb) * F)[l32];
+            const float4 ga = reinterpret_cast<const float4 *>(dout + (size_t)tgt[ea] * F)[l32];
+            const float4 gb = reinterpret_cast<const float4 *>(dout + (size_t)tgt[eb] * F)[l32];
+            acc.x += ga.x * wa.x; acc.y += ga.y * wa.y; acc.z += ga.z * wa.z; acc.w += ga.w * wa.w;
+            acc.x += gb.x * wb.x; acc.y += gb.y * wb.y; acc.z += gb.z * wb.z; acc.w += gb.w * wb.w;
+        }
+        for (; s < s1; s += 2) {
+            const int ea = t_eid[s];
+            const float4 wa = reinterpret_cast<const float4 *>(W + (size_t)(pid ? pid[ea] : ea) * F)[l32];
+            const float4 ga = reinterpret_cast<const float4 *>(dout + (size_t)tgt[ea] * F)[l32];
+            acc.x += ga.x * wa.x; acc.y += ga.y * wa.y; acc.z += ga.z * wa.z; acc.w += ga.w * wa.w;
+        }
+        acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+        acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+        if (half == 0) reinterpret_cast<float4 *>(dx + (size_t)j * F)[l32] = acc;
+    }
+}
+
+// generic width
 __global__ void __launch_bounds__(256) k_cfconv_bwd_x(const float *__restrict__ W, const float *__restrict__ dout,
                                                       const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                       const int *__restrict__ tgt, int num_atoms, int F, float *__restrict__ dx,
@@ -170,7 +205,8 @@ int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, c
     if (num_atoms == 0) return CONAN_OK;
     int blocks = (num_atoms + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    k_cfconv_bwd_x<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, num_filters, dx, pid);
+    if (num_filters == 128) k_cfconv_bwd_x128<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, dx, pid);
+    else k_cfconv_bwd_x<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, num_filters, dx, pid);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }
