@@ -136,21 +136,37 @@ static void scan_large(const int *in, int n, int *out, int *ws, hipStream_t s) {
     k_scan_block_apply<<<nblocks, SB_THREADS, 0, s>>>(in, n, boff, nblocks, out);
 }
 
-// by-source transpose, one workgroup per graph; deterministic (ascending edge id inside each source row)
-template <int PASS>
-__global__ void __launch_bounds__(RG_THREADS) k_transpose(const int *__restrict__ gptr, const int *__restrict__ rowptr,
-                                                          const int *__restrict__ col, int *__restrict__ deg,
-                                                          const int *__restrict__ t_rowptr, int *__restrict__ t_eid) {
+// by-source transpose, one workgroup per graph; deterministic (ascending edge id inside each source row).
+// The by-source lists of a graph fill exactly the edge range [e0, e1) of that graph, so the row pointers need no global
+// scan: t_rowptr[j] = e0 + (number of edges of the graph whose source is < j).  One wavefront per source atom scans the
+// graph's edges 64 at a time: ballot + popcount give the row start (scan 1) and the in-order write slots (scan 2).
+constexpr int TR_THREADS = 256;
+__global__ void __launch_bounds__(TR_THREADS) k_transpose_graph(const int *__restrict__ gptr, const int *__restrict__ rowptr,
+                                                                const int *__restrict__ col, int num_atoms,
+                                                                int *__restrict__ t_rowptr, int *__restrict__ t_eid) {
     const int g = blockIdx.x;
     const int lo = gptr[g], hi = gptr[g + 1];
+    if (g == gridDim.x - 1 && threadIdx.x == 0) t_rowptr[num_atoms] = rowptr[num_atoms];
     if (hi <= lo) return;
     const int e0 = rowptr[lo], e1 = rowptr[hi];
-    for (int j = lo + threadIdx.x; j < hi; j += RG_THREADS) {
-        int cnt = 0;
-        int base = PASS ? t_rowptr[j] : 0;
-        for (int e = e0; e < e1; ++e)
-            if (col[e] == j) { if (PASS) t_eid[base + cnt] = e; ++cnt; }
-        if (!PASS) deg[j] = cnt;
+    const int steps = (e1 - e0 + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int j = lo + wave; j < hi; j += TR_THREADS / 64) {
+        int less = 0;
+        for (int s = 0; s < steps; ++s) {
+            const int e = e0 + s * 64 + lane;
+            less += __popcll(__ballot(e < e1 && col[e] < j));
+        }
+        int base = e0 + less;
+        if (lane == 0) t_rowptr[j] = base;
+        for (int s = 0; s < steps; ++s) {
+            const int e = e0 + s * 64 + lane;
+            const bool hit = e < e1 && col[e] == j;
+            const unsigned long long m = __ballot(hit);
+            if (hit) t_eid[base + __popcll(m & below)] = e;
+            base += __popcll(m);
+        }
     }
 }
 
@@ -234,11 +250,10 @@ int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms
 
 int conan_csr_transpose(const int *graph_ptr, int num_graphs, int num_atoms, const int *rowptr, const int *col,
                         int *deg_ws, int *t_rowptr, int *t_eid, void *stream) {
-    if (!graph_ptr || !rowptr || !col || !deg_ws || !t_rowptr || !t_eid || num_graphs <= 0) return CONAN_E_BADARG;
+    if (!graph_ptr || !rowptr || !col || !t_rowptr || !t_eid || num_graphs <= 0) return CONAN_E_BADARG;
     hipStream_t s = as_stream(stream);
-    k_transpose<0><<<num_graphs, RG_THREADS, 0, s>>>(graph_ptr, rowptr, col, deg_ws, nullptr, nullptr);
-    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_ws, num_atoms, t_rowptr);
-    k_transpose<1><<<num_graphs, RG_THREADS, 0, s>>>(graph_ptr, rowptr, col, nullptr, t_rowptr, t_eid);
+    (void)deg_ws;
+    k_transpose_graph<<<num_graphs, TR_THREADS, 0, s>>>(graph_ptr, rowptr, col, num_atoms, t_rowptr, t_eid);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

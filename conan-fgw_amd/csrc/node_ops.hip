@@ -27,8 +27,17 @@ __global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__
     for (int t = threadIdx.x; t < rows * 128; t += 128) acc[t] = 0.f;
     for (int t = threadIdx.x; t < a1 - a0; t += 128) zs[t] = (int)z[a0 + t];
     __syncthreads();
-    if (c < H)
-        for (int a = a0; a < a1; ++a) acc[zs[a - a0] * 128 + threadIdx.x] += dout[(size_t)a * H + c];
+    if (c < H) {                            // loads issued 8 deep, then the (order-preserving) LDS accumulation
+        int a = a0;
+        for (; a + 8 <= a1; a += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dout[(size_t)(a + u) * H + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[zs[a + u - a0] * 128 + threadIdx.x] += v[u];
+        }
+        for (; a < a1; ++a) acc[zs[a - a0] * 128 + threadIdx.x] += dout[(size_t)a * H + c];
+    }
     __syncthreads();
     if (c < H)
         for (int r = 0; r < rows; ++r) slabs[((size_t)chunk * rows + r) * H + c] = acc[r * 128 + threadIdx.x];

@@ -53,7 +53,7 @@ int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms
                            int loop, int *deg_ws, int *rowptr, int *col, int *tgt, float *dist, void *stream);
 
 /* CSR by SOURCE of the same edge set (needed by the backward of the message passing): t_rowptr[num_atoms+1],
- * t_eid[e'] = edge id (position in the by-target CSR), ascending inside each source row. */
+ * t_eid[e'] = edge id (position in the by-target CSR), ascending inside each source row.  deg_ws is unused (may be NULL). */
 int conan_csr_transpose(const int *graph_ptr, int num_graphs, int num_atoms, const int *rowptr, const int *col,
                         int *deg_ws, int *t_rowptr, int *t_eid, void *stream);
 
