@@ -107,7 +107,7 @@ def main():
     head = ConformerAggregationHead(64, 0.2).to(dev)
     params = list(model.parameters()) + list(head.parameters())
     flat = FlatGradients(params)
-    opt = torch.optim.Adam(flat.params, lr=1e-4)
+    opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True)
 
     # live per-kernel timing of the CFConv forward kernel with HIP events on the launch stream
     ev = []

@@ -37,6 +37,7 @@ SIGNATURES = {
     "conan_ssp_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "conan_linear_wgrad_ws": (c_ll, [c_int, c_int, c_int]),
     "conan_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "conan_rbf_wgrad": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),

@@ -252,7 +252,7 @@ __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict_
 // flight).  4 wavefronts as 2x2 over the 128x128 tile (64x64 each = 2x2 accumulators); duplicates between the waves of a
 // workgroup hit L1/L2, HBM sees every row of g and x once.
 constexpr int WG_TILE = 128;
-constexpr int WG_SLICES_MAX = 512;
+constexpr int WG_SLICES_MAX = 768;      // 3 workgroups per CU
 constexpr int WG_U = 16;            // row pairs in flight
 
 __global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
@@ -420,6 +420,162 @@ __global__ void __launch_bounds__(256) k_wgrad_partial16(const float *__restrict
     }
 }
 
+// LDS-staged variant (default).  The direct kernels above split every operand value once per consuming wave (2x) and
+// keep few bytes in flight; here each value is loaded and split ONCE by a producer thread, in exactly the MFMA fragment
+// unit: 8 consecutive rows of one column (lane <-> column, so the dword loads are coalesced 128-B segments), split into
+// three bf16x8 planes and parked in LDS as three 16-byte words [plane][row group][column].  Consumers fetch a fragment
+// with three contiguous ds_read_b128.  16 rows (one MFMA k-step) per stage, double-buffered, loads issued one stage ahead.
+// KT = 128: 2x2 waves of 64x64;  KT = 64: 4 waves of 32(n) x 64(k).
+// RBF = true: the x operand is the Gaussian expansion of dist[] (GaussianSmearing) generated by the producers instead of
+// loaded — the backward of the first filter layer then reads no [P, 50] buffer at all.
+template <int KT, bool RBF>
+__global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
+                                                   int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
+                                                   const int *__restrict__ m_dev, const float *__restrict__ dist,
+                                                   const float *__restrict__ offset, float coeff) {
+    constexpr int ROWS = 16, RG = ROWS / 8, W = 128 + KT, FRAGS = RG * W, NF = (FRAGS + 255) / 256;
+    constexpr int TNB = KT == 128 ? 2 : 1;
+    __shared__ uint4 frag[2][3][RG][W];
+    if (m_dev) M = min(M, *m_dev);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = KT == 128 ? (wave >> 1) * 64 : wave * 32, k0 = KT == 128 ? (wave & 1) * 64 : 0;     // inside the tile
+    const int nb = blockIdx.y * 128, kb = blockIdx.z * KT;
+    const int slice = blockIdx.x;
+    // stages are dealt round-robin: slice s owns rows [16 t, 16 t + 16) for t = s, s + slices, ...  At any moment the
+    // resident workgroups then stream one contiguous window of g and x (all HBM channels busy) instead of `slices`
+    // streams a power-of-two stride apart.
+    const int r_begin = slice * ROWS, r_end = M, STEP = (int)gridDim.x * ROWS;
+    (void)rows_per_slice;
+    f32x16 acc[TNB][2];
+#pragma unroll
+    for (int a = 0; a < TNB; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // producer role of this thread: fragments f = tid + 256 i  ->  (row group, column); fixed for the whole kernel.
+    // Loads are unconditional (row clamped into the slice, dead columns redirected to column 0) and masked afterwards,
+    // so a stage's 8 * NF loads issue back to back without branches.
+    int f_rg[NF], f_col[NF], f_ld[NF];
+    const float *f_ptr[NF];
+    float f_off[NF], bsum[NF];
+    bool f_on[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int f = min(tid + 256 * i, FRAGS - 1);
+        f_rg[i] = f / W; f_col[i] = f - f_rg[i] * W;
+        bsum[i] = 0.f; f_off[i] = 0.f;
+        if (f_col[i] < 128) {
+            const int cc = nb + f_col[i];
+            f_on[i] = cc < N; f_ld[i] = N;
+            f_ptr[i] = g + (f_on[i] ? cc : 0);
+        } else {
+            const int cc = kb + f_col[i] - 128;
+            f_on[i] = cc < K;
+            if (RBF) { f_off[i] = f_on[i] ? offset[cc] : 0.f; f_ptr[i] = dist; f_ld[i] = 1; }
+            else { f_ptr[i] = x + (f_on[i] ? cc : 0); f_ld[i] = K; }
+        }
+    }
+    float stA[NF][8], stB[NF][8];                // two stages of loads in flight
+    auto fetch = [&](float (&st)[NF][8], int m0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = min(m0 + 8 * f_rg[i] + j, r_end - 1);
+                st[i][j] = f_ptr[i][(size_t)m * f_ld[i]];
+            }
+        }
+    };
+    auto stash = [&](int buf, float (&st)[NF][8], int m0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if (tid + 256 * i >= FRAGS) continue;
+            const bool is_g = f_col[i] < 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = f_on[i] && (m0 + 8 * f_rg[i] + j < r_end);
+                float v = st[i][j];
+                if (RBF && !is_g) { const float t = v - f_off[i]; v = expf(coeff * (t * t)); }
+                st[i][j] = ok ? v : 0.f;
+            }
+            if (is_g) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[i] += st[i][j];
+            }
+            bf16x8 p1, p2, p3;
+            wg_split3(st[i], p1, p2, p3);
+            frag[buf][0][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p1);
+            frag[buf][1][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p2);
+            frag[buf][2][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p3);
+        }
+    };
+    auto compute = [&](int buf) {
+        bf16x8 p[TNB][3], q[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int a = 0; a < TNB; ++a) p[a][pl] = __builtin_bit_cast(bf16x8, frag[buf][pl][h][n0 + 32 * a + l31]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) q[b][pl] = __builtin_bit_cast(bf16x8, frag[buf][pl][h][128 + k0 + 32 * b + l31]);
+        }
+#pragma unroll
+        for (int a = 0; a < TNB; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = wg_mma6(p[a][0], p[a][1], p[a][2], q[b][0], q[b][1], q[b][2], acc[a][b]);
+    };
+
+    if (r_begin < r_end) {
+        int m = r_begin;
+        fetch(stA, m);
+        stash(0, stA, m);
+        if (m + STEP < r_end) fetch(stA, m + STEP);
+        if (m + 2 * STEP < r_end) fetch(stB, m + 2 * STEP);
+        __syncthreads();
+        for (;;) {                                   // stage m is in buffer 0; stA holds the next stage, stB the one after
+            compute(0);
+            if (m + STEP < r_end) stash(1, stA, m + STEP);
+            if (m + 3 * STEP < r_end) fetch(stA, m + 3 * STEP);
+            __syncthreads();
+            m += STEP;
+            if (m >= r_end) break;
+            compute(1);
+            if (m + STEP < r_end) stash(0, stB, m + STEP);
+            if (m + 3 * STEP < r_end) fetch(stB, m + 3 * STEP);
+            __syncthreads();
+            m += STEP;
+            if (m >= r_end) break;
+        }
+    }
+
+    float *slab = slabs + (size_t)slice * N * K;
+#pragma unroll
+    for (int a = 0; a < TNB; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int k = kb + k0 + b * 32 + l31;
+                if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
+            }
+    if (blockIdx.z == 0) {                       // bias gradient = column sums of g, combined over the row groups in LDS
+        float *bp = reinterpret_cast<float *>(&frag[0][0][0][0]);            // [RG][128]; the stages are idle by now
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            if (tid + 256 * i < FRAGS && f_col[i] < 128) bp[f_rg[i] * 128 + f_col[i]] = bsum[i];
+        __syncthreads();
+        if (tid < 128 && nb + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) t += bp[r * 128 + tid];
+            bias_slabs[(size_t)slice * N + nb + tid] = t;
+        }
+    }
+}
+
 // slabs [slices][NK] (+ bias_slabs [slices][N]) -> out[g][NK] (+ bout[g][N]) for slice group g = blockIdx.y; fixed order.
 __global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int slices, int per_group,
                                int NK, int N, float *__restrict__ out, float *__restrict__ bout) {
@@ -445,10 +601,11 @@ __global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__r
 
 constexpr int WG_GROUPS = 16;
 
-static int wgrad_slices(int M) {
+static int wgrad_slices(int M, int K) {
     int s = (M + 127) / 128;           // >= 128 rows per slice
     if (s < 1) s = 1;
-    if (s > WG_SLICES_MAX) s = WG_SLICES_MAX;
+    const int cap = K > 64 ? 512 : WG_SLICES_MAX;      // resident workgroups per CU: 2 (128-wide k tile) or 3
+    if (s > cap) s = cap;
     return s;
 }
 
@@ -507,23 +664,37 @@ int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const in
 }
 
 long long conan_linear_wgrad_ws(int M, int K, int N) {
-    return (long long)(wgrad_slices(M) + WG_GROUPS) * ((long long)N * K + N);
+    return (long long)(wgrad_slices(M, K) + WG_GROUPS) * ((long long)N * K + N);
 }
 
-int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias,
-                       float *ws, void *stream) {
-    if (!g || !x || !dW || !ws || M < 0 || K <= 0 || N <= 0) return CONAN_E_BADARG;
-    hipStream_t s = as_stream(stream);
-    const int slices = wgrad_slices(M);
+static int wgrad_launch(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias, float *ws,
+                        hipStream_t s, const float *dist, const float *offset, float coeff) {
+    const bool rbf = dist != nullptr;
+    const int slices = wgrad_slices(M, K);
     int rows = (M + slices - 1) / slices;
     rows = ((rows + 2 * WG_U - 1) / (2 * WG_U)) * (2 * WG_U);
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * N * K;
-    dim3 grid(slices, (N + WG_TILE - 1) / WG_TILE, (K + WG_TILE - 1) / WG_TILE);
     // CONAN_LINEAR_FP32=1 forces the plain fp32-MFMA kernel (default: exact 3-way bf16 split on the bf16 MFMA)
     static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
-    // (measured at E = 518k: 227 vs 247 us for 128x128, but 186 vs 164 us for K = 50 where half a 64-wide block is padding)
-    if (fp32_only || K < 64) k_wgrad_partial<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
-    else k_wgrad_partial16<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
+    static const bool no_lds = getenv("CONAN_WGRAD_DIRECT") && atoi(getenv("CONAN_WGRAD_DIRECT")) != 0;
+    const bool lds_ok = !fp32_only && !no_lds;
+    if (rbf && !lds_ok) return CONAN_E_UNSUPPORTED;
+    if (lds_ok) {
+        const int KT = K > 64 ? 128 : 64;
+        dim3 grid(slices, (N + 127) / 128, (K + KT - 1) / KT);
+        if (KT == 128) {
+            if (rbf) k_wgrad_lds<128, true><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            else k_wgrad_lds<128, false><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
+        } else {
+            if (rbf) k_wgrad_lds<64, true><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            else k_wgrad_lds<64, false><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
+        }
+    } else {
+        dim3 grid(slices, (N + WG_TILE - 1) / WG_TILE, (K + WG_TILE - 1) / WG_TILE);
+        // (measured at E = 518k: 227 vs 247 us for 128x128, but 186 vs 164 us for K = 50 where half a 64-wide block is padding)
+        if (fp32_only || K < 64) k_wgrad_partial<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
+        else k_wgrad_partial16<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
+    }
     const int NK = N * K;
     if (slices > 2 * WG_GROUPS) {                    // two-level, both levels in a fixed order
         float *mid = bias_slabs + (size_t)slices * N, *bmid = mid + (size_t)WG_GROUPS * NK;
@@ -535,6 +706,18 @@ int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, cons
     }
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
+}
+
+int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias,
+                       float *ws, void *stream) {
+    if (!g || !x || !dW || !ws || M < 0 || K <= 0 || N <= 0) return CONAN_E_BADARG;
+    return wgrad_launch(g, x, M, K, N, m_dev, dW, dbias, ws, as_stream(stream), nullptr, nullptr, 0.f);
+}
+
+int conan_rbf_wgrad(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
+                    const int *m_dev, float *dW, float *dbias, float *ws, void *stream) {
+    if (!g || !dist || !offset || !dW || !ws || M < 0 || num_gaussians <= 0 || N <= 0) return CONAN_E_BADARG;
+    return wgrad_launch(g, nullptr, M, num_gaussians, N, m_dev, dW, dbias, ws, as_stream(stream), dist, offset, coeff);
 }
 
 }  // extern "C"

@@ -203,7 +203,7 @@ def cutoff_scale(w_raw: Tensor, graph: RadiusGraph) -> Tensor:
 class _FilterFn(torch.autograd.Function):
     """Fused filter generator (conan_filter_fwd).  Its output must be consumed by `cfconv(..., pre_cutoff_grad=True)`:
     the incoming gradient g is then w.r.t. the un-scaled filter.  Backward is composed from the edge-level GEMM kernels:
-    dw2 = g^T h1 ; gpre = (g w2) * ssp'(h1) (fused epilogue) ; dw1 = gpre^T rbf  (rbf is recomputed)."""
+    dw2 = g^T h1 ; gpre = (g w2) * ssp'(h1) (fused epilogue) ; dw1 = gpre^T rbf  (rbf regenerated inside the GEMM: conan_rbf_wgrad)."""
 
     @staticmethod
     def forward(ctx, graph, offset, coeff, w1, b1, w2, b2, use_pairs):
@@ -233,10 +233,9 @@ class _FilterFn(torch.autograd.Function):
         call("conan_linear_wgrad", ptr(g), ptr(h1), ME, F, F, ptr(md), ptr(dw2), ptr(db2), ptr(ws), stream_ptr())
         dh1 = torch.empty_like(g)
         call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
-        rbf = torch.empty(ME, Gs, dtype=f32, device=dev)
-        call("conan_rbf_fwd", ptr(dist), ptr(md), ME, ptr(_c(offset), f32), Gs, ctx.coeff, ptr(rbf), stream_ptr())
         dw1, db1 = torch.empty_like(w1), torch.empty(F, dtype=f32, device=dev)
-        call("conan_linear_wgrad", ptr(dh1), ptr(rbf), ME, Gs, F, ptr(md), ptr(dw1), ptr(db1), ptr(ws), stream_ptr())
+        call("conan_rbf_wgrad", ptr(dh1), ptr(dist), ME, ptr(_c(offset), f32), Gs, ctx.coeff, F, ptr(md), ptr(dw1), ptr(db1), ptr(ws),
+             stream_ptr())                            # rbf(dist) regenerated inside the GEMM
         return None, None, None, dw1, db1, dw2, db2, None
 
 

@@ -22,7 +22,11 @@ def shard_range(num_items: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 
 class FlatGradients:
-    """Aliases every parameter's .grad into one contiguous fp32 buffer and averages it across ranks with one all-reduce."""
+    """One contiguous fp32 buffer for all gradients: packed with ONE concatenation kernel after backward, averaged across
+    ranks with ONE all-reduce, and aliased back as every parameter's .grad for the optimizer.
+
+    zero() drops the .grad tensors instead of clearing them: autograd's AccumulateGrad then adopts each freshly produced
+    gradient without a per-parameter `grad += g` kernel (57 launches per step for SchNet), and the pack is one launch."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         seen, self.params = set(), []
@@ -33,20 +37,32 @@ class FlatGradients:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
-        off = 0
-        for p in self.params:              # re-alias in case an optimizer / autograd replaced .grad
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        """Gather the .grad tensors autograd produced into the flat buffer and alias them to it."""
+        pieces = []
+        for p, v in zip(self.params, self._views):
+            g = p.grad
+            if g is None:
+                g = torch.zeros_like(v)                 # parameter not reached by this step's graph
+            elif g.data_ptr() == v.data_ptr():
+                g = g.clone()                           # already aliased (pack() called twice): keep the value
+            pieces.append(g.reshape(-1).to(torch.float32))
+        torch.cat(pieces, out=self.flat)
+        for p, v in zip(self.params, self._views):
+            p.grad = v
 
     def all_reduce_mean(self):
+        self.pack()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / dist.get_world_size())

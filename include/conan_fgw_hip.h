@@ -98,6 +98,11 @@ int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const in
 long long conan_linear_wgrad_ws(int M, int K, int N);
 int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias,
                        float *ws, void *stream);
+/* Same with x = GaussianSmearing(dist) generated on the fly: dW[N,Gs] = g^T rbf(dist), rbf[m,k] = exp(coeff (dist[m]-offset[k])^2)
+ * (weight gradient of the first filter-network layer, schnet_no_sum.py InteractionBlock.mlp[0]; no [M,Gs] buffer is read).
+ * ws as conan_linear_wgrad_ws(M, Gs, N). */
+int conan_rbf_wgrad(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
+                    const int *m_dev, float *dW, float *dbias, float *ws, void *stream);
 
 /* rbf[e,k] = exp(coeff * (dist[e] - offset[k])^2): GaussianSmearing (PyG; schnet_no_sum.py:161,209).  `offset` is the
  * module's buffer (distance_expansion.offset), coeff = -0.5/(offset[1]-offset[0])^2.  num_edges_dev (nullable) = device

@@ -148,3 +148,44 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
     h1 = ops.linear(rbf, prm[0].detach(), prm[1].detach(), act=True, m_dev=g.num_edges_dev)
     W2 = ops.cutoff_scale(ops.linear(h1, prm[2].detach(), prm[3].detach(), m_dev=g.num_edges_dev), g)
     assert rel(W[:E].detach().cpu(), W2[:E].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (4133, 128, 64), (777, 64, 128), (2500, 32, 32), (300, 128, 52), (33, 64, 64), (5000, 256, 128)])
+def test_wgrad_lds_staged_matches_fp64(M, N, K):
+    """conan_linear_wgrad (LDS-staged bf16-split path: N % 4 == 0, K % 4 == 0) against an fp64 matmul; a device-side row
+    count below the buffer size must mask the tail rows; tolerance 1e-5 relative (fp32-class, well inside the 1e-4 bar)."""
+    from conan_fgw_amd._lib import call, lib, ptr, stream_ptr
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(M + N + K)
+    g = torch.randn(M + 40, N, generator=gen).to(dev)
+    x = torch.randn(M + 40, K, generator=gen).to(dev)
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    ws = torch.empty(int(lib().conan_linear_wgrad_ws(M + 40, K, N)), device=dev)
+    call("conan_linear_wgrad", ptr(g), ptr(x), M + 40, K, N, ptr(md), ptr(dW), ptr(db), ptr(ws), stream_ptr())
+    ref = g[:M].double().T @ x[:M].double()
+    assert rel(dW.double().cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert rel(db.double().cpu().numpy(), g[:M].double().sum(0).cpu().numpy()) < 1e-5
+    dW2 = torch.empty_like(dW)
+    call("conan_linear_wgrad", ptr(g), ptr(x), M + 40, K, N, ptr(md), ptr(dW2), ptr(db), ptr(ws), stream_ptr())
+    assert torch.equal(dW, dW2)                                     # fixed reduction order => bitwise reproducible
+
+
+@pytest.mark.parametrize("M,N,Gs", [(3000, 128, 50), (517, 64, 50), (100, 32, 20), (2000, 128, 128)])
+def test_rbf_wgrad_matches_materialised_rbf(M, N, Gs):
+    """conan_rbf_wgrad == g^T GaussianSmearing(dist) with the expansion generated inside the GEMM."""
+    from conan_fgw_amd._lib import call, lib, ptr, stream_ptr
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(M + N)
+    g = torch.randn(M + 7, N, generator=gen).to(dev)
+    dist = (torch.rand(M + 7, generator=gen) * 10).to(dev)
+    off = torch.linspace(0, 10, Gs).to(dev)
+    coeff = -0.5 / float(off[1] - off[0]) ** 2
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    dW, db = torch.empty(N, Gs, device=dev), torch.empty(N, device=dev)
+    ws = torch.empty(int(lib().conan_linear_wgrad_ws(M + 7, Gs, N)), device=dev)
+    call("conan_rbf_wgrad", ptr(g), ptr(dist), M + 7, ptr(off), Gs, coeff, N, ptr(md), ptr(dW), ptr(db), ptr(ws), stream_ptr())
+    rbf = torch.exp(coeff * (dist[:M, None].double() - off[None].double()) ** 2)
+    ref = g[:M].double().T @ rbf
+    assert rel(dW.double().cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert rel(db.double().cpu().numpy(), g[:M].double().sum(0).cpu().numpy()) < 1e-5

@@ -43,12 +43,13 @@ def _worker(rank, world, port, out_dir):
     g = torch.Generator().manual_seed(1)
     X, Y = torch.randn(16, 6, generator=g), torch.randn(16, 1, generator=g)
     lo, hi = shard_range(16, rank, world)
-    for step in range(2):                      # two steps: .grad must stay aliased to the flat buffer after zero()
+    for step in range(2):                      # two steps: zero() must not leave stale values behind
         flat.zero()
         loss = torch.nn.functional.mse_loss(model(X[lo:hi]), Y[lo:hi])
         loss.backward()
-        assert all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in flat.params)
         flat.all_reduce_mean()
+        lo_ptr, hi_ptr = flat.flat.data_ptr(), flat.flat.data_ptr() + 4 * flat.flat.numel()
+        assert all(lo_ptr <= p.grad.data_ptr() < hi_ptr for p in flat.params)     # the optimizer sees the reduced buffer
     np.save(os.path.join(out_dir, f"grad{rank}.npy"), flat.flat.numpy())
     dist.destroy_process_group()
 
