@@ -16,36 +16,44 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd(const float *__restrict__ x,
                                                     float *__restrict__ out, const int *__restrict__ pid) {
     constexpr int F = 128 * VEC;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int i = wave; i < num_atoms; i += nwaves) {
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
+    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    for (int i = a_lo; i < a_hi; i += 4) {
         const int e0 = rowptr[i], e1 = rowptr[i + 1];
         float4 acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // 2 edges per step per wave (one per half), unrolled x2 for more loads in flight
-        int e = e0 + half;
-        for (; e + 2 < e1; e += 4) {
-            const int j0 = col[e], j1 = col[e + 2];
-            const int r0 = pid ? pid[e] : e, r1 = pid ? pid[e + 2] : e + 2;      // filter row (shared by both directions of a pair)
+        // The row's source and filter-row indices are fetched once, one edge per lane (a capped row has <= 32 edges), and
+        // handed out by cross-lane reads: the W / x row loads of all edges then issue back to back instead of each
+        // waiting for its own index load.  Half-wavefront `half` takes the edges of its parity.
+        for (int base = e0; base < e1; base += 64) {
+            const int cnt = min(64, e1 - base);
+            const int my_j = lane < cnt ? col[base + lane] : 0;
+            const int my_r = lane < cnt ? (pid ? pid[base + lane] : base + lane) : 0;
+            for (int k2 = 0; k2 < cnt; k2 += 8) {             // 4 steps x 2 edges; the tail repeats the last edge with weight 0
+                int j[4], r[4];
+                float m[4];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float4 w0 = reinterpret_cast<const float4 *>(W + (size_t)r0 * F)[l32 + 32 * v];
-                const float4 w1 = reinterpret_cast<const float4 *>(W + (size_t)r1 * F)[l32 + 32 * v];
-                const float4 x0 = reinterpret_cast<const float4 *>(x + (size_t)j0 * F)[l32 + 32 * v];
-                const float4 x1 = reinterpret_cast<const float4 *>(x + (size_t)j1 * F)[l32 + 32 * v];
-                acc[v].x += x0.x * w0.x; acc[v].y += x0.y * w0.y; acc[v].z += x0.z * w0.z; acc[v].w += x0.w * w0.w;
-                acc[v].x += x1.x * w1.x; acc[v].y += x1.y * w1.y; acc[v].z += x1.z * w1.z; acc[v].w += x1.w * w1.w;
-            }
-        }
-        for (; e < e1; e += 2) {
-            const int j0 = col[e];
-            const int r0 = pid ? pid[e] : e;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k2 + 2 * u + half, kk = min(k, cnt - 1);
+                    j[u] = __shfl(my_j, kk, 64); r[u] = __shfl(my_r, kk, 64);
+                    m[u] = k < cnt ? 1.f : 0.f;
+                }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float4 w0 = reinterpret_cast<const float4 *>(W + (size_t)r0 * F)[l32 + 32 * v];
-                const float4 x0 = reinterpret_cast<const float4 *>(x + (size_t)j0 * F)[l32 + 32 * v];
-                acc[v].x += x0.x * w0.x; acc[v].y += x0.y * w0.y; acc[v].z += x0.z * w0.z; acc[v].w += x0.w * w0.w;
+                for (int v = 0; v < VEC; ++v) {
+                    float4 w4[4], x4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        w4[u] = reinterpret_cast<const float4 *>(W + (size_t)r[u] * F)[l32 + 32 * v];
+                        x4[u] = reinterpret_cast<const float4 *>(x + (size_t)j[u] * F)[l32 + 32 * v];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[v].x += m[u] * x4[u].x * w4[u].x; acc[v].y += m[u] * x4[u].y * w4[u].y;
+                        acc[v].z += m[u] * x4[u].z * w4[u].z; acc[v].w += m[u] * x4[u].w * w4[u].w;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -62,10 +70,11 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd_generic(const float *__restr
                                                             const int *__restrict__ rowptr, const int *__restrict__ col, int num_atoms,
                                                             int F, float *__restrict__ out, const int *__restrict__ pid) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
+    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
     const int F4 = F >> 2;
-    for (int i = wave; i < num_atoms; i += nwaves) {
+    for (int i = a_lo; i < a_hi; i += 4) {
         const int e0 = rowptr[i], e1 = rowptr[i + 1];
         for (int c = lane; c < F4; c += 64) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -87,26 +96,34 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_x128(const float *__restrict
                                                          const int *__restrict__ pid) {
     constexpr int F = 128;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int j = wave; j < num_atoms; j += nwaves) {
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
+    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    for (int j = a_lo; j < a_hi; j += 4) {
         const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int s = s0 + half;
-        for (; s + 2 < s1; s += 4) {
-            const int ea = t_eid[s], eb = t_eid[s + 2];
-            const float4 wa = reinterpret_cast<const float4 *>(W + (size_t)(pid ? pid[ea] : ea) * F)[l32];
-            const float4 wb = reinterpret_cast<const float4 *>(W + (size_t)(pid ? pid[eb] : eb) * F)[l32];
-            const float4 ga = reinterpret_cast<const float4 *>(dout + (size_t)tgt[ea] * F)[l32];
-            const float4 gb = reinterpret_cast<const float4 *>(dout + (size_t)tgt[eb] * F)[l32];
-            acc.x += ga.x * wa.x; acc.y += ga.y * wa.y; acc.z += ga.z * wa.z; acc.w += ga.w * wa.w;
-            acc.x += gb.x * wb.x; acc.y += gb.y * wb.y; acc.z += gb.z * wb.z; acc.w += gb.w * wb.w;
-        }
-        for (; s < s1; s += 2) {
-            const int ea = t_eid[s];
-            const float4 wa = reinterpret_cast<const float4 *>(W + (size_t)(pid ? pid[ea] : ea) * F)[l32];
-            const float4 ga = reinterpret_cast<const float4 *>(dout + (size_t)tgt[ea] * F)[l32];
-            acc.x += ga.x * wa.x; acc.y += ga.y * wa.y; acc.z += ga.z * wa.z; acc.w += ga.w * wa.w;
+        for (int base = s0; base < s1; base += 64) {          // indices one edge per lane, then cross-lane hand-out (see forward)
+            const int cnt = min(64, s1 - base);
+            const int my_e = lane < cnt ? t_eid[base + lane] : 0;
+            const int my_t = lane < cnt ? tgt[my_e] : 0;
+            const int my_r = lane < cnt ? (pid ? pid[my_e] : my_e) : 0;
+            for (int k2 = 0; k2 < cnt; k2 += 8) {
+                float4 w4[4], g4[4];
+                float m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k2 + 2 * u + half, kk = min(k, cnt - 1);
+                    const int t = __shfl(my_t, kk, 64), r = __shfl(my_r, kk, 64);
+                    m[u] = k < cnt ? 1.f : 0.f;
+                    w4[u] = reinterpret_cast<const float4 *>(W + (size_t)r * F)[l32];
+                    g4[u] = reinterpret_cast<const float4 *>(dout + (size_t)t * F)[l32];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += m[u] * g4[u].x * w4[u].x; acc.y += m[u] * g4[u].y * w4[u].y;
+                    acc.z += m[u] * g4[u].z * w4[u].z; acc.w += m[u] * g4[u].w * w4[u].w;
+                }
+            }
         }
         acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
         acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
@@ -120,10 +137,11 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_x(const float *__restrict__ 
                                                       const int *__restrict__ tgt, int num_atoms, int F, float *__restrict__ dx,
                                                       const int *__restrict__ pid) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
+    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
     const int F4 = F >> 2;
-    for (int j = wave; j < num_atoms; j += nwaves) {
+    for (int j = a_lo; j < a_hi; j += 4) {
         const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
         for (int c = lane; c < F4; c += 64) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -163,9 +181,10 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_wp(const float *__restrict__
                                                        int F, const float *__restrict__ pdist, float cutoff, float *__restrict__ dWp) {
     const int P = min(*num_pairs_dev, max_pairs);
     const int F4 = F >> 2;
-    const long long n4 = (long long)P * F4;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (P + (int)gridDim.x - 1) / (int)gridDim.x;                  // contiguous pairs per workgroup
+    const long long i_lo = (long long)lb * per * F4, i_hi = (long long)min(P, (lb + 1) * per) * F4;
+    for (long long i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {
         const int p = (int)(i / F4), c = (int)(i - (long long)p * F4);
         const int e0 = pe0[p], e1 = pe1[p];
         const float4 xa = reinterpret_cast<const float4 *>(x + (size_t)col[e0] * F)[c];
@@ -181,6 +200,56 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_wp(const float *__restrict__
     }
 }
 
+// F = 128: one wavefront per 64 pairs.  Edge ids, endpoints and the cutoff factor are computed one pair per lane (one
+// cosine per pair, not per float4), then handed out by cross-lane reads; one half-wavefront (32 lanes x float4) per pair.
+__global__ void __launch_bounds__(256) k_cfconv_bwd_wp128(const float *__restrict__ x, const float *__restrict__ dout,
+                                                          const int *__restrict__ num_pairs_dev, int max_pairs, const int *__restrict__ pe0,
+                                                          const int *__restrict__ pe1, const int *__restrict__ col, const int *__restrict__ tgt,
+                                                          const float *__restrict__ pdist, float cutoff, float *__restrict__ dWp) {
+    constexpr int F = 128;
+    const int P = min(*num_pairs_dev, max_pairs);
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (P + (int)gridDim.x - 1) / (int)gridDim.x;                  // contiguous pairs per workgroup
+    const int p_lo = lb * per, p_hi = min(P, (lb + 1) * per);
+    for (int base = p_lo + 64 * (threadIdx.x >> 6); base < p_hi; base += 256) {
+        const int cnt = min(64, p_hi - base);
+        int s0 = 0, t0 = 0, s1 = 0, t1 = 0;
+        float cc = 0.f, m1 = 0.f;
+        if (lane < cnt) {
+            const int e0 = pe0[base + lane], e1 = pe1[base + lane];
+            s0 = col[e0]; t0 = tgt[e0];
+            if (e1 >= 0) { s1 = col[e1]; t1 = tgt[e1]; m1 = 1.f; }
+            cc = 0.5f * (cosf(__fdiv_rn(pdist[base + lane] * 3.14159265358979323846f, cutoff)) + 1.0f);
+        }
+        for (int k2 = 0; k2 < cnt; k2 += 4) {                 // 2 steps x 2 pairs
+            float4 xa[2], ga[2], xb[2], gb[2];
+            float c2[2], mm[2];
+            int kk[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                kk[u] = min(k2 + 2 * u + half, cnt - 1);
+                const int a0 = __shfl(s0, kk[u], 64), b0 = __shfl(t0, kk[u], 64), a1 = __shfl(s1, kk[u], 64), b1 = __shfl(t1, kk[u], 64);
+                c2[u] = __shfl(cc, kk[u], 64); mm[u] = __shfl(m1, kk[u], 64);
+                xa[u] = reinterpret_cast<const float4 *>(x + (size_t)a0 * F)[l32];
+                ga[u] = reinterpret_cast<const float4 *>(dout + (size_t)b0 * F)[l32];
+                xb[u] = reinterpret_cast<const float4 *>(x + (size_t)a1 * F)[l32];
+                gb[u] = reinterpret_cast<const float4 *>(dout + (size_t)b1 * F)[l32];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (k2 + 2 * u + half >= cnt) continue;
+                float4 r;
+                r.x = (xa[u].x * ga[u].x + mm[u] * xb[u].x * gb[u].x) * c2[u];
+                r.y = (xa[u].y * ga[u].y + mm[u] * xb[u].y * gb[u].y) * c2[u];
+                r.z = (xa[u].z * ga[u].z + mm[u] * xb[u].z * gb[u].z) * c2[u];
+                r.w = (xa[u].w * ga[u].w + mm[u] * xb[u].w * gb[u].w) * c2[u];
+                reinterpret_cast<float4 *>(dWp + (size_t)(base + kk[u]) * F)[l32] = r;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -191,7 +260,8 @@ int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const in
     if (num_atoms == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
     int blocks = (num_atoms + 3) / 4;                 // 4 wavefronts (targets) per 256-thread workgroup
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 65536) blocks = 65536;
+    blocks = round_up8(blocks);
     if (num_filters == 128) k_cfconv_fwd<1><<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, out, pid);
     else if (num_filters == 256) k_cfconv_fwd<2><<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, out, pid);
     else k_cfconv_fwd_generic<<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, num_filters, out, pid);
@@ -204,7 +274,8 @@ int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, c
     if (!W || !dout || !t_rowptr || !t_eid || !tgt || !dx || num_atoms < 0 || num_filters <= 0 || (num_filters & 3)) return CONAN_E_BADARG;
     if (num_atoms == 0) return CONAN_OK;
     int blocks = (num_atoms + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 65536) blocks = 65536;
+    blocks = round_up8(blocks);
     if (num_filters == 128) k_cfconv_bwd_x128<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, dx, pid);
     else k_cfconv_bwd_x<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, num_filters, dx, pid);
     CONAN_LAUNCH_CHECK();
@@ -227,8 +298,11 @@ int conan_cfconv_bwd_w_pairs(const float *x, const float *dout, const int *num_p
         (num_filters & 3))
         return CONAN_E_BADARG;
     if (max_pairs == 0) return CONAN_OK;
-    k_cfconv_bwd_wp<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, num_filters, pair_dist,
-                                                          cutoff, dWp);
+    if (num_filters == 128)
+        k_cfconv_bwd_wp128<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, pair_dist, cutoff, dWp);
+    else
+        k_cfconv_bwd_wp<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, num_filters, pair_dist,
+                                                              cutoff, dWp);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -45,3 +45,11 @@ __device__ __forceinline__ float ssp_f(float v) {
 
 // exp(x) for x <= 0 with |x| up to ~1e3 on v_exp_f32: absolute error <= ~4e-8 (|x| e^x <= 0.37 scales the argument rounding).
 __device__ __forceinline__ float exp_neg_f(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8) and every XCD has a private 4 MB L2.  The gather
+// kernels remap the block index so that XCD k works on the k-th contiguous eighth of the index space: rows that are
+// re-read by neighbouring items (a conformer's atoms, the two directions of a pair) then meet in ONE L2 instead of being
+// fetched through the fabric by up to 8.  gridDim.x must be a multiple of 8.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) { return (b & 7) * (nb >> 3) + (b >> 3); }
+static inline int round_up8(int v) { return (v + 7) & ~7; }
+
