@@ -44,9 +44,16 @@ def parse():
 
 
 def cfconv_algorithmic_bytes(E, P, n_atoms, F):
-    """SURVEY.md 8(d), W materialised: E*4F [gather x_j] + 4F per UNIQUE filter row + CSR + n*4F [store out].  The filter is
-    shared by the two directions of a pair (W_ij = W_ji), so the filter tensor has P ~ E/2 rows (P = E without sharing);
-    indices are int32 here: 4*(2E + n+1) for col + pid + rowptr."""
+    """Compulsory HBM bytes of one CFConv message+aggregate launch, every tensor touched once:
+    4F per UNIQUE filter row (the filter is shared by the two directions of a pair, W_ij = W_ji: P ~ E/2 rows; P = E
+    without sharing) + n*4F [x read once: the E gathers of x_j are re-reads of those n rows] + n*4F [store out]
+    + int32 indices 4*(2E + n+1) [col, pid, rowptr]."""
+    return P * 4 * F + 2 * n_atoms * 4 * F + 4 * (2 * E + n_atoms + 1)
+
+
+def cfconv_survey_bytes(E, P, n_atoms, F):
+    """SURVEY.md 8(d) convention (W materialised, every gather of x_j counted as E*4F of traffic): an upper bound that
+    ignores cache reuse of x; reported next to the compulsory figure, not used for `frac`."""
     return E * 4 * F + P * 4 * F + 4 * (2 * E + n_atoms + 1) + n_atoms * 4 * F
 
 
@@ -221,7 +228,8 @@ def main():
             "roofline": {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_hbm.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kdur_ms, 5),
+                         "algorithmic_bytes_per_launch": alg, "survey_convention_bytes_per_launch": cfconv_survey_bytes(E, P, n_atoms, 128),
+                         "avg_launch_ms": round(kdur_ms, 5),
                          "launches_timed": len(ev)},
         }
         out["roofline_other"] = other

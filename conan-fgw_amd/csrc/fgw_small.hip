@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
         for (int r = 0; r < R; ++r) {
             const int q = w + 4 * r;
             const bool ok = q < N && lane_ok;
-            mA[r] = ok ? -(baseA[r] - 2.0 * alpha * Gl[q * P + lane]) * inv_eps : 0.0;
-            mB[r] = ok ? -(baseB[r] - 2.0 * alpha * Gl[lane * P + q]) * inv_eps : 0.0;
+            // padding entries (row/column >= N) are masked BY VALUE: -1e300 plus any u or v stays -1e300, its exp is 0, so
+            // the log-sum-exp loops below carry no per-element bounds tests (they cost an exec-mask branch each)
+            mA[r] = ok ? -(baseA[r] - 2.0 * alpha * Gl[q * P + lane]) * inv_eps : -1.0e300;
+            mB[r] = ok ? -(baseB[r] - 2.0 * alpha * Gl[lane * P + q]) * inv_eps : -1.0e300;
         }
 
         __syncthreads();                                               // G fully consumed: its storage now holds the Sinkhorn scratch
@@ -140,10 +142,10 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
             double z[R];
             double mx = -1.0e300;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; z[r] = (i < N) ? mA[r] + us[w * 64 + i] : -1.0e300; mx = z[r] > mx ? z[r] : mx; }
+            for (int r = 0; r < R; ++r) { z[r] = mA[r] + us[w * 64 + w + 4 * r]; mx = fmax(z[r], mx); }
             double sm = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) sm += exp_lse(z[r] - mx); }
+            for (int r = 0; r < R; ++r) sm += exp_lse(z[r] - mx);
             pm[w * 64 + lane] = mx; psum[w * 64 + lane] = sm;
             __syncthreads();
             {
@@ -151,16 +153,16 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
                 const double M = fmax(fmax(m0, m1), fmax(m2, m3));
                 sm = ((psum[lane] * exp_lse(m0 - M) + psum[64 + lane] * exp_lse(m1 - M)) + psum[128 + lane] * exp_lse(m2 - M)) +
                      psum[192 + lane] * exp_lse(m3 - M);
-                v_l = logb - (log_acc(sm) + M);
+                v_l = lane_ok ? logb - (log_acc(sm) + M) : 0.0;          // padding lanes keep a finite (zero) potential
             }
             vs[w * 64 + lane] = v_l;                                   // private per-wave copy: read back by this wave only
             // u_i = loga_i - logsumexp_j(Mr_ij + v_j)          layout B (pm2/psum2: second buffer => no extra barrier)
             mx = -1.0e300;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int j = w + 4 * r; z[r] = (j < N) ? mB[r] + vs[w * 64 + j] : -1.0e300; mx = z[r] > mx ? z[r] : mx; }
+            for (int r = 0; r < R; ++r) { z[r] = mB[r] + vs[w * 64 + w + 4 * r]; mx = fmax(z[r], mx); }
             sm = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int j = w + 4 * r; if (j < N) sm += exp_lse(z[r] - mx); }
+            for (int r = 0; r < R; ++r) sm += exp_lse(z[r] - mx);
             pm2[w * 64 + lane] = mx; psum2[w * 64 + lane] = sm;
             __syncthreads();
             {
@@ -168,13 +170,13 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
                 const double M = fmax(fmax(m0, m1), fmax(m2, m3));
                 sm = ((psum2[lane] * exp_lse(m0 - M) + psum2[64 + lane] * exp_lse(m1 - M)) + psum2[128 + lane] * exp_lse(m2 - M)) +
                      psum2[192 + lane] * exp_lse(m3 - M);
-                u_l = loga - (log_acc(sm) + M);
+                u_l = lane_ok ? loga - (log_acc(sm) + M) : 0.0;
             }
             us[w * 64 + lane] = u_l;
             if (ii % 10 == 0) {                                        // marginal violation (sinkhorn.py:418-433)
                 double cs = 0.0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N) cs += exp_acc(mA[r] + us[w * 64 + i] + v_l); }
+                for (int r = 0; r < R; ++r) cs += exp_acc(mA[r] + us[w * 64 + w + 4 * r] + v_l);
                 __syncthreads();                                       // previous psum fully consumed
                 psum[w * 64 + lane] = cs;
                 __syncthreads();
