@@ -101,8 +101,36 @@ __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS
 }
 
 // Variant for thin ragged borders: MFMA on the 16-aligned core, plain FMA loops for the few border rows/columns.
+// The border output owned by a thread (two passes of 64 outputs at most) depends only on (M, Nn): it is computed once per
+// kernel (two integer divisions per pass) and reused by every product of that shape.
+struct BorderIdx {
+    int i[2], j[2], count;
+    bool on[2];
+};
+__device__ __forceinline__ BorderIdx border_prepare(int M, int Nn) {
+    BorderIdx bi;
+    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
+    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
+    bi.count = nb1 + nb2;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = p * (FGW_THREADS / 4) + ((int)threadIdx.x >> 2);
+        bi.on[p] = t < bi.count;
+        bi.i[p] = 0; bi.j[p] = 0;
+        if (bi.on[p]) {
+            if (t < nb1) { bi.i[p] = Mc + t / Nn; bi.j[p] = t % Nn; }
+            else { const int q = t - nb1; bi.i[p] = q / (Nn - Nc); bi.j[p] = Nc + q % (Nn - Nc); }
+        }
+    }
+    return bi;
+}
+__device__ __forceinline__ bool border_path(int M, int Nn) {       // dispatch rule of mm_f64 (workgroup-uniform)
+    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
+    return (M - Mc) * Nn + Mc * (Nn - Nc) <= FGW_THREADS / 2 && Mc > 0 && Nc > 0;
+}
+
 template <class FX, class FW, class FS>
-__device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W, FS st) {
+__device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W, FS st, const BorderIdx &bi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mq = M >> 4, Nq = Nn >> 4;
     const int li = lane & 15, lk = lane >> 4;
@@ -129,23 +157,16 @@ __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W,
     // Border outputs: 4 lanes per output, each summing every 4th k, combined with two xor-shuffles.  This spreads the
     // (few) border dot products over all wavefronts: with one thread per output the whole border lands on wavefront 0,
     // which then holds every barrier of the caller (PMC: 58 % of the wave cycles were spent waiting).
-    const int Mc = Mq << 4, Nc = Nq << 4;
-    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc), nb = nb1 + nb2;
     const int sub = tid & 3;
-    for (int t0 = 0; t0 < nb; t0 += FGW_THREADS / 4) {
-        const int t = t0 + (tid >> 2);
-        const bool on = t < nb;
-        int i = 0, j = 0;
-        if (on) {
-            if (t < nb1) { i = Mc + t / Nn; j = t % Nn; }
-            else { const int q = t - nb1; i = q / (Nn - Nc); j = Nc + q % (Nn - Nc); }
-        }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p * (FGW_THREADS / 4) >= bi.count) break;                 // workgroup-uniform
         double a = 0.0;
-        if (on)
-            for (int k = sub; k < Kd; k += 4) a += X(i, k) * W(k, j);
+        if (bi.on[p])
+            for (int k = sub; k < Kd; k += 4) a += X(bi.i[p], k) * W(k, bi.j[p]);
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
-        if (on && sub == 0) st(i, j, a);
+        if (bi.on[p] && sub == 0) st(bi.i[p], bi.j[p], a);
     }
 }
 
@@ -153,9 +174,13 @@ __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W,
 // the FMA path than the extra mostly-empty tiles; anything thicker goes to the padded-tile path.
 template <class FX, class FW, class FS>
 __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
-    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
-    const int border = (M - Mc) * Nn + Mc * (Nn - Nc);
-    if (border <= FGW_THREADS / 2 && Mc > 0 && Nc > 0) mm_f64_border(M, Nn, Kd, X, W, st);
+    if (border_path(M, Nn)) mm_f64_border(M, Nn, Kd, X, W, st, border_prepare(M, Nn));
+    else mm_f64_pad(M, Nn, Kd, X, W, st);
+}
+// same with the border ownership prepared by the caller (products repeated inside a loop)
+template <class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st, const BorderIdx &bi) {
+    if (border_path(M, Nn)) mm_f64_border(M, Nn, Kd, X, W, st, bi);
     else mm_f64_pad(M, Nn, Kd, X, W, st);
 }
 

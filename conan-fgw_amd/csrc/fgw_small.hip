@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     // Sinkhorn scratch (6 x [4][64] doubles) aliases the two product buffers, which are dead while the Sinkhorn loop runs;
     // for tiny problems (N*P < 768) it gets its own region behind the matrices.
     double *pq = C1l + NP;                                     // [2][64] p, q
-    double *red = pq + 128;                                    // [8]
+    double *red = pq + 128;                                    // [8]: block reductions use 5; the last word is a write sink
+    float *t_dummy = reinterpret_cast<float *>(red + 7);
     const bool alias = NP >= 768;
     double *own = red + 8;
     double *pm = alias ? Gl : own;                             // [4][64] partial max
@@ -109,15 +110,16 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     }
     __syncthreads();
 
+    const BorderIdx bnn = border_prepare(N, N);                          // border ownership of the N x N products below
     int cpt = 0, sk_total = 0;
     double err = 1.0;
     while (err > (double)prm.inner_tol && cpt < prm.max_iter) {          // bregman.py:119
         // ---- A = C1 @ T ; G = A @ (2 C2)^T                                (utils.py:48-64)
         mm_f64(N, N, N, [&](int i, int k) { return C1l[i * P + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
-               [&](int i, int j, double v) { Al[i * P + j] = v; });
+               [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
         __syncthreads();
-        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return 2.0 * (double)C2l[j * P + k]; },
-               [&](int i, int j, double v) { Gl[i * P + j] = v; });
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)C2l[j * P + k]; },
+               [&](int i, int j, double v) { Gl[i * P + j] = 2.0 * v; }, bnn);
         __syncthreads();
         // ---- Mr = -(base - 2 alpha G)/eps in both layouts (sinkhorn.py:388)
         double mA[R], mB[R];
@@ -188,18 +190,17 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
         }
         sk_total += ii;
         // ---- T = exp(Mr + u + v) (sinkhorn.py:450); err = ||T - Tprev||_F when cpt % 10 == 0 (bregman.py:144-147)
+        // Branch-free: padding entries have Mr = -1e300 => exp = 0; their LDS traffic is redirected to a scratch word.
         double e2 = 0.0;
-        if (lane_ok) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int i = w + 4 * r;
-                if (i < N) {
-                    const float tn = (float)exp_acc(mA[r] + us[w * 64 + i] + v_l);
-                    const double df = (double)tn - (double)Tl[i * P + lane];
-                    e2 += df * df;
-                    Tl[i * P + lane] = tn;
-                }
-            }
+        for (int r = 0; r < R; ++r) {
+            const int i = w + 4 * r;
+            const bool ok = lane_ok && i < N;
+            float *tp = ok ? &Tl[i * P + lane] : t_dummy;
+            const float tn = (float)exp_acc(mA[r] + us[w * 64 + i] + v_l);
+            const double df = ok ? (double)tn - (double)*tp : 0.0;
+            e2 += df * df;
+            *tp = tn;
         }
         if (cpt % 10 == 0) err = sqrt(block_sum_d(e2, red));
         else __syncthreads();
@@ -218,10 +219,10 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
         mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int j) { return (double)C2l[k * P + j]; },
-               [&](int i, int j, double v) { Al[i * P + j] = v; });
+               [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
         __syncthreads();
         mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
-               [&](int i, int j, double v) { Cp[i * N + j] = v; });
+               [&](int i, int j, double v) { Cp[i * N + j] = v; }, bnn);
     }
 }
 
