@@ -57,7 +57,7 @@ def cfconv_survey_bytes(E, P, n_atoms, F):
     return E * 4 * F + P * 4 * F + 4 * (2 * E + n_atoms + 1) + n_atoms * 4 * F
 
 
-def cpu_baseline(args, mode):
+def cpu_baseline(args, mode, gpu_model=None):
     """CPU oracle ("port": oracle/schnet.py + the C FGW restatement) on the host cores, bounded sample."""
     from conan_fgw_amd.synthetic import make_batch
     from oracle.schnet import SchNetNoSumOracle
@@ -80,9 +80,22 @@ def cpu_baseline(args, mode):
     while time.perf_counter() - t0 < args.cpu_seconds:
         step(); n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(nb * n / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32, "
-                      f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; FGW = scalar C restatement"}
+    out = {"value": round(nb * n / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32, "
+                     f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; FGW = scalar C restatement"}
+    if gpu_model is not None and args.model == "schnet":
+        # the same sample through the HIP path and through the fp64 oracle with the HIP model's current weights
+        ref = SchNetNoSumOracle(128, 128, 3)
+        ref.load_state_dict({k: v.detach().cpu() for k, v in gpu_model.state_dict().items()})
+        ref = ref.double()
+        dev = next(gpu_model.parameters()).device
+        with torch.no_grad():
+            g3, gb = gpu_model.forward_w_barycenter(z.to(dev), pos.to(dev), args.conformers, batch.to(dev))
+            r3, rb = ref.forward_w_barycenter(z, pos.double(), args.conformers, batch)
+        rel = lambda a, r: float((a.detach().cpu().double() - r).norm() / r.norm())
+        out["gpu_vs_oracle_fp64"] = {"h_3d_rel_err": float(f"{rel(g3, r3):.3e}"), "h_bary_rel_err (FGW)": float(f"{rel(gb, rb):.3e}"),
+                                     "tolerance": 1e-4, "sample": f"{nb} molecules of the CPU sample, current weights"}
+    return out
 
 
 def main():
@@ -235,7 +248,7 @@ def main():
         out["roofline_other"] = other
         out["forward_only"] = fwd_extra
         if not args.no_cpu_baseline and world == 1:      # CPU oracle timed on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, args.mode)
+            out["cpu_baseline"] = cpu_baseline(args, args.mode, model)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
