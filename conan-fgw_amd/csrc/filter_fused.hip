@@ -63,9 +63,16 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     const int tiles = (E + 31) >> 5;
     if ((int)blockIdx.x * (FF_THREADS / 64) >= tiles) return;
 
-    for (int t = tid; t < F * W1P; t += FF_THREADS) {
-        const int f = t / W1P, k = t - f * W1P;
-        W1L[t] = k < Gs ? w1[(size_t)f * Gs + k] : 0.f;
+    {
+        constexpr int PER1 = (F * W1P + FF_THREADS - 1) / FF_THREADS;
+        float wv[PER1];
+#pragma unroll
+        for (int u = 0; u < PER1; ++u) {
+            const int t = tid + u * FF_THREADS, f = t / W1P, k = t - f * W1P;
+            wv[u] = (t < F * W1P && k < Gs) ? w1[(size_t)f * Gs + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PER1; ++u) { const int t = tid + u * FF_THREADS; if (t < F * W1P) W1L[t] = wv[u]; }
     }
     if (!SPLIT) {
         for (int t = tid; t < F * W2P; t += FF_THREADS) {
@@ -77,11 +84,20 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
         // fragment (GEMM1's accumulator registers 8s..8s+7 of lane-half h) enumerates them: position 8h + j holds
         // channel (j&3) + 8(j>>2) + 4h, so a lane reads its 8 k-values as one 16-byte access.
         __bf16 *W2B = reinterpret_cast<__bf16 *>(W2L);
-        for (int t = tid; t < F * F; t += FF_THREADS) {
+        // all of a thread's loads are issued before the first use: a load-convert-store loop serialises F*F/512 L2 round
+        // trips (a fixed ~15 us per launch)
+        constexpr int PER2 = (F * F + FF_THREADS - 1) / FF_THREADS;
+        float wv[PER2];
+#pragma unroll
+        for (int u = 0; u < PER2; ++u) { const int t = tid + u * FF_THREADS; wv[u] = t < F * F ? w2[t] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < PER2; ++u) {
+            const int t = tid + u * FF_THREADS;
+            if (t >= F * F) continue;
             const int f2 = t / F, f = t - f2 * F;
             const int kk = f & 15, hh = (kk >> 2) & 1, jj = (kk & 3) + 4 * (kk >> 3);
             const int colp = (f & ~15) + 8 * hh + jj;
-            const float v = w2[t];
+            const float v = wv[u];
             const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
             const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
             W2B[(0 * F + f2) * W2S + colp] = h1;

@@ -31,11 +31,15 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
 // SPLIT variant: both operands are split into three bf16 parts and the product is formed from the six significant
 // partial products on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, 2.7x the fp32 MFMA rate).  W's three images are
 // staged once per workgroup; x is split in registers after the global load.
-template <int K, int N>
+// ACT is a template parameter: the epilogue is straight-line code over 16*NB outputs per lane, and with a run-time
+// activation switch the kernel was 31 KB of code executed exactly once per wavefront at node-level sizes — rocprofv3
+// showed 45 % of the wave cycles waiting for instruction fetch (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).
+template <int K, int N, int ACT>
 __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restrict__ x, const float *__restrict__ w,
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
-                                                           int M, int w_kn, int act, float *__restrict__ y,
+                                                           int M, int w_kn, float *__restrict__ y,
                                                            const int *__restrict__ m_dev) {
+    constexpr int act = ACT;
     constexpr int NB = N / 32;
     constexpr int S = K / 16;             // MFMA k-steps
     constexpr int WS = K + 8;             // LDS pitch (bf16 elements)
@@ -46,12 +50,70 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
     const int tiles = (M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x * (LT_THREADS / 64) >= tiles) return;
-    for (int t = tid; t < N * K; t += LT_THREADS) {
-        const int n = t / K, k = t - n * K;
-        const float v = w_kn ? w[(size_t)k * N + n] : w[t];
-        const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
-        const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
-        WB[(0 * N + n) * WS + k] = h1; WB[(1 * N + n) * WS + k] = h2; WB[(2 * N + n) * WS + k] = (__bf16)r2;
+    // Staging of the three bf16 images of W as [n][k]; all of a thread's loads are in flight before the first use.
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if (!w_kn) {                                              // w is [N][K]: float4 = 4 consecutive k -> one 8-byte store per image
+        constexpr int V4 = N * K / 4, PER = (V4 + LT_THREADS - 1) / LT_THREADS;
+        float4 wv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + u * LT_THREADS;
+            wv[u] = q < V4 ? reinterpret_cast<const float4 *>(w)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + u * LT_THREADS;
+            if (q >= V4) continue;
+            const float v4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+            bf16x4 h1, h2, h3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h1[e] = (__bf16)v4[e]; const float r1 = v4[e] - (float)h1[e];
+                h2[e] = (__bf16)r1; h3[e] = (__bf16)(r1 - (float)h2[e]);
+            }
+            const int n = (4 * q) / K, k = 4 * q - n * K;
+            *reinterpret_cast<bf16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
+            *reinterpret_cast<bf16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
+            *reinterpret_cast<bf16x4 *>(&WB[(2 * N + n) * WS + k]) = h3;
+        }
+    } else {
+        // w is [K][N] (the dx GEMM of the backward reads the forward weight transposed).  A thread owns a 4(k) x 4(n) block:
+        // four float4 loads along n, transposed in registers, 8-byte stores along k.  Inside a wavefront the blocks form a
+        // 4(k4) x 16(n4) patch with lane = (n4 & 3) | (k4 << 2) | ((n4 >> 2) << 4): every 16-lane group then covers 4 rows x
+        // 4 k-blocks = 16 distinct 8-byte bank slots (rows 4 apart sit 64 B apart modulo the 256-B bank cycle).
+        constexpr int PATCHES = (K / 16) * (N / 64), PERW = (PATCHES + LT_THREADS / 64 - 1) / (LT_THREADS / 64);
+        float4 wv[PERW][4];
+        const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
+#pragma unroll
+        for (int u = 0; u < PERW; ++u) {
+            const int pt = wave + u * (LT_THREADS / 64);
+            const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * N + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PERW; ++u) {
+            const int pt = wave + u * (LT_THREADS / 64);
+            if (pt >= PATCHES) continue;
+            const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                     // row n0 + e of the image: k0 .. k0 + 3
+                const float v4[4] = {e == 0 ? wv[u][0].x : e == 1 ? wv[u][0].y : e == 2 ? wv[u][0].z : wv[u][0].w,
+                                     e == 0 ? wv[u][1].x : e == 1 ? wv[u][1].y : e == 2 ? wv[u][1].z : wv[u][1].w,
+                                     e == 0 ? wv[u][2].x : e == 1 ? wv[u][2].y : e == 2 ? wv[u][2].z : wv[u][2].w,
+                                     e == 0 ? wv[u][3].x : e == 1 ? wv[u][3].y : e == 2 ? wv[u][3].z : wv[u][3].w};
+                bf16x4 h1, h2, h3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h1[j] = (__bf16)v4[j]; const float r1 = v4[j] - (float)h1[j];
+                    h2[j] = (__bf16)r1; h3[j] = (__bf16)(r1 - (float)h2[j]);
+                }
+                *reinterpret_cast<bf16x4 *>(&WB[(0 * N + n0 + e) * WS + k0]) = h1;
+                *reinterpret_cast<bf16x4 *>(&WB[(1 * N + n0 + e) * WS + k0]) = h2;
+                *reinterpret_cast<bf16x4 *>(&WB[(2 * N + n0 + e) * WS + k0]) = h3;
+            }
+        }
     }
     for (int t = tid; t < N; t += LT_THREADS) BL[t] = bias ? bias[t] : 0.f;
     __syncthreads();
@@ -217,11 +279,22 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
     if (!fp32_only) {
         const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         const int tiles16 = (M + 31) / 32;
         int grid16 = (tiles16 + 7) / 8;
         if (grid16 > 256) grid16 = 256;
-        k_linear_t16<K, N><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, act, y, m_dev);
+#define LAUNCH16(A)                                                                                                              \
+    do {                                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds16);                                                                                   \
+        k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev);                         \
+    } while (0)
+        switch (act) {
+            case 0: LAUNCH16(0); break;
+            case 1: LAUNCH16(1); break;
+            case 2: LAUNCH16(2); break;
+            default: LAUNCH16(3); break;
+        }
+#undef LAUNCH16
         return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
     }
     const size_t lds = ((size_t)N * (K + 4) + N) * 4;
