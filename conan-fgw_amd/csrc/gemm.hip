@@ -611,16 +611,25 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce4(const float4 *__restrict_
     const bool is_w = idx < NK4, is_b = !is_w && bout && idx - NK4 < N4;
     const float4 *src = is_w ? slabs + idx : bias_slabs + (idx - NK4);
     const int stride = is_w ? NK4 : N4;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     if (is_w || is_b) {
         int s = g;
-        for (; s + 8 < slices; s += 16) {
-            const float4 v0 = src[(size_t)s * stride], v1 = src[(size_t)(s + 8) * stride];
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        for (; s + 56 < slices; s += 64) {                    // 8 independent loads in flight per trip
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
+                a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+                a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w;
+                a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
+            }
         }
-        if (s < slices) { const float4 v0 = src[(size_t)s * stride]; a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
+        for (; s < slices; s += 8) { const float4 v0 = src[(size_t)s * stride]; a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
     }
+    a0.x += a2.x; a0.y += a2.y; a0.z += a2.z; a0.w += a2.w;
+    a1.x += a3.x; a1.y += a3.y; a1.z += a3.z; a1.w += a3.w;
     part[g][c] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
     __syncthreads();
     if (g == 0 && (is_w || is_b)) {
