@@ -202,12 +202,31 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
 
 // ------------------------------------------------------------------------------------------------ backward
 // dYs[b,s,j,c] = lam_s * sum_i T[b,s,i,j] * (1/p_i) * dY[b,i,c]
+template <bool LDS>
 __global__ void __launch_bounds__(256) k_fgw_bwd(const float *__restrict__ T, const float *__restrict__ dY, const float *__restrict__ pb,
                                                  const float *__restrict__ lambdas, int K, int N, int d, float *__restrict__ dYs) {
+    extern __shared__ float bw_smem[];
     const int b = blockIdx.x / K, s = blockIdx.x % K;
     const float *Ts = T + ((size_t)b * K + s) * N * N;
     const float *g = dY + (size_t)b * N * d;
     const float lam = lambdas ? lambdas[s] : 1.0f / (float)K;
+    if (LDS) {                                                // T_s and diag(1/p) dY staged once (coalesced), products from LDS
+        float *Tl = bw_smem, *gl = bw_smem + N * N;
+        for (int t = threadIdx.x; t < N * N; t += 256) Tl[t] = Ts[t];
+        for (int t = threadIdx.x; t < N * d; t += 256) {
+            const int i = t / d;
+            const float pinv = pb ? 1.0f / pb[(size_t)b * N + i] : (float)N;
+            gl[t] = pinv * g[t];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < N * d; t += 256) {
+            const int j = t / d, c = t - j * d;
+            float a = 0.f;
+            for (int i = 0; i < N; ++i) a += Tl[i * N + j] * gl[i * d + c];
+            dYs[((size_t)b * K + s) * N * d + t] = lam * a;
+        }
+        return;
+    }
     for (int t = threadIdx.x; t < N * d; t += 256) {
         const int j = t / d, c = t - j * d;
         float a = 0.f;
@@ -407,7 +426,9 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
 int conan_fgw_barycenter_bwd(const float *T, const float *dY, const float *p, const float *lambdas, int B, int K,
                              int N, int d, float *dYs, void *stream) {
     if (!T || !dY || !dYs || B <= 0 || K <= 0 || N <= 0 || d <= 0) return CONAN_E_BADARG;
-    k_fgw_bwd<<<B * K, 256, 0, as_stream(stream)>>>(T, dY, p, lambdas, K, N, d, dYs);
+    const size_t bw_lds = ((size_t)N * N + (size_t)N * d) * sizeof(float);
+    if (bw_lds <= 64 * 1024) k_fgw_bwd<true><<<B * K, 256, bw_lds, as_stream(stream)>>>(T, dY, p, lambdas, K, N, d, dYs);
+    else k_fgw_bwd<false><<<B * K, 256, 0, as_stream(stream)>>>(T, dY, p, lambdas, K, N, d, dYs);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

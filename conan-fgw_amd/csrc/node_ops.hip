@@ -47,7 +47,15 @@ __global__ void k_embedding_bwd_reduce(const float *__restrict__ slabs, int chun
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * H) return;
     float s = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) s += slabs[(size_t)ch * rows * H + i];
+    int ch = 0;
+    for (; ch + 8 <= chunks; ch += 8) {                       // 8 loads in flight, summed in chunk order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(ch + u) * rows * H + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; ch < chunks; ++ch) s += slabs[(size_t)ch * rows * H + i];
     dweight[i] = (i / H == padding_idx) ? 0.f : s;
 }
 
