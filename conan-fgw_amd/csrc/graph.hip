@@ -242,6 +242,52 @@ __global__ void k_edge_index(const int *__restrict__ col, const int *__restrict_
     if (e < E) { ei[e] = col[e]; ei[(size_t)E + e] = tgt[e]; }
 }
 
+
+// ---- covalent-bond graph of the GAT branch ------------------------------------------------------------------------------
+// edge_index[2,E] (int64, arbitrary order, PyG convention row 0 = source, row 1 = target) -> CSR by target (col = source,
+// eid = original edge id) and CSR by source (t_pos = position of the edge in the by-target arrays, t_tgt = its target).
+// Self loops are dropped (GATConv removes them before adding its own, gat.py:9-12 -> PyG GATConv.forward).  The fill uses
+// an atomic cursor per row; every row is then sorted (insertion sort, rows are bonds: a handful of entries), so the layout —
+// and with it every floating-point summation order downstream — is deterministic.
+__global__ void k_bond_count(const int64_t *__restrict__ ei, int E, int n, int *__restrict__ deg_t, int *__restrict__ deg_s) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const int s = (int)ei[e], t = (int)ei[(size_t)E + e];
+        if (s == t || s < 0 || t < 0 || s >= n || t >= n) continue;
+        atomicAdd(&deg_t[t], 1);
+        atomicAdd(&deg_s[s], 1);
+    }
+}
+__global__ void k_bond_fill_t(const int64_t *__restrict__ ei, int E, int n, const int *__restrict__ rowptr, int *__restrict__ cursor,
+                              int *__restrict__ col, int *__restrict__ eid) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const int s = (int)ei[e], t = (int)ei[(size_t)E + e];
+        if (s == t || s < 0 || t < 0 || s >= n || t >= n) continue;
+        const int p = rowptr[t] + atomicAdd(&cursor[t], 1);
+        col[p] = s; eid[p] = e;
+    }
+}
+// sort every row by (key, val) ascending; one thread per row
+__global__ void k_rows_sort2(const int *__restrict__ rowptr, int n, int *__restrict__ key, int *__restrict__ val) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int a = rowptr[i], b = rowptr[i + 1];
+        for (int p = a + 1; p < b; ++p) {
+            const int k = key[p], v = val[p];
+            int q = p - 1;
+            while (q >= a && (key[q] > k || (key[q] == k && val[q] > v))) { key[q + 1] = key[q]; val[q + 1] = val[q]; --q; }
+            key[q + 1] = k; val[q + 1] = v;
+        }
+    }
+}
+__global__ void k_bond_fill_s(const int *__restrict__ rowptr, const int *__restrict__ col, int n, const int *__restrict__ t_rowptr,
+                              int *__restrict__ cursor, int *__restrict__ t_pos, int *__restrict__ t_tgt) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            const int s = col[p];
+            const int q = t_rowptr[s] + atomicAdd(&cursor[s], 1);
+            t_pos[q] = p; t_tgt[q] = i;
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -296,6 +342,28 @@ int conan_edge_pairs(const int *rowptr, const int *col, const int *tgt, const fl
     // k_pair_fill only for pair ids < number of pairs <= number of edges, and the scan is complete by then)
     scan_large(flag_ws, max_edges, pidx_ws, scan_ws, s);
     k_pair_fill<<<blocks, 256, 0, s>>>(rowptr, col, tgt, dist, num_edges_dev, max_edges, flag_ws, pidx_ws, pid, pair_e0, pair_e1, pair_dist);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_bond_graph_csr(const int64_t *edge_index, int num_edges, int num_nodes, int *ws, int *rowptr, int *col, int *eid,
+                         int *t_rowptr, int *t_pos, int *t_tgt, void *stream) {
+    if (num_edges < 0 || num_nodes <= 0 || !ws || !rowptr || !t_rowptr || (num_edges && (!edge_index || !col || !eid || !t_pos || !t_tgt)))
+        return CONAN_E_BADARG;
+    hipStream_t s = as_stream(stream);
+    int *deg_t = ws, *deg_s = ws + (num_nodes + 1);
+    if (hipMemsetAsync(ws, 0, sizeof(int) * 2 * (size_t)(num_nodes + 1), s) != hipSuccess) return CONAN_E_LAUNCH;
+    const int eb = num_edges ? (num_edges + 255) / 256 : 1, nb = (num_nodes + 255) / 256;
+    if (num_edges) k_bond_count<<<eb, 256, 0, s>>>(edge_index, num_edges, num_nodes, deg_t, deg_s);
+    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_t, num_nodes, rowptr);
+    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_s, num_nodes, t_rowptr);
+    if (num_edges) {
+        if (hipMemsetAsync(ws, 0, sizeof(int) * 2 * (size_t)(num_nodes + 1), s) != hipSuccess) return CONAN_E_LAUNCH;
+        k_bond_fill_t<<<eb, 256, 0, s>>>(edge_index, num_edges, num_nodes, rowptr, deg_t, col, eid);
+        k_rows_sort2<<<nb, 256, 0, s>>>(rowptr, num_nodes, col, eid);
+        k_bond_fill_s<<<nb, 256, 0, s>>>(rowptr, col, num_nodes, t_rowptr, deg_s, t_pos, t_tgt);
+        k_rows_sort2<<<nb, 256, 0, s>>>(t_rowptr, num_nodes, t_pos, t_tgt);
+    }
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

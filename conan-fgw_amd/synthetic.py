@@ -119,3 +119,40 @@ def make_config(name: str, num_molecules: Optional[int] = None, seed_offset: int
     shape, B, K = CONFIGS[name]
     idx = int(name[3:])
     return make_batch(shape, num_molecules or B, K, seed=1234 + idx + 1000 * seed_offset)
+
+
+@dataclasses.dataclass
+class BondBatch:
+    """2-D (covalent) graph of the same batch: what the reference's featurisation puts into `batch.x`, `batch.edge_index`,
+    `batch.edge_attr` (datasets.py: 9 integer atom features, 3 integer bond features, both directions of every bond)."""
+    x: np.ndarray           # [sumN, 9] float32
+    edge_index: np.ndarray  # [2, E] int64 (row 0 = source, row 1 = target), global atom ids
+    edge_attr: np.ndarray   # [E, 3] float32
+
+
+def make_bond_graph(b: ConformerBatch, seed: int = 0) -> BondBatch:
+    """Random molecular-looking bond graphs: per molecule a random tree (every atom bonded to an earlier one) plus a few
+    ring-closing bonds; the K conformers of a molecule share the 2-D graph and its features.  Edges are emitted in a shuffled
+    order (the kernels must not rely on any ordering of `edge_index`)."""
+    rng = np.random.RandomState(seed)
+    K = b.num_conformers
+    xs, srcs, dsts, attrs = [], [], [], []
+    base = 0
+    for n in b.atoms_per_molecule:
+        n = int(n)
+        feat = rng.randint(0, 6, size=(n, 9)).astype(np.float32)
+        bonds = [(i, int(rng.randint(0, i))) for i in range(1, n)]
+        for _ in range(max(0, n // 8)):
+            i, j = int(rng.randint(0, n)), int(rng.randint(0, n))
+            if i != j and (i, j) not in bonds and (j, i) not in bonds:
+                bonds.append((i, j))
+        battr = rng.randint(0, 4, size=(len(bonds), 3)).astype(np.float32)
+        for _k in range(K):
+            xs.append(feat)
+            for (i, j), a in zip(bonds, battr):
+                srcs += [base + i, base + j]; dsts += [base + j, base + i]; attrs += [a, a]
+            base += n
+    perm = rng.permutation(len(srcs))
+    ei = np.stack([np.asarray(srcs, dtype=np.int64)[perm], np.asarray(dsts, dtype=np.int64)[perm]])
+    ea = np.asarray(attrs, dtype=np.float32).reshape(-1, 3)[perm]
+    return BondBatch(np.concatenate(xs) if xs else np.zeros((0, 9), np.float32), ei, ea)

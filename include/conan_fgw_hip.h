@@ -296,6 +296,39 @@ int conan_fgw_readout_fwd(const float *Y, int B, int K, int N, int d, int mode, 
 int conan_fgw_readout_bwd(const float *Y, const float *dout, int B, int K, int N, int d, int mode, float *dY,
                           void *stream);
 
+/* ---------------------------------------------------------------------------------------------- covalent (GAT) branch
+ * GATBased (conan_fgw/src/model/graph_embeddings/gat.py:5-25): two PyG-2.3.0 GATConv layers (heads = 1, edge_dim = 3,
+ * add_self_loops with fill_value "mean", negative_slope 0.2) on the 2-D bond graph + sum readout; called from
+ * EmbeddingsWithGATAggregationBaryCenter.forward (schnet_based_models.py:166-168).  SURVEY.md 8(f) rank 1. */
+
+/* Bond graph from PyG's edge_index[2,E] (int64; row 0 = source, row 1 = target; any order; self loops dropped):
+ * CSR by target (rowptr[n+1], col[E] = source, eid[E] = original edge id) and by source (t_rowptr[n+1], t_pos[E] = position of
+ * the edge in the by-target arrays, t_tgt[E] = its target); rows sorted => deterministic layout.  ws: 2*(n+1) ints. */
+int conan_bond_graph_csr(const int64_t *edge_index, int num_edges, int num_nodes, int *ws, int *rowptr, int *col, int *eid,
+                         int *t_rowptr, int *t_pos, int *t_tgt, void *stream);
+/* v[edge_dim] = lin_edge.weight^T att_edge, so that <lin_edge(ea), att_edge> = <ea, v> (GATConv.edge_update). */
+int conan_gat_edge_vec(const float *w_edge, const float *att_edge, int channels, int edge_dim, float *v, void *stream);
+int conan_gat_edge_vec_bwd(const float *w_edge, const float *att_edge, const float *dv, int channels, int edge_dim,
+                           float *dw_edge, float *datt_edge, void *stream);
+/* a_src[i] = <h_i, att_src>, a_dst[i] = <h_i, att_dst>   (h = lin_src(x), shared with lin_dst). */
+int conan_gat_node_alpha(const float *h, const float *att_src, const float *att_dst, int n, int channels, float *a_src,
+                         float *a_dst, void *stream);
+/* out_i = sum_{j in N(i) + {i}} alpha_ji h_j + bias; alpha = softmax_i(leaky_relu(a_src[j] + a_dst[i] + <ea_ji, v>)), the self
+ * loop's ea is the mean of the incoming edge attributes.  alpha[E] (by-target order) and alpha_self[n] are saved for backward. */
+int conan_gat_aggregate_fwd(const float *h, const float *a_src, const float *a_dst, const int *rowptr, const int *col,
+                            const int *eid, const float *edge_attr, int edge_dim, const float *v, const float *bias,
+                            float negative_slope, int n, int channels, float *out, float *alpha, float *alpha_self, void *stream);
+/* Backward of the aggregation: dh[n,C] (messages + attention projections), da_src[n], da_dst[n], dv_part[n,edge_dim] (sum its
+ * columns for dv).  dpre_ws: n + E floats.  No float atomics (target rows, then by-source lists). */
+int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alpha, const float *alpha_self, const float *a_src,
+                            const float *a_dst, const float *att_src, const float *att_dst, const int *rowptr, const int *col,
+                            const int *eid, const int *t_rowptr, const int *t_pos, const int *t_tgt, const float *edge_attr,
+                            int edge_dim, const float *v, float negative_slope, int n, int channels, float *dpre_ws, float *dh,
+                            float *da_src, float *da_dst, float *dv_part, void *stream);
+/* out[c] = sum_r x[r,c], deterministic two-stage sum; ws holds conan_colsum_ws(rows, width) floats. */
+long long conan_colsum_ws(int rows, int width);
+int conan_colsum(const float *x, int rows, int width, float *out, float *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
