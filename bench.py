@@ -3,7 +3,8 @@
 
 One "step" = one training step of the stage-2 hot path on one batch of synthetic ESOL-shaped conformers resident in HBM:
 SchNetNoSum.forward_w_barycenter (radius graph, 3 interaction blocks, two heads, FGW barycenter over the K conformers)
-+ conformer-aggregation head + MSE loss, backward through all of it, one flat gradient all-reduce (RCCL) and Adam.
++ covalent GAT branch on the 2-D bond graph + conformer-aggregation head (the reference's whole stage-2 model,
+schnet_based_models.py:135-173) + MSE loss, backward through all of it, one flat gradient all-reduce (RCCL) and Adam.
 Workload at every N: BASELINE.json configs[1] per GPU (ESOL + SchNet-128, K=5, batch=256) => weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--batch B] [--no-cpu-baseline]
@@ -59,19 +60,19 @@ def cfconv_survey_bytes(E, P, n_atoms, F):
 
 def cpu_baseline(args, mode, gpu_model=None):
     """CPU oracle ("port": oracle/schnet.py + the C FGW restatement) on the host cores, bounded sample."""
-    from conan_fgw_amd.synthetic import make_batch
-    from oracle.schnet import SchNetNoSumOracle
+    from conan_fgw_amd.synthetic import make_batch, make_bond_graph
+    from oracle.head import Stage2Oracle
     nb = 8
     b = make_batch(args.shape, nb, args.conformers, seed=4321)
+    bg = make_bond_graph(b, seed=4322)
     torch.manual_seed(5)
-    m = SchNetNoSumOracle(128, 128, 3)
-    w3, wb, wo = torch.nn.Linear(64, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 1)
+    m = Stage2Oracle(args.conformers)
     z, pos, batch = torch.from_numpy(b.z), torch.from_numpy(b.pos), torch.from_numpy(b.batch)
+    bx, bei, bea = torch.from_numpy(bg.x), torch.from_numpy(bg.edge_index), torch.from_numpy(bg.edge_attr)
     y = torch.from_numpy(b.y)[:, None]
 
     def step():
-        h3, hb = m.forward_w_barycenter(z, pos, args.conformers, batch)
-        pred = wo((w3(h3) + 0.2 * wb(hb)).view(nb, args.conformers, -1).mean(1))
+        pred = m(z, pos, batch, bx, bei, bea)
         if mode == "train":
             loss = torch.nn.functional.mse_loss(pred, y)
             loss.backward()
@@ -81,20 +82,25 @@ def cpu_baseline(args, mode, gpu_model=None):
         step(); n += 1
     dt = time.perf_counter() - t0
     out = {"value": round(nb * n / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32, "
+           "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32 (SchNet + FGW + GAT + head), "
                      f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; FGW = scalar C restatement"}
     if gpu_model is not None and args.model == "schnet":
         # the same sample through the HIP path and through the fp64 oracle with the HIP model's current weights
-        ref = SchNetNoSumOracle(128, 128, 3)
+        import types
+        ref = Stage2Oracle(args.conformers)
         ref.load_state_dict({k: v.detach().cpu() for k, v in gpu_model.state_dict().items()})
         ref = ref.double()
         dev = next(gpu_model.parameters()).device
+        ns = types.SimpleNamespace(z=z.to(dev), pos=pos.to(dev), x=bx.to(dev), edge_index=bei.to(dev), edge_attr=bea.to(dev), batch=batch.to(dev))
         with torch.no_grad():
-            g3, gb = gpu_model.forward_w_barycenter(z.to(dev), pos.to(dev), args.conformers, batch.to(dev))
-            r3, rb = ref.forward_w_barycenter(z, pos.double(), args.conformers, batch)
+            gy = gpu_model(ns, None, ns.batch)
+            g3, gb = gpu_model.node_embeddings_model.forward_w_barycenter(ns.z, ns.pos, args.conformers, ns.batch)
+            ry = ref(z, pos.double(), batch, bx, bei, bea)
+            r3, rb = ref.node_embeddings_model.forward_w_barycenter(z, pos.double(), args.conformers, batch)
         rel = lambda a, r: float((a.detach().cpu().double() - r).norm() / r.norm())
-        out["gpu_vs_oracle_fp64"] = {"h_3d_rel_err": float(f"{rel(g3, r3):.3e}"), "h_bary_rel_err (FGW)": float(f"{rel(gb, rb):.3e}"),
-                                     "tolerance": 1e-4, "sample": f"{nb} molecules of the CPU sample, current weights"}
+        out["gpu_vs_oracle_fp64"] = {"y_pred_rel_err (energies)": float(f"{rel(gy, ry):.3e}"), "h_3d_rel_err": float(f"{rel(g3, r3):.3e}"),
+                                     "h_bary_rel_err (FGW)": float(f"{rel(gb, rb):.3e}"), "tolerance": 1e-4,
+                                     "sample": f"{nb} molecules of the CPU sample, current weights"}
     return out
 
 
@@ -109,23 +115,23 @@ def main():
         dist.init_process_group("nccl")              # "nccl" is RCCL on ROCm: one rank per GPU over xGMI
 
     from conan_fgw_amd import ops
-    from conan_fgw_amd.head import ConformerAggregationHead
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
     from conan_fgw_amd.parallel import FlatGradients
-    from conan_fgw_amd.schnet import SchNetNoSum
-    from conan_fgw_amd.synthetic import make_batch
+    from conan_fgw_amd.synthetic import make_batch, make_bond_graph
+    import types
 
     K = args.conformers
     b = make_batch(args.shape, args.batch, K, seed=1236 + 1000 * rank)            # cfg2 seed (1234 + 2) on rank 0
+    bg = make_bond_graph(b, seed=2236 + 1000 * rank)                              # 2-D bond graph of the same molecules
     z, pos, batch = (torch.from_numpy(a).to(dev) for a in (b.z, b.pos, b.batch))
+    data = types.SimpleNamespace(z=z, pos=pos, batch=batch, x=torch.from_numpy(bg.x).to(dev),
+                                 edge_index=torch.from_numpy(bg.edge_index).to(dev), edge_attr=torch.from_numpy(bg.edge_attr).to(dev))
     y = torch.from_numpy(b.y).to(dev)[:, None]
     torch.manual_seed(5)                                                          # train_val.py:223
-    if args.model == "visnet":
-        from conan_fgw_amd.visnet import ViSNet
-        model = ViSNet(dev, hidden_channels=128).to(dev)                                              # common.py:542-546
-    else:
-        model = SchNetNoSum(dev, hidden_channels=128, num_filters=128, num_interactions=3).to(dev)   # common.py:524-529
-    head = ConformerAggregationHead(64, 0.2).to(dev)
-    params = list(model.parameters()) + list(head.parameters())
+    # the reference's stage-2 model: backbone (common.py:524-529 / :542-546) + GAT branch + aggregation head
+    model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=args.model).to(dev)
+    cidx = model.create_aggregation_index(b.num_graphs, dev)
+    params = list(model.parameters())
     flat = FlatGradients(params)
     opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True)
 
@@ -147,16 +153,14 @@ def main():
     def step():
         if args.mode == "train":
             flat.zero()
-            h3, hb = model.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-            pred = head(h3, hb, K)
+            pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
             loss = torch.nn.functional.mse_loss(pred, y)
             loss.backward()
             flat.all_reduce_mean()
             opt.step()
         else:
             with torch.no_grad():
-                h3, hb = model.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-                head(h3, hb, K)
+                model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
 
     def barrier():
         if world > 1:
@@ -183,8 +187,7 @@ def main():
     if args.mode == "train":
         def fwd_step():
             with torch.no_grad():
-                h3, hb = model.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-                head(h3, hb, K)
+                model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
         for _ in range(2):
             fwd_step()
         torch.cuda.synchronize()
@@ -235,7 +238,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
-                                   + ("(fwd + bwd + flat-gradient all-reduce + Adam)" if args.mode == "train" else "(forward_w_barycenter + head)"),
+                                   + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce + Adam)" if args.mode == "train" else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
                        "mode": args.mode, "parallelism": f"dp{world}", "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
             "roofline": {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",

@@ -30,3 +30,61 @@ class ConformerAggregationHead(torch.nn.Module):
         x = x3 + self.agg_weight * xb                        # :170 (x_cov omitted)
         x = x.view(B, num_conformers, d).mean(dim=1)         # :171
         return ops.linear(x.contiguous(), self.out.weight, self.out.bias)    # :172  -> [B,1]
+
+
+class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
+    """The stage-2 regression model of the reference without its Lightning shell
+    (`EmbeddingsWithGATAggregationBaryCenter`, conan_fgw/src/model/schnet_based_models.py:83-173 on top of `EquivAggregation`,
+    common.py:388-423): 3-D backbone with the FGW barycenter branch + covalent GAT branch + conformer mean + regression.
+
+    Sub-module names are the reference's (`node_embeddings_model`, `gat_embeddings_model`, `transformation_matrix_3d`,
+    `transformation_matrix_bary`, `transformation_matrix_cov`, `molecular_regression_lin`), so the weights of a reference
+    checkpoint load by name.  `forward(batch, conformers_index, node_index)` keeps the reference's argument meaning: `batch`
+    carries `z, pos, x, edge_index, edge_attr, batch`; `node_index` = conformer-graph id per atom of the 3-D graphs;
+    `conformers_index` = molecule id per conformer graph (`create_aggregation_index`, common.py:414-423).
+    """
+
+    def __init__(self, num_conformers: int, device=None, model_name: str = "schnet", agg_weight: float = 0.2,
+                 max_iter: int = 100, epsilon: float = 0.1, gat_in_channels: int = 9):
+        super().__init__()
+        from .gat import GATBased
+        self.num_conformers = num_conformers
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if model_name == "schnet":                           # EquivModelsHolder.get_model("schnet", feat_dim=128), common.py:524-529
+            from .schnet import SchNetNoSum
+            self.node_embeddings_model = SchNetNoSum(device, hidden_channels=128, num_filters=128, num_interactions=3)
+        elif model_name == "visnet":                         # common.py:542-546
+            from .visnet import ViSNet
+            self.node_embeddings_model = ViSNet(device, hidden_channels=128)
+        else:
+            raise ValueError(f"unsupported model_name {model_name!r}")
+        out_channels = self.node_embeddings_model.hidden_channels // 2
+        self.gat_embeddings_model = GATBased(out_channels=128 // 2, in_channels=gat_in_channels)     # get_model("gat", feat_dim=128)
+        self.transformation_matrix_3d = Linear(out_channels, out_channels)
+        self.transformation_matrix_bary = Linear(out_channels, out_channels)
+        self.transformation_matrix_cov = Linear(out_channels, out_channels)
+        self.molecular_regression_lin = Linear(out_channels, 1)          # build_mlp(out_channels), is_complex=False
+        self.numItermax, self.epsilon, self.agg_weight = max_iter, epsilon, agg_weight
+
+    def create_aggregation_index(self, num_graphs: int, device) -> Tensor:
+        """Molecule id of every conformer graph: [0]*K + [1]*K + ... (common.py:414-423, built there from len(batch.smiles))."""
+        return torch.arange(num_graphs // self.num_conformers, device=device).repeat_interleave(self.num_conformers)
+
+    def forward(self, batch, conformers_index: Tensor, node_index: Tensor, num_graphs: int = None, max_nodes: int = None) -> Tensor:
+        K = self.num_conformers
+        x_3d, x_bary = self.node_embeddings_model.forward_w_barycenter(
+            z=batch.z, pos=batch.pos, num_conformers=K, batch=node_index, max_iter=self.numItermax, epsilon=self.epsilon,
+            **({"num_graphs": num_graphs, "max_nodes": max_nodes} if num_graphs is not None else {}))             # :153-160
+        x_bary = ops.linear(x_bary, self.transformation_matrix_bary.weight, self.transformation_matrix_bary.bias)  # :163
+        x_3d = ops.linear(x_3d, self.transformation_matrix_3d.weight, self.transformation_matrix_3d.bias)          # :164
+        x_cov = self.gat_embeddings_model(batch.x, batch.edge_index, batch.edge_attr, batch.batch,
+                                          **({"num_graphs": num_graphs} if num_graphs is not None else {}))         # :165-167
+        x_cov = ops.linear(x_cov, self.transformation_matrix_cov.weight, self.transformation_matrix_cov.bias)       # :168
+        x = x_3d + x_cov + self.agg_weight * x_bary                                                                   # :169
+        G, d = x.shape
+        # conformers_mean_aggr(x, conformers_index): the index is K consecutive copies of every molecule id, so the mean is a
+        # reshape (checked, because the reference's aggregation accepts any sorted index)
+        if conformers_index is not None and conformers_index.numel() != G:
+            raise ValueError("conformers_index must have one entry per conformer graph")
+        x = x.view(G // K, K, d).mean(dim=1)                                                                          # :170
+        return ops.linear(x.contiguous(), self.molecular_regression_lin.weight, self.molecular_regression_lin.bias)   # :171

@@ -1,0 +1,38 @@
+"""CPU restatement of the stage-2 regression model — TEST INFRASTRUCTURE ONLY.
+
+`Stage2Oracle.forward` follows EmbeddingsWithGATAggregationBaryCenter.forward
+(conan_fgw/src/model/schnet_based_models.py:135-173): x = Lin3d(h_3d) + Lin_cov(GAT(...)) + agg_weight * Lin_bary(h_bary),
+MeanAggregation over the K conformers (common.py:404), `molecular_regression_lin` = Linear(d, 1) (build_mlp, :17-28).
+The Lightning shell is not imported (pytorch_lightning / torchmetrics are absent); the pin is compositional: the backbone
+wiring is pinned by the goldens of tests/golden/make_model_golden.py, the GAT branch is unpinned (oracle/gat.py header).
+Sub-module names equal the reference's, so the product's state_dict loads strictly.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .gat import GATBasedOracle
+from .schnet import SchNetNoSumOracle
+
+
+class Stage2Oracle(nn.Module):
+    def __init__(self, num_conformers: int, agg_weight: float = 0.2, gat_in_channels: int = 9):
+        super().__init__()
+        self.num_conformers, self.agg_weight = num_conformers, agg_weight
+        self.node_embeddings_model = SchNetNoSumOracle(128, 128, 3)
+        self.gat_embeddings_model = GATBasedOracle(64, 3, gat_in_channels)
+        self.transformation_matrix_3d = nn.Linear(64, 64)
+        self.transformation_matrix_bary = nn.Linear(64, 64)
+        self.transformation_matrix_cov = nn.Linear(64, 64)
+        self.molecular_regression_lin = nn.Linear(64, 1)
+
+    def forward(self, z, pos, node_index, x, edge_index, edge_attr):
+        K = self.num_conformers
+        x_3d, x_bary = self.node_embeddings_model.forward_w_barycenter(z, pos, K, node_index)
+        x_bary = self.transformation_matrix_bary(x_bary)
+        x_3d = self.transformation_matrix_3d(x_3d)
+        x_cov = self.transformation_matrix_cov(self.gat_embeddings_model(x, edge_index, edge_attr, node_index))
+        h = x_3d + x_cov + self.agg_weight * x_bary
+        h = h.view(h.shape[0] // K, K, -1).mean(1)
+        return self.molecular_regression_lin(h)

@@ -1,0 +1,63 @@
+"""The whole stage-2 regression model (3-D backbone + FGW barycenter + covalent GAT branch + conformer mean + regression,
+schnet_based_models.py:135-173) through the HIP path vs the fp64 CPU oracle: predictions within 1e-4 relative (the bar of
+BASELINE.json for energies), gradients of representative parameters of every branch within 1e-4."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel
+from conan_fgw_amd.synthetic import make_batch, make_bond_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(B=6, K=5, seed=21):
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from oracle.head import Stage2Oracle
+    dev = torch.device("cuda:0")
+    b = make_batch("esol", B, K, seed=seed)
+    g = make_bond_graph(b, seed=seed + 1)
+    torch.manual_seed(5)
+    m = EmbeddingsWithGATAggregationBaryCenter(K, dev).to(dev)
+    ref = Stage2Oracle(K).double()
+    missing = ref.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return dev, b, g, m, ref
+
+
+def test_stage2_prediction_and_gradients_match_oracle():
+    dev, b, g, m, ref = _build()
+    t = lambda a: torch.from_numpy(a)
+    batch = types.SimpleNamespace(z=t(b.z).to(dev), pos=t(b.pos).to(dev), x=t(g.x).to(dev), edge_index=t(g.edge_index).to(dev),
+                                  edge_attr=t(g.edge_attr).to(dev), batch=t(b.batch).to(dev))
+    cidx = m.create_aggregation_index(b.num_graphs, dev)
+    assert cidx.tolist() == [i for i in range(b.num_molecules) for _ in range(b.num_conformers)]       # common.py:414-423
+    y = m(batch, cidx, batch.batch)
+    r = ref(t(b.z), t(b.pos).double(), t(b.batch), t(g.x), t(g.edge_index), t(g.edge_attr))
+    assert y.shape == (b.num_molecules, 1)
+    assert rel(y.detach().cpu().double().numpy(), r.detach().numpy()) < 1e-4
+    tgt = t(b.y)[:, None]
+    torch.nn.functional.mse_loss(y, tgt.to(dev)).backward()
+    torch.nn.functional.mse_loss(r, tgt.double()).backward()
+    gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
+    assert set(gp) == set(rp)
+    gmax = max(float(p.grad.norm()) for p in rp.values() if p.grad is not None)
+    for k in ["molecular_regression_lin.weight", "transformation_matrix_cov.weight", "transformation_matrix_bary.bias",
+              "gat_embeddings_model.gat_conv1.lin_src.weight", "gat_embeddings_model.gat_conv2.att_src",
+              "gat_embeddings_model.gat_conv1.lin_edge.weight", "node_embeddings_model.lin1_bary.weight",
+              "node_embeddings_model.interactions.0.mlp.0.weight", "node_embeddings_model.embedding.weight"]:
+        err = float((gp[k].grad.cpu().double() - rp[k].grad).norm())
+        assert err <= 1e-4 * float(rp[k].grad.norm()) + 1e-6 * gmax, (k, err, float(rp[k].grad.norm()))
+
+
+def test_stage2_hints_do_not_change_the_result():
+    dev, b, g, m, _ = _build(B=3, K=3, seed=8)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    batch = types.SimpleNamespace(z=t(b.z), pos=t(b.pos), x=t(g.x), edge_index=t(g.edge_index), edge_attr=t(g.edge_attr), batch=t(b.batch))
+    cidx = m.create_aggregation_index(b.num_graphs, dev)
+    with torch.no_grad():
+        y1 = m(batch, cidx, batch.batch)
+        y2 = m(batch, cidx, batch.batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+    assert torch.equal(y1, y2)
