@@ -42,7 +42,17 @@ __global__ void __launch_bounds__(256) k_gat_node_alpha(const float *__restrict_
     if (lane == 0) { a_src[i] = s; a_dst[i] = t; }
 }
 
-// forward aggregation; also stores the attention coefficients (alpha[p] for by-target position p, alpha_self[i])
+// forward aggregation; also stores the attention coefficients (alpha[p] for by-target position p, alpha_self[i]).
+// The row's edges are staged one per lane (source, <ea, v>, a_src[source]) — bonds: a handful per atom — so logits, max and
+// sum are wavefront reductions and the gather of the h_j rows is fed by cross-lane reads; rows longer than 64 edges take
+// the serial path below.
+__device__ __forceinline__ float gat_dot(const float *__restrict__ ea, const float *vd, int D) {
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
+    return dot;
+}
+
 __global__ void __launch_bounds__(256) k_gat_aggregate_fwd(const float *__restrict__ h, const float *__restrict__ a_src, const float *__restrict__ a_dst,
                                                            const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ eid,
                                                            const float *__restrict__ edge_attr, int D, const float *__restrict__ v,
@@ -51,53 +61,48 @@ __global__ void __launch_bounds__(256) k_gat_aggregate_fwd(const float *__restri
     const int lane = threadIdx.x & 63;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
-    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int e0 = rowptr[i], e1 = rowptr[i + 1], deg = e1 - e0;
     float vd[GAT_MAXD];
 #pragma unroll
     for (int d = 0; d < GAT_MAXD; ++d) vd[d] = d < D ? v[d] : 0.f;
-    const float ad = a_dst[i];
-    // pass 1: logits, running max, mean edge attribute (self-loop fill value)
-    float mean_dot = 0.f, mx;
-    {
-        float acc = 0.f;
-        for (int p = e0; p < e1; ++p) {
-            const float *ea = edge_attr + (size_t)eid[p] * D;
-            float dot = 0.f;
-#pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
-            acc += dot;
+    const float ad = a_dst[i], asi = a_src[i];
+    if (deg <= 64) {
+        const bool on = lane < deg;
+        const int j = on ? col[e0 + lane] : i;
+        const float dot = on ? gat_dot(edge_attr + (size_t)eid[e0 + lane] * D, vd, D) : 0.f;
+        const float logit = on ? leaky(a_src[j] + ad + dot, slope) : -3.0e38f;
+        const float mean_dot = deg > 0 ? wave_sum(dot) / (float)deg : 0.f;
+        const float l_self = leaky(asi + ad + mean_dot, slope);
+        const float mx = fmaxf(wave_max(logit), l_self);
+        const float ex = on ? expf(logit - mx) : 0.f, ex_self = expf(l_self - mx);
+        const float inv = 1.0f / (wave_sum(ex) + ex_self + 1e-16f);          // torch_geometric.utils.softmax: exp / (sum + 1e-16)
+        const float a = ex * inv, as = ex_self * inv;
+        if (on) alpha[e0 + lane] = a;
+        if (lane == 0) alpha_self[i] = as;
+        for (int c = lane; c < C; c += 64) {
+            float acc = as * h[(size_t)i * C + c];
+            for (int k = 0; k < deg; ++k) acc += __shfl(a, k, 64) * h[(size_t)__shfl(j, k, 64) * C + c];
+            out[(size_t)i * C + c] = acc + (bias ? bias[c] : 0.f);
         }
-        mean_dot = e1 > e0 ? acc / (float)(e1 - e0) : 0.f;      // <mean(ea), v> == mean(<ea, v>) up to rounding; see gat.py oracle
+        return;
     }
-    const float l_self = leaky(a_src[i] + ad + mean_dot, slope);
-    mx = l_self;
-    for (int p = e0; p < e1; ++p) {
-        const float *ea = edge_attr + (size_t)eid[p] * D;
-        float dot = 0.f;
-#pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
-        mx = fmaxf(mx, leaky(a_src[col[p]] + ad + dot, slope));
-    }
+    // ---- general path (deg > 64): serial passes over the row
+    float acc_dot = 0.f;
+    for (int p = e0; p < e1; ++p) acc_dot += gat_dot(edge_attr + (size_t)eid[p] * D, vd, D);
+    const float mean_dot = acc_dot / (float)deg;
+    const float l_self = leaky(asi + ad + mean_dot, slope);
+    float mx = l_self;
+    for (int p = e0; p < e1; ++p) mx = fmaxf(mx, leaky(a_src[col[p]] + ad + gat_dot(edge_attr + (size_t)eid[p] * D, vd, D), slope));
     float sum = expf(l_self - mx);
-    for (int p = e0; p < e1; ++p) {
-        const float *ea = edge_attr + (size_t)eid[p] * D;
-        float dot = 0.f;
-#pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
-        sum += expf(leaky(a_src[col[p]] + ad + dot, slope) - mx);
-    }
-    const float inv = 1.0f / (sum + 1e-16f);                    // torch_geometric.utils.softmax: exp / (sum + 1e-16)
+    for (int p = e0; p < e1; ++p) sum += expf(leaky(a_src[col[p]] + ad + gat_dot(edge_attr + (size_t)eid[p] * D, vd, D), slope) - mx);
+    const float inv = 1.0f / (sum + 1e-16f);
     const float as = expf(l_self - mx) * inv;
     if (lane == 0) alpha_self[i] = as;
     for (int c = lane; c < C; c += 64) {
         float acc = as * h[(size_t)i * C + c];
         for (int p = e0; p < e1; ++p) {
-            const float *ea = edge_attr + (size_t)eid[p] * D;
-            float dot = 0.f;
-#pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
             const int j = col[p];
-            const float a = expf(leaky(a_src[j] + ad + dot, slope) - mx) * inv;
+            const float a = expf(leaky(a_src[j] + ad + gat_dot(edge_attr + (size_t)eid[p] * D, vd, D), slope) - mx) * inv;
             if (c == lane && lane == 0) alpha[p] = a;
             acc += a * h[(size_t)j * C + c];
         }
@@ -105,120 +110,184 @@ __global__ void __launch_bounds__(256) k_gat_aggregate_fwd(const float *__restri
     }
 }
 
-// backward, target side: dpre per edge / self loop, da_dst, per-node contribution to dv
+// Backward.  Both kernels run on GAT_BW_WAVES persistent wavefronts (node i -> wavefront i mod GAT_BW_WAVES), and every
+// wavefront accumulates its share of the parameter gradients in registers — d att_src, d att_dst, d bias (source kernel,
+// lane <-> channel) and dv (target kernel) — and writes one partial row part[wave][3C + D]; k_gat_param_reduce sums the rows
+// in a fixed order.  No float atomics anywhere: bitwise reproducible.
+constexpr int GAT_BW_WAVES = 1024;
+
+// target side: dpre per edge / self loop, da_dst, partial dv
 __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict__ h, const float *__restrict__ dout, const float *__restrict__ alpha,
                                                         const float *__restrict__ alpha_self, const float *__restrict__ a_src,
                                                         const float *__restrict__ a_dst, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                         const int *__restrict__ eid, const float *__restrict__ edge_attr, int D,
                                                         const float *__restrict__ v, float slope, int n, int C, float *__restrict__ dpre,
-                                                        float *__restrict__ dpre_self, float *__restrict__ da_dst, float *__restrict__ dv_part) {
+                                                        float *__restrict__ dpre_self, float *__restrict__ da_dst, float *__restrict__ part, int PW) {
     const int lane = threadIdx.x & 63;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= n) return;
-    const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    float vd[GAT_MAXD];
+    const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    float vd[GAT_MAXD], dvacc[GAT_MAXD];
 #pragma unroll
-    for (int d = 0; d < GAT_MAXD; ++d) vd[d] = d < D ? v[d] : 0.f;
-    const float ad = a_dst[i];
-    // d alpha = <dout_i, h_j>;  S = sum alpha * dalpha
-    float dal_self = 0.f;
-    for (int c = lane; c < C; c += 64) dal_self += dout[(size_t)i * C + c] * h[(size_t)i * C + c];
-    dal_self = wave_sum(dal_self);
-    const float as = alpha_self[i];
-    float S = as * dal_self;
-    for (int p = e0; p < e1; ++p) {
-        const int j = col[p];
-        float da = 0.f;
-        for (int c = lane; c < C; c += 64) da += dout[(size_t)i * C + c] * h[(size_t)j * C + c];
-        da = wave_sum(da);
-        S += alpha[p] * da;
+    for (int d = 0; d < GAT_MAXD; ++d) { vd[d] = d < D ? v[d] : 0.f; dvacc[d] = 0.f; }
+    for (int i = wg; i < n; i += GAT_BW_WAVES) {
+        const int e0 = rowptr[i], e1 = rowptr[i + 1], deg = e1 - e0;
+        const float ad = a_dst[i], as = alpha_self[i];
+        float dal_self = 0.f;
+        for (int c = lane; c < C; c += 64) dal_self += dout[(size_t)i * C + c] * h[(size_t)i * C + c];
+        dal_self = wave_sum(dal_self);
+        float dad = 0.f;
+        float mean_ea[GAT_MAXD];
+#pragma unroll
+        for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] = 0.f;
+        float mean_dot = 0.f, S = as * dal_self;
+        if (deg <= 64) {
+            const bool on = lane < deg;
+            const int j = on ? col[e0 + lane] : i;
+            float ea[GAT_MAXD];
+#pragma unroll
+            for (int d = 0; d < GAT_MAXD; ++d) ea[d] = (on && d < D) ? edge_attr[(size_t)eid[e0 + lane] * D + d] : 0.f;
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < GAT_MAXD; ++d) dot += ea[d] * vd[d];
+            const float al = on ? alpha[e0 + lane] : 0.f;
+            const float pre = on ? a_src[j] + ad + dot : 0.f;
+            float dal = 0.f;                                   // <dout_i, h_j> of the edge owned by this lane
+            for (int k = 0; k < deg; ++k) {
+                const int jk = __shfl(j, k, 64);
+                float t = 0.f;
+                for (int c = lane; c < C; c += 64) t += dout[(size_t)i * C + c] * h[(size_t)jk * C + c];
+                t = wave_sum(t);
+                if (lane == k) dal = t;
+            }
+            S += wave_sum(al * dal);
+            if (deg > 0) {
+                mean_dot = wave_sum(dot) / (float)deg;
+#pragma unroll
+                for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] = wave_sum(ea[d]) / (float)deg;
+            }
+            const float g = on ? al * (dal - S) * (pre > 0.f ? 1.f : slope) : 0.f;
+            if (on) dpre[e0 + lane] = g;
+            dad += wave_sum(g);
+#pragma unroll
+            for (int d = 0; d < GAT_MAXD; ++d) dvacc[d] += wave_sum(g * ea[d]);
+        } else {
+            for (int p = e0; p < e1; ++p) {
+                const int j = col[p];
+                float da = 0.f;
+                for (int c = lane; c < C; c += 64) da += dout[(size_t)i * C + c] * h[(size_t)j * C + c];
+                S += alpha[p] * wave_sum(da);
+                const float *ea = edge_attr + (size_t)eid[p] * D;
+#pragma unroll
+                for (int d = 0; d < GAT_MAXD; ++d) if (d < D) { mean_ea[d] += ea[d]; mean_dot += ea[d] * vd[d]; }
+            }
+            mean_dot /= (float)deg;
+#pragma unroll
+            for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] /= (float)deg;
+            for (int p = e0; p < e1; ++p) {
+                const int j = col[p];
+                float da = 0.f;
+                for (int c = lane; c < C; c += 64) da += dout[(size_t)i * C + c] * h[(size_t)j * C + c];
+                da = wave_sum(da);
+                const float *ea = edge_attr + (size_t)eid[p] * D;
+                const float pre = a_src[j] + ad + gat_dot(ea, vd, D);
+                const float g = alpha[p] * (da - S) * (pre > 0.f ? 1.f : slope);
+                if (lane == 0) dpre[p] = g;
+                dad += g;
+#pragma unroll
+                for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dvacc[d] += g * ea[d];
+            }
+        }
+        {
+            const float pre = a_src[i] + ad + mean_dot;
+            const float g = as * (dal_self - S) * (pre > 0.f ? 1.f : slope);
+            if (lane == 0) dpre_self[i] = g;
+            dad += g;
+#pragma unroll
+            for (int d = 0; d < GAT_MAXD; ++d) dvacc[d] += g * mean_ea[d];
+        }
+        if (lane == 0) da_dst[i] = dad;
     }
-    float mean_ea[GAT_MAXD], dvp[GAT_MAXD];
+    if (lane == 0)
+        for (int d = 0; d < D; ++d) part[(size_t)wg * PW + 3 * C + d] = dvacc[d];
+}
+
+// source side: da_src, dh (messages sent by node j, its self loop, the two attention projections) and the partial sums of
+// d att_src, d att_dst, d bias
+__global__ void __launch_bounds__(256) k_gat_bwd_source(const float *__restrict__ h, const float *__restrict__ dout, const float *__restrict__ alpha,
+                                                        const float *__restrict__ alpha_self, const float *__restrict__ dpre,
+                                                        const float *__restrict__ dpre_self, const float *__restrict__ da_dst,
+                                                        const float *__restrict__ att_src, const float *__restrict__ att_dst,
+                                                        const int *__restrict__ t_rowptr, const int *__restrict__ t_pos, const int *__restrict__ t_tgt,
+                                                        int n, int C, float *__restrict__ dh, float *__restrict__ part, int PW) {
+    const int lane = threadIdx.x & 63;
+    const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    constexpr int MAXV = 4;                                   // C <= 256
+    float p_as[MAXV], p_ad[MAXV], p_b[MAXV];
 #pragma unroll
-    for (int d = 0; d < GAT_MAXD; ++d) { mean_ea[d] = 0.f; dvp[d] = 0.f; }
-    float mean_dot = 0.f;
-    for (int p = e0; p < e1; ++p) {
-        const float *ea = edge_attr + (size_t)eid[p] * D;
-        float dot = 0.f;
+    for (int u = 0; u < MAXV; ++u) { p_as[u] = 0.f; p_ad[u] = 0.f; p_b[u] = 0.f; }
+    for (int j = wg; j < n; j += GAT_BW_WAVES) {
+        const int q0 = t_rowptr[j], q1 = t_rowptr[j + 1], deg = q1 - q0;
+        const float dad = da_dst[j], as = alpha_self[j];
+        float das = dpre_self[j];
+        if (deg <= 64) {
+            const bool on = lane < deg;
+            const int pos = on ? t_pos[q0 + lane] : 0;
+            const int tg = on ? t_tgt[q0 + lane] : j;
+            const float al = on ? alpha[pos] : 0.f;
+            das += wave_sum(on ? dpre[pos] : 0.f);
 #pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) if (d < D) { mean_ea[d] += ea[d]; dot += ea[d] * vd[d]; }
-        mean_dot += dot;
+            for (int u = 0; u < MAXV; ++u) {
+                const int c = lane + 64 * u;
+                if (c >= C) break;
+                const float dj = dout[(size_t)j * C + c], hj = h[(size_t)j * C + c];
+                float acc = as * dj;
+                for (int k = 0; k < deg; ++k) acc += __shfl(al, k, 64) * dout[(size_t)__shfl(tg, k, 64) * C + c];
+                dh[(size_t)j * C + c] = acc + das * att_src[c] + dad * att_dst[c];
+                p_as[u] += das * hj; p_ad[u] += dad * hj; p_b[u] += dj;
+            }
+        } else {
+            for (int q = q0; q < q1; ++q) das += dpre[t_pos[q]];
+#pragma unroll
+            for (int u = 0; u < MAXV; ++u) {
+                const int c = lane + 64 * u;
+                if (c >= C) break;
+                const float dj = dout[(size_t)j * C + c], hj = h[(size_t)j * C + c];
+                float acc = as * dj;
+                for (int q = q0; q < q1; ++q) acc += alpha[t_pos[q]] * dout[(size_t)t_tgt[q] * C + c];
+                dh[(size_t)j * C + c] = acc + das * att_src[c] + dad * att_dst[c];
+                p_as[u] += das * hj; p_ad[u] += dad * hj; p_b[u] += dj;
+            }
+        }
     }
-    if (e1 > e0) {
-        const float r = 1.0f / (float)(e1 - e0);
-        mean_dot = mean_dot / (float)(e1 - e0);
 #pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] *= r;
-    }
-    float dad = 0.f;
-    {
-        const float pre = a_src[i] + ad + mean_dot;
-        const float g = as * (dal_self - S) * (pre > 0.f ? 1.f : slope);
-        if (lane == 0) dpre_self[i] = g;
-        dad += g;
-#pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) dvp[d] += g * mean_ea[d];
-    }
-    for (int p = e0; p < e1; ++p) {
-        const int j = col[p];
-        float da = 0.f;
-        for (int c = lane; c < C; c += 64) da += dout[(size_t)i * C + c] * h[(size_t)j * C + c];
-        da = wave_sum(da);
-        const float *ea = edge_attr + (size_t)eid[p] * D;
-        float dot = 0.f;
-#pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
-        const float pre = a_src[j] + ad + dot;
-        const float g = alpha[p] * (da - S) * (pre > 0.f ? 1.f : slope);
-        if (lane == 0) dpre[p] = g;
-        dad += g;
-#pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dvp[d] += g * ea[d];
-    }
-    if (lane == 0) {
-        da_dst[i] = dad;
-        for (int d = 0; d < D; ++d) dv_part[(size_t)i * D + d] = dvp[d];
+    for (int u = 0; u < MAXV; ++u) {
+        const int c = lane + 64 * u;
+        if (c >= C) break;
+        part[(size_t)wg * PW + c] = p_as[u]; part[(size_t)wg * PW + C + c] = p_ad[u]; part[(size_t)wg * PW + 2 * C + c] = p_b[u];
     }
 }
 
-// backward, source side: da_src and dh (messages sent by node j, its self loop, and the two attention projections)
-__global__ void __launch_bounds__(256) k_gat_bwd_source(const float *__restrict__ dout, const float *__restrict__ alpha, const float *__restrict__ alpha_self,
-                                                        const float *__restrict__ dpre, const float *__restrict__ dpre_self,
-                                                        const float *__restrict__ da_dst, const float *__restrict__ att_src,
-                                                        const float *__restrict__ att_dst, const int *__restrict__ t_rowptr,
-                                                        const int *__restrict__ t_pos, const int *__restrict__ t_tgt, int n, int C,
-                                                        float *__restrict__ dh, float *__restrict__ da_src) {
-    const int lane = threadIdx.x & 63;
-    const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (j >= n) return;
-    const int q0 = t_rowptr[j], q1 = t_rowptr[j + 1];
-    float das = dpre_self[j];
-    for (int q = q0; q < q1; ++q) das += dpre[t_pos[q]];
-    if (lane == 0) da_src[j] = das;
-    const float dad = da_dst[j], as = alpha_self[j];
-    for (int c = lane; c < C; c += 64) {
-        float acc = as * dout[(size_t)j * C + c];
-        for (int q = q0; q < q1; ++q) acc += alpha[t_pos[q]] * dout[(size_t)t_tgt[q] * C + c];
-        dh[(size_t)j * C + c] = acc + das * att_src[c] + dad * att_dst[c];
+// out[w] = sum over the GAT_BW_WAVES partial rows, fixed order: a workgroup owns 32 columns and splits the rows 8 ways
+__global__ void __launch_bounds__(256) k_gat_param_reduce(const float *__restrict__ part, int PW, float *__restrict__ out) {
+    __shared__ float sm[8][32];
+    const int g = threadIdx.x >> 5, c = threadIdx.x & 31, w = blockIdx.x * 32 + c;
+    float a0 = 0.f, a1 = 0.f;
+    if (w < PW) {
+        for (int r = g; r < GAT_BW_WAVES; r += 64) {            // 8 loads in flight
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(r + 8 * u) * PW + w];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += t[u]; a1 += t[u + 1]; }
+        }
     }
-}
-
-// deterministic column sums: out[c] = sum_r x[r, c]; stage 1 per 256-row chunk, stage 2 over the chunks
-constexpr int CS_CHUNK = 256;
-__global__ void __launch_bounds__(256) k_colsum_partial(const float *__restrict__ x, int rows, int width, float *__restrict__ part) {
-    const int r0 = blockIdx.x * CS_CHUNK, r1 = min(rows, r0 + CS_CHUNK);
-    for (int c = threadIdx.x; c < width; c += 256) {
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += x[(size_t)r * width + c];
-        part[(size_t)blockIdx.x * width + c] = s;
+    sm[g][c] = a0 + a1;
+    __syncthreads();
+    if (g == 0 && w < PW) {
+        float r = sm[0][c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) r += sm[q][c];
+        out[w] = r;
     }
-}
-__global__ void k_colsum_final(const float *__restrict__ part, int chunks, int width, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * width + c];
-    out[c] = s;
 }
 
 inline int wave_blocks(int n) { return (n + 3) / 4; }
@@ -263,33 +332,25 @@ int conan_gat_aggregate_fwd(const float *h, const float *a_src, const float *a_d
     return CONAN_OK;
 }
 
+long long conan_gat_bwd_ws(int n, int num_edges, int channels, int edge_dim) {
+    return 2LL * n + (num_edges > 0 ? num_edges : 1) + (long long)GAT_BW_WAVES * (3 * channels + edge_dim) + (3 * channels + edge_dim);
+}
+
 int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alpha, const float *alpha_self, const float *a_src,
                             const float *a_dst, const float *att_src, const float *att_dst, const int *rowptr, const int *col, const int *eid,
                             const int *t_rowptr, const int *t_pos, const int *t_tgt, const float *edge_attr, int edge_dim, const float *v,
-                            float negative_slope, int n, int channels, float *dpre_ws, float *dh, float *da_src, float *da_dst, float *dv_part,
-                            void *stream) {
-    if (!h || !dout || !alpha_self || !a_src || !a_dst || !att_src || !att_dst || !rowptr || !t_rowptr || !v || !dpre_ws || !dh || !da_src || !da_dst ||
-        !dv_part || n < 0 || channels <= 0 || edge_dim <= 0 || edge_dim > GAT_MAXD)
+                            float negative_slope, int n, int num_edges, int channels, float *ws, float *dh, float *dparams, void *stream) {
+    if (!h || !dout || !alpha_self || !a_src || !a_dst || !att_src || !att_dst || !rowptr || !t_rowptr || !v || !ws || !dh || !dparams || n <= 0 ||
+        channels <= 0 || channels > 256 || edge_dim <= 0 || edge_dim > GAT_MAXD || num_edges < 0)
         return CONAN_E_BADARG;
-    if (n == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
-    float *dpre_self = dpre_ws, *dpre = dpre_ws + n;             // [n] + [E]
-    k_gat_bwd_target<<<wave_blocks(n), 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
-                                                     channels, dpre, dpre_self, da_dst, dv_part);
-    k_gat_bwd_source<<<wave_blocks(n), 256, 0, s>>>(dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr, t_pos, t_tgt, n, channels,
-                                                     dh, da_src);
-    CONAN_LAUNCH_CHECK();
-    return CONAN_OK;
-}
-
-long long conan_colsum_ws(int rows, int width) { return (long long)((rows + CS_CHUNK - 1) / CS_CHUNK) * width; }
-
-int conan_colsum(const float *x, int rows, int width, float *out, float *ws, void *stream) {
-    if (!out || width <= 0 || rows < 0 || (rows && (!x || !ws))) return CONAN_E_BADARG;
-    hipStream_t s = as_stream(stream);
-    const int chunks = (rows + CS_CHUNK - 1) / CS_CHUNK;
-    if (chunks) k_colsum_partial<<<chunks, 256, 0, s>>>(x, rows, width, ws);
-    k_colsum_final<<<(width + 255) / 256, 256, 0, s>>>(ws, chunks, width, out);
+    const int PW = 3 * channels + edge_dim;
+    float *dpre_self = ws, *da_dst = ws + n, *dpre = ws + 2 * (size_t)n, *part = dpre + (num_edges > 0 ? num_edges : 1);
+    k_gat_bwd_target<<<GAT_BW_WAVES / 4, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
+                                                       channels, dpre, dpre_self, da_dst, part, PW);
+    k_gat_bwd_source<<<GAT_BW_WAVES / 4, 256, 0, s>>>(h, dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr, t_pos, t_tgt, n,
+                                                       channels, dh, part, PW);
+    k_gat_param_reduce<<<(PW + 31) / 32, 256, 0, s>>>(part, PW, dparams);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

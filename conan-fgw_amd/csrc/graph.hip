@@ -70,24 +70,38 @@ __global__ void __launch_bounds__(RG_THREADS) k_radius(const float *__restrict__
 // Single-workgroup exclusive scan, n up to a few million: out[0..n], out[n] = total.
 constexpr int SCAN_THREADS = 1024;
 __global__ void __launch_bounds__(SCAN_THREADS) k_exclusive_scan(const int *__restrict__ in, int n, int *__restrict__ out) {
-    __shared__ int part[SCAN_THREADS];
-    const int t = threadIdx.x;
+    __shared__ int wsum[SCAN_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
     const int b = t * chunk, e = min(b + chunk, n);
+    constexpr int MAXC = 32;                 // chunks of up to 32 entries (n <= 32768) live in registers: one pass over memory,
+    int v[MAXC];                             // all loads of a thread in flight at once
     int s = 0;
-    for (int i = b; i < e; ++i) s += in[i];
-    part[t] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int o = 1; o < SCAN_THREADS; o <<= 1) {
-        int v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (chunk <= MAXC) {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { v[k] = (b + k < e) ? in[b + k] : 0; }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) s += v[k];
+    } else {
+        for (int i = b; i < e; ++i) s += in[i];
     }
-    int run = t == 0 ? 0 : part[t - 1];
-    for (int i = b; i < e; ++i) { int v = in[i]; out[i] = run; run += v; }
-    if (t == SCAN_THREADS - 1) out[n] = part[SCAN_THREADS - 1];
+    // exclusive scan of the 1024 thread sums: wavefront scan by shuffles, 16 wavefront totals through LDS
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) { const int x = wsum[w]; if (w < wave) woff += x; total += x; }
+    int run = woff + inc - s;
+    if (chunk <= MAXC) {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) if (b + k < e) { out[b + k] = run; run += v[k]; }
+    } else {
+        for (int i = b; i < e; ++i) { const int x = in[i]; out[i] = run; run += x; }
+    }
+    if (t == 0) out[n] = total;
 }
 
 // Multi-workgroup exclusive scan for long inputs (the pair flags: up to cap * num_atoms entries): per-block sums, a

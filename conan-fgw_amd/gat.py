@@ -72,26 +72,17 @@ class _GATAggregateFn(torch.autograd.Function):
         n, C = h.shape
         D = w_e.shape[1]
         dev = h.device
-        dpre_ws = torch.empty(n + max(g.num_edges, 1), dtype=f32, device=dev)
+        ws = torch.empty(int(lib().conan_gat_bwd_ws(n, g.num_edges, C, D)), dtype=f32, device=dev)
         dh = torch.empty_like(h)
-        da_s, da_d = torch.empty(n, dtype=f32, device=dev), torch.empty(n, dtype=f32, device=dev)
-        dv_part = torch.empty(n, D, dtype=f32, device=dev)
+        dpar = torch.empty(3 * C + D, dtype=f32, device=dev)            # d att_src | d att_dst | d bias | dv
         call("conan_gat_aggregate_bwd", ptr(h), ptr(dout), ptr(alpha), ptr(alpha_self), ptr(al_s), ptr(al_d), ptr(a_s), ptr(a_d), ptr(g.rowptr),
-             ptr(g.col), ptr(g.eid), ptr(g.t_rowptr), ptr(g.t_pos), ptr(g.t_tgt), ptr(ea), D, ptr(v), ctx.slope, n, C, ptr(dpre_ws), ptr(dh),
-             ptr(da_s), ptr(da_d), ptr(dv_part), stream_ptr())
-        ws = torch.empty(int(max(lib().conan_colsum_ws(n, C), lib().conan_linear_wgrad_ws(n, C, 1))), dtype=f32, device=dev)
-        dv, dbias = torch.empty(D, dtype=f32, device=dev), torch.empty(C, dtype=f32, device=dev)
-        call("conan_colsum", ptr(dv_part), n, D, ptr(dv), ptr(ws), stream_ptr())
-        call("conan_colsum", ptr(dout), n, C, ptr(dbias), ptr(ws), stream_ptr())
+             ptr(g.col), ptr(g.eid), ptr(g.t_rowptr), ptr(g.t_pos), ptr(g.t_tgt), ptr(ea), D, ptr(v), ctx.slope, n, g.num_edges, C, ptr(ws), ptr(dh),
+             ptr(dpar), stream_ptr())
         dw_e, datt_e = torch.empty_like(w_e), torch.empty(C, dtype=f32, device=dev)
-        call("conan_gat_edge_vec_bwd", ptr(w_e), ptr(a_e), ptr(dv), C, D, ptr(dw_e), ptr(datt_e), stream_ptr())
-        # d att_src[c] = sum_j da_src[j] h[j,c]  (a [1,C] weight gradient with g = da_src as an [n,1] column)
-        datt_s, datt_d = torch.empty(C, dtype=f32, device=dev), torch.empty(C, dtype=f32, device=dev)
-        call("conan_linear_wgrad", ptr(da_s), ptr(h), n, C, 1, None, ptr(datt_s), None, ptr(ws), stream_ptr())
-        call("conan_linear_wgrad", ptr(da_d), ptr(h), n, C, 1, None, ptr(datt_d), None, ptr(ws), stream_ptr())
+        call("conan_gat_edge_vec_bwd", ptr(w_e), ptr(a_e), ptr(dpar[3 * C:]), C, D, ptr(dw_e), ptr(datt_e), stream_ptr())
         s_src, s_dst, s_edge = ctx.shapes
-        return (dh, datt_s.view(s_src), datt_d.view(s_dst), dw_e, datt_e.view(s_edge), dbias if ctx.needs_input_grad[5] else None,
-                None, None, None)
+        return (dh, dpar[:C].view(s_src), dpar[C:2 * C].view(s_dst), dw_e, datt_e.view(s_edge),
+                dpar[2 * C:3 * C] if ctx.needs_input_grad[5] else None, None, None, None)
 
 
 def _glorot(t: Tensor):

@@ -318,16 +318,16 @@ int conan_gat_node_alpha(const float *h, const float *att_src, const float *att_
 int conan_gat_aggregate_fwd(const float *h, const float *a_src, const float *a_dst, const int *rowptr, const int *col,
                             const int *eid, const float *edge_attr, int edge_dim, const float *v, const float *bias,
                             float negative_slope, int n, int channels, float *out, float *alpha, float *alpha_self, void *stream);
-/* Backward of the aggregation: dh[n,C] (messages + attention projections), da_src[n], da_dst[n], dv_part[n,edge_dim] (sum its
- * columns for dv).  dpre_ws: n + E floats.  No float atomics (target rows, then by-source lists). */
+/* Backward of the aggregation: dh[n,C] (messages + attention projections) and dparams[3C + edge_dim] = d att_src | d att_dst |
+ * d bias | dv (v of conan_gat_edge_vec).  ws: conan_gat_bwd_ws(n, E, C, edge_dim) floats.  Per-edge gradients are formed per
+ * target row, scattered sums per by-source list, parameter gradients as per-wavefront partials summed in a fixed order:
+ * no float atomics, bitwise reproducible.  channels <= 256. */
+long long conan_gat_bwd_ws(int n, int num_edges, int channels, int edge_dim);
 int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alpha, const float *alpha_self, const float *a_src,
                             const float *a_dst, const float *att_src, const float *att_dst, const int *rowptr, const int *col,
                             const int *eid, const int *t_rowptr, const int *t_pos, const int *t_tgt, const float *edge_attr,
-                            int edge_dim, const float *v, float negative_slope, int n, int channels, float *dpre_ws, float *dh,
-                            float *da_src, float *da_dst, float *dv_part, void *stream);
-/* out[c] = sum_r x[r,c], deterministic two-stage sum; ws holds conan_colsum_ws(rows, width) floats. */
-long long conan_colsum_ws(int rows, int width);
-int conan_colsum(const float *x, int rows, int width, float *out, float *ws, void *stream);
+                            int edge_dim, const float *v, float negative_slope, int n, int num_edges, int channels, float *ws,
+                            float *dh, float *dparams, void *stream);
 
 #ifdef __cplusplus
 }
