@@ -110,11 +110,14 @@ __global__ void __launch_bounds__(256) k_gat_aggregate_fwd(const float *__restri
     }
 }
 
-// Backward.  Both kernels run on GAT_BW_WAVES persistent wavefronts (node i -> wavefront i mod GAT_BW_WAVES), and every
-// wavefront accumulates its share of the parameter gradients in registers — d att_src, d att_dst, d bias (source kernel,
-// lane <-> channel) and dv (target kernel) — and writes one partial row part[wave][3C + D]; k_gat_param_reduce sums the rows
-// in a fixed order.  No float atomics anywhere: bitwise reproducible.
-constexpr int GAT_BW_WAVES = 1024;
+// Backward.  Both kernels run on a fixed grid of GAT_BW_WGS workgroups x 4 wavefronts (node i -> wavefront i mod
+// GAT_BW_WAVES: ~3 nodes per wavefront at 25 k atoms — the per-node work is a chain of dependent loads and reductions, so it
+// needs many wavefronts in flight).  Every wavefront accumulates its share of the parameter gradients in registers — d att_src,
+// d att_dst, d bias (source kernel, lane <-> channel) and dv (target kernel); the four wavefronts of a workgroup are combined
+// through LDS into one partial row part[workgroup][3C + D], and k_gat_param_reduce sums the rows in a fixed order.  No float
+// atomics anywhere: bitwise reproducible.
+constexpr int GAT_BW_WGS = 2048;
+constexpr int GAT_BW_WAVES = 4 * GAT_BW_WGS;
 
 // target side: dpre per edge / self loop, da_dst, partial dv
 __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict__ h, const float *__restrict__ dout, const float *__restrict__ alpha,
@@ -206,8 +209,13 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
         }
         if (lane == 0) da_dst[i] = dad;
     }
+    __shared__ float sm_dv[4][GAT_MAXD];
     if (lane == 0)
-        for (int d = 0; d < D; ++d) part[(size_t)wg * PW + 3 * C + d] = dvacc[d];
+        for (int d = 0; d < GAT_MAXD; ++d) sm_dv[threadIdx.x >> 6][d] = dvacc[d];
+    __syncthreads();
+    if (threadIdx.x < D)
+        part[(size_t)blockIdx.x * PW + 3 * C + threadIdx.x] =
+            ((sm_dv[0][threadIdx.x] + sm_dv[1][threadIdx.x]) + sm_dv[2][threadIdx.x]) + sm_dv[3][threadIdx.x];
 }
 
 // source side: da_src, dh (messages sent by node j, its self loop, the two attention projections) and the partial sums of
@@ -258,21 +266,27 @@ __global__ void __launch_bounds__(256) k_gat_bwd_source(const float *__restrict_
             }
         }
     }
+    __shared__ float sm_p[4][3][64 * MAXV];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int u = 0; u < MAXV; ++u) {
         const int c = lane + 64 * u;
-        if (c >= C) break;
-        part[(size_t)wg * PW + c] = p_as[u]; part[(size_t)wg * PW + C + c] = p_ad[u]; part[(size_t)wg * PW + 2 * C + c] = p_b[u];
+        sm_p[wv][0][c] = p_as[u]; sm_p[wv][1][c] = p_ad[u]; sm_p[wv][2][c] = p_b[u];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * C; t += 256) {
+        const int k = t / C, c = t - k * C;
+        part[(size_t)blockIdx.x * PW + t] = ((sm_p[0][k][c] + sm_p[1][k][c]) + sm_p[2][k][c]) + sm_p[3][k][c];
     }
 }
 
-// out[w] = sum over the GAT_BW_WAVES partial rows, fixed order: a workgroup owns 32 columns and splits the rows 8 ways
+// out[w] = sum over the GAT_BW_WGS partial rows, fixed order: a workgroup owns 32 columns and splits the rows 8 ways
 __global__ void __launch_bounds__(256) k_gat_param_reduce(const float *__restrict__ part, int PW, float *__restrict__ out) {
     __shared__ float sm[8][32];
     const int g = threadIdx.x >> 5, c = threadIdx.x & 31, w = blockIdx.x * 32 + c;
     float a0 = 0.f, a1 = 0.f;
     if (w < PW) {
-        for (int r = g; r < GAT_BW_WAVES; r += 64) {            // 8 loads in flight
+        for (int r = g; r < GAT_BW_WGS; r += 64) {              // 8 loads in flight
             float t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(r + 8 * u) * PW + w];
@@ -333,7 +347,7 @@ int conan_gat_aggregate_fwd(const float *h, const float *a_src, const float *a_d
 }
 
 long long conan_gat_bwd_ws(int n, int num_edges, int channels, int edge_dim) {
-    return 2LL * n + (num_edges > 0 ? num_edges : 1) + (long long)GAT_BW_WAVES * (3 * channels + edge_dim) + (3 * channels + edge_dim);
+    return 2LL * n + (num_edges > 0 ? num_edges : 1) + (long long)GAT_BW_WGS * (3 * channels + edge_dim) + (3 * channels + edge_dim);
 }
 
 int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alpha, const float *alpha_self, const float *a_src,
@@ -346,9 +360,9 @@ int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alph
     hipStream_t s = as_stream(stream);
     const int PW = 3 * channels + edge_dim;
     float *dpre_self = ws, *da_dst = ws + n, *dpre = ws + 2 * (size_t)n, *part = dpre + (num_edges > 0 ? num_edges : 1);
-    k_gat_bwd_target<<<GAT_BW_WAVES / 4, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
+    k_gat_bwd_target<<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
                                                        channels, dpre, dpre_self, da_dst, part, PW);
-    k_gat_bwd_source<<<GAT_BW_WAVES / 4, 256, 0, s>>>(h, dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr, t_pos, t_tgt, n,
+    k_gat_bwd_source<<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr, t_pos, t_tgt, n,
                                                        channels, dh, part, PW);
     k_gat_param_reduce<<<(PW + 31) / 32, 256, 0, s>>>(part, PW, dparams);
     CONAN_LAUNCH_CHECK();
