@@ -88,3 +88,24 @@ class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
             raise ValueError("conformers_index must have one entry per conformer graph")
         x = x.view(G // K, K, d).mean(dim=1)                                                                          # :170
         return ops.linear(x.contiguous(), self.molecular_regression_lin.weight, self.molecular_regression_lin.bias)   # :171
+
+
+class EmbeddingsWithGATAggregation(EmbeddingsWithGATAggregationBaryCenter):
+    """Stage-1 ("conan_fgw_pre") model: `EmbeddingsWithGATAggregation` (schnet_based_models.py:176-244).  Same sub-modules as
+    stage 2 — `transformation_matrix_bary` exists but is unused — so its `state_dict` loads strictly into the stage-2 model,
+    which is how the reference starts stage 2 (train_val.py:175-183).  forward: x = Lin3d(backbone(z, pos)) + Lin_cov(GAT(...)),
+    conformer mean, regression (:231-244)."""
+
+    def forward(self, batch, conformers_index: Tensor, node_index: Tensor, num_graphs: int = None, max_nodes: int = None) -> Tensor:
+        K = self.num_conformers
+        x_3d = self.node_embeddings_model(batch.z, batch.pos, node_index)                                            # :231
+        x_3d = ops.linear(x_3d, self.transformation_matrix_3d.weight, self.transformation_matrix_3d.bias)            # :232
+        x_cov = self.gat_embeddings_model(batch.x, batch.edge_index, batch.edge_attr, batch.batch,
+                                          **({"num_graphs": num_graphs} if num_graphs is not None else {}))           # :233-235
+        x_cov = ops.linear(x_cov, self.transformation_matrix_cov.weight, self.transformation_matrix_cov.bias)        # :236
+        x = x_3d + x_cov                                                                                               # :237
+        G, d = x.shape
+        if conformers_index is not None and conformers_index.numel() != G:
+            raise ValueError("conformers_index must have one entry per conformer graph")
+        x = x.view(G // K, K, d).mean(dim=1)                                                                           # :238
+        return ops.linear(x.contiguous(), self.molecular_regression_lin.weight, self.molecular_regression_lin.bias)    # :239

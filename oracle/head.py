@@ -36,3 +36,15 @@ class Stage2Oracle(nn.Module):
         h = x_3d + x_cov + self.agg_weight * x_bary
         h = h.view(h.shape[0] // K, K, -1).mean(1)
         return self.molecular_regression_lin(h)
+
+
+class Stage1Oracle(Stage2Oracle):
+    """EmbeddingsWithGATAggregation.forward (schnet_based_models.py:231-244): no barycenter branch."""
+
+    def forward(self, z, pos, node_index, x, edge_index, edge_attr):
+        K = self.num_conformers
+        x_3d = self.transformation_matrix_3d(self.node_embeddings_model(z, pos, node_index))
+        x_cov = self.transformation_matrix_cov(self.gat_embeddings_model(x, edge_index, edge_attr, node_index))
+        h = x_3d + x_cov
+        h = h.view(h.shape[0] // K, K, -1).mean(1)
+        return self.molecular_regression_lin(h)

@@ -61,3 +61,39 @@ def test_stage2_hints_do_not_change_the_result():
         y1 = m(batch, cidx, batch.batch)
         y2 = m(batch, cidx, batch.batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
     assert torch.equal(y1, y2)
+
+
+def test_stage1_model_and_checkpoint_round_trip_into_stage2(tmp_path):
+    """Stage 1 (`EmbeddingsWithGATAggregation`, no FGW) vs its oracle, then the two-stage recipe of the reference: the stage-1
+    `state_dict` is saved as a Lightning-style checkpoint and loaded strictly into the stage-2 model (train_val.py:175-183)."""
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregation, EmbeddingsWithGATAggregationBaryCenter
+    from oracle.head import Stage1Oracle
+    dev = torch.device("cuda:0")
+    K = 3
+    b = make_batch("esol", 4, K, seed=31)
+    g = make_bond_graph(b, seed=32)
+    torch.manual_seed(7)
+    m1 = EmbeddingsWithGATAggregation(K, dev).to(dev)
+    ref = Stage1Oracle(K).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in m1.state_dict().items()}, strict=True)
+    t = lambda a: torch.from_numpy(a)
+    batch = types.SimpleNamespace(z=t(b.z).to(dev), pos=t(b.pos).to(dev), x=t(g.x).to(dev), edge_index=t(g.edge_index).to(dev),
+                                  edge_attr=t(g.edge_attr).to(dev), batch=t(b.batch).to(dev))
+    cidx = m1.create_aggregation_index(b.num_graphs, dev)
+    y = m1(batch, cidx, batch.batch)
+    r = ref(t(b.z), t(b.pos).double(), t(b.batch), t(g.x), t(g.edge_index), t(g.edge_attr))
+    assert rel(y.detach().cpu().double().numpy(), r.detach().numpy()) < 1e-5
+    y.sum().backward()
+    assert m1.transformation_matrix_bary.weight.grad is None                 # unused in stage 1, exactly like the reference
+    assert m1.node_embeddings_model.lin2.weight.grad is not None
+    path = tmp_path / "stage1.ckpt"
+    torch.save({"state_dict": m1.state_dict()}, path)
+    torch.manual_seed(99)
+    m2 = EmbeddingsWithGATAggregationBaryCenter(K, dev).to(dev)
+    res = m2.load_state_dict(torch.load(path)["state_dict"])                 # strict
+    assert not res.missing_keys and not res.unexpected_keys
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    with torch.no_grad():
+        y2 = m2(batch, cidx, batch.batch)
+    assert y2.shape == y.shape and torch.isfinite(y2).all()
