@@ -138,9 +138,9 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
                 for (int i = lane; i < N; i += 64) { const double z = Mr[i * P + j] + u[i]; mx = z > mx ? z : mx; }
                 mx = wave_max_d(mx);
                 double sm = 0.0;
-                for (int i = lane; i < N; i += 64) sm += exp_acc(Mr[i * P + j] + u[i] - mx);
+                for (int i = lane; i < N; i += 64) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
                 sm = wave_sum_d(sm);
-                if (lane == 0) v[j] = logb[j] - (log(sm) + mx);
+                if (lane == 0) v[j] = logb[j] - (log_acc(sm) + mx);
             }
             __syncthreads();
             // u_i = loga_i - logsumexp_j(Mr_ij + v_j): one wavefront per row, lanes over columns
@@ -149,9 +149,9 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
                 for (int j = lane; j < N; j += 64) { const double z = Mr[i * P + j] + v[j]; mx = z > mx ? z : mx; }
                 mx = wave_max_d(mx);
                 double sm = 0.0;
-                for (int j = lane; j < N; j += 64) sm += exp_acc(Mr[i * P + j] + v[j] - mx);
+                for (int j = lane; j < N; j += 64) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
                 sm = wave_sum_d(sm);
-                if (lane == 0) u[i] = loga[i] - (log(sm) + mx);
+                if (lane == 0) u[i] = loga[i] - (log_acc(sm) + mx);
             }
             __syncthreads();
             if (ii % 10 == 0) {                                 // marginal violation, sinkhorn.py:418-433
