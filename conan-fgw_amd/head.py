@@ -66,20 +66,36 @@ class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
         self.molecular_regression_lin = Linear(out_channels, 1)          # build_mlp(out_channels), is_complex=False
         self.numItermax, self.epsilon, self.agg_weight = max_iter, epsilon, agg_weight
 
+    def _side_stream(self, device) -> "torch.cuda.Stream":
+        s = getattr(self, "_gat_stream", None)
+        if s is None or s.device != device:
+            s = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_gat_stream", s)       # not a module attribute: streams are not part of the state
+        return s
+
     def create_aggregation_index(self, num_graphs: int, device) -> Tensor:
         """Molecule id of every conformer graph: [0]*K + [1]*K + ... (common.py:414-423, built there from len(batch.smiles))."""
         return torch.arange(num_graphs // self.num_conformers, device=device).repeat_interleave(self.num_conformers)
 
     def forward(self, batch, conformers_index: Tensor, node_index: Tensor, num_graphs: int = None, max_nodes: int = None) -> Tensor:
         K = self.num_conformers
+        # The covalent branch depends on nothing the 3-D branch produces: it runs on a second HIP stream, next to the backbone
+        # and the FGW solve (whose last wave of workgroups leaves two thirds of the CUs idle).  autograd replays each op's
+        # backward on the stream of its forward, so the overlap carries over to the backward pass.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            x_cov = self.gat_embeddings_model(batch.x, batch.edge_index, batch.edge_attr, batch.batch,
+                                              **({"num_graphs": num_graphs} if num_graphs is not None else {}))     # :165-167
+            x_cov = ops.linear(x_cov, self.transformation_matrix_cov.weight, self.transformation_matrix_cov.bias)   # :168
         x_3d, x_bary = self.node_embeddings_model.forward_w_barycenter(
             z=batch.z, pos=batch.pos, num_conformers=K, batch=node_index, max_iter=self.numItermax, epsilon=self.epsilon,
             **({"num_graphs": num_graphs, "max_nodes": max_nodes} if num_graphs is not None else {}))             # :153-160
         x_bary = ops.linear(x_bary, self.transformation_matrix_bary.weight, self.transformation_matrix_bary.bias)  # :163
         x_3d = ops.linear(x_3d, self.transformation_matrix_3d.weight, self.transformation_matrix_3d.bias)          # :164
-        x_cov = self.gat_embeddings_model(batch.x, batch.edge_index, batch.edge_attr, batch.batch,
-                                          **({"num_graphs": num_graphs} if num_graphs is not None else {}))         # :165-167
-        x_cov = ops.linear(x_cov, self.transformation_matrix_cov.weight, self.transformation_matrix_cov.bias)       # :168
+        main.wait_stream(side)
+        x_cov.record_stream(main)
         x = x_3d + x_cov + self.agg_weight * x_bary                                                                   # :169
         G, d = x.shape
         # conformers_mean_aggr(x, conformers_index): the index is K consecutive copies of every molecule id, so the mean is a
