@@ -37,8 +37,12 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
 template <int K, int N, int ACT>
 __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restrict__ x, const float *__restrict__ w,
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
-                                                           int M, int w_kn, float *__restrict__ y,
-                                                           const int *__restrict__ m_dev) {
+                                                           int M, int w_kn, float *y,
+                                                           const int *__restrict__ m_dev, int ldx, int ldw, int ldy,
+                                                           const float *accum) {
+    // ldx / ldw / ldy: row pitches of x, w and of y / residual / accum — the launcher tiles wider layers into 64/128-wide
+    // (K, N) chunks of one strided problem; `accum` (may alias y) carries the partial sum of the previous K chunks and is
+    // added BEFORE the activation.
     constexpr int act = ACT;
     constexpr int NB = N / 32;
     constexpr int S = K / 16;             // MFMA k-steps
@@ -58,7 +62,8 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int q = tid + u * LT_THREADS;
-            wv[u] = q < V4 ? reinterpret_cast<const float4 *>(w)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = (4 * q) / K, k = 4 * q - n * K;
+            wv[u] = q < V4 ? *reinterpret_cast<const float4 *>(w + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
             const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * N + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * ldw + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < PERW; ++u) {
@@ -123,7 +128,7 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
     for (int tile = blockIdx.x * (LT_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
         const int m = (tile << 5) + l31;
         const bool valid = m < M;
-        const float *xr = x + (size_t)(valid ? m : M - 1) * K + 8 * h;
+        const float *xr = x + (size_t)(valid ? m : M - 1) * ldx + 8 * h;
         float4 xa[S], xb[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {                          // lane-half h owns k = 16s + 8h .. +7 of its row
@@ -157,8 +162,9 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!valid) continue;
-        float *yr = y + (size_t)m * N + 4 * h;
-        const float *rr = residual ? residual + (size_t)m * N + 4 * h : nullptr;
+        float *yr = y + (size_t)m * ldy + 4 * h;
+        const float *rr = residual ? residual + (size_t)m * ldy + 4 * h : nullptr;
+        const float *ar = accum ? accum + (size_t)m * ldy + 4 * h : nullptr;
         float4 rv[NB][4];
         if (rr) {
 #pragma unroll
@@ -172,6 +178,10 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
                 float v[4] = {acc[nb][4 * q] + bb.x, acc[nb][4 * q + 1] + bb.y, acc[nb][4 * q + 2] + bb.z, acc[nb][4 * q + 3] + bb.w};
+                if (ar) {
+                    const float4 av = *reinterpret_cast<const float4 *>(ar + 32 * nb + 8 * q);
+                    v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w;
+                }
                 const float r4[4] = {rr ? rv[nb][q].x : 0.f, rr ? rv[nb][q].y : 0.f, rr ? rv[nb][q].z : 0.f, rr ? rv[nb][q].w : 0.f};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -274,10 +284,11 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t(const float *__restrict
 
 template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
-             const int *m_dev, hipStream_t s) {
+             const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr) {
+    if (ldw == 0) ldw = w_kn ? N : K;
     // CONAN_LINEAR_FP32=1 forces the plain fp32-MFMA kernel (default: exact 3-way bf16 split on the bf16 MFMA)
     static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
-    if (!fp32_only) {
+    if (!fp32_only || ldx != K || ldy != N || accum) {
         const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
         const int tiles16 = (M + 31) / 32;
         int grid16 = (tiles16 + 7) / 8;
@@ -286,7 +297,7 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     do {                                                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds16);                                                                                   \
-        k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev);                         \
+        k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum);   \
     } while (0)
         switch (act) {
             case 0: LAUNCH16(0); break;
@@ -308,7 +319,24 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
 
 }  // namespace
 
-// Returns 1 and launches when (K, N) is one of the register-streamed shapes, 0 otherwise (caller falls back).
+// Returns 1 and launches when the layer can be tiled into register-streamed (K, N) chunks of 64 / 128, 0 otherwise (caller
+// falls back).  Wider layers (ViSNet's 128 -> 256 / 384 projections and their transposes, the 512 / 256-wide classification
+// SchNet) become one strided problem per (n chunk, k chunk): the k chunks of an n chunk accumulate in place through `accum`,
+// bias enters with the first k chunk, activation and residual with the last.
+template <int KC, int NC>
+static int chunk_launch(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn, int act,
+                        float *y, const int *m_dev, hipStream_t s) {
+    for (int n0 = 0; n0 < N; n0 += NC)
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            const bool first = k0 == 0, last = k0 + KC >= K;
+            const float *wc = w_kn ? w + (size_t)k0 * N + n0 : w + (size_t)n0 * K + k0;
+            const int rc = launch_t<KC, NC>(x + k0, wc, (first && bias) ? bias + n0 : nullptr, (last && residual) ? residual + n0 : nullptr, M, w_kn,
+                                            last ? act : 0, y + n0, m_dev, s, K, w_kn ? N : K, N, first ? nullptr : y + n0);
+            if (rc != CONAN_OK) return rc;
+        }
+    return CONAN_OK;
+}
+
 int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
                        int act, float *y, const int *m_dev, hipStream_t s, int *rc) {
     if (M < 1) return 0;
@@ -316,5 +344,12 @@ int conan_linear_t_try(const float *x, const float *w, const float *bias, const 
     if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
     if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
     if (K == 64 && N == 128) { *rc = launch_t<64, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
-    return 0;
+    static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
+    if (fp32_only || (K % 64) || (N % 64) || K > 1024 || N > 1024) return 0;
+    const bool k128 = (K % 128) == 0, n128 = (N % 128) == 0;
+    if (k128 && n128) *rc = chunk_launch<128, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
+    else if (k128) *rc = chunk_launch<128, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
+    else if (n128) *rc = chunk_launch<64, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
+    else *rc = chunk_launch<64, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
+    return 1;
 }
