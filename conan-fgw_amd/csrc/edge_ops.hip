@@ -36,6 +36,15 @@ __global__ void k_cutoff_scale(const float *__restrict__ dist, const int *__rest
     }
 }
 
+// zero the rows [*m_dev, rows) of a [rows, width] buffer: edge-level buffers are sized for the worst case (cap * atoms) and
+// only the tail beyond the device-side edge count has to be defined, not the whole buffer
+__global__ void k_zero_tail(float *__restrict__ buf, const int *__restrict__ m_dev, int rows, int width) {
+    const long long lo = (long long)min(*m_dev, rows) * width, hi = (long long)rows * width;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) buf[i] = 0.f;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -54,6 +63,14 @@ int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edge
     if (!dist || !in || !out || max_edges < 0 || width <= 0 || (width & 3)) return CONAN_E_BADARG;
     if (max_edges == 0) return CONAN_OK;
     k_cutoff_scale<<<2048, 256, 0, as_stream(stream)>>>(dist, num_edges_dev, max_edges, width, cutoff, in, out);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_zero_tail(float *buf, const int *m_dev, int rows, int width, void *stream) {
+    if (!buf || !m_dev || rows < 0 || width <= 0) return CONAN_E_BADARG;
+    if (rows == 0) return CONAN_OK;
+    k_zero_tail<<<512, 256, 0, as_stream(stream)>>>(buf, m_dev, rows, width);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -90,6 +90,15 @@ class RadiusGraph:
         return self.dist[: self.num_edges]
 
 
+def empty_rows(rows: int, width: int, device, m_dev: Optional[Tensor]) -> Tensor:
+    """[rows, width] fp32 buffer whose rows beyond the device-side count `m_dev` are zero (the rows below it are for the caller's
+    kernel to write): a tail-only clear instead of a full memset of a worst-case-sized edge buffer."""
+    t = torch.empty(rows, width, dtype=f32, device=device)
+    if m_dev is not None:
+        call("conan_zero_tail", ptr(t), ptr(m_dev), rows, width, stream_ptr())
+    return t
+
+
 def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
     batch = _c(batch)
     out = torch.empty(num_graphs + 1, dtype=i32, device=batch.device)
@@ -127,7 +136,7 @@ class _LinearFn(torch.autograd.Function):
             g = dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x) if md is None else torch.zeros_like(x)
+            dx = empty_rows(x.shape[0], x.shape[1], x.device, md)
             call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             ws = torch.empty(int(lib().conan_linear_wgrad_ws(M, K, N)), dtype=f32, device=x.device)

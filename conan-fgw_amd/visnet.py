@@ -101,7 +101,7 @@ class ViSNetBlock(torch.nn.Module):
         dvec = torch.empty(ME, 3, dtype=f32, device=dev)                                                     # geometry: no gradient (pos is an input)
         call("conan_visnet_edge_unit", ptr(pos.contiguous(), f32), ptr(g.col), ptr(g.tgt), ptr(md), ME, ptr(dvec), s)
         de = self.distance_expansion
-        rbf = torch.zeros(ME, de.num_rbf, dtype=f32, device=dev)
+        rbf = ops.empty_rows(ME, de.num_rbf, dev, md)
         call("conan_visnet_expnormal", ptr(g.dist), ptr(md), ME, ptr(de.means), ptr(de.betas), de.num_rbf, de.alpha, de.cutoff, ptr(rbf), s)
         x = ops.embedding(z, self.embedding.weight, None)
         # NeighborEmbedding, :387-420

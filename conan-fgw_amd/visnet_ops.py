@@ -16,11 +16,23 @@ def _new(like: Tensor, *shape):
     return torch.empty(*shape, dtype=f32, device=like.device)
 
 
+def _tail0_shape(rows: int, width: int, device, m_dev):
+    """Worst-case-sized edge buffer: only the rows beyond the device-side edge count are cleared (conan_zero_tail)."""
+    t = torch.empty(rows, width, dtype=f32, device=device)
+    if m_dev is not None:
+        call("conan_zero_tail", ptr(t), ptr(m_dev), rows, width, stream_ptr())
+    return t
+
+
+def _tail0(like: Tensor, m_dev):
+    return _tail0_shape(like.shape[0], like[0].numel(), like.device, m_dev).view(like.shape)
+
+
 class _Silu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, m_dev):
         x = _c(x)
-        y = torch.empty_like(x) if m_dev is None else torch.zeros_like(x)
+        y = _tail0(x, m_dev)
         call("conan_silu_fwd", ptr(x, f32), x.shape[0], x.shape[1], ptr(m_dev), ptr(y), stream_ptr())
         ctx.save_for_backward(x)
         ctx.m_dev = m_dev
@@ -29,7 +41,7 @@ class _Silu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        dx = torch.empty_like(x) if ctx.m_dev is None else torch.zeros_like(x)
+        dx = _tail0(x, ctx.m_dev)
         call("conan_silu_bwd", ptr(x), ptr(_c(dy)), x.shape[0], x.shape[1], ptr(ctx.m_dev), ptr(dx), stream_ptr())
         return dx, None
 
@@ -91,7 +103,7 @@ class _EdgeEmbed(torch.autograd.Function):
     def forward(ctx, x, p, graph):
         x, p = _c(x), _c(p)
         H = x.shape[1]
-        f = torch.zeros(graph.max_edges, H, dtype=f32, device=x.device)
+        f = _tail0_shape(graph.max_edges, H, x.device, graph.num_edges_dev)
         call("conan_visnet_edge_embed", ptr(x, f32), ptr(p, f32), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev), graph.max_edges, H,
              ptr(f), stream_ptr())
         ctx.save_for_backward(x, p)
@@ -103,7 +115,7 @@ class _EdgeEmbed(torch.autograd.Function):
         x, p = ctx.saved_tensors
         g = ctx.graph
         tr, te = g.transpose()
-        dp, dx = torch.zeros_like(p), torch.empty_like(x)
+        dp, dx = _tail0(p, g.num_edges_dev), torch.empty_like(x)
         call("conan_visnet_edge_embed_bwd", ptr(x), ptr(p), ptr(_c(df)), ptr(g.rowptr), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
              ptr(g.num_edges_dev), g.max_edges, x.shape[0], x.shape[1], ptr(dp), ptr(dx), stream_ptr())
         return dx, dp, None
@@ -189,7 +201,7 @@ class _AttnMessage(torch.autograd.Function):
     def forward(ctx, q, k, v, dk, dv, graph, cutoff, heads):
         q, k, v, dk, dv = (_c(t) for t in (q, k, v, dk, dv))
         n, H = q.shape
-        vmsg = torch.zeros(graph.max_edges, H, dtype=f32, device=q.device)
+        vmsg = _tail0_shape(graph.max_edges, H, q.device, graph.num_edges_dev)
         xagg = _new(q, n, H)
         call("conan_visnet_attn_message", ptr(q, f32), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(graph.rowptr), ptr(graph.col), ptr(graph.dist),
              float(cutoff), n, H, heads, ptr(vmsg), ptr(xagg), stream_ptr())
@@ -204,7 +216,7 @@ class _AttnMessage(torch.autograd.Function):
         tr, te = g.transpose()
         n, H = q.shape
         dq, dkn, dvn = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        ddk, ddv = torch.zeros_like(dk), torch.zeros_like(dv)
+        ddk, ddv = _tail0(dk, g.num_edges_dev), _tail0(dv, g.num_edges_dev)
         call("conan_visnet_attn_message_bwd", ptr(q), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(_c(dvmsg)), ptr(_c(dxagg)), ptr(g.rowptr), ptr(g.col),
              ptr(g.tgt), ptr(tr), ptr(te), ptr(g.dist), ctx.cutoff, n, H, ctx.heads, ptr(dq), ptr(dkn), ptr(dvn), ptr(ddk), ptr(ddv), stream_ptr())
         return dq, dkn, dvn, ddk, ddv, None, None, None
@@ -231,7 +243,7 @@ class _VecAggregate(torch.autograd.Function):
         g = ctx.graph
         tr, te = g.transpose()
         n, _, H = vec.shape
-        ds, dvec = torch.zeros_like(s), torch.empty_like(vec)
+        ds, dvec = _tail0(s, g.num_edges_dev), torch.empty_like(vec)
         call("conan_visnet_vec_aggregate_bwd", ptr(vec), ptr(s), ptr(dvec3), ptr(_c(dvagg)), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
              ptr(g.num_edges_dev), g.max_edges, n, H, ptr(ds), ptr(dvec), stream_ptr())
         return dvec, ds, None, None
@@ -270,7 +282,7 @@ class _EdgeUpdate(torch.autograd.Function):
     def forward(ctx, wt, ws, t, dvec3, f, graph):
         wt, ws, t, f = (_c(a) for a in (wt, ws, t, f))
         H = f.shape[1]
-        fo = torch.zeros_like(f)
+        fo = _tail0(f, graph.num_edges_dev)
         call("conan_visnet_edge_update", ptr(wt, f32), ptr(ws), ptr(t), ptr(dvec3), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev),
              graph.max_edges, H, ptr(f), ptr(fo), stream_ptr())
         ctx.save_for_backward(wt, ws, t, dvec3)
@@ -284,7 +296,7 @@ class _EdgeUpdate(torch.autograd.Function):
         tr, te = g.transpose()
         n, H = wt.shape[0] // 3, t.shape[1]
         dfo = _c(dfo)
-        dwt, dws, dt = torch.empty_like(wt), torch.empty_like(ws), torch.zeros_like(t)
+        dwt, dws, dt = torch.empty_like(wt), torch.empty_like(ws), _tail0(t, g.num_edges_dev)
         call("conan_visnet_edge_update_bwd", ptr(wt), ptr(ws), ptr(t), ptr(dvec3), ptr(dfo), ptr(g.rowptr), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
              n, H, ptr(dwt), ptr(dws), ptr(dt), stream_ptr())
         return dwt, dws, dt, None, dfo, None

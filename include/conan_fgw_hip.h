@@ -296,6 +296,9 @@ int conan_fgw_readout_fwd(const float *Y, int B, int K, int N, int d, int mode, 
 int conan_fgw_readout_bwd(const float *Y, const float *dout, int B, int K, int N, int d, int mode, float *dY,
                           void *stream);
 
+/* buf[r,:] = 0 for r in [*m_dev, rows): defines the tail of a worst-case-sized edge buffer without clearing all of it. */
+int conan_zero_tail(float *buf, const int *m_dev, int rows, int width, void *stream);
+
 /* ---------------------------------------------------------------------------------------------- covalent (GAT) branch
  * GATBased (conan_fgw/src/model/graph_embeddings/gat.py:5-25): two PyG-2.3.0 GATConv layers (heads = 1, edge_dim = 3,
  * add_self_loops with fill_value "mean", negative_slope 0.2) on the 2-D bond graph + sum readout; called from
