@@ -53,13 +53,14 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- carve
-    double *vec = reinterpret_cast<double *>(smem);          // [6*N + 8] : u, v, loga, logb, r1/y2, r2/z2, red
+    double *vec = reinterpret_cast<double *>(smem);          // [14*N + 8] : u, v, loga, logb, r1/y2, r2/z2, red, pm[4][N], psm[4][N]
     double *u = vec, *v = vec + N, *loga = vec + 2 * N, *logb = vec + 3 * N, *ra = vec + 4 * N, *rb = vec + 5 * N;
     double *red = vec + 6 * N;
+    double *pm = red + 8, *psm = pm + 4 * N;                  // per-wavefront partial (max, sum) of the log-sum-exp loops
     // LDS_MODE: all four matrices in LDS.  Otherwise only the Sinkhorn cost Mr (read 2x per Sinkhorn iteration, once by
     // rows and once by columns) stays in LDS when it fits (mr_lds); A, base and T live in an L2-resident global scratch.
     char *gs = scratch + (size_t)blockIdx.x * ((size_t)NP * 28);
-    char *ls = smem + (size_t)(6 * N + 8) * 8;
+    char *ls = smem + (size_t)(14 * N + 8) * 8;
     double *Mr = reinterpret_cast<double *>((LDS_MODE || mr_lds) ? ls : gs);
     double *Al = LDS_MODE ? Mr + NP : reinterpret_cast<double *>(gs) + NP;
     double *base = Al + NP;
@@ -132,36 +133,54 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
         // ---- log-domain Sinkhorn (sinkhorn.py:413-433)
         int ii = 0;
         for (; ii < prm.num_iter_max; ++ii) {
-            // v_j = logb_j - logsumexp_i(Mr_ij + u_i): one wavefront per column, lanes over rows
-            for (int j = wave; j < N; j += FGW_WAVES) {
+            // v_j = logb_j - logsumexp_i(Mr_ij + u_i).  lane <-> column (consecutive lanes read consecutive LDS words), the four
+            // wavefronts split the rows (i = wave, wave + 4, ...): serial (max, sum) per thread, no cross-lane fp64 reductions
+            // (a wavefront-per-column mapping spent most of its instructions in 64-bit shuffles); the four partials per column
+            // are combined through LDS.
+            for (int j = lane; j < N; j += 64) {
                 double mx = -1.0e300;
-                for (int i = lane; i < N; i += 64) { const double z = Mr[i * P + j] + u[i]; mx = z > mx ? z : mx; }
-                mx = wave_max_d(mx);
+                for (int i = wave; i < N; i += FGW_WAVES) { const double z = Mr[i * P + j] + u[i]; mx = fmax(z, mx); }
                 double sm = 0.0;
-                for (int i = lane; i < N; i += 64) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
-                sm = wave_sum_d(sm);
-                if (lane == 0) v[j] = logb[j] - (log_acc(sm) + mx);
+                for (int i = wave; i < N; i += FGW_WAVES) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
+                pm[wave * N + j] = mx; psm[wave * N + j] = sm;
             }
             __syncthreads();
-            // u_i = loga_i - logsumexp_j(Mr_ij + v_j): one wavefront per row, lanes over columns
-            for (int i = wave; i < N; i += FGW_WAVES) {
+            for (int j = tid; j < N; j += FGW_THREADS) {
+                const double m0 = pm[j], m1 = pm[N + j], m2 = pm[2 * N + j], m3 = pm[3 * N + j];
+                const double M = fmax(fmax(m0, m1), fmax(m2, m3));
+                const double sm = ((psm[j] * exp_lse(m0 - M) + psm[N + j] * exp_lse(m1 - M)) + psm[2 * N + j] * exp_lse(m2 - M)) +
+                                  psm[3 * N + j] * exp_lse(m3 - M);
+                v[j] = logb[j] - (log_acc(sm) + M);
+            }
+            __syncthreads();
+            // u_i = loga_i - logsumexp_j(Mr_ij + v_j): lane <-> row (odd pitch: conflict-free), wavefronts split the columns
+            for (int i = lane; i < N; i += 64) {
                 double mx = -1.0e300;
-                for (int j = lane; j < N; j += 64) { const double z = Mr[i * P + j] + v[j]; mx = z > mx ? z : mx; }
-                mx = wave_max_d(mx);
+                for (int j = wave; j < N; j += FGW_WAVES) { const double z = Mr[i * P + j] + v[j]; mx = fmax(z, mx); }
                 double sm = 0.0;
-                for (int j = lane; j < N; j += 64) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
-                sm = wave_sum_d(sm);
-                if (lane == 0) u[i] = loga[i] - (log_acc(sm) + mx);
+                for (int j = wave; j < N; j += FGW_WAVES) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
+                pm[wave * N + i] = mx; psm[wave * N + i] = sm;
+            }
+            __syncthreads();
+            for (int i = tid; i < N; i += FGW_THREADS) {
+                const double m0 = pm[i], m1 = pm[N + i], m2 = pm[2 * N + i], m3 = pm[3 * N + i];
+                const double M = fmax(fmax(m0, m1), fmax(m2, m3));
+                const double sm = ((psm[i] * exp_lse(m0 - M) + psm[N + i] * exp_lse(m1 - M)) + psm[2 * N + i] * exp_lse(m2 - M)) +
+                                  psm[3 * N + i] * exp_lse(m3 - M);
+                u[i] = loga[i] - (log_acc(sm) + M);
             }
             __syncthreads();
             if (ii % 10 == 0) {                                 // marginal violation, sinkhorn.py:418-433
-                double e2 = 0.0;
-                for (int j = wave; j < N; j += FGW_WAVES) {
+                for (int j = lane; j < N; j += 64) {
                     double sm = 0.0;
-                    for (int i = lane; i < N; i += 64) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
-                    sm = wave_sum_d(sm);
-                    const double df = sm - exp(logb[j]);
-                    if (lane == 0) e2 += df * df;
+                    for (int i = wave; i < N; i += FGW_WAVES) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
+                    psm[wave * N + j] = sm;
+                }
+                __syncthreads();
+                double e2 = 0.0;
+                for (int j = tid; j < N; j += FGW_THREADS) {
+                    const double df = (((psm[j] + psm[N + j]) + psm[2 * N + j]) + psm[3 * N + j]) - exp(logb[j]);
+                    e2 += df * df;
                 }
                 const double tot = block_sum_d(e2, red);
                 if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
@@ -356,7 +375,7 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
 }
 
 inline int pitch_of(int N) { return N | 1; }
-inline size_t coupling_lds(int N) { return (size_t)(6 * N + 8) * 8 + (size_t)N * pitch_of(N) * 28; }
+inline size_t coupling_lds(int N) { return (size_t)(14 * N + 8) * 8 + (size_t)N * pitch_of(N) * 28; }
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 }  // namespace
@@ -402,7 +421,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     const bool c_lds = lc <= LDS_LIMIT;
     if (c_lds && lc > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
-    const size_t vec_c = (size_t)(6 * N + 8) * 8;
+    const size_t vec_c = (size_t)(14 * N + 8) * 8;
     const size_t mr_bytes = NP * 8;
     const int mr_lds = (!c_lds && vec_c + mr_bytes <= LDS_LIMIT) ? 1 : 0;
     if (mr_lds)
