@@ -97,3 +97,41 @@ def test_gat_isolated_atoms_and_reversed_edge_order():
     r = ref(x, torch.from_numpy(ei), torch.from_numpy(ea), bt)
     assert rel(o1.detach().cpu().double().numpy(), r.detach().numpy()) < 2e-6
     assert torch.equal(o1, o2)                                               # sorted CSR => identical summation order
+
+
+def test_gat_high_degree_rows_and_empty_graph():
+    """Rows with more than 64 incoming edges take the serial path of the kernels (a star with 150 leaves, hub in both roles);
+    a batch without any bond reduces to lin(x) + bias per atom."""
+    from conan_fgw_amd.gat import GATBased
+    from oracle.gat import GATBasedOracle
+    dev = torch.device("cuda:0")
+    n = 160
+    hub = 3
+    leaves = [i for i in range(n) if i != hub][:150]
+    src = leaves + [hub] * len(leaves) + [10, 11]
+    dst = [hub] * len(leaves) + leaves + [11, 10]
+    gen = torch.Generator().manual_seed(4)
+    ei = torch.tensor([src, dst], dtype=torch.int64)
+    ea = torch.randint(0, 4, (ei.shape[1], 3), generator=gen).float()
+    x = torch.randint(0, 6, (n, 9), generator=gen).float()
+    bt = torch.cat([torch.zeros(80, dtype=torch.int64), torch.ones(80, dtype=torch.int64)])
+    torch.manual_seed(2)
+    m = GATBased().to(dev)
+    ref = GATBasedOracle().double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    out = m(x.to(dev), ei.to(dev), ea.to(dev), bt.to(dev), num_graphs=2)
+    r = ref(x, ei, ea, bt)
+    assert rel(out.detach().cpu().double().numpy(), r.detach().numpy()) < 2e-6
+    wgt = torch.randn(2, 64, generator=gen)
+    (out * wgt.to(dev)).sum().backward()
+    (r * wgt.double()).sum().backward()
+    gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
+    gmax = max(float(rp[k].grad.norm()) for k in rp)
+    for k in gp:
+        err = float((gp[k].grad.cpu().double() - rp[k].grad).norm())
+        assert err <= 1e-5 * float(rp[k].grad.norm()) + 1e-6 * gmax, (k, err)
+    # no bonds at all
+    e0 = torch.zeros(2, 0, dtype=torch.int64)
+    o0 = m(x.to(dev), e0.to(dev), torch.zeros(0, 3).to(dev), bt.to(dev), num_graphs=2)
+    r0 = ref(x, e0, torch.zeros(0, 3), bt)
+    assert rel(o0.detach().cpu().double().numpy(), r0.detach().numpy()) < 2e-6
