@@ -653,7 +653,7 @@ static int wgrad_slices(int M, int K) {
 }  // namespace
 
 int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
-                       int act, float *y, const int *m_dev, hipStream_t s, int *rc);      // gemm_t.hip
+                       int act, float *y, const int *m_dev, hipStream_t s, int *rc, float *pre_out);      // gemm_t.hip
 
 extern "C" {
 
@@ -664,7 +664,7 @@ int conan_linear_fwd(const float *x, const float *w, const float *bias, const fl
     hipStream_t s = as_stream(stream);
     {
         int rc = CONAN_OK;
-        if (conan_linear_t_try(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, &rc)) return rc;   // K, N in {64,128}
+        if (conan_linear_t_try(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, &rc, nullptr)) return rc;   // K, N multiples of 64
     }
     if (K <= 128 && N <= 128 && (K % BK) == 0) {
         const int Kp = (K + BK - 1) / BK * BK;
@@ -691,6 +691,15 @@ int conan_linear_fwd(const float *x, const float *w, const float *bias, const fl
     }
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
+}
+
+int conan_linear_act_fwd(const float *x, const float *w, const float *bias, int M, int K, int N, int act, const int *m_dev, float *y,
+                         float *pre, void *stream) {
+    if (!x || !w || !y || !pre || M < 0 || K <= 0 || N <= 0 || (act != 1 && act != 3)) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    int rc = CONAN_OK;
+    if (conan_linear_t_try(x, w, bias, nullptr, M, K, N, 0, act, y, m_dev, as_stream(stream), &rc, pre)) return rc;
+    return CONAN_E_UNSUPPORTED;
 }
 
 int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream) {

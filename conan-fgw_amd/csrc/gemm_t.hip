@@ -39,10 +39,11 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
                                                            int M, int w_kn, float *y,
                                                            const int *__restrict__ m_dev, int ldx, int ldw, int ldy,
-                                                           const float *accum) {
+                                                           const float *accum, float *pre_out) {
     // ldx / ldw / ldy: row pitches of x, w and of y / residual / accum — the launcher tiles wider layers into 64/128-wide
     // (K, N) chunks of one strided problem; `accum` (may alias y) carries the partial sum of the previous K chunks and is
-    // added BEFORE the activation.
+    // added BEFORE the activation.  pre_out (nullable): also store the pre-activation (bias and accum included), which the
+    // backward of a SiLU layer needs — one extra store instead of a separate activation kernel re-reading it.
     constexpr int act = ACT;
     constexpr int NB = N / 32;
     constexpr int S = K / 16;             // MFMA k-steps
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
                     const float4 av = *reinterpret_cast<const float4 *>(ar + 32 * nb + 8 * q);
                     v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w;
                 }
+                if (pre_out) *reinterpret_cast<float4 *>(pre_out + (size_t)m * ldy + 4 * h + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
                 const float r4[4] = {rr ? rv[nb][q].x : 0.f, rr ? rv[nb][q].y : 0.f, rr ? rv[nb][q].z : 0.f, rr ? rv[nb][q].w : 0.f};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -284,11 +286,11 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t(const float *__restrict
 
 template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
-             const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr) {
+             const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr) {
     if (ldw == 0) ldw = w_kn ? N : K;
     // CONAN_LINEAR_FP32=1 forces the plain fp32-MFMA kernel (default: exact 3-way bf16 split on the bf16 MFMA)
     static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
-    if (!fp32_only || ldx != K || ldy != N || accum) {
+    if (!fp32_only || ldx != K || ldy != N || accum || pre_out) {
         const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
         const int tiles16 = (M + 31) / 32;
         int grid16 = (tiles16 + 7) / 8;
@@ -297,7 +299,7 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     do {                                                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds16);                                                                                   \
-        k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum);   \
+        k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out); \
     } while (0)
         switch (act) {
             case 0: LAUNCH16(0); break;
@@ -325,31 +327,33 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
 // bias enters with the first k chunk, activation and residual with the last.
 template <int KC, int NC>
 static int chunk_launch(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn, int act,
-                        float *y, const int *m_dev, hipStream_t s) {
+                        float *y, const int *m_dev, hipStream_t s, float *pre_out) {
     for (int n0 = 0; n0 < N; n0 += NC)
         for (int k0 = 0; k0 < K; k0 += KC) {
             const bool first = k0 == 0, last = k0 + KC >= K;
             const float *wc = w_kn ? w + (size_t)k0 * N + n0 : w + (size_t)n0 * K + k0;
             const int rc = launch_t<KC, NC>(x + k0, wc, (first && bias) ? bias + n0 : nullptr, (last && residual) ? residual + n0 : nullptr, M, w_kn,
-                                            last ? act : 0, y + n0, m_dev, s, K, w_kn ? N : K, N, first ? nullptr : y + n0);
+                                            last ? act : 0, y + n0, m_dev, s, K, w_kn ? N : K, N, first ? nullptr : y + n0,
+                                            (last && pre_out) ? pre_out + n0 : nullptr);
             if (rc != CONAN_OK) return rc;
         }
     return CONAN_OK;
 }
 
 int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
-                       int act, float *y, const int *m_dev, hipStream_t s, int *rc) {
+                       int act, float *y, const int *m_dev, hipStream_t s, int *rc, float *pre_out) {
     if (M < 1) return 0;
-    if (K == 128 && N == 128) { *rc = launch_t<128, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
-    if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
-    if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
-    if (K == 64 && N == 128) { *rc = launch_t<64, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s); return 1; }
+    if (K == 128 && N == 128) { *rc = launch_t<128, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 128, 0, 128, nullptr, pre_out); return 1; }
+    if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 128, 0, 64, nullptr, pre_out); return 1; }
+    if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 64, nullptr, pre_out); return 1; }
+    if (K == 64 && N == 128) { *rc = launch_t<64, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 128, nullptr, pre_out); return 1; }
     static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
     if (fp32_only || (K % 64) || (N % 64) || K > 1024 || N > 1024) return 0;
+    // (fp32_only with pre_out on the four base shapes above still runs the split kernel: launch_t routes it there)
     const bool k128 = (K % 128) == 0, n128 = (N % 128) == 0;
-    if (k128 && n128) *rc = chunk_launch<128, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
-    else if (k128) *rc = chunk_launch<128, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
-    else if (n128) *rc = chunk_launch<64, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
-    else *rc = chunk_launch<64, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s);
+    if (k128 && n128) *rc = chunk_launch<128, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);
+    else if (k128) *rc = chunk_launch<128, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);
+    else if (n128) *rc = chunk_launch<64, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);
+    else *rc = chunk_launch<64, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);
     return 1;
 }

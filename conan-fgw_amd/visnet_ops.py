@@ -50,7 +50,49 @@ def silu(x, m_dev=None):
     return _Silu.apply(x, m_dev)
 
 
+class _LinearSilu(torch.autograd.Function):
+    """silu(x W^T + b) in one launch.  With gradients the kernel also stores the pre-activation (conan_linear_act_fwd); without,
+    it is the plain fused act = 3 epilogue.  Backward: g = dy * silu'(pre) (conan_silu_bwd), then the usual dx / weight-gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, m_dev):
+        x, w = _c(x), _c(w)
+        M, K = x.shape
+        N = w.shape[0]
+        need = any(ctx.needs_input_grad[:3])
+        y = _tail0_shape(M, N, x.device, m_dev)
+        if need:
+            pre = torch.empty(M, N, dtype=f32, device=x.device)
+            call("conan_linear_act_fwd", ptr(x, f32), ptr(w, f32), ptr(b), M, K, N, 3, ptr(m_dev), ptr(y), ptr(pre), stream_ptr())
+            ctx.save_for_backward(x, w, pre)
+        else:
+            call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), None, M, K, N, 0, 3, ptr(m_dev), ptr(y), stream_ptr())
+        ctx.m_dev, ctx.has_b = m_dev, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        md = ctx.m_dev
+        M, K = x.shape
+        N = w.shape[0]
+        g = _tail0(pre, md)
+        call("conan_silu_bwd", ptr(pre), ptr(_c(dy)), M, N, ptr(md), ptr(g), stream_ptr())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _tail0_shape(M, K, x.device, md)
+            call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            ws = torch.empty(int(lib().conan_linear_wgrad_ws(M, K, N)), dtype=f32, device=x.device)
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=f32, device=x.device) if ctx.has_b else None
+            call("conan_linear_wgrad", ptr(g), ptr(x), M, K, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
+        return dx, dw, db, None
+
+
 def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Tensor:
+    if act_silu and x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0:
+        return _LinearSilu.apply(x, m.weight, m.bias, m_dev)
     y = ops.linear(x, m.weight, m.bias, m_dev=m_dev)
     return silu(y, m_dev) if act_silu else y
 

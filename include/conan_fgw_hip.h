@@ -91,6 +91,12 @@ int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int 
 int conan_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N,
                      int w_kn, int act, const int *m_dev, float *y, void *stream);
 
+/* Same Linear with an activation (1 = shifted softplus, 3 = SiLU) that ALSO stores the pre-activation x W^T + b in `pre` — what the
+ * backward of a SiLU layer needs (silu' is not a function of the output) — with one extra store instead of a separate
+ * activation kernel re-reading the GEMM result.  K and N multiples of 64 (else CONAN_E_UNSUPPORTED: compose it). */
+int conan_linear_act_fwd(const float *x, const float *w, const float *bias, int M, int K, int N, int act, const int *m_dev,
+                         float *y, float *pre, void *stream);
+
 /* g[rows,width] = dy * ssp'(v) computed from the layer OUTPUT y (ssp'(v) = sigmoid(v) = 1 - 0.5*exp(-y)). In place allowed. */
 int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream);
 /* dW[N,K] = g^T @ x and dbias[N] = column sums of g (dbias nullable), deterministic two-stage reduction (no float
