@@ -45,6 +45,8 @@ SIGNATURES = {
     "conan_gat_bwd_ws": (c_ll, [c_int, c_int, c_int, c_int]),
     "conan_gat_aggregate_bwd": (c_int, [_P] * 15 + [c_int, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "conan_linear_act_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "conan_unary_fwd": (c_int, [_P, c_ll, c_int, _P, _P]),
+    "conan_unary_bwd": (c_int, [_P, _P, c_ll, c_int, _P, _P]),
     "conan_zero_tail": (c_int, [_P, _P, c_int, c_int, _P]),
     "conan_rbf_wgrad": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),

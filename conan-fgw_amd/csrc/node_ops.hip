@@ -80,6 +80,24 @@ __global__ void __launch_bounds__(64) k_segment_bcast(const float *__restrict__ 
     }
 }
 
+// ReLU / sigmoid of the classification head (schnet_based_models.py:31-45,367): tiny [B, width] tensors.  Backward from the OUTPUT:
+// relu' = (y > 0), sigmoid' = y (1 - y).
+template <int OP>      // 0 = relu, 1 = sigmoid
+__global__ void k_unary_fwd(const float *__restrict__ x, long long n, float *__restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = OP == 0 ? fmaxf(v, 0.f) : 1.0f / (1.0f + expf(-v));
+    }
+}
+template <int OP>
+__global__ void k_unary_bwd(const float *__restrict__ y, const float *__restrict__ dy, long long n, float *__restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float o = y[i];
+        dx[i] = OP == 0 ? (o > 0.f ? dy[i] : 0.f) : dy[i] * o * (1.0f - o);
+    }
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -127,6 +145,26 @@ int conan_segment_sum_bwd(const float *dout, const int *graph_ptr, int num_graph
     if (!dout || !graph_ptr || !dx || num_graphs < 0 || width <= 0) return CONAN_E_BADARG;
     if (num_graphs == 0) return CONAN_OK;
     k_segment_bcast<<<num_graphs, 64, 0, as_stream(stream)>>>(dout, graph_ptr, width, dx);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_unary_fwd(const float *x, long long count, int op, float *y, void *stream) {
+    if (count < 0 || op < 0 || op > 1 || (count && (!x || !y))) return CONAN_E_BADARG;
+    if (!count) return CONAN_OK;
+    const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
+    if (op == 0) k_unary_fwd<0><<<blocks, 256, 0, as_stream(stream)>>>(x, count, y);
+    else k_unary_fwd<1><<<blocks, 256, 0, as_stream(stream)>>>(x, count, y);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_unary_bwd(const float *y, const float *dy, long long count, int op, float *dx, void *stream) {
+    if (count < 0 || op < 0 || op > 1 || (count && (!y || !dy || !dx))) return CONAN_E_BADARG;
+    if (!count) return CONAN_OK;
+    const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
+    if (op == 0) k_unary_bwd<0><<<blocks, 256, 0, as_stream(stream)>>>(y, dy, count, dx);
+    else k_unary_bwd<1><<<blocks, 256, 0, as_stream(stream)>>>(y, dy, count, dx);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -125,3 +125,65 @@ class EmbeddingsWithGATAggregation(EmbeddingsWithGATAggregationBaryCenter):
             raise ValueError("conformers_index must have one entry per conformer graph")
         x = x.view(G // K, K, d).mean(dim=1)                                                                           # :238
         return ops.linear(x.contiguous(), self.molecular_regression_lin.weight, self.molecular_regression_lin.bias)    # :239
+
+
+class _SelfAttentionParams(torch.nn.Module):
+    """`SelfAttention(out_channels)` (attention_layer.py:17-33): the classification model constructs it (:336) but never calls
+    it in forward; it exists here so that the reference's state_dict loads strictly."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.query, self.key, self.value = Linear(dim, dim), Linear(dim, dim), Linear(dim, dim)
+
+
+class EmbeddingsWithGATAggregationClassificationBaryCenter(EmbeddingsWithGATAggregationBaryCenter):
+    """Classification twin (schnet_based_models.py:308-369 on EquivAggregationClassification, common.py:426-466): SchNet with
+    hidden 512 / 256 filters / 10 gaussians / cutoff 10 (common.py:513-522), 256-wide GAT and transformations, the three-layer
+    ReLU MLP of `build_mlp_class(is_complex=True)` (:31-45) and a sigmoid (:367).  Sub-module names as in the reference
+    (`molecular_regression_lin.{0,2,4}`, `self_attention.*`)."""
+
+    def __init__(self, num_conformers: int, device=None, agg_weight: float = 0.2, gat_in_channels: int = 9):
+        torch.nn.Module.__init__(self)
+        from .gat import GATBased
+        from .schnet import SchNetNoSum
+        self.num_conformers = num_conformers
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.node_embeddings_model = SchNetNoSum(device, hidden_channels=512, cutoff=10.0, num_gaussians=10, num_filters=256,
+                                                 num_interactions=3)                       # get_model("schnet", feat_dim=512, cutoff=10.0)
+        out_channels = self.node_embeddings_model.hidden_channels // 2                      # 256
+        self.gat_embeddings_model = GATBased(out_channels=512 // 2, in_channels=gat_in_channels)    # get_model("gat", feat_dim=512)
+        self.transformation_matrix_3d = Linear(out_channels, out_channels)
+        self.transformation_matrix_cov = Linear(out_channels, out_channels)
+        self.transformation_matrix_bary = Linear(out_channels, out_channels)
+        self.molecular_regression_lin = torch.nn.Sequential(                                # build_mlp_class(out_channels, is_complex=True)
+            Linear(out_channels, out_channels), torch.nn.ReLU(), Linear(out_channels, out_channels // 2), torch.nn.ReLU(),
+            Linear(out_channels // 2, 1))
+        self.self_attention = _SelfAttentionParams(out_channels)
+        self.numItermax, self.epsilon, self.agg_weight = 100, 0.1, agg_weight
+
+    def forward(self, batch, conformers_index: Tensor, node_index: Tensor, num_graphs: int = None, max_nodes: int = None) -> Tensor:
+        K = self.num_conformers
+        main = torch.cuda.current_stream()
+        side = self._side_stream(main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                                                                                # covalent branch next to the 3-D branch
+            x_cov = self.gat_embeddings_model(batch.x, batch.edge_index, batch.edge_attr, batch.batch,
+                                              **({"num_graphs": num_graphs} if num_graphs is not None else {}))     # :359-361
+            x_cov = ops.linear(x_cov, self.transformation_matrix_cov.weight, self.transformation_matrix_cov.bias)   # :362
+        x_3d, x_bary = self.node_embeddings_model.forward_w_barycenter(
+            z=batch.z, pos=batch.pos, num_conformers=K, batch=node_index,
+            **({"num_graphs": num_graphs, "max_nodes": max_nodes} if num_graphs is not None else {}))             # :351-353
+        x_3d = ops.linear(x_3d, self.transformation_matrix_3d.weight, self.transformation_matrix_3d.bias)          # :356
+        x_bary = ops.linear(x_bary, self.transformation_matrix_bary.weight, self.transformation_matrix_bary.bias)  # :357
+        main.wait_stream(side)
+        x_cov.record_stream(main)
+        x = x_3d + x_cov + self.agg_weight * x_bary                                                                   # :364
+        G, d = x.shape
+        if conformers_index is not None and conformers_index.numel() != G:
+            raise ValueError("conformers_index must have one entry per conformer graph")
+        x = x.view(G // K, K, d).mean(dim=1).contiguous()                                                             # :365
+        mlp = self.molecular_regression_lin
+        x = ops.relu(ops.linear(x, mlp[0].weight, mlp[0].bias))                                                       # :366
+        x = ops.relu(ops.linear(x, mlp[2].weight, mlp[2].bias))
+        x = ops.linear(x, mlp[4].weight, mlp[4].bias)
+        return ops.sigmoid(x)                                                                                         # :367

@@ -152,6 +152,32 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: bool =
     return _LinearFn.apply(x, weight, bias, residual, 1 if act else 0, m_dev)
 
 
+class _UnaryFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("conan_unary_fwd", ptr(x, f32), x.numel(), op, ptr(y), stream_ptr())
+        ctx.op = op
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        call("conan_unary_bwd", ptr(y), ptr(_c(dy)), y.numel(), ctx.op, ptr(dx), stream_ptr())
+        return dx, None
+
+
+def relu(x: Tensor) -> Tensor:
+    return _UnaryFn.apply(x, 0)
+
+
+def sigmoid(x: Tensor) -> Tensor:
+    return _UnaryFn.apply(x, 1)
+
+
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, weight, padding_idx):

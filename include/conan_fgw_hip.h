@@ -302,6 +302,11 @@ int conan_fgw_readout_fwd(const float *Y, int B, int K, int N, int d, int mode, 
 int conan_fgw_readout_bwd(const float *Y, const float *dout, int B, int K, int N, int d, int mode, float *dY,
                           void *stream);
 
+/* Elementwise activations of the classification head (build_mlp_class + torch.sigmoid, schnet_based_models.py:31-45,367):
+ * op 0 = ReLU, 1 = sigmoid; the backward takes the forward OUTPUT y (relu' = [y > 0], sigmoid' = y (1 - y)). */
+int conan_unary_fwd(const float *x, long long count, int op, float *y, void *stream);
+int conan_unary_bwd(const float *y, const float *dy, long long count, int op, float *dx, void *stream);
+
 /* buf[r,:] = 0 for r in [*m_dev, rows): defines the tail of a worst-case-sized edge buffer without clearing all of it. */
 int conan_zero_tail(float *buf, const int *m_dev, int rows, int width, void *stream);
 

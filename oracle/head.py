@@ -48,3 +48,29 @@ class Stage1Oracle(Stage2Oracle):
         h = x_3d + x_cov
         h = h.view(h.shape[0] // K, K, -1).mean(1)
         return self.molecular_regression_lin(h)
+
+
+class Stage2ClassificationOracle(nn.Module):
+    """EmbeddingsWithGATAggregationClassificationBaryCenter.forward (schnet_based_models.py:350-369): SchNet 512 / 256 filters /
+    10 gaussians (common.py:513-522), 256-wide branches, build_mlp_class(is_complex=True) (:31-45), sigmoid."""
+
+    def __init__(self, num_conformers: int, agg_weight: float = 0.2, gat_in_channels: int = 9):
+        super().__init__()
+        self.num_conformers, self.agg_weight = num_conformers, agg_weight
+        self.node_embeddings_model = SchNetNoSumOracle(512, 256, 3, num_gaussians=10, cutoff=10.0)
+        self.gat_embeddings_model = GATBasedOracle(256, 3, gat_in_channels)
+        self.transformation_matrix_3d = nn.Linear(256, 256)
+        self.transformation_matrix_cov = nn.Linear(256, 256)
+        self.transformation_matrix_bary = nn.Linear(256, 256)
+        self.molecular_regression_lin = nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 1))
+        self.self_attention = nn.ModuleDict({"query": nn.Linear(256, 256), "key": nn.Linear(256, 256), "value": nn.Linear(256, 256)})
+
+    def forward(self, z, pos, node_index, x, edge_index, edge_attr):
+        K = self.num_conformers
+        x_3d, x_bary = self.node_embeddings_model.forward_w_barycenter(z, pos, K, node_index)
+        x_3d = self.transformation_matrix_3d(x_3d)
+        x_bary = self.transformation_matrix_bary(x_bary)
+        x_cov = self.transformation_matrix_cov(self.gat_embeddings_model(x, edge_index, edge_attr, node_index))
+        h = x_3d + x_cov + self.agg_weight * x_bary
+        h = h.view(h.shape[0] // K, K, -1).mean(1)
+        return torch.sigmoid(self.molecular_regression_lin(h))

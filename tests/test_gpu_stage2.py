@@ -97,3 +97,38 @@ def test_stage1_model_and_checkpoint_round_trip_into_stage2(tmp_path):
     with torch.no_grad():
         y2 = m2(batch, cidx, batch.batch)
     assert y2.shape == y.shape and torch.isfinite(y2).all()
+
+
+def test_classification_stage2_matches_oracle():
+    """Classification twin (SchNet 512 / 256 filters / 10 gaussians, 256-wide GAT, ReLU MLP, sigmoid; schnet_based_models.py:308-369):
+    probabilities within 1e-4 of the fp64 oracle, BCE gradients of parameters of every branch within 1e-4, strict state_dict."""
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationClassificationBaryCenter
+    from oracle.head import Stage2ClassificationOracle
+    dev = torch.device("cuda:0")
+    K = 3
+    b = make_batch("esol", 4, K, seed=41)
+    g = make_bond_graph(b, seed=42)
+    torch.manual_seed(9)
+    m = EmbeddingsWithGATAggregationClassificationBaryCenter(K, dev).to(dev)
+    ref = Stage2ClassificationOracle(K).double()
+    res = ref.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert m.node_embeddings_model.hidden_channels == 512 and m.molecular_regression_lin[2].weight.shape == (128, 256)
+    t = lambda a: torch.from_numpy(a)
+    batch = types.SimpleNamespace(z=t(b.z).to(dev), pos=t(b.pos).to(dev), x=t(g.x).to(dev), edge_index=t(g.edge_index).to(dev),
+                                  edge_attr=t(g.edge_attr).to(dev), batch=t(b.batch).to(dev))
+    p = m(batch, m.create_aggregation_index(b.num_graphs, dev), batch.batch)
+    r = ref(t(b.z), t(b.pos).double(), t(b.batch), t(g.x), t(g.edge_index), t(g.edge_attr))
+    assert p.shape == (b.num_molecules, 1) and float(p.detach().min()) > 0.0 and float(p.detach().max()) < 1.0
+    assert rel(p.detach().cpu().double().numpy(), r.detach().numpy()) < 1e-4
+    lab = torch.tensor([[1.0], [0.0], [1.0], [0.0]])
+    torch.nn.functional.binary_cross_entropy(p, lab.to(dev)).backward()
+    torch.nn.functional.binary_cross_entropy(r, lab.double()).backward()
+    gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
+    gmax = max(float(q.grad.norm()) for q in rp.values() if q.grad is not None)
+    for k in ["molecular_regression_lin.0.weight", "molecular_regression_lin.4.bias", "transformation_matrix_bary.weight",
+              "gat_embeddings_model.gat_conv2.lin_src.weight", "node_embeddings_model.lin2_bary.weight",
+              "node_embeddings_model.interactions.2.mlp.2.weight", "node_embeddings_model.interactions.0.conv.lin1.weight"]:
+        err = float((gp[k].grad.cpu().double() - rp[k].grad).norm())
+        assert err <= 1e-4 * float(rp[k].grad.norm()) + 1e-6 * gmax, (k, err, float(rp[k].grad.norm()))
+    assert m.self_attention.query.weight.grad is None                       # constructed, never used (like the reference)
