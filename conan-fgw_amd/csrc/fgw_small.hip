@@ -237,38 +237,69 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
     const int N = D.N, d = D.d, K = D.K, NN = N * N, Nd = N * d;
     const int tid = threadIdx.x;
     double ef2 = 0.0, es2 = 0.0;
+    // The K contributions of U consecutive elements per thread are requested together (K * U loads in flight): the kernel is a
+    // handful of L2 round trips per molecule, so its time is the number of dependent trips, not the byte count.
+    constexpr int U = 4;
     if (!prm.fixed_features) {
         double *Yb = Yw + (size_t)b * Nd;
-        for (int t = tid; t < Nd; t += FGW_THREADS) {
-            const int i = t / d;
-            const double pinv = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
-            double acc = 0.0;
-            for (int s = 0; s < K; ++s) {
-                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
-                acc += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;              // utils.py:94
+        for (int t0 = tid; t0 < Nd; t0 += U * FGW_THREADS) {
+            double acc[U], old[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * FGW_THREADS;
+                acc[u] = 0.0; old[u] = 0.0;
+                if (t < Nd) {
+                    old[u] = Yb[t];
+                    for (int s = 0; s < K; ++s) {
+                        const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                        const int i = t / d;
+                        const double pinv = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
+                        acc[u] += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;          // utils.py:94
+                    }
+                }
             }
-            const double df = acc - Yb[t];
-            ef2 += df * df;
-            Yb[t] = acc;
-            Yout[(size_t)b * Nd + t] = (float)acc;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * FGW_THREADS;
+                if (t < Nd) {
+                    const double df = acc[u] - old[u];
+                    ef2 += df * df;
+                    Yb[t] = acc[u];
+                    Yout[(size_t)b * Nd + t] = (float)acc[u];
+                }
+            }
         }
     }
     if (!prm.fixed_structure) {
         double *Cb = Cw + (size_t)b * NN;
-        for (int t = tid; t < NN; t += FGW_THREADS) {
-            const int i = t / N, j = t - i * N;
-            const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
-            const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
-            double acc = 0.0;
-            for (int s = 0; s < K; ++s) {
-                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
-                acc += lam * Cpart[((size_t)b * K + s) * NN + t];                     // utils.py:70
+        for (int t0 = tid; t0 < NN; t0 += U * FGW_THREADS) {
+            double acc[U], old[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * FGW_THREADS;
+                acc[u] = 0.0; old[u] = 0.0;
+                if (t < NN) {
+                    old[u] = Cb[t];
+                    for (int s = 0; s < K; ++s) {
+                        const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                        acc[u] += lam * Cpart[((size_t)b * K + s) * NN + t];                 // utils.py:70
+                    }
+                }
             }
-            const double cn = acc / (pi * pj);                                         // :72-73
-            const double df = cn - Cb[t];
-            es2 += df * df;
-            Cb[t] = cn;
-            Cout[(size_t)b * NN + t] = (float)cn;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * FGW_THREADS;
+                if (t < NN) {
+                    const int i = t / N, j = t - i * N;
+                    const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+                    const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
+                    const double cn = acc[u] / (pi * pj);                                      // :72-73
+                    const double df = cn - old[u];
+                    es2 += df * df;
+                    Cb[t] = cn;
+                    Cout[(size_t)b * NN + t] = (float)cn;
+                }
+            }
         }
     }
     const double ef = sqrt(block_sum_d(ef2, red));
