@@ -18,6 +18,7 @@ def test_oracle_gat_softmax_rows_and_self_loops():
     assert torch.allclose(out[3], h[3] + conv.bias) and torch.allclose(out[4], h[4] + conv.bias)     # nodes 3, 4 have no bonds
     # node 0 has one neighbour: out_0 is a convex combination of h_0 and h_1
     w = torch.linalg.lstsq(torch.stack([h[0], h[1]], 1), (out[0] - conv.bias)[:, None]).solution.flatten()
+    w = w.detach()
     assert abs(float(w.sum()) - 1.0) < 1e-9 and (w > 0).all()
 
 
