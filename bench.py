@@ -81,7 +81,15 @@ def cpu_baseline(args, mode, gpu_model=None):
     while time.perf_counter() - t0 < args.cpu_seconds:
         step(); n += 1
     dt = time.perf_counter() - t0
+    # the same oracle, forward only (end-to-end forward next to the training step), ~3 s
+    with torch.no_grad():
+        m(z, pos, batch, bx, bei, bea)
+        tf0 = time.perf_counter(); nfw = 0
+        while time.perf_counter() - tf0 < min(3.0, args.cpu_seconds):
+            m(z, pos, batch, bx, bei, bea); nfw += 1
+        fwd_rate = nb * nfw / (time.perf_counter() - tf0)
     out = {"value": round(nb * n / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+           "forward_only_molecules_per_s": round(fwd_rate, 3),
            "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32 (SchNet + FGW + GAT + head), "
                      f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; FGW = scalar C restatement"}
     if gpu_model is not None and args.model == "schnet":
