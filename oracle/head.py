@@ -17,10 +17,14 @@ from .schnet import SchNetNoSumOracle
 
 
 class Stage2Oracle(nn.Module):
-    def __init__(self, num_conformers: int, agg_weight: float = 0.2, gat_in_channels: int = 9):
+    def __init__(self, num_conformers: int, agg_weight: float = 0.2, gat_in_channels: int = 9, model_name: str = "schnet"):
         super().__init__()
         self.num_conformers, self.agg_weight = num_conformers, agg_weight
-        self.node_embeddings_model = SchNetNoSumOracle(128, 128, 3)
+        if model_name == "visnet":                                  # EquivModelsHolder.get_model("visnet", feat_dim=128), common.py:542-546
+            from .visnet import ViSNetOracle
+            self.node_embeddings_model = ViSNetOracle(128)
+        else:
+            self.node_embeddings_model = SchNetNoSumOracle(128, 128, 3)
         self.gat_embeddings_model = GATBasedOracle(64, 3, gat_in_channels)
         self.transformation_matrix_3d = nn.Linear(64, 64)
         self.transformation_matrix_bary = nn.Linear(64, 64)

@@ -132,3 +132,26 @@ def test_classification_stage2_matches_oracle():
         err = float((gp[k].grad.cpu().double() - rp[k].grad).norm())
         assert err <= 1e-4 * float(rp[k].grad.norm()) + 1e-6 * gmax, (k, err, float(rp[k].grad.norm()))
     assert m.self_attention.query.weight.grad is None                       # constructed, never used (like the reference)
+
+
+def test_stage2_with_visnet_backbone_matches_oracle():
+    """model_name="visnet" (common.py:542-546): the same stage-2 assembly on the ViSNet backbone; BACE-sized conformers."""
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from oracle.head import Stage2Oracle
+    dev = torch.device("cuda:0")
+    K = 2
+    b = make_batch("bace", 2, K, seed=61)
+    g = make_bond_graph(b, seed=62)
+    torch.manual_seed(4)
+    m = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name="visnet").to(dev)
+    ref = Stage2Oracle(K, model_name="visnet").double()
+    res = ref.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    t = lambda a: torch.from_numpy(a)
+    batch = types.SimpleNamespace(z=t(b.z).to(dev), pos=t(b.pos).to(dev), x=t(g.x).to(dev), edge_index=t(g.edge_index).to(dev),
+                                  edge_attr=t(g.edge_attr).to(dev), batch=t(b.batch).to(dev))
+    with torch.no_grad():
+        y = m(batch, m.create_aggregation_index(b.num_graphs, dev), batch.batch)
+        r = ref(t(b.z), t(b.pos).double(), t(b.batch), t(g.x), t(g.edge_index), t(g.edge_attr))
+    assert y.shape == (b.num_molecules, 1)
+    assert rel(y.cpu().double().numpy(), r.numpy()) < 1e-4
