@@ -1,5 +1,9 @@
 """Capture one whole training step (forward, backward, gradient pack, fused Adam) of the stage-2 model into a HIP graph and
-compare replay time with eager execution."""
+compare replay time with eager execution.
+
+Note: every eager step before the capture runs on a side stream (the PyTorch recipe).  Capturing after steps that ran on the
+legacy default stream leaves AccumulateGrad nodes bound to that stream and capture_end crashes — which is why bench.py does not
+do this in-process after its eager measurement."""
 import os, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
