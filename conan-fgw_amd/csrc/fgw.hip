@@ -39,7 +39,7 @@ __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict
 // ------------------------------------------------------------------------------------------------ coupling solve
 // One workgroup per (molecule b, input graph s).  Matrices (pitch P): Tl fp32, Mr/Al/base fp64.
 // LDS_MODE: the four matrices live in LDS; otherwise in a per-workgroup global scratch (large N).
-template <bool LDS_MODE>
+template <bool LDS_MODE, bool KL>      // KL: loss_fun = "kl_loss", see fgw_small.hip
 __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
         double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
         for (int k = 0; k < N; ++k) {
             const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
-            r1 += c1 * c1 * u[k];
-            r2 += v[k] * (c2 * c2);
+            r1 += (KL ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * u[k];
+            r2 += v[k] * (KL ? c2 : c2 * c2);
         }
         for (int c = 0; c < d; ++c) {
             const double yy = Y[i * d + c], zz = (double)Z[i * d + c];
@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
         mm_f64(N, N, N, [&](int i, int k) { return C1[i * N + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
                [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return 2.0 * (double)C2[j * N + k]; },
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
+               [&](int k, int j) { const double cv = (double)C2[j * N + k]; return KL ? log(cv + 1e-15) : 2.0 * cv; },
                [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
         for (int i = tid; i < N; i += FGW_THREADS) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
         __syncthreads();
@@ -211,7 +212,8 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     }
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int j) { return (double)C2[k * N + j]; },
+        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
+               [&](int k, int j) { const double cv = (double)C2[k * N + j]; return KL ? log(cv > 1e-15 ? cv : 1e-15) : cv; },
                [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
         mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
@@ -415,27 +417,41 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     double *Ypart = reinterpret_cast<double *>(w);
     double *Cpart = Ypart + (size_t)B * K * N * d;
     const bool small = conan_fgw_small_supported(N, d);
+    const bool kl = params->loss_fun != 0;
+    if (params->loss_fun != 0 && params->loss_fun != 1) return CONAN_E_BADARG;
 
     k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
     const size_t lc = coupling_lds(N);
     const bool c_lds = lc <= LDS_LIMIT;
     if (c_lds && lc > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+    }
     const size_t vec_c = (size_t)(14 * N + 8) * 8;
     const size_t mr_bytes = NP * 8;
     const int mr_lds = (!c_lds && vec_c + mr_bytes <= LDS_LIMIT) ? 1 : 0;
     if (mr_lds)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(vec_c + mr_bytes));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(vec_c + mr_bytes));
+    }
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         if (small)
             conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, s);
+        else if (c_lds && kl)
+            k_fgw_coupling<true, true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
         else if (c_lds)
-            k_fgw_coupling<true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
+            k_fgw_coupling<true, false><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
+        else if (kl)
+            k_fgw_coupling<false, true><<<B * K, FGW_THREADS, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
+                                                                                                     active, T, info, sc_c, mr_lds, Ypart, Cpart);
         else
-            k_fgw_coupling<false><<<B * K, FGW_THREADS, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
-                                                                                               active, T, info, sc_c, mr_lds, Ypart, Cpart);
+            k_fgw_coupling<false, false><<<B * K, FGW_THREADS, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
+                                                                                                      active, T, info, sc_c, mr_lds, Ypart, Cpart);
         conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, s);
     }
     CONAN_LAUNCH_CHECK();

@@ -15,7 +15,11 @@
 
 namespace {
 
-template <int R>
+// KL = true: loss_fun = "kl_loss" (utils.py:20-32,76-87): f1(a) = a log(a + 1e-15) - a, f2(b) = b, h2(b) = log(b + 1e-15) in the
+// gradient, log(clamp(C_s, 1e-15)) in the structure update (exp applied by the update kernel).  The logarithms are evaluated in
+// fp64 where the operand is fetched (the kl path is a capability of the signature, not a tuned path); KL = false compiles to
+// exactly the square-loss kernel.
+template <int R, bool KL>
 __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_small(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
         double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
         for (int k = 0; k < N; ++k) {
             const double c1 = C1l[tid * P + k], c2 = (double)C2l[tid * P + k];
-            r1 += c1 * c1 * pq[k]; r2 += pq[64 + k] * (c2 * c2);
+            r1 += (KL ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * pq[k]; r2 += pq[64 + k] * (KL ? c2 : c2 * c2);
         }
         for (int c = 0; c < d; ++c) { const double yy = y_zero ? 0.0 : Y[(size_t)tid * d + c], zz = (double)Z[(size_t)tid * d + c]; y2 += yy * yy; z2 += zz * zz; }
         pm[tid] = r1; pm[64 + tid] = r2; psum[tid] = y2; psum[64 + tid] = z2;
@@ -118,8 +122,9 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
         mm_f64(N, N, N, [&](int i, int k) { return C1l[i * P + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
                [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
         __syncthreads();
-        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)C2l[j * P + k]; },
-               [&](int i, int j, double v) { Gl[i * P + j] = 2.0 * v; }, bnn);
+        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
+               [&](int k, int j) { const double cv = (double)C2l[j * P + k]; return KL ? log(cv + 1e-15) : cv; },
+               [&](int i, int j, double v) { Gl[i * P + j] = KL ? v : 2.0 * v; }, bnn);
         __syncthreads();
         // ---- Mr = -(base - 2 alpha G)/eps in both layouts (sinkhorn.py:388)
         double mA[R], mB[R];
@@ -218,7 +223,8 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     }
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int j) { return (double)C2l[k * P + j]; },
+        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
+               [&](int k, int j) { const double cv = (double)C2l[k * P + j]; return KL ? log(cv > 1e-15 ? cv : 1e-15) : cv; },
                [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
         __syncthreads();
         mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
@@ -293,7 +299,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
                     const int i = t / N, j = t - i * N;
                     const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
                     const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
-                    const double cn = acc[u] / (pi * pj);                                      // :72-73
+                    const double cn = prm.loss_fun ? exp(acc[u] / (pi * pj)) : acc[u] / (pi * pj);     // :72-73 / :86-87
                     const double df = cn - old[u];
                     es2 += df * df;
                     Cb[t] = cn;
@@ -334,15 +340,24 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
 #define LAUNCH(RR)                                                                                                              \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR>),                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR, KLV>),                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
-        k_fgw_coupling_small<RR><<<grid, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw,     \
+        k_fgw_coupling_small<RR, KLV><<<grid, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, \
                                                                 info, Ypart, Cpart);                                            \
     } while (0)
-    if (R <= 6) LAUNCH(6);
-    else if (R <= 9) LAUNCH(9);
-    else if (R <= 12) LAUNCH(12);
-    else LAUNCH(16);
+    if (prm.loss_fun) {
+        constexpr bool KLV = true;
+        if (R <= 6) LAUNCH(6);
+        else if (R <= 9) LAUNCH(9);
+        else if (R <= 12) LAUNCH(12);
+        else LAUNCH(16);
+    } else {
+        constexpr bool KLV = false;
+        if (R <= 6) LAUNCH(6);
+        else if (R <= 9) LAUNCH(9);
+        else if (R <= 12) LAUNCH(12);
+        else LAUNCH(16);
+    }
 #undef LAUNCH
 }
 

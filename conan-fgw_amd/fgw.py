@@ -2,9 +2,9 @@
 (conan_fgw/src/model/fgw/barycenter.py:7-31 `fgw_barycenters`, :393-399 `normalize_tensor`).
 
 Same argument names, defaults and error behaviour (`ValueError` for unknown `loss_fun` / `stop_criterion` / `solver`,
-barycenter.py:33-44).  Option values that exist in the reference but are not reached by any model
-(`kl_loss`, `BAPG`, `PPA`, `stop_criterion="loss"` — the latter is broken in the reference itself) raise
-`NotImplementedError`.  Runs on the GPU only.
+barycenter.py:33-44).  `loss_fun` = "square_loss" (every model) or "kl_loss" (utils.py:20-32,76-87).  Option values that exist in
+the reference but are not reached by any model (`BAPG`, `PPA`, `stop_criterion="loss"` — the latter is broken in the reference
+itself) raise `NotImplementedError`.  Runs on the GPU only.
 """
 from __future__ import annotations
 
@@ -26,9 +26,9 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
         raise ValueError(f"Unknown `stop_criterion='{stop_criterion}'`. Use one of: {'barycenter', 'loss'}.")
     if solver not in ["PGD", "PPA", "BAPG"]:
         raise ValueError("Unknown solver '%s'. Pick one in ['PGD', 'PPA', 'BAPG']." % solver)
-    if loss_fun != "square_loss" or solver != "PGD" or stop_criterion != "barycenter":
-        raise NotImplementedError("only loss_fun='square_loss', solver='PGD', stop_criterion='barycenter' (the path every "
-                                  "ConAN model takes, schnet_no_sum.py:281-306) is implemented on this backend")
+    if solver != "PGD" or stop_criterion != "barycenter":
+        raise NotImplementedError("only solver='PGD', stop_criterion='barycenter' (the path every ConAN model takes, "
+                                  "schnet_no_sum.py:281-306) is implemented on this backend")
     if not symmetric:
         raise NotImplementedError("symmetric=False is not reached by any ConAN model")
     method = kwargs.pop("method", "sinkhorn_log")
@@ -59,7 +59,7 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
         Ys_t.view(1, K, N, d), Cs_t.view(1, K, N, N), ps=ps_t, p=p_t, lambdas=lam,
         init_C=init_C.to(torch.float32).view(1, N, N), init_Y=None if init_Y is None else init_Y.to(torch.float32).view(1, N, d),
         alpha=alpha, epsilon=epsilon, max_iter=max_iter, tol=tol, inner_tol=1e-4, num_iter_max=num_iter_max, stop_thr=stop_thr,
-        fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT)
+        fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT, loss_fun=loss_fun)
     if not log:
         return Y[0], C[0]
     outer = int(info[0, 0].item())

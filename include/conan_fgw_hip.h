@@ -271,6 +271,7 @@ typedef struct conan_fgw_params {
     int fixed_structure;    /* keep C = init_C                         (:291) */
     int fixed_features;     /* keep Y = init_Y                         (:292) */
     int warmstart;          /* warmstartT: start each coupling solve from the previous outer iteration's T (:285) */
+    int loss_fun;           /* 0 = "square_loss" (:295, every model), 1 = "kl_loss" (utils.py:20-32,76-87) */
 } conan_fgw_params;
 
 /* Workspace size in BYTES for conan_fgw_barycenter_fwd. */

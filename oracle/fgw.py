@@ -55,12 +55,13 @@ def fgw_barycenter(Ys, Cs, ps=None, lambdas=None, init_C=None, N=None, p=None, d
     C = np.zeros((N, N), dt); T = np.zeros((K, N, n), dt)
     ef = np.full((mi,), np.nan, dt); es = np.full((mi,), np.nan, dt)
     iters = np.zeros((1 + mi * K * (1 + mi),), np.int32)
-    fn = getattr(lib(), "conan_oracle_fgw_barycenter" + suf)
+    loss = {"square_loss": 0, "kl_loss": 1}[o.get("loss_fun", "square_loss")]
+    fn = getattr(lib(), "conan_oracle_fgw_barycenter_loss" + suf)
     rc = fn(ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(n), ctypes.c_int(d), _p(Ys), _p(Cs), _p(ps), _p(p_arr),
             _p(lambdas), _p(init_C), cr(o["alpha"]), cr(o["epsilon"]), ctypes.c_int(mi), cr(o["tol"]),
             cr(o["inner_tol"]), ctypes.c_int(int(o["numItermax"])), cr(o["stopThr"]),
             ctypes.c_int(int(bool(o["fixed_structure"]))), ctypes.c_int(int(bool(o["fixed_features"]))),
-            _p(Y), _p(C), _p(T), _p(ef), _p(es), _p(iters))
+            _p(Y), _p(C), _p(T), _p(ef), _p(es), _p(iters), ctypes.c_int(loss))
     if rc != 0:
         raise RuntimeError("oracle fgw_barycenter failed rc=%d" % rc)
     outer = int(iters[0])

@@ -90,9 +90,15 @@ static void FN(sqdist)(int n1, int n2, int d, const REAL *X, const REAL *Y, REAL
  * initialised to outer(p,q) (bregman.py:98-101).  Returns PGD iterations executed;
  * sk_iters[cpt] receives the Sinkhorn iteration count of each PGD step (may be NULL).
  * work: 6*n1*n2 + n1 + n2 REALs. */
+/* loss_fun: 0 = "square_loss" (f1 = a^2, f2 = b^2, h1 = a, h2 = 2b), 1 = "kl_loss" (f1 = a log(a + 1e-15) - a, f2 = b,
+ * h1 = a, h2 = log(b + 1e-15)) — utils.py:6-32. */
+static REAL FN(lf_f1)(REAL a, int kl) { return kl ? a * FN(r_log)(a + (REAL)1e-15) - a : a * a; }
+static REAL FN(lf_f2)(REAL b, int kl) { return kl ? b : b * b; }
+static REAL FN(lf_h2)(REAL b, int kl) { return kl ? FN(r_log)(b + (REAL)1e-15) : 2 * b; }
+
 static int FN(fgw_projected)(int n1, int n2, const REAL *M, const REAL *C1, const REAL *C2, const REAL *p,
                              const REAL *q, REAL alpha, REAL epsilon, int have_G0, int max_iter, REAL tol,
-                             int numItermax, REAL stopThr, REAL *T, int *sk_iters, REAL *work)
+                             int numItermax, REAL stopThr, REAL *T, int *sk_iters, REAL *work, int loss_fun)
 {
     REAL *constC = work, *A = work + n1 * n2, *tens = A + n1 * n2, *Tprev = tens + n1 * n2;
     REAL *Mr = Tprev + n1 * n2, *Tn = Mr + n1 * n2, *u = Tn + n1 * n2, *v = u + n1;
@@ -103,12 +109,12 @@ static int FN(fgw_projected)(int n1, int n2, const REAL *M, const REAL *C1, cons
     /* init_matrix, utils.py:39-43: constC = f1(C1) p 1^T + 1 q^T f2(C2)^T ; hC1 = C1 ; hC2 = 2 C2 */
     for (i = 0; i < n1; ++i) {
         REAL r1 = 0;
-        for (k = 0; k < n1; ++k) r1 += C1[i * n1 + k] * C1[i * n1 + k] * p[k];
+        for (k = 0; k < n1; ++k) r1 += FN(lf_f1)(C1[i * n1 + k], loss_fun) * p[k];
         for (j = 0; j < n2; ++j) constC[i * n2 + j] = r1;
     }
     for (j = 0; j < n2; ++j) {
         REAL r2 = 0;
-        for (k = 0; k < n2; ++k) r2 += q[k] * (C2[j * n2 + k] * C2[j * n2 + k]);
+        for (k = 0; k < n2; ++k) r2 += q[k] * FN(lf_f2)(C2[j * n2 + k], loss_fun);
         for (i = 0; i < n1; ++i) constC[i * n2 + j] += r2;
     }
     while (err > tol && cpt < max_iter) {                 /* bregman.py:119 */
@@ -123,7 +129,7 @@ static int FN(fgw_projected)(int n1, int n2, const REAL *M, const REAL *C1, cons
         for (i = 0; i < n1; ++i)
             for (j = 0; j < n2; ++j) {
                 REAL s = 0;
-                for (k = 0; k < n2; ++k) s += A[i * n2 + k] * (2 * C2[j * n2 + k]);
+                for (k = 0; k < n2; ++k) s += A[i * n2 + k] * FN(lf_h2)(C2[j * n2 + k], loss_fun);
                 /* gwggrad = 2*(constC + A) ; tens = alpha*gw + (1-alpha)*M   bregman.py:124-125 */
                 tens[i * n2 + j] = alpha * (2 * (constC[i * n2 + j] + s)) + (1 - alpha) * M[i * n2 + j];
             }
@@ -169,7 +175,7 @@ REAL FN(conan_oracle_fgw_dist)(int n1, int n2, const REAL *M, const REAL *C1, co
     return (1 - alpha) * lin + alpha * gw;
 }
 
-/* barycenter.py:7-225 (fgw_barycenters) restricted to: loss_fun="square_loss", solver="PGD",
+/* barycenter.py:7-225 (fgw_barycenters) restricted to: loss_fun="square_loss" or "kl_loss", solver="PGD",
  * stop_criterion="barycenter", warmstartT=True, symmetric=True, init_C given, init_Y=None, p given or
  * uniform, every input graph of the same size n (the production glue always pads to N_max,
  * schnet_no_sum.py:242-252) — n may differ from N.
@@ -180,11 +186,11 @@ REAL FN(conan_oracle_fgw_dist)(int n1, int n2, const REAL *M, const REAL *C1, co
  *   iters[0] = outer iterations executed; then for outer o, graph s at base 1 + (o*K+s)*(1+max_iter):
  *   [PGD iterations, Sinkhorn iterations of PGD step 0, 1, ...].
  * Returns 0, or -1 on allocation failure / bad arguments. */
-int FN(conan_oracle_fgw_barycenter)(int N, int K, int n, int d, const REAL *Ys, const REAL *Cs, const REAL *ps,
-                                    const REAL *p_in, const REAL *lambdas, const REAL *init_C, REAL alpha,
-                                    REAL epsilon, int max_iter, REAL tol, REAL inner_tol, int numItermax,
-                                    REAL stopThr, int fixed_structure, int fixed_features, REAL *Y, REAL *C, REAL *T,
-                                    REAL *err_feature, REAL *err_structure, int *iters)
+int FN(conan_oracle_fgw_barycenter_loss)(int N, int K, int n, int d, const REAL *Ys, const REAL *Cs, const REAL *ps,
+                                         const REAL *p_in, const REAL *lambdas, const REAL *init_C, REAL alpha,
+                                         REAL epsilon, int max_iter, REAL tol, REAL inner_tol, int numItermax,
+                                         REAL stopThr, int fixed_structure, int fixed_features, REAL *Y, REAL *C, REAL *T,
+                                         REAL *err_feature, REAL *err_structure, int *iters, int loss_fun)
 {
     int s, i, j, k, c, cpt = 0;
     REAL ef = (REAL)1e15, es = (REAL)1e15;                /* barycenter.py:89-91 */
@@ -209,7 +215,7 @@ int FN(conan_oracle_fgw_barycenter)(int N, int K, int n, int d, const REAL *Ys, 
             int *it = iters ? iters + 1 + ((size_t)cpt * K + s) * (1 + max_iter) : 0;
             int npgd = FN(fgw_projected)(N, n, Ms + s * nn, C, Cs + (size_t)s * n * n, p, ps + (size_t)s * n, alpha,
                                          epsilon, have_T[s], max_iter, inner_tol, numItermax, stopThr,
-                                         T + s * nn, it ? it + 1 : 0, work);
+                                         T + s * nn, it ? it + 1 : 0, work, loss_fun);
             if (it) it[0] = npgd;
             have_T[s] = 1;
         }
@@ -235,7 +241,11 @@ int FN(conan_oracle_fgw_barycenter)(int N, int K, int n, int d, const REAL *Ys, 
                 for (i = 0; i < N; ++i)
                     for (j = 0; j < n; ++j) {
                         REAL a = 0;
-                        for (k = 0; k < n; ++k) a += Ts[(size_t)i * n + k] * Csp[k * n + j];
+                        for (k = 0; k < n; ++k) {         /* kl_loss: log(clamp(Cs, min=1e-15)), utils.py:80-81 */
+                            REAL cv = Csp[k * n + j];
+                            if (loss_fun) cv = FN(r_log)(cv > (REAL)1e-15 ? cv : (REAL)1e-15);
+                            a += Ts[(size_t)i * n + k] * cv;
+                        }
                         TC[(size_t)i * n + j] = a;
                     }
                 for (i = 0; i < N; ++i)
@@ -245,7 +255,10 @@ int FN(conan_oracle_fgw_barycenter)(int N, int K, int n, int d, const REAL *Ys, 
                         C[i * N + j] += lambdas[s] * a;
                     }
             }
-            for (i = 0; i < N; ++i) for (j = 0; j < N; ++j) C[i * N + j] /= (p[i] * p[j]);
+            for (i = 0; i < N; ++i) for (j = 0; j < N; ++j) {
+                C[i * N + j] /= (p[i] * p[j]);
+                if (loss_fun) C[i * N + j] = FN(r_exp)(C[i * N + j]);          /* update_kl_loss utils.py:86-87 */
+            }
         }
         ef = 0; es = 0;                                   /* :186-192 */
         if (!fixed_features) {
@@ -265,6 +278,17 @@ int FN(conan_oracle_fgw_barycenter)(int N, int K, int n, int d, const REAL *Ys, 
     }
     free(p); free(Ms); free(Yprev); free(Cprev); free(TC); free(work); free(have_T);
     return 0;
+}
+
+int FN(conan_oracle_fgw_barycenter)(int N, int K, int n, int d, const REAL *Ys, const REAL *Cs, const REAL *ps,
+                                    const REAL *p_in, const REAL *lambdas, const REAL *init_C, REAL alpha,
+                                    REAL epsilon, int max_iter, REAL tol, REAL inner_tol, int numItermax,
+                                    REAL stopThr, int fixed_structure, int fixed_features, REAL *Y, REAL *C, REAL *T,
+                                    REAL *err_feature, REAL *err_structure, int *iters)
+{
+    return FN(conan_oracle_fgw_barycenter_loss)(N, K, n, d, Ys, Cs, ps, p_in, lambdas, init_C, alpha, epsilon, max_iter, tol, inner_tol,
+                                                numItermax, stopThr, fixed_structure, fixed_features, Y, C, T, err_feature,
+                                                err_structure, iters, 0);
 }
 
 /* Backward of the block given the saved couplings (Y is the only output carrying

@@ -114,7 +114,7 @@ def run_ref(Ys, Cs, dtype, **over):
     fd = []
     with torch.no_grad():
         for s in range(K):
-            _, lg = ref_breg.fgw(log["Ms"][s], C, Csl[s], log["p"], ps[s], "square_loss", args["epsilon"], True, args["alpha"],
+            _, lg = ref_breg.fgw(log["Ms"][s], C, Csl[s], log["p"], ps[s], args["loss_fun"], args["epsilon"], True, args["alpha"],
                                  log["T"][s], 0, 1e-4, solver="PGD", method="sinkhorn_log", log=True,
                                  numItermax=args["numItermax"], stopThr=args["stopThr"])
             fd.append(float(lg["fgw_dist"]))
@@ -181,5 +181,27 @@ def main():
     print("cfm_log.npz written")
 
 
+KL_CASES = [c for c in CASES if c[0] in ("k5_n9_d3", "k5_n20p4_d64", "k3_n15p5_d64", "k5_n30p3_d64_r5")]
+
+
+def main_kl():
+    """loss_fun="kl_loss" (utils.py:20-32,76-87): same inputs as the square-loss cases, written to fgw_kl_*.npz.
+    Run as `python make_fgw_golden.py kl`; the square-loss fixtures are not touched."""
+    for name, seed, K, n_real, n_pad, d, r in KL_CASES:
+        Ys, Cs = make_inputs(seed, K, n_real, n_pad, d, r, 0.5)
+        r32 = run_ref(Ys, Cs, torch.float32, loss_fun="kl_loss")
+        r64 = run_ref(Ys, Cs, torch.float64, loss_fun="kl_loss")
+        rec = dict(Ys=Ys, Cs=Cs.astype(np.uint8))
+        for tag, rr in (("r32", r32), ("r64", r64)):
+            for k, v in rr.items():
+                if tag == "r64" and k == "grad_w":
+                    continue
+                rec[f"{tag}_{k}"] = v.astype(np.float32) if (tag == "r32" and v.dtype.kind == "f") else v
+        np.savez_compressed(os.path.join(HERE, f"fgw_kl_{name}.npz"), **rec)
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        print(f"kl {name}: outer32={len(r32['err_feature'])} outer64={len(r64['err_feature'])} relY={rel(r32['Y'], r64['Y']):.2e} "
+              f"relC={rel(r32['C'], r64['C']):.2e} relT={rel(r32['T'], r64['T']):.2e} finite={np.isfinite(r64['C']).all()}")
+
+
 if __name__ == "__main__":
-    main()
+    main_kl() if (len(sys.argv) > 1 and sys.argv[1] == "kl") else main()

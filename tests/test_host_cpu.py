@@ -48,6 +48,8 @@ def test_fgw_barycenters_error_behaviour():
     with pytest.raises(ValueError, match="fixed"):
         pfgw.fgw_barycenters(3, Ys, Cs, fixed_structure=True)
     with pytest.raises(NotImplementedError):
+        pfgw.fgw_barycenters(3, Ys, Cs, solver="BAPG", init_C=Cs[0])
+    with pytest.raises(RuntimeError, match="GPU only"):          # kl_loss is implemented; CPU tensors are refused (no CPU path)
         pfgw.fgw_barycenters(3, Ys, Cs, loss_fun="kl_loss", init_C=Cs[0])
 
 

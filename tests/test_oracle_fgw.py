@@ -77,3 +77,25 @@ def test_oracle_f32_within_reference_noise_floor(path):
         assert e32 <= 1e-4 or e64 <= 3 * yard + 1e-6, (key, e32, e64, yard)
     ro, rr = r["Y"].sum(0), g["r64_Y"].sum(0)      # the readout the model consumes (schnet_no_sum.py:308)
     assert rel(ro, rr) < 1e-4
+
+
+def test_oracle_kl_loss_matches_reference_goldens():
+    """loss_fun="kl_loss" (utils.py:20-32,76-87): the f64 restatement reproduces the reference's fp64 run (same iteration counts,
+    1e-9 on Y / C / T); the f32 build stays inside the reference's own fp32-vs-fp64 spread (Appendix-F protocol)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fgw_kl_*.npz")))
+    assert len(files) == 4
+    for f in files:
+        g = np.load(f)
+        Ys, Cs = g["Ys"], g["Cs"].astype(np.float32)
+        o64 = fgw.fgw_barycenter(Ys, Cs, dtype=np.float64, loss_fun="kl_loss")
+        assert o64["outer"] == len(g["r64_err_feature"])
+        assert np.array_equal(o64["pgd"], g["r64_pgd"])
+        assert np.array_equal(o64["sinkhorn"][:, :, : g["r64_sinkhorn"].shape[2]], g["r64_sinkhorn"])
+        for k in ("Y", "C", "T"):
+            assert rel(o64[k], g["r64_" + k]) < 1e-9, (f, k)
+        o32 = fgw.fgw_barycenter(Ys, Cs, dtype=np.float32, loss_fun="kl_loss")
+        for k in ("Y", "C"):
+            yard = rel(g["r32_" + k].astype(np.float64), g["r64_" + k])
+            assert rel(o32[k].astype(np.float64), g["r32_" + k].astype(np.float64)) <= 1e-4 or \
+                rel(o32[k].astype(np.float64), g["r64_" + k]) <= 2.0 * yard + 1e-6, (f, k)
