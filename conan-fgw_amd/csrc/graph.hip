@@ -166,23 +166,24 @@ __global__ void __launch_bounds__(TR_THREADS) k_transpose_graph(const int *__res
     const int steps = (e1 - e0 + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (steps <= 8) {
-        // the usual case (a conformer has <= 512 edges): the graph's sources are read ONCE into registers, every source atom
+    constexpr int TR_REG = 18;             // 18 x 64 = 1 152 edges: every conformer of <= 36 atoms at cap 32
+    if (steps <= TR_REG) {
+        // the usual case: the graph's sources are read ONCE into registers, every source atom
         // is then placed with ballots alone (no memory traffic inside the per-atom loop)
-        int cv[8];
+        int cv[TR_REG];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < TR_REG; ++s) {
             const int e = e0 + s * 64 + lane;
             cv[s] = (s < steps && e < e1) ? col[e] : 0x7fffffff;
         }
         for (int j = lo + wave; j < hi; j += TR_THREADS / 64) {
             int less = 0;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) less += __popcll(__ballot(cv[s] < j));
+            for (int s = 0; s < TR_REG; ++s) less += __popcll(__ballot(cv[s] < j));
             int base = e0 + less;
             if (lane == 0) t_rowptr[j] = base;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < TR_REG; ++s) {
                 const bool hit = cv[s] == j;
                 const unsigned long long m = __ballot(hit);
                 if (hit) t_eid[base + __popcll(m & below)] = e0 + s * 64 + lane;
