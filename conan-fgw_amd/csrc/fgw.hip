@@ -39,13 +39,17 @@ __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict
 // ------------------------------------------------------------------------------------------------ coupling solve
 // One workgroup per (molecule b, input graph s).  Matrices (pitch P): Tl fp32, Mr/Al/base fp64.
 // LDS_MODE: the four matrices live in LDS; otherwise in a per-workgroup global scratch (large N).
-template <bool LDS_MODE, bool KL>      // KL: loss_fun = "kl_loss", see fgw_small.hip
-__global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
+// NW wavefronts per workgroup (8 = 512 threads): a workgroup's time is its dependent chain (tools/fgw_scaling.py), and at N ~ 80-110
+// the chain is made of serial loops over N/NW rows and of N^2/256/NW product tiles per wavefront, so twice the wavefronts shorten
+// it; residency is bound by LDS (the Sinkhorn cost, 2 workgroups per CU) either way.
+template <bool LDS_MODE, bool KL, int NW>      // KL: loss_fun = "kl_loss", see fgw_small.hip
+__global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch, int mr_lds,
     double *__restrict__ Ypart, double *__restrict__ Cpart) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 64 * NW;
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
     const int N = D.N, P = D.P, d = D.d;
@@ -53,14 +57,14 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- carve
-    double *vec = reinterpret_cast<double *>(smem);          // [14*N + 8] : u, v, loga, logb, r1/y2, r2/z2, red, pm[4][N], psm[4][N]
+    double *vec = reinterpret_cast<double *>(smem);          // [(6 + 2 NW)*N + 16] : u, v, loga, logb, r1/y2, r2/z2, red, pm[NW][N], psm[NW][N]
     double *u = vec, *v = vec + N, *loga = vec + 2 * N, *logb = vec + 3 * N, *ra = vec + 4 * N, *rb = vec + 5 * N;
     double *red = vec + 6 * N;
-    double *pm = red + 8, *psm = pm + 4 * N;                  // per-wavefront partial (max, sum) of the log-sum-exp loops
+    double *pm = red + 16, *psm = pm + NW * N;                // per-wavefront partial (max, sum) of the log-sum-exp loops
     // LDS_MODE: all four matrices in LDS.  Otherwise only the Sinkhorn cost Mr (read 2x per Sinkhorn iteration, once by
     // rows and once by columns) stays in LDS when it fits (mr_lds); A, base and T live in an L2-resident global scratch.
     char *gs = scratch + (size_t)blockIdx.x * ((size_t)NP * 28);
-    char *ls = smem + (size_t)(14 * N + 8) * 8;
+    char *ls = smem + (size_t)((6 + 2 * NW) * N + 16) * 8;
     double *Mr = reinterpret_cast<double *>((LDS_MODE || mr_lds) ? ls : gs);
     double *Al = LDS_MODE ? Mr + NP : reinterpret_cast<double *>(gs) + NP;
     double *base = Al + NP;
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     const double alpha = (double)prm.alpha, eps = (double)prm.epsilon;
 
     // ---- marginals: p (barycenter), q = ps[s]; uniform when not given (barycenter.py:50-51, schnet_no_sum.py:264-279)
-    for (int i = tid; i < N; i += FGW_THREADS) {
+    for (int i = tid; i < N; i += NT) {
         const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
         const double qi = ps ? (double)ps[((size_t)b * D.K + s) * N + i] : 1.0 / (double)N;
         loga[i] = log(pi); logb[i] = log(qi);
@@ -82,13 +86,13 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     }
     __syncthreads();
     // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
-    for (int t = tid; t < NN; t += FGW_THREADS) {
+    for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
         Tl[i * P + j] = (outer > 0 && prm.warmstart) ? Tg[t] : (float)(u[i] * v[j]);
     }
     // ---- init_matrix (utils.py:39-43): constC[i][j] = sum_k C1[i,k]^2 p_k + sum_k q_k C2[j,k]^2 ; squared feature norms
     double *y2a = Al, *z2a = Al + N;                            // Al is not live yet
-    for (int i = tid; i < N; i += FGW_THREADS) {
+    for (int i = tid; i < N; i += NT) {
         double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
         for (int k = 0; k < N; ++k) {
             const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
@@ -105,10 +109,10 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     // ---- base = alpha*2*constC + (1-alpha)*M,  M = clamp(|y_i|^2 + |z_j|^2 - 2 y_i.z_j, 0)   (utils.py:154-171, bregman.py:124-125)
     // dot(Y_i, Z_j) on fp64 MFMA straight from global memory (L2-resident), then the elementwise assembly
     if (!y_zero)
-        mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
+        mm_f64<NW>(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
                [&](int i, int j, double v) { base[i * P + j] = v; });
     __syncthreads();
-    for (int t = tid; t < NN; t += FGW_THREADS) {
+    for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
         double m = -2.0 * (y_zero ? 0.0 : base[i * P + j]);    // utils.py:159-161
         m += y2a[i]; m += z2a[j];
@@ -123,13 +127,13 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
     while (err > (double)prm.inner_tol && cpt < prm.max_iter) {
         // A = C1 @ T ; G = A @ (2 C2)^T on fp64 MFMA ; tens = base - 2*alpha*G ; Mr = -tens/eps
         // (utils.py:48-64, bregman.py:124-125, sinkhorn.py:388)
-        mm_f64(N, N, N, [&](int i, int k) { return C1[i * N + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
+        mm_f64<NW>(N, N, N, [&](int i, int k) { return C1[i * N + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
                [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
+        mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
                [&](int k, int j) { const double cv = (double)C2[j * N + k]; return KL ? log(cv + 1e-15) : 2.0 * cv; },
                [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
-        for (int i = tid; i < N; i += FGW_THREADS) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
+        for (int i = tid; i < N; i += NT) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
         __syncthreads();
         // ---- log-domain Sinkhorn (sinkhorn.py:413-433)
         int ii = 0;
@@ -140,83 +144,90 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_coupling(
             // are combined through LDS.
             for (int j = lane; j < N; j += 64) {
                 double mx = -1.0e300;
-                for (int i = wave; i < N; i += FGW_WAVES) { const double z = Mr[i * P + j] + u[i]; mx = fmax(z, mx); }
+                for (int i = wave; i < N; i += NW) { const double z = Mr[i * P + j] + u[i]; mx = fmax(z, mx); }
                 double sm = 0.0;
-                for (int i = wave; i < N; i += FGW_WAVES) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
+                for (int i = wave; i < N; i += NW) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
                 pm[wave * N + j] = mx; psm[wave * N + j] = sm;
             }
             __syncthreads();
-            for (int j = tid; j < N; j += FGW_THREADS) {
-                const double m0 = pm[j], m1 = pm[N + j], m2 = pm[2 * N + j], m3 = pm[3 * N + j];
-                const double M = fmax(fmax(m0, m1), fmax(m2, m3));
-                const double sm = ((psm[j] * exp_lse(m0 - M) + psm[N + j] * exp_lse(m1 - M)) + psm[2 * N + j] * exp_lse(m2 - M)) +
-                                  psm[3 * N + j] * exp_lse(m3 - M);
+            for (int j = tid; j < N; j += NT) {
+                double M = pm[j];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) M = fmax(M, pm[w * N + j]);
+                double sm = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sm += psm[w * N + j] * exp_lse(pm[w * N + j] - M);
                 v[j] = logb[j] - (log_acc(sm) + M);
             }
             __syncthreads();
             // u_i = loga_i - logsumexp_j(Mr_ij + v_j): lane <-> row (odd pitch: conflict-free), wavefronts split the columns
             for (int i = lane; i < N; i += 64) {
                 double mx = -1.0e300;
-                for (int j = wave; j < N; j += FGW_WAVES) { const double z = Mr[i * P + j] + v[j]; mx = fmax(z, mx); }
+                for (int j = wave; j < N; j += NW) { const double z = Mr[i * P + j] + v[j]; mx = fmax(z, mx); }
                 double sm = 0.0;
-                for (int j = wave; j < N; j += FGW_WAVES) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
+                for (int j = wave; j < N; j += NW) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
                 pm[wave * N + i] = mx; psm[wave * N + i] = sm;
             }
             __syncthreads();
-            for (int i = tid; i < N; i += FGW_THREADS) {
-                const double m0 = pm[i], m1 = pm[N + i], m2 = pm[2 * N + i], m3 = pm[3 * N + i];
-                const double M = fmax(fmax(m0, m1), fmax(m2, m3));
-                const double sm = ((psm[i] * exp_lse(m0 - M) + psm[N + i] * exp_lse(m1 - M)) + psm[2 * N + i] * exp_lse(m2 - M)) +
-                                  psm[3 * N + i] * exp_lse(m3 - M);
+            for (int i = tid; i < N; i += NT) {
+                double M = pm[i];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) M = fmax(M, pm[w * N + i]);
+                double sm = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sm += psm[w * N + i] * exp_lse(pm[w * N + i] - M);
                 u[i] = loga[i] - (log_acc(sm) + M);
             }
             __syncthreads();
             if (ii % 10 == 0) {                                 // marginal violation, sinkhorn.py:418-433
                 for (int j = lane; j < N; j += 64) {
                     double sm = 0.0;
-                    for (int i = wave; i < N; i += FGW_WAVES) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
+                    for (int i = wave; i < N; i += NW) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
                     psm[wave * N + j] = sm;
                 }
                 __syncthreads();
                 double e2 = 0.0;
-                for (int j = tid; j < N; j += FGW_THREADS) {
-                    const double df = (((psm[j] + psm[N + j]) + psm[2 * N + j]) + psm[3 * N + j]) - exp(logb[j]);
+                for (int j = tid; j < N; j += NT) {
+                    double cs = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
+                    const double df = cs - exp(logb[j]);
                     e2 += df * df;
                 }
-                const double tot = block_sum_d(e2, red);
+                const double tot = block_sum_d<NW>(e2, red);
                 if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
             }
         }
         sk_total += ii;
         // ---- T = exp(Mr + u + v) (sinkhorn.py:450); err = ||T - Tprev||_F evaluated when cpt % 10 == 0 (bregman.py:144-147)
         double e2 = 0.0;
-        for (int t = tid; t < NN; t += FGW_THREADS) {
+        for (int t = tid; t < NN; t += NT) {
             const int i = t / N, j = t - i * N;
             const float tn = (float)exp_acc(Mr[i * P + j] + u[i] + v[j]);
             const double df = (double)tn - (double)Tl[i * P + j];
             e2 += df * df;
             Tl[i * P + j] = tn;
         }
-        if (cpt % 10 == 0) err = sqrt(block_sum_d(e2, red));
+        if (cpt % 10 == 0) err = sqrt(block_sum_d<NW>(e2, red));
         else __syncthreads();
         ++cpt;
     }
     __syncthreads();
-    for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
+    for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
     // ---- contributions to the barycenter update (summed over s by k_fgw_update_parts)
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
+        mm_f64<NW>(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
                [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
+        mm_f64<NW>(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
                [&](int k, int j) { const double cv = (double)C2[k * N + j]; return KL ? log(cv > 1e-15 ? cv : 1e-15) : cv; },
                [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
+        mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
                [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
 }
@@ -377,7 +388,8 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
 }
 
 inline int pitch_of(int N) { return N | 1; }
-inline size_t coupling_lds(int N) { return (size_t)(14 * N + 8) * 8 + (size_t)N * pitch_of(N) * 28; }
+constexpr int GEN_NW = 8;                   // wavefronts per workgroup of the large-N coupling kernel
+inline size_t coupling_lds(int N) { return (size_t)((6 + 2 * GEN_NW) * N + 16) * 8 + (size_t)N * pitch_of(N) * 28; }
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 }  // namespace
@@ -425,17 +437,17 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     const bool c_lds = lc <= LDS_LIMIT;
     if (c_lds && lc > 64 * 1024)
     {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, false, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, true, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
     }
-    const size_t vec_c = (size_t)(14 * N + 8) * 8;
+    const size_t vec_c = (size_t)((6 + 2 * GEN_NW) * N + 16) * 8;
     const size_t mr_bytes = NP * 8;
     const int mr_lds = (!c_lds && vec_c + mr_bytes <= LDS_LIMIT) ? 1 : 0;
     if (mr_lds)
     {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, false, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(vec_c + mr_bytes));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, true, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(vec_c + mr_bytes));
     }
     for (int outer = 0; outer < params->max_iter; ++outer) {
@@ -443,14 +455,14 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
         if (small)
             conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, s);
         else if (c_lds && kl)
-            k_fgw_coupling<true, true><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
+            k_fgw_coupling<true, true, GEN_NW><<<B * K, 64 * GEN_NW, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
         else if (c_lds)
-            k_fgw_coupling<true, false><<<B * K, FGW_THREADS, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
+            k_fgw_coupling<true, false, GEN_NW><<<B * K, 64 * GEN_NW, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
         else if (kl)
-            k_fgw_coupling<false, true><<<B * K, FGW_THREADS, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
+            k_fgw_coupling<false, true, GEN_NW><<<B * K, 64 * GEN_NW, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
                                                                                                      active, T, info, sc_c, mr_lds, Ypart, Cpart);
         else
-            k_fgw_coupling<false, false><<<B * K, FGW_THREADS, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
+            k_fgw_coupling<false, false, GEN_NW><<<B * K, 64 * GEN_NW, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
                                                                                                       active, T, info, sc_c, mr_lds, Ypart, Cpart);
         conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, s);
     }

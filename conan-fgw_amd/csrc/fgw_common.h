@@ -39,6 +39,7 @@ __device__ __forceinline__ double wave_max_d(double v) {
 }
 
 // block-wide sum of one double per thread; result broadcast to every thread. red[] has FGW_WAVES+1 doubles.
+template <int NW = FGW_WAVES>
 __device__ __forceinline__ double block_sum_d(double v, double *red) {
     v = wave_sum_d(v);
     __syncthreads();
@@ -46,7 +47,7 @@ __device__ __forceinline__ double block_sum_d(double v, double *red) {
     __syncthreads();
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < FGW_WAVES; ++w) s += red[w];
+    for (int w = 0; w < NW; ++w) s += red[w];
     return s;
 }
 
@@ -66,12 +67,12 @@ __device__ __forceinline__ double exp_lse(double x) {
 // X(i,k), W(k,j) are element readers, st(i,j,v) the writer.  Fragment layout: A lane l -> X[i0 + (l&15)][k0 + (l>>4)],
 // B lane l -> W[k0 + (l>>4)][j0 + (l&15)], D reg q lane l -> row i0 + (l>>4) + 4q, col j0 + (l&15).
 // Workgroup-collective (tiles are dealt round-robin to the wavefronts); no barrier inside.
-template <class FX, class FW, class FS>
+template <int NW = FGW_WAVES, class FX, class FW, class FS>
 __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS st) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
-    for (int t = wave; t < Mq * Nq; t += FGW_WAVES) {
+    for (int t = wave; t < Mq * Nq; t += NW) {
         const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
         const int ia = i0 + li, jb = j0 + li;
         const bool ra = ia < M, cb = jb < Nn;
@@ -107,6 +108,7 @@ struct BorderIdx {
     int i[2], j[2], count;
     bool on[2];
 };
+template <int NW = FGW_WAVES>
 __device__ __forceinline__ BorderIdx border_prepare(int M, int Nn) {
     BorderIdx bi;
     const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
@@ -114,7 +116,7 @@ __device__ __forceinline__ BorderIdx border_prepare(int M, int Nn) {
     bi.count = nb1 + nb2;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int t = p * (FGW_THREADS / 4) + ((int)threadIdx.x >> 2);
+        const int t = p * (NW * 16) + ((int)threadIdx.x >> 2);
         bi.on[p] = t < bi.count;
         bi.i[p] = 0; bi.j[p] = 0;
         if (bi.on[p]) {
@@ -124,17 +126,18 @@ __device__ __forceinline__ BorderIdx border_prepare(int M, int Nn) {
     }
     return bi;
 }
+template <int NW = FGW_WAVES>
 __device__ __forceinline__ bool border_path(int M, int Nn) {       // dispatch rule of mm_f64 (workgroup-uniform)
     const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
-    return (M - Mc) * Nn + Mc * (Nn - Nc) <= FGW_THREADS / 2 && Mc > 0 && Nc > 0;
+    return (M - Mc) * Nn + Mc * (Nn - Nc) <= NW * 32 && Mc > 0 && Nc > 0;
 }
 
-template <class FX, class FW, class FS>
+template <int NW = FGW_WAVES, class FX, class FW, class FS>
 __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W, FS st, const BorderIdx &bi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mq = M >> 4, Nq = Nn >> 4;
     const int li = lane & 15, lk = lane >> 4;
-    for (int t = wave; t < Mq * Nq; t += FGW_WAVES) {
+    for (int t = wave; t < Mq * Nq; t += NW) {
         const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         int k0 = 0;
@@ -160,7 +163,7 @@ __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W,
     const int sub = tid & 3;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        if (p * (FGW_THREADS / 4) >= bi.count) break;                 // workgroup-uniform
+        if (p * (NW * 16) >= bi.count) break;                 // workgroup-uniform
         double a = 0.0;
         if (bi.on[p])
             for (int k = sub; k < Kd; k += 4) a += X(bi.i[p], k) * W(k, bi.j[p]);
@@ -172,10 +175,10 @@ __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W,
 
 // Dispatch (workgroup-uniform): a border of at most one pass of the 256 threads (e.g. N = 33: 65 outputs) is cheaper on
 // the FMA path than the extra mostly-empty tiles; anything thicker goes to the padded-tile path.
-template <class FX, class FW, class FS>
+template <int NW = FGW_WAVES, class FX, class FW, class FS>
 __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
-    if (border_path(M, Nn)) mm_f64_border(M, Nn, Kd, X, W, st, border_prepare(M, Nn));
-    else mm_f64_pad(M, Nn, Kd, X, W, st);
+    if (border_path<NW>(M, Nn)) mm_f64_border<NW>(M, Nn, Kd, X, W, st, border_prepare<NW>(M, Nn));
+    else mm_f64_pad<NW>(M, Nn, Kd, X, W, st);
 }
 // same with the border ownership prepared by the caller (products repeated inside a loop)
 template <class FX, class FW, class FS>
