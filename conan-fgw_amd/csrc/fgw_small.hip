@@ -233,11 +233,12 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
 }
 
 // Barycenter update from the per-graph contributions: elementwise, one workgroup per molecule.
-__global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
+constexpr int UPD_THREADS = 1024;       // the kernel is a few dependent L2 round trips per molecule: more threads, fewer trips each
+__global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
     const float *__restrict__ pb, const float *__restrict__ lambdas, FgwDims D, conan_fgw_params prm, int outer,
     const double *__restrict__ Ypart, const double *__restrict__ Cpart, double *__restrict__ Cw, double *__restrict__ Yw,
     int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout) {
-    __shared__ double red[8];
+    __shared__ double red[UPD_THREADS / 64 + 1];
     const int b = blockIdx.x;
     if (!active[b]) return;
     const int N = D.N, d = D.d, K = D.K, NN = N * N, Nd = N * d;
@@ -248,11 +249,11 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
     constexpr int U = 4;
     if (!prm.fixed_features) {
         double *Yb = Yw + (size_t)b * Nd;
-        for (int t0 = tid; t0 < Nd; t0 += U * FGW_THREADS) {
+        for (int t0 = tid; t0 < Nd; t0 += U * UPD_THREADS) {
             double acc[U], old[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + u * FGW_THREADS;
+                const int t = t0 + u * UPD_THREADS;
                 acc[u] = 0.0; old[u] = 0.0;
                 if (t < Nd) {
                     old[u] = Yb[t];
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + u * FGW_THREADS;
+                const int t = t0 + u * UPD_THREADS;
                 if (t < Nd) {
                     const double df = acc[u] - old[u];
                     ef2 += df * df;
@@ -278,11 +279,11 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
     }
     if (!prm.fixed_structure) {
         double *Cb = Cw + (size_t)b * NN;
-        for (int t0 = tid; t0 < NN; t0 += U * FGW_THREADS) {
+        for (int t0 = tid; t0 < NN; t0 += U * UPD_THREADS) {
             double acc[U], old[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + u * FGW_THREADS;
+                const int t = t0 + u * UPD_THREADS;
                 acc[u] = 0.0; old[u] = 0.0;
                 if (t < NN) {
                     old[u] = Cb[t];
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + u * FGW_THREADS;
+                const int t = t0 + u * UPD_THREADS;
                 if (t < NN) {
                     const int i = t / N, j = t - i * N;
                     const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
@@ -308,8 +309,8 @@ __global__ void __launch_bounds__(FGW_THREADS) k_fgw_update_parts(
             }
         }
     }
-    const double ef = sqrt(block_sum_d(ef2, red));
-    const double es = sqrt(block_sum_d(es2, red));
+    const double ef = sqrt(block_sum_d<UPD_THREADS / 64>(ef2, red));
+    const double es = sqrt(block_sum_d<UPD_THREADS / 64>(es2, red));
     if (tid == 0) {
         errs[((size_t)b * 2 + 0) * prm.max_iter + outer] = (float)ef;
         errs[((size_t)b * 2 + 1) * prm.max_iter + outer] = (float)es;
@@ -364,5 +365,5 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
                             const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
                             float *errs, float *Yout, float *Cout, hipStream_t s) {
-    k_fgw_update_parts<<<D.B, FGW_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout);
+    k_fgw_update_parts<<<D.B, UPD_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout);
 }
