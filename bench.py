@@ -145,6 +145,7 @@ def main():
 
     # live per-kernel timing of the CFConv forward kernel with HIP events on the launch stream
     ev = []
+    ev_empty = []
     ev_other = {"conan_filter_fwd": [], "conan_fgw_barycenter_fwd": []}
     orig_call = ops.call
 
@@ -153,6 +154,10 @@ def main():
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); orig_call(name, *a); e.record()
             (ev if name == "conan_cfconv_fwd" else ev_other[name]).append((s, e))
+            if name == "conan_cfconv_fwd":       # an EMPTY bracket right behind it: what two event packets cost on this queue by themselves
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record(); e0.record()
+                ev_empty.append((s0, e0))
         else:
             orig_call(name, *a)
     timed_call.on = False
@@ -214,6 +219,7 @@ def main():
     P = int(_g.pairs().num_pairs_dev.item()) if args.model == "schnet" else E
     n_atoms = int(z.shape[0])
     kdur_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+    empty_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_empty])) if ev_empty else float("nan")
     # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately and
     # committed under profiles/; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE) -- only valid for the default workload
     traffic = None
@@ -254,6 +260,10 @@ def main():
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_hbm.json (separate rocprofv3 --pmc passes)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "survey_convention_bytes_per_launch": cfconv_survey_bytes(E, P, n_atoms, 128),
                          "avg_launch_ms": round(kdur_ms, 5),
+                         "empty_event_bracket_ms": round(empty_ms, 5),
+                         "note": "avg_launch_ms is the raw HIP-event bracket around the launch (start event, kernel, end event on the launch "
+                                 "stream); it contains the cost of the event packets themselves, measured live as empty_event_bracket_ms; "
+                                 "rocprofv3's kernel-only duration (profiles/) is therefore shorter by about that amount. frac uses the raw bracket.",
                          "launches_timed": len(ev)},
         }
         out["roofline_other"] = other
