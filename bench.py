@@ -7,29 +7,35 @@ SchNetNoSum.forward_w_barycenter (radius graph, 3 interaction blocks, two heads,
 schnet_based_models.py:135-173) + MSE loss, backward through all of it, one flat gradient all-reduce (RCCL) and Adam.
 Workload at every N: BASELINE.json configs[1] per GPU (ESOL + SchNet-128, K=5, batch=256) => weak scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--batch B] [--eager] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around the CFConv gather/segment-sum kernel
-(the HBM-bound kernel BASELINE.json's target is quoted on); `cpu_baseline` times the CPU oracle on a bounded sample.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one process per GPU, before anything
+touches the GPU) — both launch forms end in the same per-rank code.
+
+Execution of the timed steps: the step is captured once into HIP graphs (forward + backward + gradient pack | all-reduce |
+Adam) and the K timed steps replay them — the same kernels, no host work on the critical path; `--eager` times the plain
+Python step instead, and the eager rate is always reported beside the graph rate.  Prints ONE JSON line on rank 0.
+`roofline` is measured with HIP events around the CFConv gather/segment-sum kernel (the HBM-bound kernel BASELINE.json's
+target is quoted on) in a separate short eager pass AFTER the timed region, so the instrumentation never sits inside the
+number it annotates; `cpu_baseline` times the CPU oracle on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TF = 157.3      # dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -39,9 +45,30 @@ def parse():
     ap.add_argument("--conformers", type=int, default=5)
     ap.add_argument("--shape", default="esol")
     ap.add_argument("--model", choices=["schnet", "visnet"], default="schnet", help="backbone (BASELINE.json configs[3] = visnet + bace)")
+    ap.add_argument("--eager", action="store_true", help="time the eager Python step instead of the HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the whole CPU-baseline leg")
+    ap.add_argument("--cpu-full", action="store_true", help="SURVEY 8(d) protocol in full: 3 warm-up + 10 timed batches per leg")
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int, script: str, script_args, env=None) -> int:
+    """Start n ranks of `script` on this node through torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous) and
+    return its exit code.  Called before anything in this process has touched the GPU; the children are fresh interpreters."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(script_args)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    return subprocess.call(cmd, env=e)
 
 
 def cfconv_algorithmic_bytes(E, P, n_atoms, F):
@@ -58,69 +85,123 @@ def cfconv_survey_bytes(E, P, n_atoms, F):
     return E * 4 * F + P * 4 * F + 4 * (2 * E + n_atoms + 1) + n_atoms * 4 * F
 
 
-def cpu_baseline(args, mode, gpu_model=None):
-    """CPU oracle ("port": oracle/schnet.py + the C FGW restatement) on the host cores, bounded sample."""
+# ---------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args, gpu_model=None):
+    """the CPU oracle ("port": oracle/schnet.py + the C restatement of the FGW solver) on the host cores, on
+    BASELINE.json configs[0] (ESOL + SchNet, K=5, batch=32): (i) FGW only, (ii) backbone only, (iii) end-to-end forward, plus the
+    training step, each at 1 thread and at all cores, median over the timed batches.  Full protocol (--cpu-full): 3 warm-up +
+    10 timed batches per leg; default: the same legs inside a wall-clock budget (>= 1 warm-up, >= 2 timed)."""
+    import numpy as np
+    import torch
     from conan_fgw_amd.synthetic import make_batch, make_bond_graph
+    from oracle import fgw as ofgw
     from oracle.head import Stage2Oracle
-    nb = 8
-    b = make_batch(args.shape, nb, args.conformers, seed=4321)
-    bg = make_bond_graph(b, seed=4322)
+    from oracle.pyg_semantics import to_dense_adj, to_dense_batch
+    from oracle.schnet import normalize_tensor
+
+    nb, K = 32, args.conformers
+    b = make_batch(args.shape, nb, K, seed=1235)                              # cfg1 seed (1234 + 1)
+    bg = make_bond_graph(b, seed=2235)
     torch.manual_seed(5)
-    m = Stage2Oracle(args.conformers)
+    m = Stage2Oracle(K, model_name=args.model)
     z, pos, batch = torch.from_numpy(b.z), torch.from_numpy(b.pos), torch.from_numpy(b.batch)
     bx, bei, bea = torch.from_numpy(bg.x), torch.from_numpy(bg.edge_index), torch.from_numpy(bg.edge_attr)
     y = torch.from_numpy(b.y)[:, None]
+    bb = m.node_embeddings_model
+    with torch.no_grad():                                                    # FGW-only inputs: what _compute_barycenter hands the solver
+        _h, hb = bb.forward_3d_bary(z, pos, batch)
+        ei, _ = bb.interaction_graph(pos, batch)
+        dense, _ = to_dense_batch(hb, batch)
+        adj = to_dense_adj(ei, batch).to(hb.dtype)
+        fgw_in = []
+        for i in range(nb):
+            slab = dense[i * K:(i + 1) * K] + bb.FEATURE_SHIFT
+            fgw_in.append((torch.stack([normalize_tensor(s, 0.1, 2.0) for s in slab]).numpy(), adj[i * K:(i + 1) * K].numpy()))
 
-    def step():
-        pred = m(z, pos, batch, bx, bei, bea)
-        if mode == "train":
-            loss = torch.nn.functional.mse_loss(pred, y)
-            loss.backward()
-    step()
-    t0 = time.perf_counter(); n = 0
-    while time.perf_counter() - t0 < args.cpu_seconds:
-        step(); n += 1
-    dt = time.perf_counter() - t0
-    # the same oracle, forward only (SURVEY.md 8(d): end-to-end forward next to the training step), ~3 s
-    with torch.no_grad():
-        m(z, pos, batch, bx, bei, bea)
-        tf0 = time.perf_counter(); nfw = 0
-        while time.perf_counter() - tf0 < min(3.0, args.cpu_seconds):
-            m(z, pos, batch, bx, bei, bea); nfw += 1
-        fwd_rate = nb * nfw / (time.perf_counter() - tf0)
-    out = {"value": round(nb * n / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-           "forward_only_molecules_per_s": round(fwd_rate, 3),
-           "sample": f"{n} {mode} steps of {nb} {args.shape}-shaped molecules (K={args.conformers}), CPU oracle fp32 (SchNet + FGW + GAT + head), "
-                     f"{torch.get_num_threads()} torch threads of {os.cpu_count()} host cores; FGW = scalar C restatement"}
+    def leg_fgw():
+        for Ys, Cs in fgw_in:
+            ofgw.fgw_barycenter(Ys, Cs, dtype=np.float32)
+
+    def leg_backbone():
+        with torch.no_grad():
+            bb.forward_3d_bary(z, pos, batch)
+
+    def leg_fwd():
+        with torch.no_grad():
+            m(z, pos, batch, bx, bei, bea)
+
+    def leg_train():
+        for p in m.parameters():
+            p.grad = None
+        torch.nn.functional.mse_loss(m(z, pos, batch, bx, bei, bea), y).backward()
+
+    legs = [("fgw_only", leg_fgw), ("backbone_only", leg_backbone), ("end_to_end_forward", leg_fwd), ("train_step", leg_train)]
+    all_cores = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    configs = [1] + ([all_cores] if all_cores > 1 else [])
+    budget = args.cpu_seconds / (len(legs) * len(configs))
+    table = {}
+    t_start = time.perf_counter()
+    for nt in configs:
+        torch.set_num_threads(nt)
+        for name, fn in legs:
+            warm, timed = (3, 10) if args.cpu_full else (1, 10)
+            t0 = time.perf_counter()
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(timed):
+                t1 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t1)
+                if not args.cpu_full and len(ts) >= 2 and time.perf_counter() - t0 > budget:
+                    break
+            table[f"{name}@{nt}t"] = {"molecules_per_s": round(nb / float(np.median(ts)), 2), "timed_batches": len(ts)}
+    torch.set_num_threads(default_threads)
+    key = ("train_step" if args.mode == "train" else "end_to_end_forward") + f"@{configs[-1]}t"
+    out = {"value": table[key]["molecules_per_s"], "unit": "molecules/s", "cores": configs[-1], "kind": "port",
+           "sample": f"{args.shape.upper()}-shaped batch of {nb} molecules (BASELINE configs[0]), K={K}: median of {table[key]['timed_batches']} "
+                     f"{'training steps' if args.mode == 'train' else 'forwards'} of the CPU oracle in fp32 (SchNet trunk in torch, FGW = scalar C restatement, "
+                     f"GAT + head), {configs[-1]} torch threads on {all_cores} host cores; legs = SURVEY 8(d) (i)-(iii) + training step at 1 thread and all cores",
+           "protocol": "3 warm-up + 10 timed, median" if args.cpu_full else f"1 warm-up + 2..10 timed inside {args.cpu_seconds:.0f} s, median",
+           "legs": table, "host_cores": all_cores, "wall_s": round(time.perf_counter() - t_start, 1)}
     if gpu_model is not None and args.model == "schnet":
         # the same sample through the HIP path and through the fp64 oracle with the HIP model's current weights
         import types
-        ref = Stage2Oracle(args.conformers)
+        ref = Stage2Oracle(K)
         ref.load_state_dict({k: v.detach().cpu() for k, v in gpu_model.state_dict().items()})
         ref = ref.double()
         dev = next(gpu_model.parameters()).device
-        ns = types.SimpleNamespace(z=z.to(dev), pos=pos.to(dev), x=bx.to(dev), edge_index=bei.to(dev), edge_attr=bea.to(dev), batch=batch.to(dev))
+        sel = b.graph_ptr[8 * K]                                              # first 8 molecules (the fp64 oracle is slow)
+        zs, ps_, bs = z[:sel], pos[:sel], batch[:sel]
+        eb = (bei[0] < sel) & (bei[1] < sel)
+        ns = types.SimpleNamespace(z=zs.to(dev), pos=ps_.to(dev), x=bx[:sel].to(dev), edge_index=bei[:, eb].to(dev), edge_attr=bea[eb].to(dev), batch=bs.to(dev))
         with torch.no_grad():
             gy = gpu_model(ns, None, ns.batch)
-            g3, gb = gpu_model.node_embeddings_model.forward_w_barycenter(ns.z, ns.pos, args.conformers, ns.batch)
-            ry = ref(z, pos.double(), batch, bx, bei, bea)
-            r3, rb = ref.node_embeddings_model.forward_w_barycenter(z, pos.double(), args.conformers, batch)
+            g3, gb = gpu_model.node_embeddings_model.forward_w_barycenter(ns.z, ns.pos, K, ns.batch)
+            ry = ref(zs, ps_.double(), bs, bx[:sel], bei[:, eb], bea[eb])
+            r3, rb = ref.node_embeddings_model.forward_w_barycenter(zs, ps_.double(), K, bs)
         rel = lambda a, r: float((a.detach().cpu().double() - r).norm() / r.norm())
         out["gpu_vs_oracle_fp64"] = {"y_pred_rel_err (energies)": float(f"{rel(gy, ry):.3e}"), "h_3d_rel_err": float(f"{rel(g3, r3):.3e}"),
                                      "h_bary_rel_err (FGW)": float(f"{rel(gb, rb):.3e}"), "tolerance": 1e-4,
-                                     "sample": f"{nb} molecules of the CPU sample, current weights"}
+                                     "sample": "first 8 molecules of the CPU sample, current weights"}
     return out
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")              # "nccl" is RCCL on ROCm: one rank per GPU over xGMI
+        dist.init_process_group("nccl", device_id=dev)              # "nccl" is RCCL on ROCm: one rank per GPU over xGMI
 
     from conan_fgw_amd import ops
     from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
@@ -139,140 +220,250 @@ def main():
     # the reference's stage-2 model: backbone (common.py:524-529 / :542-546) + GAT branch + aggregation head
     model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=args.model).to(dev)
     cidx = model.create_aggregation_index(b.num_graphs, dev)
-    params = list(model.parameters())
-    flat = FlatGradients(params)
-    opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True)
+    flat = FlatGradients(model.parameters())
+    opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True, capturable=True)
+    loss_out = torch.zeros((), device=dev)
+    train = args.mode == "train"
+    inv_world = 1.0 / world
 
-    # live per-kernel timing of the CFConv forward kernel with HIP events on the launch stream
-    ev = []
-    ev_empty = []
-    ev_other = {"conan_filter_fwd": [], "conan_fgw_barycenter_fwd": []}
-    orig_call = ops.call
+    def fwd_bwd():
+        flat.zero()
+        pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+        loss = torch.nn.functional.mse_loss(pred, y)
+        loss.backward()
+        loss_out.copy_(loss.detach())
 
-    def timed_call(name, *a):
-        if timed_call.on and (name == "conan_cfconv_fwd" or name in ev_other):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(); orig_call(name, *a); e.record()
-            (ev if name == "conan_cfconv_fwd" else ev_other[name]).append((s, e))
-            if name == "conan_cfconv_fwd":       # an EMPTY bracket right behind it: what two event packets cost on this queue by themselves
-                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s0.record(); e0.record()
-                ev_empty.append((s0, e0))
-        else:
-            orig_call(name, *a)
-    timed_call.on = False
-    ops.call = timed_call
-
-    def step():
-        if args.mode == "train":
-            flat.zero()
-            pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-            loss = torch.nn.functional.mse_loss(pred, y)
-            loss.backward()
-            flat.all_reduce_mean()
+    def eager_step():
+        if train:
+            fwd_bwd()
+            flat.all_reduce_mean()                 # pack + (world > 1) RCCL all-reduce(s) + mean
             opt.step()
         else:
             with torch.no_grad():
                 model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
 
     def barrier():
-        if world > 1:
+        if use_dist and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    timed_call.on = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timed_call.on = False
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step_fn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist and world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
-    # forward-only throughput of the same workload (outside the timed region; this rank's shard)
-    fwd_extra = None
-    if args.mode == "train":
-        def fwd_step():
-            with torch.no_grad():
-                model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-        for _ in range(2):
-            fwd_step()
+    # Everything below runs on a side stream: HIP-graph capture needs a non-default stream, and autograd binds its
+    # accumulation nodes to the stream of the first backward.
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    ev, ev_empty = [], []
+    ev_other = {"conan_filter_fwd": [], "conan_fgw_barycenter_fwd": []}
+    with torch.cuda.stream(side):
+        # ---- eager warm-up (also: gradient-order calibration for the overlapped all-reduce of the eager step)
+        overlap = train and use_dist and world > 1
+        if overlap:
+            flat.enable_overlap()
+        eager_step()
+        buckets = flat.calibrate() if overlap else (0, len(flat.params))
+        for _ in range(max(1, args.warmup) - 1):
+            eager_step()
         torch.cuda.synchronize()
-        tf = time.perf_counter()
-        nf = max(5, args.steps // 2)
-        for _ in range(nf):
-            fwd_step()
-        torch.cuda.synchronize()
-        tf = (time.perf_counter() - tf) / nf
-        fwd_extra = {"molecules_per_s_per_gpu": round(args.batch / tf, 1), "ms_per_step": round(1e3 * tf, 4)}
 
-    # edge statistics of this rank's batch (device graph of the last step is rebuilt here only for reporting)
-    gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
-    _g = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32)
-    E = _g.num_edges
-    P = int(_g.pairs().num_pairs_dev.item()) if args.model == "schnet" else E
+        # ---- eager rate (always measured; it is `value` only with --eager)
+        n_eager = args.steps if args.eager else max(3, min(args.steps, 10))
+        dt_eager = timed(eager_step, n_eager)
+        loss_eager = float(loss_out)
+
+        # ---- HIP-graph capture of the same step: A = forward + backward + pack | all-reduce (eager RCCL call between the two
+        # replays, world > 1 only) | B = mean + Adam.  Same kernels as the eager step, zero host work between them.
+        dt_graph, graph_err = None, None
+        if not args.eager:
+            flat.suspend_overlap(True)
+            try:
+                gA = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gA, stream=side):
+                    if train:
+                        fwd_bwd()
+                        flat.pack()
+                    else:
+                        with torch.no_grad():
+                            model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+                gB = None
+                if train:
+                    gB = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gB, stream=side, pool=gA.pool()):
+                        if world > 1:
+                            flat.flat.mul_(inv_world)
+                        opt.step()
+
+                def graph_step():
+                    gA.replay()
+                    if train:
+                        if world > 1:
+                            dist.all_reduce(flat.flat, op=dist.ReduceOp.SUM)
+                        gB.replay()
+                for _ in range(max(2, args.warmup)):
+                    graph_step()
+                dt_graph = timed(graph_step, args.steps)
+            except Exception as e:                                   # capture is an optimisation of the launch path, never a requirement
+                graph_err = f"{type(e).__name__}: {e}"[:300]
+                torch.cuda.synchronize()
+            flat.suspend_overlap(False)
+        loss_last = float(loss_out)
+
+        # ---- all-reduce cost by itself (world > 1): the flat buffer, 20 back-to-back calls
+        ar_us = None
+        if train and use_dist:
+            probe = torch.zeros_like(flat.flat)
+            for _ in range(3):
+                dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            ar_us = 1e6 * (time.perf_counter() - t0) / 20
+
+        # ---- forward-only rate of the same workload (this rank's shard)
+        fwd_extra = None
+        if train:
+            def fwd_step():
+                with torch.no_grad():
+                    model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+            for _ in range(2):
+                fwd_step()
+            torch.cuda.synchronize()
+            nf = max(5, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(nf):
+                fwd_step()
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - t0) / nf
+            fwd_extra = {"molecules_per_s_per_gpu": round(args.batch / tf, 1), "ms_per_step": round(1e3 * tf, 4), "execution": "eager"}
+
+        # ---- per-kernel HIP-event brackets: a separate short eager pass, outside every timed region
+        orig_call = ops.call
+
+        def timed_call(name, *a):
+            if name == "conan_cfconv_fwd" or name in ev_other:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); orig_call(name, *a); e.record()
+                (ev if name == "conan_cfconv_fwd" else ev_other[name]).append((s, e))
+                if name == "conan_cfconv_fwd":   # an EMPTY bracket right behind it: what two event packets cost on this queue by themselves
+                    s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s0.record(); e0.record()
+                    ev_empty.append((s0, e0))
+            else:
+                orig_call(name, *a)
+        ops.call = timed_call
+        try:
+            for _ in range(10):
+                eager_step()
+            torch.cuda.synchronize()
+        finally:
+            ops.call = orig_call
+
+        # edge statistics of this rank's batch (reporting only)
+        gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
+        cutoff = 10.0 if args.model == "schnet" else 5.0
+        _g = ops.RadiusGraph(pos, gp, b.num_graphs, cutoff, 32, loop=args.model != "schnet")
+        E = _g.num_edges
+        P = int(_g.pairs().num_pairs_dev.item()) if args.model == "schnet" else E
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    use_graph = dt_graph is not None
+    dt, steps = (dt_graph, args.steps) if use_graph else (dt_eager, n_eager)
     n_atoms = int(z.shape[0])
-    kdur_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
-    empty_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_empty])) if ev_empty else float("nan")
+    mean_ms = lambda pairs: float(np.mean([s.elapsed_time(e) for s, e in pairs])) if pairs else float("nan")
+    kdur_ms, empty_ms = mean_ms(ev), mean_ms(ev_empty)
     # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately and
-    # committed under profiles/; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE) -- only valid for the default workload
-    traffic = None
-    try:
-        if args.shape == "esol" and args.batch == 256 and K == 5:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]["k_cfconv_fwd<1>"]
-            traffic = int(pm["traffic_bytes_corrected"])
-    except Exception:
-        traffic = None
-    alg = cfconv_algorithmic_bytes(E, P, n_atoms, 128)
-    achieved = alg / (kdur_ms * 1e-3) / 1e9
-
+    # committed under profiles/) -- only valid for the default workload
+    traffic, traffic_src = None, None
+    if args.shape == "esol" and args.batch == 256 and K == 5 and args.model == "schnet":
+        for name in ("r2_pmc_hbm.json", "r1_pmc_hbm.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["k_cfconv_fwd<1>"]
+                traffic, traffic_src = int(pm["traffic_bytes_corrected"]), f"profiles/{name} (separate rocprofv3 --pmc passes)"
+                break
+            except Exception:
+                continue
+    roofline = None
+    if ev:
+        alg = cfconv_algorithmic_bytes(E, P, n_atoms, 128)
+        achieved = alg / (kdur_ms * 1e-3) / 1e9
+        roofline = {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": alg, "survey_convention_bytes_per_launch": cfconv_survey_bytes(E, P, n_atoms, 128),
+                    "avg_launch_ms": round(kdur_ms, 5), "empty_event_bracket_ms": round(empty_ms, 5),
+                    "note": "avg_launch_ms is the raw HIP-event bracket around the launch (start event, kernel, end event on the launch "
+                            "stream), taken in a separate eager pass after the timed region; it contains the cost of the event packets "
+                            "themselves (empty_event_bracket_ms), so rocprofv3's kernel-only duration (profiles/) is shorter by about that "
+                            "amount. frac uses the raw bracket and the compulsory bytes.",
+                    "launches_timed": len(ev)}
     other = []
     if ev_other["conan_filter_fwd"]:
-        t_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_other["conan_filter_fwd"]]))
+        t_ms = mean_ms(ev_other["conan_filter_fwd"])
         fl = P * 2.0 * (50 * 128 + 128 * 128)                       # (2*Gs*F + 2*F*F) per filter row; P rows (pairs)
         other.append({"kernel": "k_filter_fused (rbf -> filter MLP -> cosine cutoff)", "bound": "mfma", "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2),
-                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / (t_ms * 1e-3) / 1e12 / 157.3, 4), "avg_launch_ms": round(t_ms, 5),
+                      "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), "avg_launch_ms": round(t_ms, 5),
                       "note": "fp32-equivalent algorithmic FLOP vs the fp32 MFMA peak; the second GEMM runs as an exact 3-way bf16 split"})
     if ev_other["conan_fgw_barycenter_fwd"]:
-        t_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_other["conan_fgw_barycenter_fwd"]]))
+        t_ms = mean_ms(ev_other["conan_fgw_barycenter_fwd"])
+        N_, d_ = b.max_nodes, 64
+        fgw_bytes = 4 * (2 * K * N_ ** 2 + K * N_ * d_ + N_ * d_ + N_ ** 2)
+        fgw_flop = 5 * K * 5 * (4 * N_ ** 3 + 5 * 12 * N_ ** 2)    # outer 5 x K x PGD 5 x (4N^3 + Sinkhorn 5 x ~12N^2), worst case
         other.append({"kernel": "FGW barycenter, whole batched solve (init + 5 x (coupling + update))", "bound": "fp64 issue / latency",
                       "avg_ms": round(t_ms, 4), "us_per_molecule": round(1e3 * t_ms / args.batch, 3),
-                      "algorithmic_bytes_per_molecule": 4 * (2 * K * b.max_nodes ** 2 + K * b.max_nodes * 64 + b.max_nodes * 64 + b.max_nodes ** 2)})
+                      "algorithmic_bytes_per_molecule": fgw_bytes, "worst_case_flop_per_molecule": fgw_flop,
+                      "achieved_fp64_tflops_upper": round(args.batch * fgw_flop / (t_ms * 1e-3) / 1e12, 3), "fp64_peak_tflops": 78.6,
+                      "hbm_gbs_of_algorithmic_bytes": round(args.batch * fgw_bytes / (t_ms * 1e-3) / 1e9, 1)})
     if rank == 0:
-        mol = args.batch * world * args.steps
+        mol = args.batch * world * steps
+        exe = ("HIP-graph replay (fwd+bwd+pack | RCCL all-reduce | Adam)" if train else "HIP-graph replay") if use_graph else "eager"
         out = {
             "metric": "molecules/s (K=5 conformers)", "value": round(mol / dt, 1), "unit": "molecules/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
-                                   + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce + Adam)" if args.mode == "train" else "(forward_w_barycenter + GAT branch + head)"),
+                                   + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
-                       "mode": args.mode, "parallelism": f"dp{world}", "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
-            "roofline": {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_hbm.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "algorithmic_bytes_per_launch": alg, "survey_convention_bytes_per_launch": cfconv_survey_bytes(E, P, n_atoms, 128),
-                         "avg_launch_ms": round(kdur_ms, 5),
-                         "empty_event_bracket_ms": round(empty_ms, 5),
-                         "note": "avg_launch_ms is the raw HIP-event bracket around the launch (start event, kernel, end event on the launch "
-                                 "stream); it contains the cost of the event packets themselves, measured live as empty_event_bracket_ms; "
-                                 "rocprofv3's kernel-only duration (profiles/) is therefore shorter by about that amount. frac uses the raw bracket.",
-                         "launches_timed": len(ev)},
+                       "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "allreduce_us": None if ar_us is None else round(ar_us, 1),
+            "allreduce": {"payload_bytes": int(flat.flat.numel()) * 4, "calls_per_step": (1 if world > 1 else 0) if use_graph else flat.last_allreduce_launches,
+                          "eager_overlap_buckets": list(buckets)},
+            "eager": {"molecules_per_s": round(args.batch * world * n_eager / dt_eager, 1), "ms_per_step": round(1e3 * dt_eager / n_eager, 4), "steps": n_eager},
+            "graph_capture_error": graph_err,
+            "loss": {"after_eager_phase": loss_eager, "last": loss_last},
+            "roofline": roofline,
         }
         out["roofline_other"] = other
         out["forward_only"] = fwd_extra
         if not args.no_cpu_baseline and world == 1:      # CPU oracle timed on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, args.mode, model)
+            out["cpu_baseline"] = cpu_baseline(args, model)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks here, before this process touches the GPU
+        sys.exit(spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,11 @@
 #include "fgw_common.h"
 
 namespace {
+// bytes of global scratch per coupling workgroup (Mr, A, base fp64 + T fp32 = 28 B per matrix entry), rounded to 16 B so that every
+// workgroup's fp64 region is aligned whatever the parity of N*P
+__host__ __device__ inline size_t coupling_scratch_stride(size_t NP) { return (NP * 28 + 15) / 16 * 16; }
+}
+namespace {
 
 // ------------------------------------------------------------------------------------------------ init
 __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict__ init_C, const float *__restrict__ init_Y,
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     double *pm = red + 16, *psm = pm + NW * N;                // per-wavefront partial (max, sum) of the log-sum-exp loops
     // LDS_MODE: all four matrices in LDS.  Otherwise only the Sinkhorn cost Mr (read 2x per Sinkhorn iteration, once by
     // rows and once by columns) stays in LDS when it fits (mr_lds); A, base and T live in an L2-resident global scratch.
-    char *gs = scratch + (size_t)blockIdx.x * ((size_t)NP * 28);
+    char *gs = scratch + (size_t)blockIdx.x * coupling_scratch_stride(NP);     // 16-byte aligned per workgroup
     char *ls = smem + (size_t)((6 + 2 * NW) * N + 16) * 8;
     double *Mr = reinterpret_cast<double *>((LDS_MODE || mr_lds) ? ls : gs);
     double *Al = LDS_MODE ? Mr + NP : reinterpret_cast<double *>(gs) + NP;
@@ -278,7 +283,12 @@ __global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat,
                                                  float *__restrict__ Ys, float *__restrict__ Cs, float *__restrict__ minmax) {
     __shared__ float smn[4], smx[4];
     const int g = blockIdx.x;
-    const int lo = gptr[g], n = gptr[g + 1] - lo;
+    const int lo = gptr[g], n_raw = gptr[g + 1] - lo;
+    // N is a caller-supplied hint (max_nodes).  A conformer with more atoms than N cannot be represented: nothing is
+    // read or written outside this graph's [N,d] / [N,N] slabs, and the slab's min/max are poisoned with NaN so that the
+    // whole molecule's output is NaN (visible) instead of silently wrong.
+    const bool overflow = n_raw > N;
+    const int n = overflow ? N : n_raw;
     const int tid = threadIdx.x;
     float mn = 3.0e38f, mx = -3.0e38f;
     for (int t = tid; t < n * d; t += 256) { const float v = feat[(size_t)lo * d + t] + shift; mn = fminf(mn, v); mx = fmaxf(mx, v); }
@@ -288,6 +298,7 @@ __global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat,
     __syncthreads();
     mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
     mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    if (overflow) mn = mx = __builtin_nanf("");
     if (tid == 0) { minmax[g * 2] = mn; minmax[g * 2 + 1] = mx; }
     const float scale = b - a, range = mx - mn;
     float *Yg = Ys + (size_t)g * N * d;
@@ -302,7 +313,7 @@ __global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat,
     for (int i = tid; i < n; i += 256) {
         for (int e = rowptr[lo + i]; e < rowptr[lo + i + 1]; ++e) {
             const int j = col[e] - lo;
-            Cg[j * N + i] += 1.0f;                  // distinct (src, tgt) per thread: no race
+            if (j < N) Cg[j * N + i] += 1.0f;       // distinct (src, tgt) per thread: no race
         }
     }
 }
@@ -314,7 +325,8 @@ __global__ void __launch_bounds__(256) k_densify_bwd(const float *__restrict__ f
                                                      float *__restrict__ dfeat) {
     __shared__ float red[3][4];
     const int g = blockIdx.x;
-    const int lo = gptr[g], n = gptr[g + 1] - lo;
+    const int lo = gptr[g], n_raw = gptr[g + 1] - lo;
+    const int n = n_raw > N ? N : n_raw;          // overflowing conformer (see k_densify): minmax is NaN, so is every gradient
     const int tid = threadIdx.x;
     const float mn = minmax[g * 2], mx = minmax[g * 2 + 1];
     const float s = b - a, r = mx - mn;
@@ -346,6 +358,7 @@ __global__ void __launch_bounds__(256) k_densify_bwd(const float *__restrict__ f
         if (x == mx) gx += dmx / tot[3];
         dfeat[(size_t)lo * d + t] = gx;
     }
+    for (int t = n * d + tid; t < n_raw * d; t += 256) dfeat[(size_t)lo * d + t] = __builtin_nanf("");
 }
 
 // F_bary readout (schnet_no_sum.py:308-312 ; visnet.py:233-248)
@@ -388,6 +401,7 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
 }
 
 inline int pitch_of(int N) { return N | 1; }
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 constexpr int GEN_NW = 8;                   // wavefronts per workgroup of the large-N coupling kernel
 inline size_t coupling_lds(int N) { return (size_t)((6 + 2 * GEN_NW) * N + 16) * 8 + (size_t)N * pitch_of(N) * 28; }
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -400,11 +414,11 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d) {
     if (B <= 0 || K <= 0 || N <= 0 || d <= 0) return 0;
     const size_t NN = (size_t)N * N, NP = (size_t)N * pitch_of(N);
     size_t bytes = 0;
-    bytes += (size_t)B * NN * 8;               // Cw
-    bytes += (size_t)B * N * d * 8;            // Yw
-    bytes += (size_t)B * 4 + 256;              // active
-    bytes += (size_t)B * K * NP * 28 + 256;    // coupling scratch (global mode)
-    bytes += (size_t)B * NP * 16 + 256;        // update scratch (global mode)
+    bytes += al256((size_t)B * NN * 8);               // Cw          (every region starts 256-byte aligned)
+    bytes += al256((size_t)B * N * d * 8);            // Yw
+    bytes += al256((size_t)B * 4);                    // active
+    bytes += al256((size_t)B * K * coupling_scratch_stride(NP));    // coupling scratch (global mode)
+    bytes += al256((size_t)B * NP * 16);              // update scratch (global mode)
     bytes += conan_fgw_small_part_bytes(B, K, N, d);   // per-graph update contributions (register-resident path)
     return (long long)bytes;
 }
@@ -421,11 +435,11 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     FgwDims D{B, K, N, d, pitch_of(N)};
     const size_t NN = (size_t)N * N, NP = (size_t)N * D.P;
     char *w = static_cast<char *>(workspace);
-    double *Cw = reinterpret_cast<double *>(w); w += (size_t)B * NN * 8;
-    double *Yw = reinterpret_cast<double *>(w); w += (size_t)B * N * d * 8;
-    int *active = reinterpret_cast<int *>(w); w += (((size_t)B * 4 + 255) / 256) * 256;
-    char *sc_c = w; w += (((size_t)B * K * NP * 28 + 255) / 256) * 256;
-    w += (((size_t)B * NP * 16 + 255) / 256) * 256;        // (reserved)
+    double *Cw = reinterpret_cast<double *>(w); w += al256((size_t)B * NN * 8);
+    double *Yw = reinterpret_cast<double *>(w); w += al256((size_t)B * N * d * 8);
+    int *active = reinterpret_cast<int *>(w); w += al256((size_t)B * 4);
+    char *sc_c = w; w += al256((size_t)B * K * coupling_scratch_stride(NP));
+    w += al256((size_t)B * NP * 16);        // (reserved)
     double *Ypart = reinterpret_cast<double *>(w);
     double *Cpart = Ypart + (size_t)B * K * N * d;
     const bool small = conan_fgw_small_supported(N, d);

@@ -15,9 +15,9 @@
 //                                match: no LDS round trip, no cross-lane traffic between the two GEMMs.
 // The A operands (the two weight matrices, <= 98 KB) are staged once per workgroup in LDS and read with conflict-free
 // ds_read_b128 (4 k-steps per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
-// v_mfma_f32_32x32x2_f32 back to back (exact fp32).
+// MFMAs back to back: GEMM1 on v_mfma_f32_32x32x2_f32, GEMM2 as an exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16
+// (fp32-class accuracy; there is no other arithmetic mode and no environment switch).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -43,18 +43,17 @@ constexpr int GP = 56;        // gaussians padded to a multiple of 8 (zero weigh
 constexpr int W1P = 60;       // LDS pitch of W1 rows  (60 = 4*15: 16 consecutive rows hit 16 distinct 16-B slots)
 constexpr int FF_THREADS = 512;
 
-template <int F, bool SPLIT>
+template <int F>
 __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     const float *__restrict__ dist, const int *__restrict__ num_edges_dev, int max_edges, const float *__restrict__ offset,
     int Gs, float coeff, float cutoff, const float *__restrict__ w1, const float *__restrict__ b1,
-    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out, int dbg) {
+    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out) {
     constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
-    constexpr int W2P = F + 4;            // LDS pitch of W2 rows (fp32 image)
     constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (bf16 elements; 16-B slots stay distinct)
-    constexpr int W2WORDS = SPLIT ? (3 * F * W2S) / 2 : F * W2P;      // floats occupied by the W2 image(s)
+    constexpr int W2WORDS = (3 * F * W2S) / 2;      // floats occupied by the three bf16 W2 images
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *W1L = lds;                     // [F][W1P]
-    float *W2L = W1L + F * W1P;           // fp32 [F][W2P]  |  SPLIT: 3 x bf16 [F][W2S], columns permuted per 16-group
+    float *W2L = W1L + F * W1P;           // 3 x bf16 [F][W2S], columns permuted per 16-group
     float *B1L = W2L + W2WORDS;           // [F]
     float *B2L = B1L + F;                 // [F]
     float *OFL = B2L + F;                 // [GP]
@@ -74,12 +73,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
         for (int u = 0; u < PER1; ++u) { const int t = tid + u * FF_THREADS; if (t < F * W1P) W1L[t] = wv[u]; }
     }
-    if (!SPLIT) {
-        for (int t = tid; t < F * W2P; t += FF_THREADS) {
-            const int f2 = t / W2P, f = t - f2 * W2P;
-            W2L[t] = f < F ? w2[(size_t)f2 * F + f] : 0.f;
-        }
-    } else {
+    {
         // three bf16 images of W2; inside every group of 16 input channels the columns are stored in the order the B
         // fragment (GEMM1's accumulator registers 8s..8s+7 of lane-half h) enumerates them: position 8h + j holds
         // channel (j&3) + 8(j>>2) + 4h, so a lane reads its 8 k-values as one 16-byte access.
@@ -159,7 +153,6 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&B1L[32 * mb + 8 * q + 4 * h]);
-                if (dbg & 2) continue;
                 acc1[mb][4 * q + 0] = ssp_f(acc1[mb][4 * q + 0] + bb.x);
                 acc1[mb][4 * q + 1] = ssp_f(acc1[mb][4 * q + 1] + bb.y);
                 acc1[mb][4 * q + 2] = ssp_f(acc1[mb][4 * q + 2] + bb.z);
@@ -184,7 +177,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             for (int nb = 0; nb < NG; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
-            if constexpr (SPLIT) {
+            {
                 const __bf16 *W2B = reinterpret_cast<const __bf16 *>(W2L);
 #pragma unroll
                 for (int ms = 0; ms < 2 * MB; ++ms) {
@@ -211,32 +204,9 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {
-                float4 a_cur[NG], a_nxt[NG];
-#pragma unroll
-                for (int nb = 0; nb < NG; ++nb) a_cur[nb] = *reinterpret_cast<const float4 *>(&W2L[(32 * (n0 + nb) + l31) * W2P + 4 * h]);
-#pragma unroll
-                for (int mq = 0; mq < 4 * MB; ++mq) {
-                    const int mb = mq >> 2, q = mq & 3;
-                    const int kb = 32 * mb + 8 * q + 4 * h;      // channels held by registers 4q..4q+3 of this half
-                    if (mq + 1 < 4 * MB) {
-#pragma unroll
-                        for (int nb = 0; nb < NG; ++nb) a_nxt[nb] = *reinterpret_cast<const float4 *>(&W2L[(32 * (n0 + nb) + l31) * W2P + kb + 8]);
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NG; ++nb) {
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].x, acc1[mb][4 * q + 0], acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].y, acc1[mb][4 * q + 1], acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].z, acc1[mb][4 * q + 2], acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].w, acc1[mb][4 * q + 3], acc2[nb], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nb = 0; nb < NG; ++nb) a_cur[nb] = a_nxt[nb];
-                }
             }
             // epilogue: + b2, * C(d), store W[e, 32nb + 8q + 4h .. +3]
-            if (valid && !(dbg & 1)) {
+            if (valid) {
 #pragma unroll
                 for (int nb = 0; nb < NG; ++nb)
 #pragma unroll
@@ -254,17 +224,16 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     }
 }
 
-template <int F, bool SPLIT>
+template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    const size_t lds = ((size_t)F * W1P + (SPLIT ? (size_t)(3 * F * (F + 8)) / 2 : (size_t)F * (F + 4)) + 2 * F + GP) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = ((size_t)F * W1P + (size_t)(3 * F * (F + 8)) / 2 + 2 * F + GP) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;
     if (grid > 256) grid = 256;                           // one persistent 8-wave workgroup per CU
-    static int dbg = getenv("CONAN_FILTER_DEBUG") ? atoi(getenv("CONAN_FILTER_DEBUG")) : 0;
-    k_filter_fused<F, SPLIT><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, dbg);
+    k_filter_fused<F><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1);
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
@@ -283,11 +252,7 @@ int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges,
     if (!conan_filter_fused_supported(num_gaussians, num_filters)) return CONAN_E_UNSUPPORTED;
     if (max_edges == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
-    // CONAN_FILTER_FP32=1 forces the plain fp32-MFMA second GEMM (default: exact 3-way bf16 split on the bf16 MFMA)
-    static const bool fp32_only = getenv("CONAN_FILTER_FP32") && atoi(getenv("CONAN_FILTER_FP32")) != 0;
-#define CONAN_FF(FV)                                                                                                                   \
-    return fp32_only ? launch<FV, false>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s) \
-                     : launch<FV, true>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s)
+#define CONAN_FF(FV) return launch<FV>(dist, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, W, h1_out, s)
     switch (num_filters) {
         case 32: CONAN_FF(32);
         case 64: CONAN_FF(64);

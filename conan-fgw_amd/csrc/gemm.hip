@@ -8,7 +8,6 @@
 // with odd pitches (33 / BN+1 floats) so that both the transposed staging writes and the MFMA fragment reads
 // (lane -> row for A, lane -> column for B) are bank-conflict free with ds_read_b32.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -246,92 +245,12 @@ __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict_
 // ---- weight gradient: dW[N,K] = g^T @ x, reduction over the M rows ---------------------------------------------
 // Stage 1: the rows are cut into slices, one workgroup per (slice, 128x128 tile of dW), partial slabs written per slice.
 // Stage 2: the per-slice slabs are summed in a fixed order => bitwise reproducible, no float atomics.
-// Operands come straight from global memory in their natural layout: for a pair of rows (m, m+1) lane (l31, h) loads
-// g[m+h][n0 + l31] (A: lane -> n) and x[m+h][k0 + l31] (B: lane -> k) — each half-wavefront reads one contiguous 128-B
-// segment, no LDS, no barrier; WG_U row pairs are requested before their MFMAs issue (4*WG_U dword loads per lane in
-// flight).  4 wavefronts as 2x2 over the 128x128 tile (64x64 each = 2x2 accumulators); duplicates between the waves of a
-// workgroup hit L1/L2, HBM sees every row of g and x once.
-constexpr int WG_TILE = 128;
 constexpr int WG_SLICES_MAX = 768;      // 3 workgroups per CU
 constexpr int WG_U = 16;            // row pairs in flight
 
-__global__ void __launch_bounds__(256) k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
-                                                       int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
-                                                       const int *__restrict__ m_dev) {
-    if (m_dev) M = min(M, *m_dev);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * WG_TILE + wm * 64, k0 = blockIdx.z * WG_TILE + wn * 64;
-    const int slice = blockIdx.x;
-    const int r_begin = slice * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
-    const bool wave_active = (n0 < N) && (k0 < K);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bs0 = 0.f, bs1 = 0.f;          // bias gradient partials of columns n0 + l31, n0 + 32 + l31 (rows of parity h)
-    const bool na0 = n0 + l31 < N, na1 = n0 + 32 + l31 < N, ka0 = k0 + l31 < K, ka1 = k0 + 32 + l31 < K;
-    if (wave_active) {
-        const float *gp = g + n0 + l31, *xp = x + k0 + l31;
-        int m = r_begin;
-        for (; m + 2 * WG_U <= r_end; m += 2 * WG_U) {
-            float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
-#pragma unroll
-            for (int u = 0; u < WG_U; ++u) {
-                const size_t row = (size_t)(m + 2 * u + h);
-                a0[u] = na0 ? gp[row * N] : 0.f;
-                a1[u] = na1 ? gp[row * N + 32] : 0.f;
-                b0[u] = ka0 ? xp[row * K] : 0.f;
-                b1[u] = ka1 ? xp[row * K + 32] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < WG_U; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
-                bs0 += a0[u]; bs1 += a1[u];
-            }
-        }
-        for (; m < r_end; m += 2) {          // ragged tail: rows past r_end contribute zeros
-            const int row = m + h;
-            const bool ok = row < r_end;
-            const float a0 = (ok && na0) ? gp[(size_t)row * N] : 0.f, a1 = (ok && na1) ? gp[(size_t)row * N + 32] : 0.f;
-            const float b0 = (ok && ka0) ? xp[(size_t)row * K] : 0.f, b1 = (ok && ka1) ? xp[(size_t)row * K + 32] : 0.f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            bs0 += a0; bs1 += a1;
-        }
-        float *slab = slabs + (size_t)slice * N * K;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int k = k0 + b * 32 + l31;
-                    if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
-                }
-    }
-    // bias gradient: the wn == 0 waves of the blockIdx.z == 0 column own it; combine the two row parities
-    if (blockIdx.z == 0 && wn == 0 && n0 < N) {
-        bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
-        if (h == 0) {
-            if (na0) bias_slabs[(size_t)slice * N + n0 + l31] = bs0;
-            if (na1) bias_slabs[(size_t)slice * N + n0 + 32 + l31] = bs1;
-        }
-    }
-}
 
-// bf16-split variant of the direct weight gradient: 16 rows per MFMA step; both operand fragments (8 consecutive rows of
-// one column per lane) are split exactly into three bf16 parts in registers, six partial products per 32x32 block on
+// bf16-split arithmetic of the weight gradient: 16 rows per MFMA step; an operand fragment (8 consecutive rows of one
+// column per lane) is split exactly into three bf16 parts, six partial products per 32x32 block on
 // v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, 2.7x the fp32 MFMA rate).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void wg_split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
@@ -355,73 +274,8 @@ __device__ __forceinline__ f32x16 wg_mma6(const bf16x8 &a1, const bf16x8 &a2, co
     return acc;
 }
 
-__global__ void __launch_bounds__(256) k_wgrad_partial16(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
-                                                         int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
-                                                         const int *__restrict__ m_dev) {
-    if (m_dev) M = min(M, *m_dev);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * WG_TILE + wm * 64, k0 = blockIdx.z * WG_TILE + wn * 64;
-    const int slice = blockIdx.x;
-    const int r_begin = slice * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
-    const bool wave_active = (n0 < N) && (k0 < K);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bs0 = 0.f, bs1 = 0.f;
-    const bool na0 = n0 + l31 < N, na1 = n0 + 32 + l31 < N, ka0 = k0 + l31 < K, ka1 = k0 + 32 + l31 < K;
-    if (wave_active) {
-        const float *gp = g + n0 + l31, *xp = x + k0 + l31;
-        for (int m = r_begin; m < r_end; m += 16) {           // lane-half h owns rows m + 8h .. m + 8h + 7
-            float a0[8], a1[8], b0[8], b1[8];
-            const bool full = m + 16 <= r_end;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = m + 8 * h + j;
-                const bool ok = full || row < r_end;
-                const size_t rr = (size_t)(ok ? row : r_begin);
-                const float ga0 = na0 ? gp[rr * N] : 0.f, ga1 = na1 ? gp[rr * N + 32] : 0.f;
-                const float xb0 = ka0 ? xp[rr * K] : 0.f, xb1 = ka1 ? xp[rr * K + 32] : 0.f;
-                a0[j] = ok ? ga0 : 0.f; a1[j] = ok ? ga1 : 0.f; b0[j] = ok ? xb0 : 0.f; b1[j] = ok ? xb1 : 0.f;
-            }
-            bf16x8 p0[3], p1[3], q0[3], q1[3];
-            wg_split3(a0, p0[0], p0[1], p0[2]); wg_split3(a1, p1[0], p1[1], p1[2]);
-            wg_split3(b0, q0[0], q0[1], q0[2]); wg_split3(b1, q1[0], q1[1], q1[2]);
-            acc[0][0] = wg_mma6(p0[0], p0[1], p0[2], q0[0], q0[1], q0[2], acc[0][0]);
-            acc[0][1] = wg_mma6(p0[0], p0[1], p0[2], q1[0], q1[1], q1[2], acc[0][1]);
-            acc[1][0] = wg_mma6(p1[0], p1[1], p1[2], q0[0], q0[1], q0[2], acc[1][0]);
-            acc[1][1] = wg_mma6(p1[0], p1[1], p1[2], q1[0], q1[1], q1[2], acc[1][1]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { bs0 += a0[j]; bs1 += a1[j]; }
-        }
-        float *slab = slabs + (size_t)slice * N * K;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int k = k0 + b * 32 + l31;
-                    if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
-                }
-    }
-    if (blockIdx.z == 0 && wn == 0 && n0 < N) {
-        bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
-        if (h == 0) {
-            if (na0) bias_slabs[(size_t)slice * N + n0 + l31] = bs0;
-            if (na1) bias_slabs[(size_t)slice * N + n0 + 32 + l31] = bs1;
-        }
-    }
-}
 
-// LDS-staged variant (default).  The direct kernels above split every operand value once per consuming wave (2x) and
-// keep few bytes in flight; here each value is loaded and split ONCE by a producer thread, in exactly the MFMA fragment
+// LDS-staged weight gradient.  Each value is loaded and split ONCE by a producer thread, in exactly the MFMA fragment
 // unit: 8 consecutive rows of one column (lane <-> column, so the dword loads are coalesced 128-B segments), split into
 // three bf16x8 planes and parked in LDS as three 16-byte words [plane][row group][column].  Consumers fetch a fragment
 // with three contiguous ds_read_b128.  16 rows (one MFMA k-step) per stage, double-buffered, loads issued one stage ahead.
@@ -724,12 +578,7 @@ static int wgrad_launch(const float *g, const float *x, int M, int K, int N, con
     int rows = (M + slices - 1) / slices;
     rows = ((rows + 2 * WG_U - 1) / (2 * WG_U)) * (2 * WG_U);
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * N * K;
-    // CONAN_LINEAR_FP32=1 forces the plain fp32-MFMA kernel (default: exact 3-way bf16 split on the bf16 MFMA)
-    static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
-    static const bool no_lds = getenv("CONAN_WGRAD_DIRECT") && atoi(getenv("CONAN_WGRAD_DIRECT")) != 0;
-    const bool lds_ok = !fp32_only && !no_lds;
-    if (rbf && !lds_ok) return CONAN_E_UNSUPPORTED;
-    if (lds_ok) {
+    {
         const int KT = K > 64 ? 128 : 64;
         dim3 grid(slices, (N + 127) / 128, (K + KT - 1) / KT);
         if (KT == 128) {
@@ -739,11 +588,6 @@ static int wgrad_launch(const float *g, const float *x, int M, int K, int N, con
             if (rbf) k_wgrad_lds<64, true><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
             else k_wgrad_lds<64, false><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
         }
-    } else {
-        dim3 grid(slices, (N + WG_TILE - 1) / WG_TILE, (K + WG_TILE - 1) / WG_TILE);
-        // (measured at E = 518k: 227 vs 247 us for 128x128, but 186 vs 164 us for K = 50 where half a 64-wide block is padding)
-        if (fp32_only || K < 64) k_wgrad_partial<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
-        else k_wgrad_partial16<<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev);
     }
     const int NK = N * K;
     if ((NK & 3) == 0 && (N & 3) == 0) {

@@ -8,7 +8,6 @@
 // fragments, software-pipelined one group ahead.  The accumulators (D layout: row = feature, column = x row) are
 // stored / combined with `residual` as float4 per lane.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -198,124 +197,26 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
 }
 
 template <int K, int N>
-__global__ void __launch_bounds__(LT_THREADS) k_linear_t(const float *__restrict__ x, const float *__restrict__ w,
-                                                         const float *__restrict__ bias, const float *__restrict__ residual,
-                                                         int M, int w_kn, int act, float *__restrict__ y,
-                                                         const int *__restrict__ m_dev) {
-    constexpr int NB = N / 32;            // output row blocks
-    constexpr int G = K / 8;              // k groups (8 k's per group: 4 per lane-half)
-    constexpr int WP = K + 4;             // LDS pitch of a W row (16 consecutive rows -> 16 distinct 16-B slots)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *WL = lds;                      // [N][WP]
-    float *BL = WL + N * WP;              // [N]
-    if (m_dev) M = min(M, *m_dev);
-    const int tiles = (M + 31) >> 5;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x * (LT_THREADS / 64) >= tiles) return;
-    // stage W as [n][k] (torch Linear layout when w_kn == 0; transposed on the fly when W is [K][N])
-    for (int t = tid; t < N * K; t += LT_THREADS) {
-        const int n = t / K, k = t - n * K;
-        WL[n * WP + k] = w_kn ? w[(size_t)k * N + n] : w[t];
-    }
-    for (int t = tid; t < N; t += LT_THREADS) BL[t] = bias ? bias[t] : 0.f;
-    __syncthreads();
-
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wave_stride = gridDim.x * (LT_THREADS / 64);
-    for (int tile = blockIdx.x * (LT_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
-        const int m = (tile << 5) + l31;
-        const bool valid = m < M;
-        const float *xr = x + (size_t)(valid ? m : M - 1) * K + 4 * h;
-        float4 xb[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) xb[g] = *reinterpret_cast<const float4 *>(xr + 8 * g);     // all loads in flight at once
-        f32x16 acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        float4 a_cur[NB], a_nxt[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) a_cur[nb] = *reinterpret_cast<const float4 *>(&WL[(32 * nb + l31) * WP + 4 * h]);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g + 1 < G) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) a_nxt[nb] = *reinterpret_cast<const float4 *>(&WL[(32 * nb + l31) * WP + 8 * (g + 1) + 4 * h]);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].x, xb[g].x, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].y, xb[g].y, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].z, xb[g].z, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb].w, xb[g].w, acc[nb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) a_cur[nb] = a_nxt[nb];
-        }
-        if (!valid) continue;
-        // epilogue: registers 4q..4q+3 of block nb, half h = features 32nb + 8q + 4h .. +3 of row m
-        float *yr = y + (size_t)m * N + 4 * h;
-        const float *rr = residual ? residual + (size_t)m * N + 4 * h : nullptr;
-        float4 rv[NB][4];
-        if (rr) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
-                float v[4] = {acc[nb][4 * q] + bb.x, acc[nb][4 * q + 1] + bb.y, acc[nb][4 * q + 2] + bb.z, acc[nb][4 * q + 3] + bb.w};
-                const float r4[4] = {rr ? rv[nb][q].x : 0.f, rr ? rv[nb][q].y : 0.f, rr ? rv[nb][q].z : 0.f, rr ? rv[nb][q].w : 0.f};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (act == 1) v[u] = ssp_f(v[u]);
-                    else if (act == 3) v[u] = v[u] / (1.0f + __expf(-v[u]));
-                    if (act == 2) v[u] *= 1.0f - 0.5f * __expf(-r4[u]);
-                    else if (rr) v[u] += r4[u];
-                }
-                *reinterpret_cast<float4 *>(yr + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-    }
-}
-
-template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
              const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr) {
     if (ldw == 0) ldw = w_kn ? N : K;
-    // CONAN_LINEAR_FP32=1 forces the plain fp32-MFMA kernel (default: exact 3-way bf16 split on the bf16 MFMA)
-    static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
-    if (!fp32_only || ldx != K || ldy != N || accum || pre_out) {
-        const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
-        const int tiles16 = (M + 31) / 32;
-        int grid16 = (tiles16 + 7) / 8;
-        if (grid16 > 256) grid16 = 256;
+    const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
+    const int tiles16 = (M + 31) / 32;
+    int grid16 = (tiles16 + 7) / 8;
+    if (grid16 > 256) grid16 = 256;
 #define LAUNCH16(A)                                                                                                              \
     do {                                                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds16);                                                                                   \
         k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out); \
     } while (0)
-        switch (act) {
-            case 0: LAUNCH16(0); break;
-            case 1: LAUNCH16(1); break;
-            case 2: LAUNCH16(2); break;
-            default: LAUNCH16(3); break;
-        }
-#undef LAUNCH16
-        return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+    switch (act) {
+        case 0: LAUNCH16(0); break;
+        case 1: LAUNCH16(1); break;
+        case 2: LAUNCH16(2); break;
+        default: LAUNCH16(3); break;
     }
-    const size_t lds = ((size_t)N * (K + 4) + N) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t<K, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int tiles = (M + 31) / 32;
-    int grid = (tiles + 7) / 8;
-    if (grid > 256) grid = 256;
-    k_linear_t<K, N><<<grid, LT_THREADS, lds, s>>>(x, w, bias, residual, M, w_kn, act, y, m_dev);
+#undef LAUNCH16
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
@@ -347,9 +248,7 @@ int conan_linear_t_try(const float *x, const float *w, const float *bias, const 
     if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 128, 0, 64, nullptr, pre_out); return 1; }
     if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 64, nullptr, pre_out); return 1; }
     if (K == 64 && N == 128) { *rc = launch_t<64, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 128, nullptr, pre_out); return 1; }
-    static const bool fp32_only = getenv("CONAN_LINEAR_FP32") && atoi(getenv("CONAN_LINEAR_FP32")) != 0;
-    if (fp32_only || (K % 64) || (N % 64) || K > 1024 || N > 1024) return 0;
-    // (fp32_only with pre_out on the four base shapes above still runs the split kernel: launch_t routes it there)
+    if ((K % 64) || (N % 64) || K > 1024 || N > 1024) return 0;
     const bool k128 = (K % 128) == 0, n128 = (N % 128) == 0;
     if (k128 && n128) *rc = chunk_launch<128, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);
     else if (k128) *rc = chunk_launch<128, 64>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);

@@ -49,21 +49,28 @@ __global__ void __launch_bounds__(RG_THREADS) k_radius(const float *__restrict__
         float ax, ay, az;
         if (in_lds) { ax = sp[i * 3]; ay = sp[i * 3 + 1]; az = sp[i * 3 + 2]; }
         else { ax = pos[(size_t)(lo + i) * 3]; ay = pos[(size_t)(lo + i) * 3 + 1]; az = pos[(size_t)(lo + i) * 3 + 2]; }
-        int cnt = 0;
+        // torch-cluster 1.6.1: radius(x, x, r, batch, batch, loop ? cap : cap + 1) scans the sources of the graph in ascending
+        // index order INCLUDING the target itself and stops after `limit` hits; radius_graph drops the self pair afterwards.
+        // A target with >= cap + 1 lower-index in-range atoms therefore keeps cap + 1 edges (its own hit never enters the
+        // window), every other truncated target keeps cap.
+        const int limit = loop ? cap : cap + 1;
+        int cnt = 0, out = 0;
         int base = PASS ? rowptr[lo + i] : 0;
-        for (int j = 0; j < n && cnt < cap; ++j) {
-            if (!loop && j == i) continue;
+        for (int j = 0; j < n && cnt < limit; ++j) {
             float bx, by, bz;
             if (in_lds) { bx = sp[j * 3]; by = sp[j * 3 + 1]; bz = sp[j * 3 + 2]; }
             else { bx = pos[(size_t)(lo + j) * 3]; by = pos[(size_t)(lo + j) * 3 + 1]; bz = pos[(size_t)(lo + j) * 3 + 2]; }
             // the reference's edge_weight is ||pos[row]-pos[col]|| with row = source j, col = target i: same d2 by symmetry
             float d2 = dist2_rn(bx, by, bz, ax, ay, az);
             if (d2 < r2) {
-                if (PASS) { col[base + cnt] = lo + j; tgt[base + cnt] = lo + i; dist[base + cnt] = __fsqrt_rn(d2); }
                 ++cnt;
+                if (loop || j != i) {
+                    if (PASS) { col[base + out] = lo + j; tgt[base + out] = lo + i; dist[base + out] = __fsqrt_rn(d2); }
+                    ++out;
+                }
             }
         }
-        if (!PASS) deg[lo + i] = cnt;
+        if (!PASS) deg[lo + i] = out;
     }
 }
 

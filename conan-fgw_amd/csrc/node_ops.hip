@@ -3,13 +3,18 @@
 
 namespace {
 
-__global__ void k_embedding_fwd(const int64_t *__restrict__ z, const float *__restrict__ weight, int n, int H4,
+// An index outside [0, rows) (torch.nn.Embedding device-asserts there) never reads out of bounds: its output row is NaN,
+// which poisons the loss visibly instead of corrupting silently.
+__global__ void k_embedding_fwd(const int64_t *__restrict__ z, const float *__restrict__ weight, int n, int H4, int rows,
                                 float *__restrict__ out) {
     const long long total = (long long)n * H4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int a = (int)(i / H4), c = (int)(i - (long long)a * H4);
-        reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(weight)[(size_t)z[a] * H4 + c];
+        const long long r = z[a];
+        const float qn = __builtin_nanf("");
+        reinterpret_cast<float4 *>(out)[i] = (r >= 0 && r < rows) ? reinterpret_cast<const float4 *>(weight)[(size_t)r * H4 + c]
+                                                                   : make_float4(qn, qn, qn, qn);
     }
 }
 
@@ -25,7 +30,10 @@ __global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__
     const int chunk = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
     const int a0 = chunk * EMB_CHUNK, a1 = min(n, a0 + EMB_CHUNK);
     for (int t = threadIdx.x; t < rows * 128; t += 128) acc[t] = 0.f;
-    for (int t = threadIdx.x; t < a1 - a0; t += 128) zs[t] = (int)z[a0 + t];
+    for (int t = threadIdx.x; t < a1 - a0; t += 128) {          // out-of-range indices (NaN rows in the forward) add nothing
+        const long long r = z[a0 + t];
+        zs[t] = (r >= 0 && r < rows) ? (int)r : -1;
+    }
     __syncthreads();
     if (c < H) {                            // loads issued 8 deep, then the (order-preserving) LDS accumulation
         int a = a0;
@@ -34,9 +42,9 @@ __global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = dout[(size_t)(a + u) * H + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[zs[a + u - a0] * 128 + threadIdx.x] += v[u];
+            for (int u = 0; u < 8; ++u) { const int r = zs[a + u - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += v[u]; }
         }
-        for (; a < a1; ++a) acc[zs[a - a0] * 128 + threadIdx.x] += dout[(size_t)a * H + c];
+        for (; a < a1; ++a) { const int r = zs[a - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += dout[(size_t)a * H + c]; }
     }
     __syncthreads();
     if (c < H)
@@ -86,14 +94,14 @@ template <int OP>      // 0 = relu, 1 = sigmoid
 __global__ void k_unary_fwd(const float *__restrict__ x, long long n, float *__restrict__ y) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = x[i];
-        y[i] = OP == 0 ? fmaxf(v, 0.f) : 1.0f / (1.0f + expf(-v));
+        y[i] = OP == 0 ? fmaxf(v, 0.f) : OP == 1 ? 1.0f / (1.0f + expf(-v)) : ssp_f(v);
     }
 }
 template <int OP>
 __global__ void k_unary_bwd(const float *__restrict__ y, const float *__restrict__ dy, long long n, float *__restrict__ dx) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float o = y[i];
-        dx[i] = OP == 0 ? (o > 0.f ? dy[i] : 0.f) : dy[i] * o * (1.0f - o);
+        dx[i] = OP == 0 ? (o > 0.f ? dy[i] : 0.f) : OP == 1 ? dy[i] * o * (1.0f - o) : dy[i] * (1.0f - 0.5f * __expf(-o));
     }
 }
 
@@ -102,13 +110,13 @@ __global__ void k_unary_bwd(const float *__restrict__ y, const float *__restrict
 
 extern "C" {
 
-int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, int hidden, float *out, void *stream) {
-    if (!z || !weight || !out || num_atoms < 0 || hidden <= 0 || (hidden & 3)) return CONAN_E_BADARG;
+int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, int hidden, int num_embeddings, float *out, void *stream) {
+    if (!z || !weight || !out || num_atoms < 0 || hidden <= 0 || (hidden & 3) || num_embeddings <= 0) return CONAN_E_BADARG;
     if (num_atoms == 0) return CONAN_OK;
     long long total = (long long)num_atoms * (hidden >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    k_embedding_fwd<<<blocks, 256, 0, as_stream(stream)>>>(z, weight, num_atoms, hidden >> 2, out);
+    k_embedding_fwd<<<blocks, 256, 0, as_stream(stream)>>>(z, weight, num_atoms, hidden >> 2, num_embeddings, out);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }
@@ -150,21 +158,23 @@ int conan_segment_sum_bwd(const float *dout, const int *graph_ptr, int num_graph
 }
 
 int conan_unary_fwd(const float *x, long long count, int op, float *y, void *stream) {
-    if (count < 0 || op < 0 || op > 1 || (count && (!x || !y))) return CONAN_E_BADARG;
+    if (count < 0 || op < 0 || op > 2 || (count && (!x || !y))) return CONAN_E_BADARG;
     if (!count) return CONAN_OK;
     const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
     if (op == 0) k_unary_fwd<0><<<blocks, 256, 0, as_stream(stream)>>>(x, count, y);
-    else k_unary_fwd<1><<<blocks, 256, 0, as_stream(stream)>>>(x, count, y);
+    else if (op == 1) k_unary_fwd<1><<<blocks, 256, 0, as_stream(stream)>>>(x, count, y);
+    else k_unary_fwd<2><<<blocks, 256, 0, as_stream(stream)>>>(x, count, y);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }
 
 int conan_unary_bwd(const float *y, const float *dy, long long count, int op, float *dx, void *stream) {
-    if (count < 0 || op < 0 || op > 1 || (count && (!y || !dy || !dx))) return CONAN_E_BADARG;
+    if (count < 0 || op < 0 || op > 2 || (count && (!y || !dy || !dx))) return CONAN_E_BADARG;
     if (!count) return CONAN_OK;
     const int blocks = (int)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
     if (op == 0) k_unary_bwd<0><<<blocks, 256, 0, as_stream(stream)>>>(y, dy, count, dx);
-    else k_unary_bwd<1><<<blocks, 256, 0, as_stream(stream)>>>(y, dy, count, dx);
+    else if (op == 1) k_unary_bwd<1><<<blocks, 256, 0, as_stream(stream)>>>(y, dy, count, dx);
+    else k_unary_bwd<2><<<blocks, 256, 0, as_stream(stream)>>>(y, dy, count, dx);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

@@ -4,7 +4,7 @@
 Same argument names, defaults and error behaviour (`ValueError` for unknown `loss_fun` / `stop_criterion` / `solver`,
 barycenter.py:33-44).  `loss_fun` = "square_loss" (every model) or "kl_loss" (utils.py:20-32,76-87).  Option values that exist in
 the reference but are not reached by any model (`BAPG`, `PPA`, `stop_criterion="loss"` — the latter is broken in the reference
-itself) raise `NotImplementedError`.  Runs on the GPU only.
+itself, SURVEY.md 8c — and input graphs whose node count differs from N) raise `NotImplementedError`.  Runs on the GPU only.
 """
 from __future__ import annotations
 
@@ -40,14 +40,23 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
         raise ValueError("If C is fixed it must be initialized")
     if fixed_features and init_Y is None:
         raise ValueError("If Y is fixed it must be initialized")
-    if init_C is None:
-        raise NotImplementedError("random init_C (barycenter.py:61-65, torch.randn on the host) is not reproduced; pass init_C")
 
     Ys_t = torch.stack([y.to(torch.float32) for y in Ys]) if not torch.is_tensor(Ys) else Ys
     Cs_t = torch.stack([c.to(torch.float32) for c in Cs]) if not torch.is_tensor(Cs) else Cs
     K, n, d = Ys_t.shape
     if n != N or Cs_t.shape[1] != N:
         raise NotImplementedError("input graphs must all have N nodes (the ConAN glue pads them, schnet_no_sum.py:242-252)")
+    if init_C is None:
+        # barycenter.py:61-65: torch.manual_seed(seed); xalea = torch.randn(N, 2); C = dist(xalea, xalea) — a host-side random
+        # squared-distance matrix (utils.py:154-171 with X is Y: clamped at 0, zero diagonal).  Reproduced draw for draw,
+        # including the reference's re-seeding of the global generator; N x 2 numbers of initialisation, not the solver.
+        torch.manual_seed(seed)
+        xalea = torch.randn(N, 2)
+        a2 = torch.einsum("ij,ij->i", xalea, xalea)
+        c0 = -2 * (xalea @ xalea.T)
+        c0 += a2[:, None]
+        c0 += a2[None, :]
+        init_C = (torch.clamp(c0, min=0) * (1 - torch.eye(N))).to(Ys_t.device)
     ps_t = None
     if ps is not None:
         ps_t = (torch.stack(list(ps)) if not torch.is_tensor(ps) else ps).to(torch.float32).view(1, K, N)

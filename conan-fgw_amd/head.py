@@ -1,9 +1,9 @@
-"""Regression head of the reference's stage-2 model without the covalent (GAT) branch.
+"""The reference's conformer-aggregation models on top of the MI355X backbones (without their Lightning shell).
 
 `EmbeddingsWithGATAggregationBaryCenter.forward` (conan_fgw/src/model/schnet_based_models.py:135-173) combines
 x = Lin3d(h_3d) + Lin_cov(GAT(...)) + agg_weight * Lin_bary(h_bary), averages over the K conformers and applies the final
-linear.  The GAT branch is outside this build's scope; this head reproduces the rest so that the
-benchmark and the training tests have a loss to differentiate.  All linears run on conan_linear_fwd.
+linear; the stage-1 and classification twins (:176-244, :308-369) are the same assembly.  Backbones come from
+`EquivModelsHolder.get_model` exactly like the reference (common.py:400-402,444-446).  All linears run on conan_linear_fwd.
 """
 from __future__ import annotations
 
@@ -14,22 +14,33 @@ from torch.nn import Linear
 from . import ops
 
 
-class ConformerAggregationHead(torch.nn.Module):
-    def __init__(self, feat_dim: int = 64, agg_weight: float = 0.2):
-        super().__init__()
-        self.agg_weight = agg_weight                         # config `agg-weight`, config_parser.py default 0.2
-        self.lin_3d = Linear(feat_dim, feat_dim)             # schnet_based_models.py:94-110
-        self.lin_bary = Linear(feat_dim, feat_dim)
-        self.out = Linear(feat_dim, 1)
+class EquivModelsHolder:
+    """`EquivModelsHolder.get_model(name, device, **kwargs)` of the reference (conan_fgw/src/model/common.py:469-546) for the
+    backbones this backend implements: the object the Lightning models store as `node_embeddings_model` /
+    `gat_embeddings_model`.  Same names, same keyword meaning (`feat_dim`, optional `cutoff` selecting the classification
+    SchNet), same hyper-parameter literals."""
 
-    def forward(self, h_3d: Tensor, h_bary: Tensor, num_conformers: int) -> Tensor:
-        G, d = h_3d.shape
-        B = G // num_conformers
-        x3 = ops.linear(h_3d, self.lin_3d.weight, self.lin_3d.bias)
-        xb = ops.linear(h_bary, self.lin_bary.weight, self.lin_bary.bias)
-        x = x3 + self.agg_weight * xb                        # :170 (x_cov omitted)
-        x = x.view(B, num_conformers, d).mean(dim=1)         # :171
-        return ops.linear(x.contiguous(), self.out.weight, self.out.bias)    # :172  -> [B,1]
+    @staticmethod
+    def get_model(name: str, device, **kwargs):
+        if name == "schnet":
+            from .schnet import SchNetNoSum
+            if "cutoff" in kwargs:                                  # common.py:513-522 (classification: 256 filters, 10 gaussians)
+                return SchNetNoSum(device, hidden_channels=kwargs.get("feat_dim"), use_covalent=False, cutoff=kwargs.get("cutoff"),
+                                   num_gaussians=10, num_filters=256, num_interactions=3)
+            return SchNetNoSum(device, hidden_channels=kwargs.get("feat_dim"), use_covalent=False, num_interactions=3)   # :524-529
+        if name == "gat":
+            from .gat import GATBased
+            return GATBased(out_channels=kwargs.get("feat_dim") // 2)                                                   # :534-537
+        if name == "visnet":
+            from .visnet import ViSNet
+            return ViSNet(device, hidden_channels=kwargs.get("feat_dim"))                                               # :542-546
+        raise ValueError(f"get_model({name!r}): not a backbone of the MI355X hot path (schnet, visnet, gat); DimeNet / ESAN / "
+                         "schnet_covalent variants are not reachable from train_val.py and are not built here")
+
+
+def get_model(name: str, device, **kwargs):
+    """Module-level alias of `EquivModelsHolder.get_model` (`conan_fgw_amd.get_model`)."""
+    return EquivModelsHolder.get_model(name, device, **kwargs)
 
 
 class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
@@ -50,16 +61,10 @@ class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
         from .gat import GATBased
         self.num_conformers = num_conformers
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        if model_name == "schnet":                           # EquivModelsHolder.get_model("schnet", feat_dim=128), common.py:524-529
-            from .schnet import SchNetNoSum
-            self.node_embeddings_model = SchNetNoSum(device, hidden_channels=128, num_filters=128, num_interactions=3)
-        elif model_name == "visnet":                         # common.py:542-546
-            from .visnet import ViSNet
-            self.node_embeddings_model = ViSNet(device, hidden_channels=128)
-        else:
-            raise ValueError(f"unsupported model_name {model_name!r}")
+        self.node_embeddings_model = EquivModelsHolder.get_model(model_name, device, feat_dim=128)    # common.py:400-402
         out_channels = self.node_embeddings_model.hidden_channels // 2
-        self.gat_embeddings_model = GATBased(out_channels=128 // 2, in_channels=gat_in_channels)     # get_model("gat", feat_dim=128)
+        self.gat_embeddings_model = (EquivModelsHolder.get_model("gat", device, feat_dim=128) if gat_in_channels == 9
+                                     else GATBased(out_channels=128 // 2, in_channels=gat_in_channels))      # schnet_based_models.py:96
         self.transformation_matrix_3d = Linear(out_channels, out_channels)
         self.transformation_matrix_bary = Linear(out_channels, out_channels)
         self.transformation_matrix_cov = Linear(out_channels, out_channels)
@@ -73,7 +78,25 @@ class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
             object.__setattr__(self, "_gat_stream", s)       # not a module attribute: streams are not part of the state
         return s
 
-    def create_aggregation_index(self, num_graphs: int, device) -> Tensor:
+    def forward_dummy(self, batch, conformers_index, node_index):
+        """`load_dummy` (conan_fgw/src/model/utils.py:23-33) calls this once on a CPU mini-batch before the DDP wrap, to
+        materialise PyG's lazily-shaped GATConv parameters (schnet_based_models.py:112-133).  Every parameter of this backend
+        has its final shape at construction, so there is nothing to materialise: a no-op returning None like the reference's
+        method (which also discards its activations).  It must not raise on CPU inputs — it is the one call the harness makes
+        before the model is moved to the GPU."""
+        return None
+
+    def create_aggregation_index(self, num_graphs, device=None) -> Tensor:
+        """Molecule id of every conformer graph.  Accepts the reference's argument — the collated batch, from which the
+        reference counts conformer graphs as len(batch.smiles) (common.py:414-423) — or the number of graphs directly."""
+        if not isinstance(num_graphs, int):
+            batch = num_graphs
+            num_graphs = len(batch.smiles) if hasattr(batch, "smiles") else int(batch.num_graphs)
+            if device is None:
+                device = batch.z.device
+        return self._aggregation_index(num_graphs, device)
+
+    def _aggregation_index(self, num_graphs: int, device) -> Tensor:
         """Molecule id of every conformer graph: [0]*K + [1]*K + ... (common.py:414-423, built there from len(batch.smiles))."""
         return torch.arange(num_graphs // self.num_conformers, device=device).repeat_interleave(self.num_conformers)
 
@@ -145,13 +168,12 @@ class EmbeddingsWithGATAggregationClassificationBaryCenter(EmbeddingsWithGATAggr
     def __init__(self, num_conformers: int, device=None, agg_weight: float = 0.2, gat_in_channels: int = 9):
         torch.nn.Module.__init__(self)
         from .gat import GATBased
-        from .schnet import SchNetNoSum
         self.num_conformers = num_conformers
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.node_embeddings_model = SchNetNoSum(device, hidden_channels=512, cutoff=10.0, num_gaussians=10, num_filters=256,
-                                                 num_interactions=3)                       # get_model("schnet", feat_dim=512, cutoff=10.0)
+        self.node_embeddings_model = EquivModelsHolder.get_model("schnet", device, feat_dim=512, cutoff=10.0)   # common.py:444-446
         out_channels = self.node_embeddings_model.hidden_channels // 2                      # 256
-        self.gat_embeddings_model = GATBased(out_channels=512 // 2, in_channels=gat_in_channels)    # get_model("gat", feat_dim=512)
+        self.gat_embeddings_model = (EquivModelsHolder.get_model("gat", device, feat_dim=512) if gat_in_channels == 9
+                                     else GATBased(out_channels=512 // 2, in_channels=gat_in_channels))
         self.transformation_matrix_3d = Linear(out_channels, out_channels)
         self.transformation_matrix_cov = Linear(out_channels, out_channels)
         self.transformation_matrix_bary = Linear(out_channels, out_channels)

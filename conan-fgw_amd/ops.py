@@ -35,7 +35,8 @@ class RadiusGraph:
         dev = pos.device
         self.num_atoms, self.num_graphs, self.graph_ptr = n, num_graphs, graph_ptr
         self.cutoff, self.cap, self.loop = float(cutoff), int(max_num_neighbors), bool(loop)
-        self.max_edges = max(1, n * self.cap)
+        # worst case per target: cap + 1 edges without self loops (the self hit may fall outside torch-cluster's cap + 1 window)
+        self.max_edges = max(1, n * (self.cap if self.loop else self.cap + 1))
         self.rowptr = torch.empty(n + 1, dtype=i32, device=dev)
         self.col = torch.empty(self.max_edges, dtype=i32, device=dev)
         self.tgt = torch.empty(self.max_edges, dtype=i32, device=dev)
@@ -178,12 +179,16 @@ def sigmoid(x: Tensor) -> Tensor:
     return _UnaryFn.apply(x, 1)
 
 
+def shifted_softplus(x: Tensor) -> Tensor:
+    return _UnaryFn.apply(x, 2)
+
+
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, weight, padding_idx):
         z, weight = _c(z), _c(weight)
         out = torch.empty(z.shape[0], weight.shape[1], dtype=f32, device=weight.device)
-        call("conan_embedding_fwd", ptr(z, i64), ptr(weight, f32), z.shape[0], weight.shape[1], ptr(out), stream_ptr())
+        call("conan_embedding_fwd", ptr(z, i64), ptr(weight, f32), z.shape[0], weight.shape[1], weight.shape[0], ptr(out), stream_ptr())
         ctx.save_for_backward(z)
         ctx.shape, ctx.padding_idx = weight.shape, padding_idx
         return out

@@ -1,14 +1,16 @@
-"""Data parallelism for the ConAN hot path: one process per GPU, molecules sharded across ranks, ONE flat-buffer
-all-reduce of the gradients per step (RCCL over xGMI through torch.distributed's "nccl" backend).
+"""Data parallelism for the ConAN hot path: one process per GPU, molecules sharded across ranks, the gradients averaged
+through ONE flat fp32 buffer (RCCL over xGMI through torch.distributed's "nccl" backend).
 
 The reference uses Lightning's "ddp_find_unused_parameters_false" (conan_fgw/src/trainer.py:315-319) with a
 DistributedSampler(shuffle=False) (data/datamodules.py:40-41).  The gradient payload is ~1.1 MB (SchNet-128), i.e. the
-collective is latency-bound on xGMI, so it is issued exactly once per step on one contiguous fp32 buffer that the
-parameters' .grad tensors alias — no per-parameter collectives, no bucket copies.
+collective is latency-bound on xGMI (7 point-to-point links per GPU): it is issued on one contiguous buffer that the
+parameters' .grad tensors alias afterwards — never per parameter.  In the eager step the buffer is cut into two buckets in
+the order autograd produces the gradients: the first (output-side layers) is reduced on RCCL's own stream while the rest of
+the backward still runs, the second right after backward.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -21,12 +23,25 @@ def shard_range(num_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 class FlatGradients:
-    """One contiguous fp32 buffer for all gradients: packed with ONE concatenation kernel after backward, averaged across
-    ranks with ONE all-reduce, and aliased back as every parameter's .grad for the optimizer.
+    """One contiguous fp32 buffer for all gradients: packed with one concatenation kernel per bucket, averaged across ranks
+    with one all-reduce per bucket, and aliased back as every parameter's .grad for the optimizer.
 
     zero() drops the .grad tensors instead of clearing them: autograd's AccumulateGrad then adopts each freshly produced
-    gradient without a per-parameter `grad += g` kernel (57 launches per step for SchNet), and the pack is one launch."""
+    gradient without a per-parameter `grad += g` kernel (57 launches per step for SchNet), and the pack is one launch.
+
+    Overlap (eager steps, world_size > 1): `enable_overlap()` registers post-accumulate hooks that only count.  The first
+    backward records the order (and stream) in which gradients appear; `calibrate()` then lays the buffer out in that order
+    and puts the leading gradients produced on the calling stream — about `early_fraction` of the bytes — into bucket 0.
+    From then on the hook that completes bucket 0 packs it and starts its all-reduce asynchronously (the collective runs on
+    the process group's stream, behind the work already queued on the current one) while backward continues;
+    `all_reduce_mean()` packs and reduces bucket 1 and waits for both.  Gradients produced on other streams (the covalent
+    branch runs on a side stream) always land in bucket 1, which is reduced after backward() has joined every stream.
+    """
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         seen, self.params = set(), []
@@ -37,32 +52,127 @@ class FlatGradients:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._views: List[torch.Tensor] = []
+        self._layout(list(range(len(self.params))), len(self.params))
+        self._hooks: list = []
+        self._overlap = False
+        self._order: Optional[list] = None          # calibration record: (param index, produced on the calling stream?)
+        self._pending = 0
+        self._work = None
+        self.last_allreduce_launches = 0
+
+    # ------------------------------------------------------------------------------------------------ layout
+    def _layout(self, order: List[int], n_early: int):
+        """Parameters in `order`; the first n_early of them form bucket 0 (== everything when no overlap is configured)."""
+        self._order_idx = order
+        self._views: List[Optional[torch.Tensor]] = [None] * len(self.params)
         off = 0
-        for p in self.params:
-            self._views.append(self.flat[off:off + p.numel()].view_as(p))
+        self._split = 0
+        for k, i in enumerate(order):
+            p = self.params[i]
+            self._views[i] = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+            if k + 1 == n_early:
+                self._split = off
+        self._early = set(order[:n_early])
+        self._n_early = n_early
 
     def zero(self):
         for p in self.params:
             p.grad = None
+        self._pending = self._n_early if self._overlap else 0
+        self._work = None
 
-    def pack(self):
-        """Gather the .grad tensors autograd produced into the flat buffer and alias them to it."""
+    # ------------------------------------------------------------------------------------------------ pack
+    def _pack(self, idx: List[int], out: torch.Tensor):
         pieces = []
-        for p, v in zip(self.params, self._views):
+        for i in idx:
+            p, v = self.params[i], self._views[i]
             g = p.grad
             if g is None:
                 g = torch.zeros_like(v)                 # parameter not reached by this step's graph
             elif g.data_ptr() == v.data_ptr():
-                g = g.clone()                           # already aliased (pack() called twice): keep the value
+                g = g.clone()                           # already aliased (packed twice): keep the value
             pieces.append(g.reshape(-1).to(torch.float32))
-        torch.cat(pieces, out=self.flat)
-        for p, v in zip(self.params, self._views):
-            p.grad = v
+        if pieces:
+            torch.cat(pieces, out=out)
+        for i in idx:
+            self.params[i].grad = self._views[i]
 
+    def pack(self):
+        """Gather the .grad tensors autograd produced into the flat buffer and alias them to it."""
+        self._pack(self._order_idx, self.flat)
+
+    # ------------------------------------------------------------------------------------------------ overlap
+    def enable_overlap(self, early_fraction: float = 0.5):
+        """Start recording the gradient production order; call `calibrate()` after one backward."""
+        self._frac = float(early_fraction)
+        self._order = []
+        main = torch.cuda.current_stream() if self.flat.is_cuda else None
+        index = {id(p): i for i, p in enumerate(self.params)}
+
+        def hook(p):
+            i = index[id(p)]
+            if self._order is not None:
+                on_main = (not self.flat.is_cuda) or torch.cuda.current_stream() == main
+                self._order.append((i, on_main))
+            elif self._overlap and i in self._early:
+                self._pending -= 1
+                if self._pending == 0:
+                    self._fire_early()
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+
+    def calibrate(self):
+        """Fix the buffer layout from the recorded production order.  Returns (gradients in bucket 0, gradients in total)."""
+        rec, self._order = self._order or [], None
+        seen, order, on_main = set(), [], []
+        for i, m in rec:
+            if i not in seen:
+                seen.add(i)
+                order.append(i)
+                on_main.append(m)
+        total, early_bytes, early = self.flat.numel(), 0, []
+        for k, i in enumerate(order):           # bucket 0 = the first calling-stream gradients up to the byte target
+            if not on_main[k]:
+                continue                        # produced on a side stream: reduced after backward has joined the streams
+            if early_bytes >= self._frac * total:
+                break
+            early_bytes += self.params[i].numel()
+            early.append(i)
+        es = set(early)
+        order = early + [i for i in order if i not in es] + [i for i in range(len(self.params)) if i not in seen]
+        self._overlap = 0 < len(early) < len(order) and _world() > 1
+        self._layout(order, len(early) if self._overlap else len(order))
+        for p in self.params:                   # .grad views of the old layout are stale
+            p.grad = None
+        return (len(early) if self._overlap else 0), len(order)
+
+    def suspend_overlap(self, flag: bool = True):
+        """Turn the early bucket off / on again (e.g. while a HIP graph is captured: the collective is issued between replays)."""
+        if flag and self._overlap:
+            self._overlap, self._suspended = False, True
+        elif not flag and getattr(self, "_suspended", False):
+            self._overlap, self._suspended = True, False
+
+    def _fire_early(self):
+        idx = self._order_idx[: self._n_early]
+        self._pack(idx, self.flat[: self._split])
+        self._work = dist.all_reduce(self.flat[: self._split], op=dist.ReduceOp.SUM, async_op=True)
+
+    # ------------------------------------------------------------------------------------------------ reduce
     def all_reduce_mean(self):
+        world = _world()
+        self.last_allreduce_launches = 0
+        if self._overlap and self._work is not None:
+            self._pack(self._order_idx[self._n_early:], self.flat[self._split:])
+            w2 = dist.all_reduce(self.flat[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+            self._work.wait(); w2.wait()
+            self._work = None
+            self.last_allreduce_launches = 2
+            self.flat.mul_(1.0 / world)
+            return
         self.pack()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / dist.get_world_size())
+            self.last_allreduce_launches = 1
+            self.flat.mul_(1.0 / world)

@@ -32,15 +32,16 @@ OptTensor = Optional[Tensor]
 
 
 class ShiftedSoftplus(torch.nn.Module):
-    """softplus(x) - ln 2.  Parameter-free marker module: the activation is fused into the epilogue of
-    `conan_linear_fwd`; it is kept so that `interactions.{i}.mlp` has the reference's Sequential indices (0, 2)."""
+    """softplus(x) - ln 2 (PyG `ShiftedSoftplus`).  On the model path the activation is fused into the epilogue of
+    `conan_linear_fwd`; the module keeps `interactions.{i}.mlp`'s Sequential indices (0, 2) and, called directly (the
+    reference's `self.act(h)`, schnet_no_sum.py:178,227,231), runs the stand-alone HIP kernel."""
 
     def __init__(self):
         super().__init__()
         self.shift = math.log(2.0)
 
-    def forward(self, x: Tensor) -> Tensor:  # pragma: no cover - not on the product path
-        raise RuntimeError("ShiftedSoftplus is fused into conan_linear_fwd on this backend")
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.shifted_softplus(x)
 
 
 class GaussianSmearing(torch.nn.Module):

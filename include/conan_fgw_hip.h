@@ -45,9 +45,11 @@ int conan_graph_ptr_from_batch(const int64_t *batch, int num_atoms, int num_grap
 
 /* Fixed-radius neighbour search: replaces torch_cluster.radius_graph as reached through
  * RadiusInteractionGraph.forward (schnet_no_sum.py:160,208,342; visnet.py:276; torch_geometric_visnet.py:331-337).
- * Edge (j -> i) iff same graph, (loop or j != i), d2 < r*r strictly with d2 = fl(fl(dx*dx + dy*dy) + dz*dz) (no FMA),
- * and j is among the `cap` smallest-index qualifying sources of i.
- * Outputs: rowptr[num_atoms+1]; col/tgt/dist sized for cap*num_atoms entries (only rowptr[num_atoms] are written);
+ * Candidate (j, i) iff same graph and d2 < r*r strictly with d2 = fl(fl(dx*dx + dy*dy) + dz*dz) (no FMA); the target itself is a
+ * candidate.  Per target the first `limit` candidates in ascending source index are kept, limit = loop ? cap : cap + 1
+ * (torch-cluster 1.6.1: radius_graph calls radius(x, x, r, batch, batch, cap if loop else cap + 1)), then the self pair is
+ * dropped unless `loop`: a target with >= cap + 1 lower-index candidates keeps cap + 1 edges, any other truncated one cap.
+ * Outputs: rowptr[num_atoms+1]; col/tgt/dist sized for (loop ? cap : cap + 1)*num_atoms entries (rowptr[num_atoms] are written);
  * dist[e] = sqrt(d2) = the reference's edge_weight.  `deg_ws[num_atoms+1]` is scratch. */
 int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms, int num_graphs, float r, int cap,
                            int loop, int *deg_ws, int *rowptr, int *col, int *tgt, float *dist, void *stream);
@@ -72,15 +74,21 @@ int conan_edge_index_i64(const int *col, const int *tgt, int num_edges, int64_t 
 
 /* ---------------------------------------------------------------------------------------------- SchNet trunk */
 
-/* out[a, :] = weight[z[a], :]  (torch.nn.Embedding(100, H, padding_idx=0); schnet_no_sum.py:159,207). */
-int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, int hidden, float *out, void *stream);
+/* out[a, :] = weight[z[a], :]  (torch.nn.Embedding(100, H, padding_idx=0); schnet_no_sum.py:159,207).  weight is
+ * [num_embeddings, hidden]; an index outside [0, num_embeddings) (a device assert in torch) yields a NaN row and
+ * contributes nothing to the backward — never an out-of-bounds access. */
+int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, int hidden, int num_embeddings, float *out,
+                        void *stream);
 /* dweight[r, :] = sum_{a: z[a]==r} dout[a, :] (row padding_idx = 0), deterministic two-stage reduction;
  * ws holds conan_embedding_bwd_ws(...) floats; num_embeddings <= 100. */
 long long conan_embedding_bwd_ws(int num_atoms, int hidden, int num_embeddings);
 int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int hidden, int num_embeddings,
                         int padding_idx, float *dweight, float *ws, void *stream);
 
-/* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]) on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
+/* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]).  Arithmetic: K, N multiples of 64 run as an exact 3-way bf16 split
+ * of both operands (v = p1 + p2 + p3, six partial products per block on v_mfma_f32_32x32x16_bf16, fp32 accumulation):
+ * fp32-CLASS accuracy (measured 2e-6 relative to an fp64 reference, the same as a plain fp32 GEMM), not bit-identical to
+ * an fp32 FMA chain; other shapes run on the fp32 MFMA (v_mfma_f32_32x32x2_f32).  No reduced-precision mode exists.
  * W is torch.nn.Linear's [N,K] when w_kn == 0, or a [K,N] matrix when w_kn == 1 (used by the backward: dx = g @ W).
  * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2), 3 = SiLU, 2 = multiply by ssp'(.) evaluated from `residual`, which
  * then holds the saved OUTPUT o of an ssp layer (ssp' = 1 - 0.5*exp(-o)) instead of being added: the fused backward
@@ -122,8 +130,9 @@ int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edge
 
 /* Fused continuous-filter generator: for every edge e
  *   W[e,:] = ( mlp2( ssp( mlp0( rbf(dist[e]) ) ) ) ) * 0.5*(cos(dist[e]*pi/cutoff)+1)
- * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel with both GEMMs on fp32 MFMA and
- * every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
+ * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel, the first GEMM on the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), the second as an exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy,
+ * see conan_linear_fwd), every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
  * are the torch Linear parameters of interactions.{i}.mlp.{0,2}.  h1_out (nullable) receives ssp(mlp0(rbf)) [E,F] for the
  * backward.  Supported shapes: conan_filter_fused_supported(Gs, F) (Gs <= 56, F in {32,64,128}); otherwise
  * CONAN_E_UNSUPPORTED and the caller composes conan_rbf_fwd / conan_linear_fwd / conan_cutoff_scale. */
@@ -303,8 +312,10 @@ int conan_fgw_readout_fwd(const float *Y, int B, int K, int N, int d, int mode, 
 int conan_fgw_readout_bwd(const float *Y, const float *dout, int B, int K, int N, int d, int mode, float *dY,
                           void *stream);
 
-/* Elementwise activations of the classification head (build_mlp_class + torch.sigmoid, schnet_based_models.py:31-45,367):
- * op 0 = ReLU, 1 = sigmoid; the backward takes the forward OUTPUT y (relu' = [y > 0], sigmoid' = y (1 - y)). */
+/* Elementwise activations: op 0 = ReLU, 1 = sigmoid (classification head: build_mlp_class + torch.sigmoid,
+ * schnet_based_models.py:31-45,367), 2 = shifted softplus (PyG ShiftedSoftplus as a stand-alone module, `SchNetNoSum.act`,
+ * schnet_no_sum.py:178,227,231 — on the model path it is fused into conan_linear_fwd).  The backward takes the forward
+ * OUTPUT y (relu' = [y > 0], sigmoid' = y (1 - y), ssp' = 1 - 0.5 exp(-y)). */
 int conan_unary_fwd(const float *x, long long count, int op, float *y, void *stream);
 int conan_unary_bwd(const float *y, const float *dy, long long count, int op, float *dx, void *stream);
 

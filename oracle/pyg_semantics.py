@@ -11,11 +11,14 @@ the reference's own glue (`forward_3d_bary`, `_compute_barycenter`, `forward_w_b
 by importing the reference files over these names (tests/golden/make_model_golden.py).
 
 Conventions fixed here (and used identically by the HIP kernels):
- * radius_graph: edge (j -> i) iff same graph, j != i (unless loop), d2 < r*r STRICTLY, with
-   d2 = fl(fl(dx*dx + dy*dy) + dz*dz) evaluated in the dtype of `pos` without FMA contraction; when a target has more
-   than `max_num_neighbors` candidates the ones with the smallest source index are kept (torch-cluster's CUDA rule:
-   linear scan in index order, radius_cuda.cu); edges are emitted grouped by target i ascending, sources ascending;
-   edge_index[0] = source j, edge_index[1] = target i (flow source_to_target).
+ * radius_graph: candidate (j, i) iff same graph and d2 < r*r STRICTLY, with d2 = fl(fl(dx*dx + dy*dy) + dz*dz)
+   evaluated in the dtype of `pos` without FMA contraction; the target itself is a candidate.  Per target the first
+   `limit` candidates in ascending source index are kept, limit = cap if loop else cap + 1 (torch-cluster 1.6.1:
+   radius_graph -> radius(x, x, r, batch, batch, cap if loop else cap + 1); linear scan in index order = its CUDA
+   kernel radius_cuda.cu, the CPU KD-tree order is unspecified when truncating), and only THEN are self pairs removed
+   (unless loop).  So a target with >= cap + 1 lower-index candidates keeps cap + 1 = 33 edges, any other truncated
+   target keeps cap.  Edges are emitted grouped by target i ascending, sources ascending; edge_index[0] = source j,
+   edge_index[1] = target i (flow source_to_target).
 """
 from __future__ import annotations
 
@@ -49,12 +52,15 @@ def radius_graph(x: Tensor, r: float, batch: OptTensor = None, loop: bool = Fals
         diff = p[:, None, :] - p[None, :, :]               # [i, j, 3] = pos_i - pos_j
         sq = diff * diff
         d2 = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
-        ok = d2 < r2
+        ok = d2 < r2                                        # the target itself is a candidate (d2 = 0)
+        # torch-cluster 1.6.1 radius_graph: radius(x, x, r, batch, batch, cap if loop else cap + 1) keeps the first `limit`
+        # candidates in ascending source index (the CUDA kernel's linear scan; the CPU KD-tree order is unspecified when it
+        # truncates), THEN removes the self pairs: a target with >= cap + 1 lower-index candidates keeps cap + 1 edges.
+        limit = max_num_neighbors if loop else max_num_neighbors + 1
+        rank = ok.cumsum(1)
+        ok = ok & (rank <= limit)
         if not loop:
             ok = ok & ~torch.eye(hi - lo, dtype=torch.bool)
-        # keep the first `cap` sources (ascending j) for every target i
-        rank = ok.cumsum(1)
-        ok = ok & (rank <= max_num_neighbors)
         i_idx, j_idx = ok.nonzero(as_tuple=True)            # sorted by i then j
         rows.append(j_idx + lo)
         cols.append(i_idx + lo)

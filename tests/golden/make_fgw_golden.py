@@ -92,7 +92,7 @@ def make_inputs(seed, K, n_real, n_pad, d, r, shift=0.5):
     return Ys.astype(np.float32), Cs
 
 
-def run_ref(Ys, Cs, dtype, **over):
+def run_ref(Ys, Cs, dtype, _init_first=True, **over):
     K, N, d = Ys.shape
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dtype)
     args = dict(PROD); args.update(over)
@@ -101,7 +101,7 @@ def run_ref(Ys, Cs, dtype, **over):
     ps = [torch.ones(N, dtype=dtype) / N for _ in range(K)]
     lambdas = torch.ones(K, dtype=dtype) / K
     with Counter() as cnt:
-        Y, C, log = ref_bary.fgw_barycenters(N=N, Ys=Ysl, Cs=Csl, ps=ps, lambdas=lambdas, init_C=Csl[0], **args)
+        Y, C, log = ref_bary.fgw_barycenters(N=N, Ys=Ysl, Cs=Csl, ps=ps, lambdas=lambdas, init_C=Csl[0] if _init_first else None, **args)
     outer = len(log["err_feature"])
     mi = args["max_iter"]
     pgd = np.zeros((outer, K), np.int32); sk = np.zeros((outer, K, mi), np.int32)
@@ -203,5 +203,21 @@ def main_kl():
               f"relC={rel(r32['C'], r64['C']):.2e} relT={rel(r32['T'], r64['T']):.2e} finite={np.isfinite(r64['C']).all()}")
 
 
+def main_randinit():
+    """init_C=None: the reference draws its own initial structure (barycenter.py:61-65: torch.manual_seed(seed); randn(N, 2); dist).
+    Run as `python make_fgw_golden.py randinit`; writes fgw_randinit_*.npz only."""
+    for name, seed, K, n_real, n_pad, d, r in [c for c in CASES if c[0] in ("k5_n9_d3", "k3_n15p5_d64")]:
+        Ys, Cs = make_inputs(seed, K, n_real, n_pad, d, r, 0.5)
+        rec = dict(Ys=Ys, Cs=Cs.astype(np.uint8), seed=np.int64(3))
+        for tag, dt in (("r32", torch.float32), ("r64", torch.float64)):
+            rr = run_ref(Ys, Cs, dt, _init_first=False, seed=3)
+            for k in ("Y", "C", "T", "err_feature", "err_structure", "pgd", "sinkhorn"):
+                rec[f"{tag}_{k}"] = rr[k].astype(np.float32) if (tag == "r32" and rr[k].dtype.kind == "f") else rr[k]
+        np.savez_compressed(os.path.join(HERE, f"fgw_randinit_{name}.npz"), **rec)
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        print(f"randinit {name}: outer={len(rec['r64_err_feature'])} relY={rel(rec['r32_Y'], rec['r64_Y']):.2e} relC={rel(rec['r32_C'], rec['r64_C']):.2e}")
+
+
 if __name__ == "__main__":
-    main_kl() if (len(sys.argv) > 1 and sys.argv[1] == "kl") else main()
+    mode = sys.argv[1] if len(sys.argv) > 1 else ""
+    {"kl": main_kl, "randinit": main_randinit}.get(mode, main)()

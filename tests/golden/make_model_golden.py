@@ -79,6 +79,8 @@ def main():
         ("b2_k3_h32", "freesolv", 2, 3, 101, 32, None),
         ("b4_k5_h128", "esol", 4, 5, 102, 128, None),
         ("b3_k5_h64_stretched", "esol", 3, 5, 103, 64, 16.0),
+        # Lipophilicity-shaped conformers (n > 33 at r = 10 A): the neighbour cap truncates (33-candidate window incl. self)
+        ("b2_k3_h32_lipo", "lipo", 2, 3, 104, 32, None),
     ]
     for name, shape, B, K, seed, H, box in cases:
         torch.manual_seed(5)                         # train_val.py:223

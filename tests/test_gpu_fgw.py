@@ -215,3 +215,47 @@ def test_kl_loss_generic_kernel_matches_oracle():
         e64 = rel(got.double().cpu().numpy(), ref[key])
         yard = rel(r32[key].astype(np.float64), ref[key])
         assert e64 <= 1e-4 or e64 <= yard, (key, e64, yard)
+
+
+@pytest.mark.parametrize("name", ["k5_n9_d3", "k3_n15p5_d64"])
+def test_random_initial_structure_matches_reference(name, golden_dir):
+    """init_C=None (barycenter.py:61-65): the initial structure is torch.manual_seed(seed); dist(randn(N, 2)) drawn on the host.
+    Golden made by the reference's own solver (tests/golden/make_fgw_golden.py randinit)."""
+    g = np.load(os.path.join(golden_dir, f"fgw_randinit_{name}.npz"))
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev)
+    K, N, d = g["Ys"].shape
+    Y, C, log = pfgw.fgw_barycenters(
+        N=N, Ys=[t(y) for y in g["Ys"]], Cs=[t(c) for c in g["Cs"]], ps=[torch.ones(N, device=dev) / N] * K, lambdas=torch.ones(K) / K,
+        warmstartT=True, symmetric=True, method="sinkhorn_log", alpha=0.1, solver="PGD", fixed_structure=False, fixed_features=False,
+        epsilon=0.1, p=None, loss_fun="square_loss", max_iter=5, tol=1e-2, numItermax=5, stopThr=1e-2, verbose=False, log=True,
+        init_C=None, init_X=None, random_state=None, seed=int(g["seed"]))
+    assert log["n_outer"] == len(g["r64_err_feature"])
+    for key, val in (("Y", Y), ("C", C)):
+        yard = rel(g["r32_" + key], g["r64_" + key])
+        e32, e64 = rel(val.cpu().numpy(), g["r32_" + key]), rel(val.cpu().numpy(), g["r64_" + key])
+        assert e32 <= 1e-4 or e64 <= max(yard, 1e-5), (key, e32, e64, yard)
+
+
+def test_densify_with_a_too_small_node_hint_poisons_instead_of_corrupting():
+    """`max_nodes` is a caller-supplied hint.  A conformer with more atoms than the hint must not write outside its
+    slab; its slab becomes NaN (visible), the other graphs are untouched."""
+    b = make_batch("esol", 3, 2, seed=33)
+    pos = torch.from_numpy(b.pos).to(dev); batch = torch.from_numpy(b.batch).to(dev)
+    gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
+    g = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32)
+    n_per = np.repeat(b.atoms_per_molecule, 2)
+    N = int(np.sort(np.unique(n_per))[-2]) if len(np.unique(n_per)) > 1 else int(n_per.max()) - 1     # smaller than the largest conformer
+    feat = torch.randn(len(b.z), 16, device=dev, requires_grad=True)
+    G = b.num_graphs
+    Ys, Cs = ops.fgw_densify(feat, g, N, 0.5)
+    Ys_ok, Cs_ok = ops.fgw_densify(feat, g, int(n_per.max()), 0.5)
+    torch.cuda.synchronize()
+    for k in range(G):
+        if n_per[k] > N:
+            assert torch.isnan(Ys[k]).all()
+            assert torch.isfinite(Cs[k]).all() and float(Cs[k].max()) <= 1.0
+        else:
+            assert torch.isfinite(Ys[k]).all()
+            assert torch.equal(Cs[k], Cs_ok[k, :N, :N])
+    Ys.nan_to_num().sum().backward()
+    assert feat.grad is not None and feat.grad.shape == feat.shape

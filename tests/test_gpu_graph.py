@@ -22,7 +22,7 @@ def _graph(b, cutoff, cap, loop=False):
 @pytest.mark.parametrize("shape,B,K,box,cutoff,cap,loop", [
     ("esol", 16, 5, None, 10.0, 32, False),        # complete graphs, production SchNet
     ("esol", 16, 5, 16.0, 10.0, 32, False),        # stretched: cutoff actually prunes
-    ("lipo", 6, 5, None, 10.0, 32, False),         # n > 33: cap-32 truncation active (smallest source index rule)
+    ("lipo", 6, 5, None, 10.0, 32, False),         # n > 33: truncation active (first cap+1 candidates incl. self, then drop self)
     ("bace", 4, 5, None, 5.0, 32, False),          # ViSNet FGW adjacency (visnet.py:90)
     ("bace", 4, 5, None, 5.0, 32, True),           # ViSNet Distance(): loop=True, cap includes self
     ("freesolv", 8, 20, 12.0, 3.0, 4, False),      # tiny cap
@@ -40,7 +40,7 @@ def test_radius_graph_bit_exact(shape, B, K, box, cutoff, cap, loop):
     assert np.abs(g.edge_weight().cpu().numpy() - ew).max() <= 1e-6 * max(1.0, ew.max())
     # CSR invariants + transpose
     rowptr = g.rowptr.cpu().numpy()
-    assert rowptr[0] == 0 and rowptr[-1] == ref.shape[1] and np.all(np.diff(rowptr) <= cap)
+    assert rowptr[0] == 0 and rowptr[-1] == ref.shape[1] and np.all(np.diff(rowptr) <= (cap if loop else cap + 1))
     t_rowptr, t_eid = g.transpose()
     t_rowptr, t_eid = t_rowptr.cpu().numpy(), t_eid.cpu().numpy()[: ref.shape[1]]
     assert sorted(t_eid.tolist()) == list(range(ref.shape[1]))
@@ -59,6 +59,34 @@ def test_golden_edge_index():
         g = ops.RadiusGraph(pos, ops.graph_ptr_from_batch(batch, G), G, 10.0, 32)
         assert np.array_equal(g.edge_index().cpu().numpy(), gd["edge_index"])
         assert rel(g.edge_weight().cpu().numpy(), gd["r64_edge_weight"]) < 1e-6
+
+
+def test_truncation_window_includes_self():
+    """torch-cluster 1.6.1: radius_graph(loop=False) = radius(..., cap + 1) in ascending source order INCLUDING the target, then
+    the self pair is removed.  40 atoms, all within the cutoff: targets with local index < 33 find themselves inside the
+    33-candidate window and keep 32 edges (sources 0..32 without self); targets >= 33 never reach themselves and keep 33
+    (sources 0..32).  With loop=True the window is cap = 32 candidates and nothing is removed."""
+    rng = np.random.RandomState(5)
+    n, G = 40, 3
+    pos = torch.from_numpy(rng.uniform(0, 4.0, size=(n * G, 3)).astype(np.float32)).to(dev)
+    batch = torch.arange(G, device=dev).repeat_interleave(n)
+    gp = ops.graph_ptr_from_batch(batch, G)
+    g = ops.RadiusGraph(pos, gp, G, 10.0, 32)
+    deg = np.diff(g.rowptr.cpu().numpy()).reshape(G, n)
+    assert np.all(deg[:, :33] == 32) and np.all(deg[:, 33:] == 33)
+    ei = g.edge_index().cpu()
+    assert torch.equal(ei, ps.radius_graph(pos.cpu(), 10.0, batch.cpu(), max_num_neighbors=32))
+    src = ei[0].numpy().reshape(-1) - (ei[1].numpy() // n) * n
+    assert src.max() == 32                                             # no source beyond the window
+    gl = ops.RadiusGraph(pos, gp, G, 10.0, 32, loop=True)
+    assert np.all(np.diff(gl.rowptr.cpu().numpy()) == 32)
+    assert torch.equal(gl.edge_index().cpu(), ps.radius_graph(pos.cpu(), 10.0, batch.cpu(), loop=True, max_num_neighbors=32))
+    # every downstream consumer handles 33-edge rows: transpose is a permutation, pairs cover every edge
+    E = g.num_edges
+    t_rowptr, t_eid = g.transpose()
+    assert sorted(t_eid[:E].cpu().tolist()) == list(range(E))
+    pid = g.pairs().pid[:E].cpu().numpy()
+    assert pid.min() == 0 and pid.max() == int(g.num_pairs_dev.item()) - 1
 
 
 def test_empty_and_single_atom_graphs():

@@ -220,3 +220,27 @@ def test_linear_wide_layers_are_tiled_into_strided_chunks(M, K, N, act, w_kn):
         ref = pre * (1.0 - 0.5 * torch.exp(-r))
     assert rel(y[:M].double().cpu().numpy(), ref.cpu().numpy()) < 2e-6
     assert torch.isnan(y[M:]).all()                                 # rows beyond the device-side count are not touched
+
+
+def test_embedding_out_of_range_index_is_nan_not_out_of_bounds():
+    """torch.nn.Embedding device-asserts on an index outside [0, num_embeddings); here the row is NaN and the backward skips it."""
+    w = torch.randn(100, 64, device=dev, requires_grad=True)
+    z = torch.tensor([1, 6, 100, 8, -3, 99], device=dev)
+    out = ops.embedding(z, w, 0)
+    assert torch.isnan(out[2]).all() and torch.isnan(out[4]).all()
+    ok = [0, 1, 3, 5]
+    assert torch.equal(out[ok], w.detach()[z[ok]])
+    out.nan_to_num().sum().backward()
+    ref = torch.zeros(100, 64, device=dev)
+    ref[[1, 6, 8, 99]] = 1.0
+    assert torch.equal(w.grad, ref)
+
+
+def test_shifted_softplus_module_runs_on_the_hip_kernel():
+    from conan_fgw_amd.schnet import ShiftedSoftplus
+    x = torch.linspace(-30, 30, 1001, device=dev).requires_grad_(True)
+    y = ShiftedSoftplus()(x)
+    r = torch.nn.functional.softplus(x.detach().double()) - np.log(2.0)
+    assert float((y.detach().double() - r).abs().max()) < 3e-6
+    y.sum().backward()
+    assert float((x.grad.double() - torch.sigmoid(x.detach().double())).abs().max()) < 1e-6

@@ -79,3 +79,29 @@ def test_visnet_state_dict_matches_reference_class():
     assert sum(p.numel() for p in ViSNet(torch.device("cpu"), hidden_channels=128).parameters()) == 1798472
     with pytest.raises(RuntimeError, match="GPU only"):
         m(torch.ones(3, dtype=torch.long), torch.rand(3, 3), torch.zeros(3, dtype=torch.long))
+
+
+def test_get_model_mirrors_the_reference_factory():
+    """EquivModelsHolder.get_model(name, device, **kwargs) (common.py:469-546): same names, keyword meaning and literals."""
+    import types
+    import conan_fgw_amd
+    from conan_fgw_amd.gat import GATBased
+    from conan_fgw_amd.head import EquivModelsHolder, EmbeddingsWithGATAggregationBaryCenter
+    from conan_fgw_amd.visnet import ViSNet
+    cpu = torch.device("cpu")
+    m = EquivModelsHolder.get_model("schnet", cpu, feat_dim=128)                      # common.py:524-529 (EquivAggregation :400-402)
+    assert isinstance(m, SchNetNoSum) and (m.hidden_channels, m.num_filters, m.num_gaussians, m.num_interactions, m.cutoff) == (128, 128, 50, 3, 10.0)
+    m = conan_fgw_amd.get_model("schnet", cpu, feat_dim=512, cutoff=10.0)             # :513-522 (EquivAggregationClassification :444-446)
+    assert (m.hidden_channels, m.num_filters, m.num_gaussians, m.num_interactions, m.cutoff) == (512, 256, 10, 3, 10.0)
+    assert isinstance(conan_fgw_amd.get_model("visnet", cpu, feat_dim=128), ViSNet)
+    g = conan_fgw_amd.get_model("gat", cpu, feat_dim=128)
+    assert isinstance(g, GATBased) and g.gat_conv2.out_channels == 64
+    with pytest.raises(ValueError):
+        conan_fgw_amd.get_model("dimenet", cpu, feat_dim=128)
+    # load_dummy (model/utils.py:23-33) calls forward_dummy on a CPU mini-batch before the DDP wrap: a harmless no-op here
+    model = EmbeddingsWithGATAggregationBaryCenter(5, cpu)
+    batch = types.SimpleNamespace(z=torch.ones(4, dtype=torch.long), pos=torch.rand(4, 3), x=torch.zeros(4, 9), edge_index=torch.zeros(2, 0, dtype=torch.long),
+                                  edge_attr=torch.zeros(0, 3), batch=torch.zeros(4, dtype=torch.long), smiles=["C"] * 10)
+    idx = model.create_aggregation_index(batch)                                      # the reference's argument: the collated batch
+    assert idx.tolist() == [0] * 5 + [1] * 5 and idx.dtype == torch.long
+    assert model.forward_dummy(batch, idx, batch.batch) is None

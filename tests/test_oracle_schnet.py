@@ -54,3 +54,39 @@ def test_oracle_matches_reference_class(path, tag, dtype, tol):
         for name, p in m.named_parameters():
             ref = g[f"{tag}_grad:{name}"]
             assert rel(p.grad.numpy(), ref) < (1e-7 if tag == "r64" else 2e-3), name
+
+
+def _radius_scan(pos, lo, hi, r, cap, loop):
+    """torch-cluster 1.6.1 written out as its CUDA kernel's loops (radius_cuda.cu: one query, linear scan over the example's
+    points in index order, stop after max_num_neighbors hits) + radius_graph's post-filter of the self pairs."""
+    limit = cap if loop else cap + 1
+    rows, cols = [], []
+    r2 = np.float32(r) * np.float32(r)
+    for i in range(lo, hi):
+        cnt = 0
+        for j in range(lo, hi):
+            d = pos[j] - pos[i]
+            sq = d * d
+            if np.float32(np.float32(sq[0] + sq[1]) + sq[2]) < r2:
+                if loop or j != i:
+                    rows.append(j); cols.append(i)
+                cnt += 1
+            if cnt >= limit:
+                break
+    return np.array([rows, cols], dtype=np.int64)
+
+
+@pytest.mark.parametrize("n,r,cap,loop", [(40, 10.0, 32, False), (40, 10.0, 32, True), (47, 3.0, 8, False), (20, 10.0, 32, False)])
+def test_radius_graph_truncation_rule(n, r, cap, loop):
+    """radius(x, x, r, ..., cap+1) INCLUDING self, then self pairs dropped: a target with >= cap+1 lower-index
+    in-range atoms keeps cap+1 edges."""
+    from oracle import pyg_semantics as ps
+    rng = np.random.RandomState(n)
+    pos = rng.uniform(0, 4.0, size=(2 * n, 3)).astype(np.float32)
+    batch = torch.arange(2).repeat_interleave(n)
+    ei = ps.radius_graph(torch.from_numpy(pos), r, batch, loop=loop, max_num_neighbors=cap).numpy()
+    ref = np.concatenate([_radius_scan(pos, 0, n, r, cap, loop), _radius_scan(pos, n, 2 * n, r, cap, loop)], axis=1)
+    assert np.array_equal(ei, ref)
+    if n == 40 and not loop:
+        deg = np.bincount(ei[1], minlength=2 * n).reshape(2, n)
+        assert np.all(deg[:, :33] == 32) and np.all(deg[:, 33:] == 33)

@@ -72,3 +72,41 @@ def test_flat_gradients_deduplicates_shared_parameters():
     m = SchNetNoSum(torch.device("cpu"), hidden_channels=32, num_filters=32, num_interactions=2)
     flat = FlatGradients(m.parameters())
     assert flat.flat.numel() == sum(p.numel() for p in m.parameters())      # mlp / conv.nn aliases counted once
+
+
+def test_bench_spawn_path_forms_an_n_rank_group(tmp_path):
+    """`python bench.py --gpus N` (no WORLD_SIZE in the environment) must start N ranks itself: bench.spawn_ranks drives
+    torch.distributed.run exactly as the driver's launch line does.  The child here is tests/_rank_probe.py (gloo, CPU): the
+    rank plumbing + the REAL parameter set of SchNetNoSum through FlatGradients with the overlapped early bucket."""
+    import json
+    import subprocess
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    code = ("import sys, bench; sys.exit(bench.spawn_ranks(2, %r, ['--gpus', '2', '--steps', '3']))"
+            % os.path.join(ROOT, "tests", "_rank_probe.py"))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout                                 # ONE JSON line, from rank 0
+    out = json.loads(line[0])
+    assert out["n_ranks"] == 2 and out["args"] == ["--gpus", "2", "--steps", "3"]
+    assert out["ok"] and out["aliased"]
+    assert 0 < out["early"] < out["total"] and out["launches"] == [2, 2]      # early bucket + late bucket, every step
+    # and bench.main() takes that branch exactly when --gpus > 1 and no WORLD_SIZE is set
+    a = bench.parse(["--gpus", "4"])
+    assert a.gpus == 4 and "WORLD_SIZE" not in env
+
+
+def test_overlap_falls_back_to_one_allreduce_when_single_process():
+    m = _toy_model()
+    flat = FlatGradients(m.parameters())
+    flat.enable_overlap()
+    flat.zero(); m(torch.randn(4, 6)).sum().backward()
+    early, total = flat.calibrate()
+    assert early == 0 and total == 4                                # world size 1: no early bucket
+    flat.zero(); m(torch.randn(4, 6)).sum().backward()
+    g = [p.grad.clone() for p in flat.params]
+    flat.all_reduce_mean()
+    for p, gg in zip(flat.params, g):
+        assert torch.equal(p.grad, gg)
+    assert flat.last_allreduce_launches == 0
