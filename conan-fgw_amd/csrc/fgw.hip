@@ -442,11 +442,14 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     w += al256((size_t)B * NP * 16);        // (reserved)
     double *Ypart = reinterpret_cast<double *>(w);
     double *Cpart = Ypart + (size_t)B * K * N * d;
+    double *zvec = Cpart + (size_t)B * K * NN;              // [B,K,2N]  |z_j|^2, r2_j      (register-resident path)
+    double *yvec = zvec + (size_t)B * K * 2 * N;            // [B,2N]    |y_i|^2, r1_i
     const bool small = conan_fgw_small_supported(N, d);
     const bool kl = params->loss_fun != 0;
     if (params->loss_fun != 0 && params->loss_fun != 1) return CONAN_E_BADARG;
 
     k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
+    if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, s);
     const size_t lc = coupling_lds(N);
     const bool c_lds = lc <= LDS_LIMIT;
     if (c_lds && lc > 64 * 1024)
@@ -467,7 +470,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         if (small)
-            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, s);
+            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, s);
         else if (c_lds && kl)
             k_fgw_coupling<true, true, GEN_NW><<<B * K, 64 * GEN_NW, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
         else if (c_lds)
@@ -478,7 +481,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
         else
             k_fgw_coupling<false, false, GEN_NW><<<B * K, 64 * GEN_NW, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
                                                                                                       active, T, info, sc_c, mr_lds, Ypart, Cpart);
-        conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, s);
+        conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, small ? yvec : nullptr, s);
     }
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;

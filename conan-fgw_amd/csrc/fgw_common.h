@@ -19,6 +19,32 @@ __device__ __forceinline__ double exp_acc(double x) {
     return ldexp((double)e, (int)n);
 }
 
+// Branch-free exp(x) for |x| <= 700 (the scaling form's K = exp(Mr - ref)): 2^n from integer arithmetic on the exponent field,
+// the fraction on v_exp_f32; n and the rounded t come from the 1.5 * 2^52 shift trick (two fp64 adds instead of v_rndne_f64 +
+// v_cvt_i32_f64 + v_ldexp_f64).  Arguments below -700 give 0 (also covers the -1e300 padding mask), above +700 give +inf
+// (the caller's range check on the sums then takes the exact path).  Relative error ~1e-7 (the fp32 exp2 of the fraction),
+// the same as exp_acc.
+__device__ __forceinline__ double exp_fast(double x) {
+    const double xc = fmin(fmax(x, -700.0), 700.0);
+    const double t = xc * 1.4426950408889634074;
+    const double sh = t + 6755399441055744.0;                        // 1.5 * 2^52: the low word now holds rint(t) as an int
+    const int n = __double2loint(sh);
+    const double f = t - (sh - 6755399441055744.0);                  // in [-0.5, 0.5]
+    const double e = (double)__builtin_amdgcn_exp2f((float)f);
+    const double scale = __hiloint2double((n + 1023) << 20, 0);      // 2^n, |n| <= 1010
+    const double r = e * scale;
+    return x > -700.0 ? (x < 700.0 ? r : __builtin_inf()) : 0.0;
+}
+
+// 1 / s for a positive normal s: v_rcp_f64 seed (~2^-27 relative... refined by two Newton steps to ~1 ulp); no division fix-up
+// sequence (the operands here are sums in [1e-150, 1e150], checked by the caller).
+__device__ __forceinline__ double rcp_pos(double s) {
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    r = fma(fma(-s, r, 1.0), r, r);
+    return r;
+}
+
 // log(s) for s in [1, 2^20]: v_log_f32 seed (1 ulp of fp32) refined by one Newton step y <- y + (s*exp(-y) - 1) - r^2/2,
 // which squares the relative error: ~1e-14.  Replaces the ~100-instruction ocml fp64 log in the Sinkhorn loops.
 __device__ __forceinline__ double log_acc(double s) {
@@ -165,8 +191,25 @@ __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W,
     for (int p = 0; p < 2; ++p) {
         if (p * (NW * 16) >= bi.count) break;                 // workgroup-uniform
         double a = 0.0;
-        if (bi.on[p])
-            for (int k = sub; k < Kd; k += 4) a += X(bi.i[p], k) * W(k, bi.j[p]);
+        if (bi.on[p]) {
+            // operands of 8 k-steps are requested together, then multiplied: the serial form of this loop is one LDS (or L2)
+            // round trip per step, and the border then costs more than the MFMA core it completes
+            int k = sub;
+            for (; k + 28 < Kd; k += 32) {
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xa[u] = X(bi.i[p], k + 4 * u); wb[u] = W(k + 4 * u, bi.j[p]); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += xa[u] * wb[u];
+            }
+            if (k < Kd) {                                   // tail: up to 8 steps, clamped loads with zeroed products
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int kk = k + 4 * u < Kd ? k + 4 * u : Kd - 1; xa[u] = X(bi.i[p], kk); wb[u] = W(kk, bi.j[p]); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (k + 4 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
         if (bi.on[p] && sub == 0) st(bi.i[p], bi.j[p], a);
@@ -187,12 +230,103 @@ __device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st,
     else mm_f64_pad(M, Nn, Kd, X, W, st);
 }
 
+// ---- Products whose operands live in LDS with a fixed pitch (the register-resident coupling kernel) -----------------------------
+// D[M x Nn] = X[M x Kd] @ W[Kd x Nn]; X(i,k) = X[i*pX + k]; W(k,j) = W[k*pW + j] (WT = false) or W[j*pW + k] (WT = true); element types
+// float or double.  Same tiling, fragment layout, summation order and border rule as mm_f64 above (results are bitwise equal); what
+// changes is the address arithmetic: with element-reader lambdas the compiler re-derives i*pitch + k for every operand (a matrix
+// product of 33^3 spent ~700 VALU instructions per wave around 9 MFMAs); here each lane owns two running pointers and the k loop
+// is pointer + immediate offset.
+template <bool WT, typename TW>
+__device__ __forceinline__ double mm_w_at(const TW *W, int pW, int k, int j) { return (double)(WT ? W[j * pW + k] : W[k * pW + j]); }
+
+template <int NW = FGW_WAVES, bool WT, typename TX, typename TW, class FS>
+__device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
+                                       const BorderIdx &bi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool border = border_path<NW>(M, Nn);
+    const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;
+    const int kfull = Kd & ~3;                                  // k-steps with all four lk rows valid
+    const int wstep = WT ? 4 : 4 * pW;                          // W pointer advance per k-step
+    for (int t = wave; t < Mq * Nq; t += NW) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool ra = ia < M, cb = jb < Nn;                   // always true on the border path
+        const TX *xp = X + (ra ? ia : M - 1) * pX + lk;
+        const TW *wp = WT ? W + (cb ? jb : Nn - 1) * pW + lk : W + lk * pW + (cb ? jb : Nn - 1);
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        int k0 = 0;
+        for (; k0 + 16 <= kfull; k0 += 16) {                    // 4 k-steps per trip: 8 operand reads in flight before the MFMAs
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = (double)xp[4 * u]; b[u] = (double)wp[u * wstep]; }
+            xp += 16; wp += 4 * wstep;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
+        }
+        for (; k0 < kfull; k0 += 4) {
+            const double a = (double)xp[0], b = (double)wp[0];
+            xp += 4; wp += wstep;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a : 0.0, cb ? b : 0.0, acc, 0, 0, 0);
+        }
+        if (k0 < Kd) {                                          // ragged last step: rows lk >= Kd - k0 contribute zero
+            const bool kin = k0 + lk < Kd;
+            const int back = kin ? 0 : lk;                      // stay inside the matrix for the masked lanes
+            const double a = (double)xp[-back], b = (double)(WT ? wp[-back] : wp[-back * pW]);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + lk + 4 * q;
+            if (i < M && cb) st(i, jb, acc[q]);
+        }
+    }
+    if (!border) return;
+    // border outputs: 4 lanes per output, lane `sub` sums k = sub, sub + 4, ... (same order as mm_f64_border)
+    const int sub = tid & 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p * (NW * 16) >= bi.count) break;                   // workgroup-uniform
+        double acc = 0.0;
+        if (bi.on[p]) {
+            const TX *xp = X + bi.i[p] * pX + sub;
+            const TW *wp = WT ? W + bi.j[p] * pW + sub : W + sub * pW + bi.j[p];
+            int k = sub;
+            for (; k + 28 < Kd; k += 32) {
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xa[u] = (double)xp[4 * u]; wb[u] = (double)wp[u * wstep]; }
+                xp += 32; wp += 8 * wstep;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += xa[u] * wb[u];
+            }
+            if (k < Kd) {                                       // tail: up to 8 steps, clamped reads with zeroed products
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int uu = k + 4 * u < Kd ? u : 0;
+                    xa[u] = (double)xp[4 * uu]; wb[u] = (double)wp[uu * wstep];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (k + 4 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (bi.on[p] && sub == 0) st(bi.i[p], bi.j[p], acc);
+    }
+}
+
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
 bool conan_fgw_small_supported(int N, int d);
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
+void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
+                             const double *Cw, const double *Yw, double *zvec, double *yvec, hipStream_t s);
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
-                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, hipStream_t s);
+                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
+                              const double *yvec, hipStream_t s);
+// yvec (nullable): the register-resident path's per-molecule vectors, refreshed after every update
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
                             const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
-                            float *errs, float *Yout, float *Cout, hipStream_t s);
+                            float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s);
