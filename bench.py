@@ -141,7 +141,12 @@ def cpu_baseline(args, gpu_model=None):
     except AttributeError:
         all_cores = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    configs = [1] + ([all_cores] if all_cores > 1 else [])
+    # "All cores": this path is op-dispatch bound (the reference's FGW loop does not scale at all) and torch's
+    # intra-op pool collapses when oversubscribed (256 threads on the 256-CPU GPU host: 0.5 molecules/s against 55 at 1
+    # thread, profiles/r2_cpu_baseline_full.json), so the default run times 1 thread and one 16-thread NUMA-local pool;
+    # --cpu-full times 1 thread and literally all cores.  `value` is the best of the measured thread counts.
+    many = all_cores if args.cpu_full else min(16, all_cores)
+    configs = [1] + ([many] if many > 1 else [])
     budget = args.cpu_seconds / (len(legs) * len(configs))
     table = {}
     t_start = time.perf_counter()
@@ -168,11 +173,13 @@ def cpu_baseline(args, gpu_model=None):
                                       "warmed": not (len(ts) == 1 and ts[0] == cold)}
             print(f"[cpu_baseline] {name}@{nt}t: {table[f'{name}@{nt}t']}  ({time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
     torch.set_num_threads(default_threads)
-    key = ("train_step" if args.mode == "train" else "end_to_end_forward") + f"@{configs[-1]}t"
-    out = {"value": table[key]["molecules_per_s"], "unit": "molecules/s", "cores": configs[-1], "kind": "port",
+    leg = "train_step" if args.mode == "train" else "end_to_end_forward"
+    best = max(configs, key=lambda nt: table[f"{leg}@{nt}t"]["molecules_per_s"])
+    key = f"{leg}@{best}t"
+    out = {"value": table[key]["molecules_per_s"], "unit": "molecules/s", "cores": best, "kind": "port",
            "sample": f"{args.shape.upper()}-shaped batch of {nb} molecules (BASELINE configs[0]), K={K}: median of {table[key]['timed_batches']} "
                      f"{'training steps' if args.mode == 'train' else 'forwards'} of the CPU oracle in fp32 (SchNet trunk in torch, FGW = scalar C restatement, "
-                     f"GAT + head), {configs[-1]} torch threads on {all_cores} host cores; legs = SURVEY 8(d) (i)-(iii) + training step at 1 thread and all cores",
+                     f"GAT + head), {best} torch thread(s) (the faster of {configs}) on {all_cores} host cores; legs = SURVEY 8(d) (i)-(iii) + training step",
            "protocol": "3 warm-up + 10 timed, median" if args.cpu_full else f"1 warm-up + 1..10 timed per leg inside a {args.cpu_seconds:.0f} s budget, median",
            "legs": table, "host_cores": all_cores, "wall_s": round(time.perf_counter() - t_start, 1)}
     if gpu_model is not None and args.model == "schnet":
@@ -222,9 +229,14 @@ def run_rank(args):
     K = args.conformers
     b = make_batch(args.shape, args.batch, K, seed=1236 + 1000 * rank)            # cfg2 seed (1234 + 2) on rank 0
     bg = make_bond_graph(b, seed=2236 + 1000 * rank)                              # 2-D bond graph of the same molecules
-    z, pos, batch = (torch.from_numpy(a).to(dev) for a in (b.z, b.pos, b.batch))
-    data = types.SimpleNamespace(z=z, pos=pos, batch=batch, x=torch.from_numpy(bg.x).to(dev),
-                                 edge_index=torch.from_numpy(bg.edge_index).to(dev), edge_attr=torch.from_numpy(bg.edge_attr).to(dev))
+    # The batch reaches the device the way a training loop would deliver it: dataset items (one molecule, K conformers each)
+    # through the collator — pinned pack, one H2D copy, device-side expansion (conan-fgw_amd/collate.py).  static=True: fixed
+    # tensor addresses, which the captured HIP graphs below need.  The timed steps run on this resident batch.
+    from conan_fgw_amd.collate import DeviceCollator, molecules_from_synthetic
+    items = molecules_from_synthetic(b, bg)
+    collator = DeviceCollator(dev, K, depth=2, static=True)
+    data = collator(items).wait()
+    z, pos, batch = data.z, data.pos, data.batch
     y = torch.from_numpy(b.y).to(dev)[:, None]
     torch.manual_seed(5)                                                          # train_val.py:223
     # the reference's stage-2 model: backbone (common.py:524-529 / :542-546) + GAT branch + aggregation head
@@ -328,6 +340,30 @@ def run_rank(args):
                 torch.cuda.synchronize()
             flat.suspend_overlap(False)
         loss_last = float(loss_out)
+
+        # ---- the same step fed by the input pipeline: every step re-collates the batch on the host (C pack into a pinned
+        # buffer), copies it (one H2D transfer on the copy stream, overlapping the previous step) and expands it on the device.
+        # PCIe-inclusive rate: reported beside `value`, never as `value`.
+        pipe = None
+        try:
+            step_fn = graph_step if dt_graph is not None else eager_step
+            def pipe_step():
+                collator(items).wait()
+                step_fn()
+            for _ in range(2):
+                pipe_step()
+            n_pipe = max(5, args.steps // 2)
+            dt_pipe = timed(pipe_step, n_pipe)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                collator.pack(items)
+            host_ms = 1e3 * (time.perf_counter() - t0) / 5
+            pipe = {"molecules_per_s": round(args.batch * world * n_pipe / dt_pipe, 1), "ms_per_step": round(1e3 * dt_pipe / n_pipe, 4), "steps": n_pipe,
+                    "packed_bytes_per_batch": collator.last_packed_bytes, "host_pack_ms": round(host_ms, 4),
+                    "what": "collate (C pack, pinned) + 1 H2D copy + device expansion + the step, per step; copy overlaps the previous step"}
+        except Exception as e:
+            pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
 
         # ---- all-reduce cost by itself (world > 1): the flat buffer, 20 back-to-back calls
         ar_us = None
@@ -454,6 +490,7 @@ def run_rank(args):
             "allreduce": {"payload_bytes": int(flat.flat.numel()) * 4, "calls_per_step": (1 if world > 1 else 0) if use_graph else flat.last_allreduce_launches,
                           "eager_overlap_buckets": list(buckets)},
             "eager": {"molecules_per_s": round(args.batch * world * n_eager / dt_eager, 1), "ms_per_step": round(1e3 * dt_eager / n_eager, 4), "steps": n_eager},
+            "with_input_pipeline": pipe,
             "graph_capture_error": graph_err,
             "loss": {"after_eager_phase": loss_eager, "last": loss_last},
             "roofline": roofline,

@@ -21,10 +21,19 @@ class FgwParams(ctypes.Structure):
                 ("warmstart", c_int), ("loss_fun", c_int)]
 
 
+class BatchLayout(ctypes.Structure):
+    """Mirror of `conan_batch_layout` (include/conan_fgw_hip.h)."""
+    _fields_ = [(n, c_int) for n in ("B", "K", "num_graphs", "num_atoms", "num_bond_edges", "max_nodes", "x_dim", "ea_dim")] + \
+               [(n, c_ll) for n in ("off_atom_off", "off_bond_off", "off_z", "off_pos", "off_x", "off_bsrc", "off_bdst", "off_battr", "off_y", "bytes")]
+
+
 # name -> (restype, argtypes); kept in the header's order.  tests/test_abi.py checks this table against the header.
 _P = c_void_p
 SIGNATURES = {
     "conan_abi_version": (c_int, []),
+    "conan_collate_layout": (c_int, [c_int, c_int, _P, _P, c_int, c_int, ctypes.POINTER(BatchLayout)]),
+    "conan_collate_pack": (c_int, [ctypes.POINTER(BatchLayout), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "conan_collate_unpack": (c_int, [_P, ctypes.POINTER(BatchLayout), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_graph_ptr_from_batch": (c_int, [_P, c_int, c_int, _P, _P]),
     "conan_radius_graph_csr": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "conan_csr_transpose": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),

@@ -37,6 +37,45 @@ extern "C" {
 /* Library / device probe.  Returns the ABI version (1). */
 int conan_abi_version(void);
 
+/* ---------------------------------------------------------------------------------------------- batch assembly */
+
+/* Byte layout of one packed batch: what the host writes (pinned) and ONE H2D copy moves.  The K conformers of a molecule
+ * share z, the 2-D bond graph and its features, so each molecule is packed once; sections are 16-byte aligned. */
+typedef struct conan_batch_layout {
+    int B, K;                /* molecules, conformers per molecule */
+    int num_graphs;          /* B*K conformer graphs, molecule-major (datasets.py:170-199) */
+    int num_atoms;           /* atoms over all conformer graphs */
+    int num_bond_edges;      /* directed 2-D bond edges over all conformer graphs */
+    int max_nodes;           /* atoms of the largest conformer = N_max of to_dense_batch (schnet_no_sum.py:242) */
+    int x_dim, ea_dim;       /* atom / bond feature widths (9 / 3 for PyG from_smiles) */
+    long long off_atom_off, off_bond_off;   /* int32 [B+1] prefix sums of atoms / bond edges per molecule */
+    long long off_z;         /* int32 [sum n] */
+    long long off_pos;       /* float [sum K*n*3]: per molecule [K][n][3] */
+    long long off_x;         /* float [sum n*x_dim] */
+    long long off_bsrc, off_bdst;           /* int32 [sum e] molecule-local atom indices */
+    long long off_battr;     /* float [sum e*ea_dim] */
+    long long off_y;         /* float [B] */
+    long long bytes;         /* size of the packed buffer */
+} conan_batch_layout;
+
+/* (host) Layout for B molecules of n_atoms[m] atoms and n_bonds[m] directed bond edges, K conformers each. */
+int conan_collate_layout(int B, int K, const int *n_atoms, const int *n_bonds, int x_dim, int ea_dim, conan_batch_layout *layout);
+/* (host) Pack B dataset items — what LargeConformerBasedDataset.get returns per molecule (datasets.py:133-148): z[m][n] int64,
+ * pos[m][K][n][3], x[m][n][x_dim], edge_index[m][2][e] (molecule-local), edge_attr[m][e][ea_dim], y[m] — into `packed`
+ * (layout->bytes bytes, pinned host memory for an asynchronous copy).  All pointers are HOST pointers.  Replaces the
+ * Python loops + Batch.from_data_list of collate_fn (datasets.py:170-199). */
+int conan_collate_pack(const conan_batch_layout *layout, const int *n_atoms, const int *n_bonds, const int64_t *const *z,
+                       const float *const *pos, const float *const *x, const int64_t *const *edge_index,
+                       const float *const *edge_attr, const float *y, void *packed);
+/* (device) Expand a packed batch (already copied to the device) into the flat tensors of the reference's model API:
+ * z[A] int64, pos[A,3], batch[A] int64 (= batch_node_index = data_batch.batch), x[A,x_dim], edge_index[2,E] int64 with node
+ * offsets (Batch.from_data_list), edge_attr[E,ea_dim], y[G] (every conformer Data carries its molecule's target),
+ * graph_ptr[G+1] int32 and conformers_index[G] int64 (create_aggregation_index, common.py:414-423).  `layout` is a HOST
+ * pointer (passed to the kernel by value). */
+int conan_collate_unpack(const void *packed_dev, const conan_batch_layout *layout, int64_t *z, float *pos, int64_t *batch,
+                         float *x, int64_t *edge_index, float *edge_attr, float *y, int *graph_ptr, int64_t *conformers_index,
+                         void *stream);
+
 /* ---------------------------------------------------------------------------------------------- graph construction */
 
 /* graph_ptr[G+1] from the sorted per-atom graph id vector the reference passes around (`batch`,
