@@ -17,6 +17,9 @@
 // side of that yard-stick at negligible cost (the per-molecule matrices are tiny and MI355X runs fp64 FMA at half the
 // fp32 rate).  exp() is evaluated as 2^n * v_exp_f32(frac) with the range reduction done in fp64 (1 ulp of fp32).
 #include "fgw_common.h"
+#ifdef CONAN_FGW_PROFILE
+FGW_PROF_ACCESSOR(conan_debug_fgw_prof_large)
+#endif
 
 namespace {
 // bytes of global scratch per coupling workgroup (Mr, A, base fp64 + T fp32 = 28 B per matrix entry), rounded to 16 B so that every
@@ -60,6 +63,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FGW_PROF_DECL;
 
     // ---- carve
     double *vec = reinterpret_cast<double *>(smem);          // [(6 + 2 NW)*N + 16] : u, v, loga, logb, r1/y2, r2/z2, red, pm[NW][N], psm[NW][N]
@@ -97,26 +101,39 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     }
     // ---- init_matrix (utils.py:39-43): constC[i][j] = sum_k C1[i,k]^2 p_k + sum_k q_k C2[j,k]^2 ; squared feature norms
     double *y2a = Al, *z2a = Al + N;                            // Al is not live yet
-    for (int i = tid; i < N; i += NT) {
-        double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
-        for (int k = 0; k < N; ++k) {
-            const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
-            r1 += (KL ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * u[k];
-            r2 += v[k] * (KL ? c2 : c2 * c2);
+    {   // 8 lanes per index, strided partial sums combined by xor-shuffles (fixed order): one thread per index walked N + d
+        // dependent L2 round trips
+        constexpr int LPI = 8;
+        for (int i0 = 0; i0 < N; i0 += NT / LPI) {
+            const int i = i0 + tid / LPI, sub = tid % LPI;
+            double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
+            if (i < N) {
+                for (int k = sub; k < N; k += LPI) {
+                    const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
+                    r1 += (KL ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * u[k];
+                    r2 += v[k] * (KL ? c2 : c2 * c2);
+                }
+                for (int c = sub; c < d; c += LPI) {
+                    const double yy = Y[i * d + c], zz = (double)Z[i * d + c];
+                    y2 += yy * yy; z2 += zz * zz;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < LPI; o <<= 1) {
+                r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); y2 += __shfl_xor(y2, o, 64); z2 += __shfl_xor(z2, o, 64);
+            }
+            if (i < N && sub == 0) { ra[i] = r1; rb[i] = r2; y2a[i] = y2; z2a[i] = z2; }
         }
-        for (int c = 0; c < d; ++c) {
-            const double yy = Y[i * d + c], zz = (double)Z[i * d + c];
-            y2 += yy * yy; z2 += zz * zz;
-        }
-        ra[i] = r1; rb[i] = r2; y2a[i] = y2; z2a[i] = z2;
     }
     __syncthreads();
+    FGW_PROF(0);      // staging: T0, per-index vectors
     // ---- base = alpha*2*constC + (1-alpha)*M,  M = clamp(|y_i|^2 + |z_j|^2 - 2 y_i.z_j, 0)   (utils.py:154-171, bregman.py:124-125)
     // dot(Y_i, Z_j) on fp64 MFMA straight from global memory (L2-resident), then the elementwise assembly
     if (!y_zero)
         mm_f64<NW>(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
                [&](int i, int j, double v) { base[i * P + j] = v; });
     __syncthreads();
+    FGW_PROF(1);      // dot(Y, Z)
     for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
         double m = -2.0 * (y_zero ? 0.0 : base[i * P + j]);    // utils.py:159-161
@@ -125,6 +142,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         base[i * P + j] = 2.0 * alpha * (ra[i] + rb[j]) + (1.0 - alpha) * m;
     }
     __syncthreads();
+    for (int i = tid; i < N; i += NT) { ra[i] = exp(loga[i]); rb[i] = exp(logb[i]); }      // p_i, q_j for the scaling form (r1 / r2 are consumed)
+    double *pa = ra, *qb = rb;
+    FGW_PROF(2);      // base
 
     // ---- projected gradient loop (bregman.py:119-157)
     int cpt = 0, sk_total = 0;
@@ -135,80 +155,173 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         mm_f64<NW>(N, N, N, [&](int i, int k) { return C1[i * N + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
                [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
-               [&](int k, int j) { const double cv = (double)C2[j * N + k]; return KL ? log(cv + 1e-15) : 2.0 * cv; },
-               [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
-        for (int i = tid; i < N; i += NT) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
+        FGW_PROF(3);  // A = C1 @ T
+        auto form_mr = [&]() {
+            mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
+                   [&](int k, int j) { const double cv = (double)C2[j * N + k]; return KL ? log(cv + 1e-15) : 2.0 * cv; },
+                   [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
+        };
+        form_mr();
         __syncthreads();
-        // ---- log-domain Sinkhorn (sinkhorn.py:413-433)
+        FGW_PROF(4);  // G, Mr
+        // ---- Sinkhorn in its matrix-scaling form, in place on Mr (see fgw_small.hip): K = exp(Mr - Mr_jj) with the first column
+        // step folded in, then alternating passes   K <- K diag(f), row sums -> g = a / rowsum   (lane <-> row)   and
+        // K <- diag(g) K, column sums -> f = b / colsum   (lane <-> column): one multiply-add per entry and half-iteration instead
+        // of two exp.  After a row-scaled pass K is exp(Mr + u + v) of the reference iteration (sinkhorn.py:415-416), its column
+        // sums are the marginal check (:418-433) and feed the next v update.  A sum outside [1e-150, 1e150] (or not finite) sends
+        // the call to the exact log-domain path below.  u[] holds the row factors g, v[] the column factors f.
         int ii = 0;
-        for (; ii < prm.num_iter_max; ++ii) {
-            // v_j = logb_j - logsumexp_i(Mr_ij + u_i).  lane <-> column (consecutive lanes read consecutive LDS words), the four
-            // wavefronts split the rows (i = wave, wave + 4, ...): serial (max, sum) per thread, no cross-lane fp64 reductions
-            // (a wavefront-per-column mapping spent most of its instructions in 64-bit shuffles); the four partials per column
-            // are combined through LDS.
-            for (int j = lane; j < N; j += 64) {
-                double mx = -1.0e300;
-                for (int i = wave; i < N; i += NW) { const double z = Mr[i * P + j] + u[i]; mx = fmax(z, mx); }
-                double sm = 0.0;
-                for (int i = wave; i < N; i += NW) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
-                pm[wave * N + j] = mx; psm[wave * N + j] = sm;
-            }
-            __syncthreads();
+        bool exact = false;
+        auto bad = [](double x) { return !(x > 1e-150 && x < 1e150); };
+        auto any_bad = [&](bool mine) {                                   // workgroup-wide OR; every thread gets the result
+            const double tot = block_sum_d<NW>(mine ? 1.0 : 0.0, red);
+            return tot > 0.0;
+        };
+        for (int j = tid; j < N; j += NT) v[j] = Mr[j * P + j];          // column references (the diagonal), before K overwrites them
+        __syncthreads();
+        for (int j = lane; j < N; j += 64) {                              // K = exp(Mr - ref_j), partial column sums
+            const double ref = v[j];
+            double cs = 0.0;
+            for (int i = wave; i < N; i += NW) { const double k = exp_fast(Mr[i * P + j] - ref); Mr[i * P + j] = k; cs += k; }
+            psm[wave * N + j] = cs;
+        }
+        __syncthreads();
+        {
+            bool mine = false;
             for (int j = tid; j < N; j += NT) {
-                double M = pm[j];
+                double cs = 0.0;
 #pragma unroll
-                for (int w = 1; w < NW; ++w) M = fmax(M, pm[w * N + j]);
-                double sm = 0.0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sm += psm[w * N + j] * exp_lse(pm[w * N + j] - M);
-                v[j] = logb[j] - (log_acc(sm) + M);
+                for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
+                mine |= bad(cs);
+                v[j] = qb[j] / cs;                                        // f_j of the first v update (u = 0)
             }
-            __syncthreads();
-            // u_i = loga_i - logsumexp_j(Mr_ij + v_j): lane <-> row (odd pitch: conflict-free), wavefronts split the columns
+            exact = any_bad(mine);                                        // (barriers inside: v[] is published)
+        }
+        FGW_PROF(5);  // K = exp(Mr - ref), first column step
+        for (; !exact && ii < prm.num_iter_max; ++ii) {
+            // K <- K diag(f); row sums                                                         (sinkhorn.py:415 applied, :416 prepared)
             for (int i = lane; i < N; i += 64) {
-                double mx = -1.0e300;
-                for (int j = wave; j < N; j += NW) { const double z = Mr[i * P + j] + v[j]; mx = fmax(z, mx); }
-                double sm = 0.0;
-                for (int j = wave; j < N; j += NW) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
-                pm[wave * N + i] = mx; psm[wave * N + i] = sm;
+                double rs = 0.0;
+                for (int j = wave; j < N; j += NW) { const double k = Mr[i * P + j] * v[j]; Mr[i * P + j] = k; rs += k; }
+                pm[wave * N + i] = rs;
             }
             __syncthreads();
-            for (int i = tid; i < N; i += NT) {
-                double M = pm[i];
+            {
+                bool mine = false;
+                for (int i = tid; i < N; i += NT) {
+                    double rs = 0.0;
 #pragma unroll
-                for (int w = 1; w < NW; ++w) M = fmax(M, pm[w * N + i]);
-                double sm = 0.0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sm += psm[w * N + i] * exp_lse(pm[w * N + i] - M);
-                u[i] = loga[i] - (log_acc(sm) + M);
-            }
-            __syncthreads();
-            if (ii % 10 == 0) {                                 // marginal violation, sinkhorn.py:418-433
-                for (int j = lane; j < N; j += 64) {
-                    double sm = 0.0;
-                    for (int i = wave; i < N; i += NW) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
-                    psm[wave * N + j] = sm;
+                    for (int w = 0; w < NW; ++w) rs += pm[w * N + i];
+                    mine |= bad(rs);
+                    u[i] = pa[i] / rs;
                 }
-                __syncthreads();
+                if (any_bad(mine)) { exact = true; break; }
+            }
+            // K <- diag(g) K; column sums = marginals of the iterate                           (sinkhorn.py:416 applied)
+            for (int j = lane; j < N; j += 64) {
+                double cs = 0.0;
+                for (int i = wave; i < N; i += NW) { const double k = Mr[i * P + j] * u[i]; Mr[i * P + j] = k; cs += k; }
+                psm[wave * N + j] = cs;
+            }
+            __syncthreads();
+            {
+                bool mine = false;
                 double e2 = 0.0;
                 for (int j = tid; j < N; j += NT) {
                     double cs = 0.0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
-                    const double df = cs - exp(logb[j]);
+                    mine |= bad(cs);
+                    const double df = cs - qb[j];
                     e2 += df * df;
+                    v[j] = qb[j] / cs;                                    // f_j of the next v update
                 }
-                const double tot = block_sum_d<NW>(e2, red);
-                if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
+                if (any_bad(mine)) { exact = true; break; }
+                if (ii % 10 == 0) {                                       // marginal violation, sinkhorn.py:418-433
+                    const double tot = block_sum_d<NW>(e2, red);
+                    if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
+                }
             }
         }
+        if (exact) {
+            // ---- exact log-domain Sinkhorn (sinkhorn.py:393-433), restarted from u = v = 0 on a re-formed Mr
+            __syncthreads();
+            form_mr();
+            for (int i = tid; i < N; i += NT) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
+            __syncthreads();
+            for (ii = 0; ii < prm.num_iter_max; ++ii) {
+                // v_j = logb_j - logsumexp_i(Mr_ij + u_i).  lane <-> column (consecutive lanes read consecutive LDS words), the
+                // wavefronts split the rows: serial (max, sum) per thread, no cross-lane fp64 reductions; the partials per column
+                // are combined through LDS.
+                for (int j = lane; j < N; j += 64) {
+                    double mx = -1.0e300;
+                    for (int i = wave; i < N; i += NW) { const double z = Mr[i * P + j] + u[i]; mx = fmax(z, mx); }
+                    double sm = 0.0;
+                    for (int i = wave; i < N; i += NW) sm += exp_lse(Mr[i * P + j] + u[i] - mx);      // argument <= 0: fp32 exponent unit
+                    pm[wave * N + j] = mx; psm[wave * N + j] = sm;
+                }
+                __syncthreads();
+                for (int j = tid; j < N; j += NT) {
+                    double M = pm[j];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) M = fmax(M, pm[w * N + j]);
+                    double sm = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sm += psm[w * N + j] * exp_lse(pm[w * N + j] - M);
+                    v[j] = logb[j] - (log_acc(sm) + M);
+                }
+                __syncthreads();
+                // u_i = loga_i - logsumexp_j(Mr_ij + v_j): lane <-> row (odd pitch: conflict-free), wavefronts split the columns
+                for (int i = lane; i < N; i += 64) {
+                    double mx = -1.0e300;
+                    for (int j = wave; j < N; j += NW) { const double z = Mr[i * P + j] + v[j]; mx = fmax(z, mx); }
+                    double sm = 0.0;
+                    for (int j = wave; j < N; j += NW) sm += exp_lse(Mr[i * P + j] + v[j] - mx);
+                    pm[wave * N + i] = mx; psm[wave * N + i] = sm;
+                }
+                __syncthreads();
+                for (int i = tid; i < N; i += NT) {
+                    double M = pm[i];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) M = fmax(M, pm[w * N + i]);
+                    double sm = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sm += psm[w * N + i] * exp_lse(pm[w * N + i] - M);
+                    u[i] = loga[i] - (log_acc(sm) + M);
+                }
+                __syncthreads();
+                if (ii % 10 == 0) {                                 // marginal violation, sinkhorn.py:418-433
+                    for (int j = lane; j < N; j += 64) {
+                        double sm = 0.0;
+                        for (int i = wave; i < N; i += NW) sm += exp_acc(Mr[i * P + j] + u[i] + v[j]);
+                        psm[wave * N + j] = sm;
+                    }
+                    __syncthreads();
+                    double e2 = 0.0;
+                    for (int j = tid; j < N; j += NT) {
+                        double cs = 0.0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
+                        const double df = cs - qb[j];
+                        e2 += df * df;
+                    }
+                    const double tot = block_sum_d<NW>(e2, red);
+                    if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
+                }
+            }
+            for (int t = tid; t < NN; t += NT) {                    // K = exp(Mr + u + v) in place: both paths hand the same state on
+                const int i = t / N, j = t - i * N;
+                Mr[i * P + j] = exp_acc(Mr[i * P + j] + u[i] + v[j]);
+            }
+            __syncthreads();
+        }
         sk_total += ii;
+        FGW_PROF(6);  // Sinkhorn iterations
         // ---- T = exp(Mr + u + v) (sinkhorn.py:450); err = ||T - Tprev||_F evaluated when cpt % 10 == 0 (bregman.py:144-147)
         double e2 = 0.0;
         for (int t = tid; t < NN; t += NT) {
             const int i = t / N, j = t - i * N;
-            const float tn = (float)exp_acc(Mr[i * P + j] + u[i] + v[j]);
+            const float tn = (float)Mr[i * P + j];                  // the scaled coupling = exp(Mr + u + v), sinkhorn.py:450
             const double df = (double)tn - (double)Tl[i * P + j];
             e2 += df * df;
             Tl[i * P + j] = tn;
@@ -216,16 +329,19 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         if (cpt % 10 == 0) err = sqrt(block_sum_d<NW>(e2, red));
         else __syncthreads();
         ++cpt;
+        FGW_PROF(7);  // T store + err
     }
     __syncthreads();
     for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
+    FGW_PROF(8);      // T -> global
     // ---- contributions to the barycenter update (summed over s by k_fgw_update_parts)
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
         mm_f64<NW>(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
                [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
+    FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
         mm_f64<NW>(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
@@ -235,6 +351,8 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
                [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
+    FGW_PROF(10);     // Cpart = T @ C2 @ T^T
+    FGW_PROF_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------ backward

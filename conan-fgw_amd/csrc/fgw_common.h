@@ -2,6 +2,38 @@
 #pragma once
 #include "common.h"
 
+// Phase timing of the coupling kernels (tools/fgw_phase_profile.py builds a private library with -DCONAN_FGW_PROFILE; the product
+// library is compiled without it and contains none of this).  Thread 0 of every workgroup accumulates the 100 MHz wall-clock ticks
+// between marks in registers and adds them to the global slots once, at the end.
+#ifdef CONAN_FGW_PROFILE
+static __device__ long long g_fgw_prof[32];            // one copy per translation unit (no relocatable device code)
+#define FGW_PROF_ACCESSOR(name)                                                          \
+    extern "C" int name(long long *out, int reset) {                                     \
+        if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fgw_prof), sizeof(long long) * 32) != hipSuccess) return -2; \
+        if (reset) { long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fgw_prof), z, sizeof(z)) != hipSuccess) return -2; } \
+        return 0;                                                                        \
+    }
+#define FGW_PROF_DECL long long prof_t = wall_clock64(); const long long prof_w0 = prof_t, prof_c0 = clock64(); long long prof_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FGW_PROF(k)                                                                      \
+    do {                                                                                 \
+        const long long t_ = wall_clock64();                                             \
+        prof_acc[k] += t_ - prof_t;                                                      \
+        prof_t = t_;                                                                     \
+    } while (0)
+#define FGW_PROF_FLUSH                                                                   \
+    do {                                                                                 \
+        if (threadIdx.x == 0) {                                                          \
+            for (int k_ = 0; k_ < 11; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[k_]), (unsigned long long)prof_acc[k_]); \
+            atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[20]), (unsigned long long)(clock64() - prof_c0));      \
+            atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[21]), (unsigned long long)(wall_clock64() - prof_w0)); \
+        }                                                                                \
+    } while (0)
+#else
+#define FGW_PROF_DECL
+#define FGW_PROF(k)
+#define FGW_PROF_FLUSH
+#endif
+
 constexpr int FGW_THREADS = 256;
 constexpr int FGW_WAVES = FGW_THREADS / 64;
 
@@ -105,19 +137,35 @@ __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS
         const int ic = ra ? ia : M - 1, jc = cb ? jb : Nn - 1;          // clamped: loads stay in range, values masked
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         int k0 = 0;
-        for (; k0 + 16 <= Kd; k0 += 16) {                 // 4 k-steps per trip: 8 operand loads in flight before the MFMAs
+        // Operands of this path come from global memory (L2) in the large-N kernel: a trip is one dependent round trip, so a
+        // trip carries 8 k-steps (16 loads in flight) while K allows, then 4, then the ragged tail.  Same MFMA order as before.
+        for (; k0 + 32 <= Kd; k0 += 32) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = X(ic, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, jc); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
+        }
+        for (; k0 + 16 <= Kd; k0 += 16) {
             double a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { a[u] = X(ic, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, jc); }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
         }
-        for (; k0 < Kd; k0 += 4) {
-            const int k = k0 + lk;
-            const bool kin = k < Kd;
-            const int kc = kin ? k : Kd - 1;
-            const double a = X(ic, kc), b = W(kc, jc);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc, 0, 0, 0);
+        if (k0 < Kd) {                                    // up to 4 remaining k-steps in ONE trip, clamped loads with zeroed operands
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + lk, kc = k < Kd ? k : Kd - 1;
+                a[u] = X(ic, kc); b[u] = W(kc, jc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool kin = k0 + 4 * u + lk < Kd;
+                if (k0 + 4 * u < Kd)                       // workgroup-uniform
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a[u] : 0.0, (cb && kin) ? b[u] : 0.0, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

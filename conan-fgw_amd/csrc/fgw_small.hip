@@ -22,35 +22,7 @@
 #include "fgw_common.h"
 
 #ifdef CONAN_FGW_PROFILE
-// Phase timing of the coupling kernel (tools/fgw_phase_profile.py builds a private library with this macro; the product
-// library is compiled without it and contains none of this).  Thread 0 of every workgroup adds the 100 MHz wall-clock ticks
-// spent since its previous mark to slot k.
-__device__ long long g_fgw_prof[32];
-#define FGW_PROF_DECL long long prof_t = wall_clock64(); const long long prof_w0 = prof_t, prof_c0 = clock64(); long long prof_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define FGW_PROF(k)                                                                      \
-    do {                                                                                 \
-        const long long t_ = wall_clock64();                                             \
-        prof_acc[k] += t_ - prof_t;                                                      \
-        prof_t = t_;                                                                     \
-    } while (0)
-#define FGW_PROF_FLUSH                                                                   \
-    do {                                                                                 \
-        if (threadIdx.x == 0)                                                            \
-        {                                                                                \
-            for (int k_ = 0; k_ < 11; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[k_]), (unsigned long long)prof_acc[k_]); \
-            atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[20]), (unsigned long long)(clock64() - prof_c0));      \
-            atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[21]), (unsigned long long)(wall_clock64() - prof_w0)); \
-        }                                                                                \
-    } while (0)
-extern "C" int conan_debug_fgw_prof(long long *out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fgw_prof), sizeof(long long) * 32) != hipSuccess) return -2;
-    if (reset) { long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fgw_prof), z, sizeof(z)) != hipSuccess) return -2; }
-    return 0;
-}
-#else
-#define FGW_PROF_DECL
-#define FGW_PROF(k)
-#define FGW_PROF_FLUSH
+FGW_PROF_ACCESSOR(conan_debug_fgw_prof)
 #endif
 
 namespace {

@@ -15,21 +15,24 @@ from conan_fgw_amd import _lib
 _lib._SO = os.path.join(tmp, "pkg", "libconan_fgw_hip.so")
 from conan_fgw_amd import ops
 L = _lib.lib()
-L.conan_debug_fgw_prof.restype = ctypes.c_int
-L.conan_debug_fgw_prof.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+for _n in ("conan_debug_fgw_prof", "conan_debug_fgw_prof_large"):
+    getattr(L, _n).restype = ctypes.c_int
+    getattr(L, _n).argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
 dev = torch.device("cuda:0")
 B, K, N, d = int(os.environ.get("PROF_B", 256)), 5, int(os.environ.get("PROF_N", 33)), 64
 g = torch.Generator().manual_seed(0)
 Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
+print(f"B={B} K={K} N={N} d={d}  ({'register-resident kernel, N <= 64' if N <= 64 else 'large-N kernel'})")
 A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
 for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 32)()
-L.conan_debug_fgw_prof(buf, 1)
+PROF = L.conan_debug_fgw_prof if N <= 64 else L.conan_debug_fgw_prof_large
+PROF(buf, 1)
 reps = 5
 for _ in range(reps): out = ops.fgw_barycenter_batched(Ys, Cs)
 torch.cuda.synchronize()
-L.conan_debug_fgw_prof(buf, 0)
+PROF(buf, 0)
 names = ["staging", "T0 + dot(Y,Z)", "base registers", "A = C1 @ T", "G = A @ 2C2^T", "K = exp(Mr-max) + 1st column step", "Sinkhorn iterations",
          "T store + err", "T -> global", "Ypart = T @ Z", "Cpart = T C2 T^T"]
 launches = reps * 5
