@@ -1,0 +1,79 @@
+"""Every BASELINE.json config at its STATED size through the HIP path, checked by size-independent properties (the oracle
+finishes such batches in minutes, not seconds, so full-size parity is by invariants; the same shapes are compared with the oracle
+entry by entry at small batch sizes in test_gpu_schnet / test_gpu_shapes / test_gpu_visnet):
+  * rows of h_bary are identical within a molecule (schnet_no_sum.py:309-312: the barycenter readout is repeated K times);
+  * E(3) invariance: a random rotation + translation of every conformer leaves h_3d unchanged to fp32 rounding and h_bary to the FGW noise
+    floor (distances are recomputed in fp32, so neighbour lists at the cutoff edge may flip: tolerance, not equality);
+  * batch-position independence: a molecule's h_3d does not depend on which other molecules share the batch; its h_bary does only
+    through N_max, so a sub-batch that keeps the largest molecule reproduces it;
+  * the FGW solver's own invariants at full size: iteration counts within their bounds, couplings non-negative with row marginals 1/N.
+configs: [1] ESOL+SchNet B=256 K=5; [2] Lipophilicity+SchNet 1024 over 8 GPUs = 128 per GPU; [3] BACE+ViSNet K=5 (B=64); [4] FreeSolv K=20 (B=64)."""
+import numpy as np
+import pytest
+import torch
+
+from conan_fgw_amd.synthetic import make_batch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def _model(name):
+    import conan_fgw_amd
+    torch.manual_seed(5)
+    m = conan_fgw_amd.get_model(name, dev, feat_dim=128).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.03 * torch.randn_like(p))
+    return m
+
+
+def _rot(seed):
+    q, _ = np.linalg.qr(np.random.RandomState(seed).normal(size=(3, 3)))
+    return (q * np.sign(np.linalg.det(q))).astype(np.float32)
+
+
+CASES = [("cfg2", "schnet", "esol", 256, 5), ("cfg3_per_gpu", "schnet", "lipo", 128, 5), ("cfg4", "visnet", "bace", 64, 5), ("cfg5", "schnet", "freesolv", 64, 20)]
+
+
+@pytest.mark.parametrize("tag,model_name,shape,B,K", CASES, ids=[c[0] for c in CASES])
+def test_full_size_invariants(tag, model_name, shape, B, K):
+    b = make_batch(shape, B, K, seed=1234 + len(tag))
+    m = _model(model_name)
+    z, pos, batch = (torch.from_numpy(a).to(dev) for a in (b.z, b.pos, b.batch))
+    with torch.no_grad():
+        h3, hb = m.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+        info = m.last_fgw["info"].cpu().numpy()
+        T = m.last_fgw["T"]
+        assert torch.isfinite(h3).all() and torch.isfinite(hb).all()
+        hbv = hb.view(B, K, -1)
+        assert torch.equal(hbv, hbv[:, :1].expand_as(hbv))                                   # identical rows within a molecule
+        # FGW invariants at full size
+        assert info[:, 0].min() >= 1 and info[:, 0].max() <= 5                               # outer iterations (max_iter = 5)
+        assert info[:, 1].max() <= 5 * 5 * K and info[:, 2].max() <= 5 * 5 * 5 * K            # PGD <= 5 per (outer, s); Sinkhorn <= 5 per PGD
+        assert float(T.min()) >= 0.0
+        rows = T.sum(-1)                                                                      # the last half-step fixes the row marginals
+        assert float((rows - 1.0 / b.max_nodes).abs().max()) < 1e-6
+        # E(3): rotate + translate every conformer by its own rigid motion
+        gp = b.graph_ptr
+        pos2 = b.pos.copy()
+        for g in range(0, b.num_graphs, max(1, b.num_graphs // 64)):                          # a spread of conformers (all would be the same test)
+            pos2[gp[g]:gp[g + 1]] = pos2[gp[g]:gp[g + 1]] @ _rot(g).T + np.float32(g % 7 - 3)
+        h3r, hbr = m.forward_w_barycenter(z, torch.from_numpy(pos2).to(dev), K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+        rel = lambda a, c: float((a - c).norm() / c.norm())
+        assert rel(h3r, h3) < 2e-4, rel(h3r, h3)
+        assert rel(hbr, hb) < 2e-3, rel(hbr, hb)
+        # a sub-batch that keeps the largest molecule (same N_max): identical outputs for its molecules
+        big = int(np.argmax(b.atoms_per_molecule))
+        keep = sorted(set([big, 0, 1, B - 1]))
+        sel_atoms = np.concatenate([np.arange(gp[mm * K], gp[(mm + 1) * K]) for mm in keep])
+        zb, pb = z[sel_atoms], pos[sel_atoms]
+        nb = np.repeat(b.atoms_per_molecule[keep], K)
+        bb = torch.from_numpy(np.repeat(np.arange(len(keep) * K), nb)).to(dev)
+        h3s, hbs = m.forward_w_barycenter(zb, pb, K, bb, num_graphs=len(keep) * K, max_nodes=b.max_nodes)
+        rows_full = np.concatenate([np.arange(mm * K, (mm + 1) * K) for mm in keep])
+        if model_name == "schnet":
+            assert torch.equal(h3s, h3[rows_full])                                            # bitwise: per-graph work, fixed reduction orders
+            assert torch.equal(hbs, hb[rows_full])
+        else:                                                                                 # ViSNet's Linear layers pick their kernel by row count
+            assert rel(h3s, h3[rows_full]) < 1e-6 and rel(hbs, hb[rows_full]) < 1e-5
