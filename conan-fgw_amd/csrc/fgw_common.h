@@ -137,15 +137,6 @@ __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS
         const int ic = ra ? ia : M - 1, jc = cb ? jb : Nn - 1;          // clamped: loads stay in range, values masked
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         int k0 = 0;
-        // Operands of this path come from global memory (L2) in the large-N kernel: a trip is one dependent round trip, so a
-        // trip carries 8 k-steps (16 loads in flight) while K allows, then 4, then the ragged tail.  Same MFMA order as before.
-        for (; k0 + 32 <= Kd; k0 += 32) {
-            double a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a[u] = X(ic, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, jc); }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
-        }
         for (; k0 + 16 <= Kd; k0 += 16) {
             double a[4], b[4];
 #pragma unroll
