@@ -293,15 +293,19 @@ __device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restri
         const bool ra = ia < M, cb = jb < Nn;                   // always true on the border path
         const TX *xp = X + (ra ? ia : M - 1) * pX + lk;
         const TW *wp = WT ? W + (cb ? jb : Nn - 1) * pW + lk : W + lk * pW + (cb ? jb : Nn - 1);
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        // two accumulators (even / odd k-steps): the products of a tile form one dependent MFMA chain, and that chain — not the
+        // matrix pipe — is what a 33-wide product waits for
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
         int k0 = 0;
         for (; k0 + 16 <= kfull; k0 += 16) {                    // 4 k-steps per trip: 8 operand reads in flight before the MFMAs
             double a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { a[u] = (double)xp[4 * u]; b[u] = (double)wp[u * wstep]; }
             xp += 16; wp += 4 * wstep;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[0] : 0.0, cb ? b[0] : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[1] : 0.0, cb ? b[1] : 0.0, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[2] : 0.0, cb ? b[2] : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[3] : 0.0, cb ? b[3] : 0.0, acc2, 0, 0, 0);
         }
         for (; k0 < kfull; k0 += 4) {
             const double a = (double)xp[0], b = (double)wp[0];
@@ -312,15 +316,54 @@ __device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restri
             const bool kin = k0 + lk < Kd;
             const int back = kin ? 0 : lk;                      // stay inside the matrix for the masked lanes
             const double a = (double)xp[-back], b = (double)(WT ? wp[-back] : wp[-back * pW]);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc2, 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + lk + 4 * q;
-            if (i < M && cb) st(i, jb, acc[q]);
+            if (i < M && cb) st(i, jb, acc[q] + acc2[q]);
         }
     }
     if (!border) return;
+    if (bi.count <= NW * 21) {
+        // thin border (N = 33: 65 outputs): THREE lanes per output and a single pass — with four, the 65th output costs a whole second
+        // pass; lane `sub3` sums k = sub3, sub3 + 3, ...  Triples are formed inside a wavefront (lanes 0..62: 21 outputs per wavefront).
+        const int o = wave * 21 + lane / 3, sub3 = lane % 3;
+        const bool on = lane < 63 && o < bi.count;
+        const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4, nb1 = (M - Mc) * Nn;
+        int bi_i = 0, bi_j = 0;
+        if (on) {
+            if (o < nb1) { bi_i = Mc + o / Nn; bi_j = o % Nn; }
+            else { const int q = o - nb1; bi_i = q / (Nn - Nc); bi_j = Nc + q % (Nn - Nc); }
+        }
+        double acc = 0.0;
+        if (on) {
+            const int ws3 = WT ? 3 : 3 * pW;
+            const TX *xp = X + bi_i * pX + sub3;
+            const TW *wp = WT ? W + bi_j * pW + sub3 : W + sub3 * pW + bi_j;
+            int k = sub3;
+            for (; k + 9 < Kd; k += 12) {                       // 4 steps per trip (8 reads in flight), two partial sums
+                double xa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xa[u] = (double)xp[3 * u]; wb[u] = (double)wp[u * ws3]; }
+                xp += 12; wp += 4 * ws3;
+                acc += (xa[0] * wb[0] + xa[2] * wb[2]) + (xa[1] * wb[1] + xa[3] * wb[3]);
+            }
+            if (k < Kd) {                                       // tail: up to 4 steps, clamped reads with zeroed products
+                double xa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int uu = k + 3 * u < Kd ? u : 0;
+                    xa[u] = (double)xp[3 * uu]; wb[u] = (double)wp[uu * ws3];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += (k + 3 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
+        const double a1 = __shfl(acc, lane + 1, 64), a2 = __shfl(acc, lane + 2, 64);      // the triple's other two partial sums
+        if (on && sub3 == 0) st(bi_i, bi_j, acc + a1 + a2);
+        return;
+    }
     // border outputs: 4 lanes per output, lane `sub` sums k = sub, sub + 4, ... (same order as mm_f64_border)
     const int sub = tid & 3;
 #pragma unroll

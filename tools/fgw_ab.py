@@ -7,7 +7,7 @@ tmp = tempfile.mkdtemp(prefix="conan_ab_")
 os.makedirs(os.path.join(tmp, "include")); shutil.copy(os.path.join(ROOT, "include", "conan_fgw_hip.h"), os.path.join(tmp, "include"))
 src = os.path.join(tmp, "pkg", "csrc"); shutil.copytree(os.path.join(ROOT, "conan-fgw_amd", "csrc"), src, ignore=shutil.ignore_patterns("*.o"))
 for f in os.listdir(OVR):
-    shutil.copy(os.path.join(ROOT, "tools", "_ab", "csrc", f), os.path.join(src, f))
+    shutil.copy(os.path.join(OVR, f), os.path.join(src, f))
 subprocess.check_call(["make", "-C", src, "-s", "-j16"])
 code = r'''
 import sys, time, torch
