@@ -46,6 +46,7 @@ def parse(argv=None):
     ap.add_argument("--shape", default="esol")
     ap.add_argument("--model", choices=["schnet", "visnet"], default="schnet", help="backbone (BASELINE.json configs[3] = visnet + bace)")
     ap.add_argument("--eager", action="store_true", help="time the eager Python step instead of the HIP-graph replay")
+    ap.add_argument("--overlap", action="store_true", help="eager step: reduce the early gradient bucket while backward still runs (parallel.FlatGradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the whole CPU-baseline leg")
     ap.add_argument("--cpu-full", action="store_true", help="SURVEY 8(d) protocol in full: 3 warm-up + 10 timed batches per leg")
@@ -290,7 +291,7 @@ def run_rank(args):
     ev_other = {"conan_filter_fwd": [], "conan_fgw_barycenter_fwd": []}
     with torch.cuda.stream(side):
         # ---- eager warm-up (also: gradient-order calibration for the overlapped all-reduce of the eager step)
-        overlap = train and use_dist and world > 1
+        overlap = args.overlap and train and use_dist and world > 1      # opt-in: the default run keeps ONE collective per step on every path
         if overlap:
             flat.enable_overlap()
         eager_step()

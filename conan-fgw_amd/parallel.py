@@ -142,6 +142,14 @@ class FlatGradients:
         es = set(early)
         order = early + [i for i in order if i not in es] + [i for i in range(len(self.params)) if i not in seen]
         self._overlap = 0 < len(early) < len(order) and _world() > 1
+        if _world() > 1:
+            # every rank must cut the buffer at the same element, or the two collectives would not match: agree on the layout
+            # (min == max of a layout checksum over the ranks), else fall back to the single all-reduce everywhere
+            chk = float(sum((k + 1) * (i + 1) for k, i in enumerate(early)) % 1000003) if self._overlap else -1.0
+            t = torch.tensor([chk, -chk], dtype=torch.float64, device=self.flat.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if t[0].item() != chk or -t[1].item() != chk or chk < 0:
+                self._overlap = False
         self._layout(order, len(early) if self._overlap else len(order))
         for p in self.params:                   # .grad views of the old layout are stale
             p.grad = None

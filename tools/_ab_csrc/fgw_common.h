@@ -1,0 +1,414 @@
+// Shared device helpers of the FGW barycenter kernels (fgw.hip: generic path, fgw_small.hip: register-resident path).
+#pragma once
+#include "common.h"
+
+// Phase timing of the coupling kernels (tools/fgw_phase_profile.py builds a private library with -DCONAN_FGW_PROFILE; the product
+// library is compiled without it and contains none of this).  Thread 0 of every workgroup accumulates the 100 MHz wall-clock ticks
+// between marks in registers and adds them to the global slots once, at the end.
+#ifdef CONAN_FGW_PROFILE
+static __device__ long long g_fgw_prof[32];            // one copy per translation unit (no relocatable device code)
+#define FGW_PROF_ACCESSOR(name)                                                          \
+    extern "C" int name(long long *out, int reset) {                                     \
+        if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fgw_prof), sizeof(long long) * 32) != hipSuccess) return -2; \
+        if (reset) { long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fgw_prof), z, sizeof(z)) != hipSuccess) return -2; } \
+        return 0;                                                                        \
+    }
+#define FGW_PROF_DECL long long prof_t = wall_clock64(); const long long prof_w0 = prof_t, prof_c0 = clock64(); long long prof_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FGW_PROF(k)                                                                      \
+    do {                                                                                 \
+        const long long t_ = wall_clock64();                                             \
+        prof_acc[k] += t_ - prof_t;                                                      \
+        prof_t = t_;                                                                     \
+    } while (0)
+#define FGW_PROF_FLUSH                                                                   \
+    do {                                                                                 \
+        if (threadIdx.x == 0) {                                                          \
+            for (int k_ = 0; k_ < 11; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[k_]), (unsigned long long)prof_acc[k_]); \
+            atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[20]), (unsigned long long)(clock64() - prof_c0));      \
+            atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[21]), (unsigned long long)(wall_clock64() - prof_w0)); \
+        }                                                                                \
+    } while (0)
+#else
+#define FGW_PROF_DECL
+#define FGW_PROF(k)
+#define FGW_PROF_FLUSH
+#endif
+
+constexpr int FGW_THREADS = 256;
+constexpr int FGW_WAVES = FGW_THREADS / 64;
+
+struct FgwDims {
+    int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
+};
+
+__device__ __forceinline__ double exp_acc(double x) {
+    // exp(x) = 2^(x*log2e); integer part applied with ldexp, fractional part on the fp32 transcendental unit.
+    if (x < -745.0) return 0.0;
+    const double t = x * 1.4426950408889634074;
+    const double n = rint(t);
+    const float f = (float)(t - n);
+    const float e = __builtin_amdgcn_exp2f(f);
+    return ldexp((double)e, (int)n);
+}
+
+// Branch-free exp(x) for |x| <= 700 (the scaling form's K = exp(Mr - ref)): 2^n from integer arithmetic on the exponent field,
+// the fraction on v_exp_f32; n and the rounded t come from the 1.5 * 2^52 shift trick (two fp64 adds instead of v_rndne_f64 +
+// v_cvt_i32_f64 + v_ldexp_f64).  Arguments below -700 give 0 (also covers the -1e300 padding mask), above +700 give +inf
+// (the caller's range check on the sums then takes the exact path).  Relative error ~1e-7 (the fp32 exp2 of the fraction),
+// the same as exp_acc.
+__device__ __forceinline__ double exp_fast(double x) {
+    const double xc = fmin(fmax(x, -700.0), 700.0);
+    const double t = xc * 1.4426950408889634074;
+    const double sh = t + 6755399441055744.0;                        // 1.5 * 2^52: the low word now holds rint(t) as an int
+    const int n = __double2loint(sh);
+    const double f = t - (sh - 6755399441055744.0);                  // in [-0.5, 0.5]
+    const double e = (double)__builtin_amdgcn_exp2f((float)f);
+    const double scale = __hiloint2double((n + 1023) << 20, 0);      // 2^n, |n| <= 1010
+    const double r = e * scale;
+    return x > -700.0 ? (x < 700.0 ? r : __builtin_inf()) : 0.0;
+}
+
+// 1 / s for a positive normal s: v_rcp_f64 seed (~2^-27 relative... refined by two Newton steps to ~1 ulp); no division fix-up
+// sequence (the operands here are sums in [1e-150, 1e150], checked by the caller).
+__device__ __forceinline__ double rcp_pos(double s) {
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    r = fma(fma(-s, r, 1.0), r, r);
+    return r;
+}
+
+// log(s) for s in [1, 2^20]: v_log_f32 seed (1 ulp of fp32) refined by one Newton step y <- y + (s*exp(-y) - 1) - r^2/2,
+// which squares the relative error: ~1e-14.  Replaces the ~100-instruction ocml fp64 log in the Sinkhorn loops.
+__device__ __forceinline__ double log_acc(double s) {
+    const double y0 = (double)(__builtin_amdgcn_logf((float)s) * 0.693147180559945309f);
+    const double r = s * exp_acc(-y0) - 1.0;
+    return y0 + (r - 0.5 * r * r);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// block-wide sum of one double per thread; result broadcast to every thread. red[] has FGW_WAVES+1 doubles.
+template <int NW = FGW_WAVES>
+__device__ __forceinline__ double block_sum_d(double v, double *red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
+}
+
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// exp(x) for x <= 0 in the log-sum-exp loops: x is a difference formed in fp64, so converting it to fp32 keeps a relative
+// precision of 2^-24 in the exponent; terms below e^-80 cannot change an fp64 sum whose largest term is 1.
+__device__ __forceinline__ double exp_lse(double x) {
+    const float f = (float)x;
+    return (double)__builtin_amdgcn_exp2f(f * 1.44269504088896340736f);
+}
+
+// D[M x Nn] = X[M x Kd] @ W[Kd x Nn] with fp64 MFMA (v_mfma_f64_16x16x4_f64).  The problem is covered by ceil(M/16) x
+// ceil(Nn/16) tiles; out-of-range operand elements are read as 0 and out-of-range results are not stored, so ragged
+// sizes (N = 33) need no separate border code (a VALU border loop serialises on the one wavefront that owns it).
+// X(i,k), W(k,j) are element readers, st(i,j,v) the writer.  Fragment layout: A lane l -> X[i0 + (l&15)][k0 + (l>>4)],
+// B lane l -> W[k0 + (l>>4)][j0 + (l&15)], D reg q lane l -> row i0 + (l>>4) + 4q, col j0 + (l&15).
+// Workgroup-collective (tiles are dealt round-robin to the wavefronts); no barrier inside.
+template <int NW = FGW_WAVES, class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS st) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < Mq * Nq; t += NW) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool ra = ia < M, cb = jb < Nn;
+        const int ic = ra ? ia : M - 1, jc = cb ? jb : Nn - 1;          // clamped: loads stay in range, values masked
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        int k0 = 0;
+        for (; k0 + 16 <= Kd; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = X(ic, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, jc); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[u] : 0.0, cb ? b[u] : 0.0, acc, 0, 0, 0);
+        }
+        if (k0 < Kd) {                                    // up to 4 remaining k-steps in ONE trip, clamped loads with zeroed operands
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + lk, kc = k < Kd ? k : Kd - 1;
+                a[u] = X(ic, kc); b[u] = W(kc, jc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool kin = k0 + 4 * u + lk < Kd;
+                if (k0 + 4 * u < Kd)                       // workgroup-uniform
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a[u] : 0.0, (cb && kin) ? b[u] : 0.0, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + lk + 4 * q;
+            if (i < M && cb) st(i, jb, acc[q]);
+        }
+    }
+}
+
+// Variant for thin ragged borders: MFMA on the 16-aligned core, plain FMA loops for the few border rows/columns.
+// The border output owned by a thread (two passes of 64 outputs at most) depends only on (M, Nn): it is computed once per
+// kernel (two integer divisions per pass) and reused by every product of that shape.
+struct BorderIdx {
+    int i[2], j[2], count;
+    bool on[2];
+};
+template <int NW = FGW_WAVES>
+__device__ __forceinline__ BorderIdx border_prepare(int M, int Nn) {
+    BorderIdx bi;
+    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
+    const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
+    bi.count = nb1 + nb2;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = p * (NW * 16) + ((int)threadIdx.x >> 2);
+        bi.on[p] = t < bi.count;
+        bi.i[p] = 0; bi.j[p] = 0;
+        if (bi.on[p]) {
+            if (t < nb1) { bi.i[p] = Mc + t / Nn; bi.j[p] = t % Nn; }
+            else { const int q = t - nb1; bi.i[p] = q / (Nn - Nc); bi.j[p] = Nc + q % (Nn - Nc); }
+        }
+    }
+    return bi;
+}
+template <int NW = FGW_WAVES>
+__device__ __forceinline__ bool border_path(int M, int Nn) {       // dispatch rule of mm_f64 (workgroup-uniform)
+    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
+    return (M - Mc) * Nn + Mc * (Nn - Nc) <= NW * 32 && Mc > 0 && Nc > 0;
+}
+
+template <int NW = FGW_WAVES, class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W, FS st, const BorderIdx &bi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Mq = M >> 4, Nq = Nn >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < Mq * Nq; t += NW) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        int k0 = 0;
+        for (; k0 + 16 <= Kd; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = X(i0 + li, k0 + 4 * u + lk); b[u] = W(k0 + 4 * u + lk, j0 + li); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+        for (; k0 < Kd; k0 += 4) {
+            const int k = k0 + lk;
+            const double a = k < Kd ? X(i0 + li, k) : 0.0;
+            const double b = k < Kd ? W(k, j0 + li) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st(i0 + lk + 4 * q, j0 + li, acc[q]);
+    }
+    // Border outputs: 4 lanes per output, each summing every 4th k, combined with two xor-shuffles.  This spreads the
+    // (few) border dot products over all wavefronts: with one thread per output the whole border lands on wavefront 0,
+    // which then holds every barrier of the caller (PMC: 58 % of the wave cycles were spent waiting).
+    const int sub = tid & 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p * (NW * 16) >= bi.count) break;                 // workgroup-uniform
+        double a = 0.0;
+        if (bi.on[p]) {
+            // operands of 8 k-steps are requested together, then multiplied: the serial form of this loop is one LDS (or L2)
+            // round trip per step, and the border then costs more than the MFMA core it completes
+            int k = sub;
+            for (; k + 28 < Kd; k += 32) {
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xa[u] = X(bi.i[p], k + 4 * u); wb[u] = W(k + 4 * u, bi.j[p]); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += xa[u] * wb[u];
+            }
+            if (k < Kd) {                                   // tail: up to 8 steps, clamped loads with zeroed products
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int kk = k + 4 * u < Kd ? k + 4 * u : Kd - 1; xa[u] = X(bi.i[p], kk); wb[u] = W(kk, bi.j[p]); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (k + 4 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (bi.on[p] && sub == 0) st(bi.i[p], bi.j[p], a);
+    }
+}
+
+// Dispatch (workgroup-uniform): a border of at most one pass of the 256 threads (e.g. N = 33: 65 outputs) is cheaper on
+// the FMA path than the extra mostly-empty tiles; anything thicker goes to the padded-tile path.
+template <int NW = FGW_WAVES, class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st) {
+    if (border_path<NW>(M, Nn)) mm_f64_border<NW>(M, Nn, Kd, X, W, st, border_prepare<NW>(M, Nn));
+    else mm_f64_pad<NW>(M, Nn, Kd, X, W, st);
+}
+// same with the border ownership prepared by the caller (products repeated inside a loop)
+template <class FX, class FW, class FS>
+__device__ __forceinline__ void mm_f64(int M, int Nn, int Kd, FX X, FW W, FS st, const BorderIdx &bi) {
+    if (border_path(M, Nn)) mm_f64_border(M, Nn, Kd, X, W, st, bi);
+    else mm_f64_pad(M, Nn, Kd, X, W, st);
+}
+
+// ---- Products whose operands live in LDS with a fixed pitch (the register-resident coupling kernel) -----------------------------
+// D[M x Nn] = X[M x Kd] @ W[Kd x Nn]; X(i,k) = X[i*pX + k]; W(k,j) = W[k*pW + j] (WT = false) or W[j*pW + k] (WT = true); element types
+// float or double.  Same tiling, fragment layout, summation order and border rule as mm_f64 above (results are bitwise equal); what
+// changes is the address arithmetic: with element-reader lambdas the compiler re-derives i*pitch + k for every operand (a matrix
+// product of 33^3 spent ~700 VALU instructions per wave around 9 MFMAs); here each lane owns two running pointers and the k loop
+// is pointer + immediate offset.
+template <bool WT, typename TW>
+__device__ __forceinline__ double mm_w_at(const TW *W, int pW, int k, int j) { return (double)(WT ? W[j * pW + k] : W[k * pW + j]); }
+
+template <int NW = FGW_WAVES, bool WT, typename TX, typename TW, class FS>
+__device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
+                                       const BorderIdx &bi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool border = border_path<NW>(M, Nn);
+    const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;
+    const int kfull = Kd & ~3;                                  // k-steps with all four lk rows valid
+    const int wstep = WT ? 4 : 4 * pW;                          // W pointer advance per k-step
+    for (int t = wave; t < Mq * Nq; t += NW) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool ra = ia < M, cb = jb < Nn;                   // always true on the border path
+        const TX *xp = X + (ra ? ia : M - 1) * pX + lk;
+        const TW *wp = WT ? W + (cb ? jb : Nn - 1) * pW + lk : W + lk * pW + (cb ? jb : Nn - 1);
+        // two accumulators (even / odd k-steps): the products of a tile form one dependent MFMA chain, and that chain — not the
+        // matrix pipe — is what a 33-wide product waits for
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        int k0 = 0;
+        for (; k0 + 16 <= kfull; k0 += 16) {                    // 4 k-steps per trip: 8 operand reads in flight before the MFMAs
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = (double)xp[4 * u]; b[u] = (double)wp[u * wstep]; }
+            xp += 16; wp += 4 * wstep;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[0] : 0.0, cb ? b[0] : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[1] : 0.0, cb ? b[1] : 0.0, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[2] : 0.0, cb ? b[2] : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[3] : 0.0, cb ? b[3] : 0.0, acc2, 0, 0, 0);
+        }
+        for (; k0 < kfull; k0 += 4) {
+            const double a = (double)xp[0], b = (double)wp[0];
+            xp += 4; wp += wstep;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a : 0.0, cb ? b : 0.0, acc, 0, 0, 0);
+        }
+        if (k0 < Kd) {                                          // ragged last step: rows lk >= Kd - k0 contribute zero
+            const bool kin = k0 + lk < Kd;
+            const int back = kin ? 0 : lk;                      // stay inside the matrix for the masked lanes
+            const double a = (double)xp[-back], b = (double)(WT ? wp[-back] : wp[-back * pW]);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + lk + 4 * q;
+            if (i < M && cb) st(i, jb, acc[q] + acc2[q]);
+        }
+    }
+    if (!border) return;
+    if (bi.count <= NW * 21) {
+        // thin border (N = 33: 65 outputs): THREE lanes per output and a single pass — with four, the 65th output costs a whole second
+        // pass; lane `sub3` sums k = sub3, sub3 + 3, ...  Triples are formed inside a wavefront (lanes 0..62: 21 outputs per wavefront).
+        const int o = wave * 21 + lane / 3, sub3 = lane % 3;
+        const bool on = lane < 63 && o < bi.count;
+        const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4, nb1 = (M - Mc) * Nn;
+        int bi_i = 0, bi_j = 0;
+        if (on) {
+            if (o < nb1) { bi_i = Mc + o / Nn; bi_j = o % Nn; }
+            else { const int q = o - nb1; bi_i = q / (Nn - Nc); bi_j = Nc + q % (Nn - Nc); }
+        }
+        double acc = 0.0;
+        if (on) {
+            const int ws3 = WT ? 3 : 3 * pW;
+            const TX *xp = X + bi_i * pX + sub3;
+            const TW *wp = WT ? W + bi_j * pW + sub3 : W + sub3 * pW + bi_j;
+            int k = sub3;
+            for (; k + 9 < Kd; k += 12) {                       // 4 steps per trip (8 reads in flight), two partial sums
+                double xa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xa[u] = (double)xp[3 * u]; wb[u] = (double)wp[u * ws3]; }
+                xp += 12; wp += 4 * ws3;
+                acc += (xa[0] * wb[0] + xa[2] * wb[2]) + (xa[1] * wb[1] + xa[3] * wb[3]);
+            }
+            if (k < Kd) {                                       // tail: up to 4 steps, clamped reads with zeroed products
+                double xa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int uu = k + 3 * u < Kd ? u : 0;
+                    xa[u] = (double)xp[3 * uu]; wb[u] = (double)wp[uu * ws3];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += (k + 3 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
+        const double a1 = __shfl(acc, lane + 1, 64), a2 = __shfl(acc, lane + 2, 64);      // the triple's other two partial sums
+        if (on && sub3 == 0) st(bi_i, bi_j, acc + a1 + a2);
+        return;
+    }
+    // border outputs: 4 lanes per output, lane `sub` sums k = sub, sub + 4, ... (same order as mm_f64_border)
+    const int sub = tid & 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p * (NW * 16) >= bi.count) break;                   // workgroup-uniform
+        double acc = 0.0;
+        if (bi.on[p]) {
+            const TX *xp = X + bi.i[p] * pX + sub;
+            const TW *wp = WT ? W + bi.j[p] * pW + sub : W + sub * pW + bi.j[p];
+            int k = sub;
+            for (; k + 28 < Kd; k += 32) {
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xa[u] = (double)xp[4 * u]; wb[u] = (double)wp[u * wstep]; }
+                xp += 32; wp += 8 * wstep;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += xa[u] * wb[u];
+            }
+            if (k < Kd) {                                       // tail: up to 8 steps, clamped reads with zeroed products
+                double xa[8], wb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int uu = k + 4 * u < Kd ? u : 0;
+                    xa[u] = (double)xp[4 * uu]; wb[u] = (double)wp[uu * wstep];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (k + 4 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (bi.on[p] && sub == 0) st(bi.i[p], bi.j[p], acc);
+    }
+}
+
+// Launchers of the register-resident path (fgw_small.hip), N <= 64.
+bool conan_fgw_small_supported(int N, int d);
+size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
+void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
+                             const double *Cw, const double *Yw, double *zvec, double *yvec, hipStream_t s);
+void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
+                              conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
+                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
+                              const double *yvec, hipStream_t s);
+// yvec (nullable): the register-resident path's per-molecule vectors, refreshed after every update
+void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
+                            const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
+                            float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s);

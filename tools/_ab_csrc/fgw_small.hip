@@ -1,0 +1,584 @@
+// FGW coupling solve for N <= 64 barycenter nodes (every ESOL/FreeSolv-shaped batch): register-resident Sinkhorn.
+//
+// Same algorithm and citations as fgw.hip (bregman.py:70-167, sinkhorn.py:318-450, utils.py:39-95).  What changes is the
+// mapping to the CU.  A 256-thread workgroup (4 wavefronts) owns one (molecule, input graph) problem:
+//
+//   lane  <-> column j (layout A)  /  lane <-> row i (layout B),      wavefront w <-> index residue (w + 4r), r < R
+//
+// Every thread keeps its R entries of the N x N matrix in registers in BOTH layouts, so that a column reduction (over rows)
+// and a row reduction (over columns) are each a serial loop over registers followed by a 4-way combine through LDS: no
+// cross-lane shuffles of fp64 values, one barrier per half-iteration.
+//
+// Sinkhorn runs in its MATRIX-SCALING form on the coupling itself: with T = exp(Mr + u 1^T + 1 v^T) the log-domain update
+// v <- logb - logsumexp_i(Mr + u) (sinkhorn.py:415) is T <- T diag(b / colsum(T)) and the u update (:416) is
+// T <- diag(a / rowsum(T)) T — the same iteration, algebraically, with one division per row/column instead of N exp + 1 log,
+// and the marginal check (:418-433) and the returned coupling (:450) are the state itself.  The first column step
+// (u = v = 0) is formed in the log domain against a per-column reference (the diagonal entry), K = exp(Mr - Mr_jj), which
+// keeps K inside the fp64 range for any cost spread below ~600 eps; should a row or column sum ever leave [1e-150, 1e150]
+// (never seen on conformer features) the workgroup restarts that Sinkhorn call on the exact log-sum-exp path below.
+// The two N^3 products of the gradient use the same mapping with T, C1 (fp64), C2 resident in LDS, one operand
+// broadcast per FMA.  At the end the workgroup also forms its contribution to the barycenter update
+// (T_s @ Ys_s and T_s @ Cs_s @ T_s^T) while T is still in LDS; the update kernel is then a K-term elementwise sum.
+#include "fgw_common.h"
+
+#ifdef CONAN_FGW_PROFILE
+FGW_PROF_ACCESSOR(conan_debug_fgw_prof)
+#endif
+
+namespace {
+
+constexpr int SK_SCRATCH_DOUBLES = 3 * 256 + 2 * 64;      // Sinkhorn scratch: three [4][64] partial buffers + two [64] factor vectors
+
+// KL = true: loss_fun = "kl_loss" (utils.py:20-32,76-87): f1(a) = a log(a + 1e-15) - a, f2(b) = b, h2(b) = log(b + 1e-15) in the
+// gradient, log(clamp(C_s, 1e-15)) in the structure update (exp applied by the update kernel).  The logarithms are evaluated in
+// fp64 where the operand is fetched (the kl path is a capability of the signature, not a tuned path); KL = false compiles to
+// exactly the square-loss kernel.
+template <int R, bool KL>
+__global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_small(
+    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
+    FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
+    double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    if (!active[b]) return;
+    const int N = D.N, P = D.P, d = D.d;
+    const int NN = N * N, NP = N * P;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool lane_ok = lane < N;
+    FGW_PROF_DECL;
+
+    // ---- LDS carve (doubles first).  The constant part of the Sinkhorn cost ("base") lives in LDS, not in registers: holding it
+    // in both layouts costs 4R VGPRs, which pushed the kernel over the 168-VGPR budget of three resident workgroups per CU, and
+    // a spilled register here is a scratch (memory) round trip inside every phase of the loop.
+    double *Al = reinterpret_cast<double *>(smem);            // [N,P]  A = C1 @ T ; dot(Y,Z) ; T @ C2
+    double *Gl = Al + NP;                                      // [N,P]  G = A @ (2 C2)^T ; later the Sinkhorn scratch
+    double *C1l = Gl + NP;                                     // [N,P]
+    double *Bl = C1l + NP;                                     // [N,P]  base = 2 alpha constC + (1 - alpha) M
+    double *pq = Bl + NP;                                      // [2][64] p, q
+    double *red = pq + 128;                                    // [8]: block reductions use 5; the last word is a write sink
+    float *t_dummy = reinterpret_cast<float *>(red + 7);
+    double *vec4 = red + 8;                                    // [4][64]: r1_i, r2_j, |y_i|^2, |z_j|^2 (k_fgw_small_vectors / update kernel)
+    // Sinkhorn scratch, 7 KB: three [4][64] partial buffers and two [64] factor vectors.  It overlays A — dead once G = A (2 C2)^T
+    // is complete, which the barrier behind that product already guarantees — when A is large enough, else it has its own
+    // region behind the vectors.
+    const bool alias = (size_t)NP >= SK_SCRATCH_DOUBLES;
+    double *own = vec4 + 256;
+    double *bufC = alias ? Al : own;                           // [4][64] column partials
+    double *bufK = bufC + 256;                                 // [4][64] column partials of the marginal check
+    double *bufR = bufK + 256;                                 // [4][64] row partials
+    double *fcp = bufR + 256;                                  // [64] column factors f_j (every wave writes the same values)
+    double *gcp = fcp + 64;                                    // [64] row factors g_i
+    float *Tl = reinterpret_cast<float *>(own + (alias ? 0 : SK_SCRATCH_DOUBLES));     // [N,P]
+    float *C2l = Tl + NP;                                      // [N,P]
+    // Y and Z are staged in LDS for the prologue's dot(Y, Z) when they fit (d <= 2P): Y (fp64 [N,d]) over A|G, Z (fp32 [N,d])
+    // over base, the product lands in C1's storage, and C1 itself waits in registers until base has consumed it.  Every
+    // global load of the prologue is issued before the first LDS store: one memory round trip instead of one per loop trip.
+    // Epilogue: Z again over G for T @ Z.  Otherwise the products read Y / Z from global memory (L2-resident).
+    double *Yl = Al;
+    float *Zl = reinterpret_cast<float *>(Bl);
+    float *Zl2 = reinterpret_cast<float *>(Gl);
+    const bool yz_lds = d <= 2 * P;
+    const bool z_lds = (size_t)N * d * sizeof(float) <= (size_t)NP * sizeof(double);
+
+    const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
+    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
+    const double *C1 = Cw + (size_t)b * NN;
+    const double *Y = Yw + (size_t)b * N * d;
+    float *Tg = Tw + ((size_t)b * D.K + s) * NN;
+    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
+
+    // ---- loads first ...
+    constexpr int EPT = (16 * R * R + FGW_THREADS - 1) / FGW_THREADS;      // matrix entries per thread (N <= 4R)
+    double c1v[EPT];
+    float c2v[EPT], tv[EPT];
+    const bool warm = outer > 0 && prm.warmstart;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int t = tid + u * FGW_THREADS, tc = t < NN ? t : NN - 1;
+        c1v[u] = C1[tc]; c2v[u] = C2[tc]; tv[u] = warm ? Tg[tc] : 0.f;
+    }
+    const double p_own = tid < N ? (pb ? (double)pb[(size_t)b * N + tid] : 1.0 / (double)N) : 1.0;
+    const double q_own = tid < N ? (ps ? (double)ps[((size_t)b * D.K + s) * N + tid] : 1.0 / (double)N) : 1.0;
+    double vec_own;
+    {   // r1_i = sum_k f1(C1[i,k]) p_k, |y_i|^2 (per molecule, refreshed by the update kernel); r2_j = sum_k q_k f2(C2[j,k]), |z_j|^2 (static)
+        const int v = tid >> 6, i = tid & 63;
+        const double *src = (v == 0 || v == 2) ? yvec + (size_t)b * 2 * N + (v == 0 ? N : 0) : zvec + ((size_t)b * D.K + s) * 2 * N + (v == 1 ? N : 0);
+        vec_own = src[i < N ? i : N - 1];
+        vec_own = i < N ? vec_own : 0.0;
+    }
+    const bool stage_yz = yz_lds && !y_zero;
+    if (stage_yz) {
+        const int Nd = N * d;
+        for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
+            double yv[4]; float zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS, tc = t < Nd ? t : Nd - 1; yv[u] = Y[tc]; zv[u] = Z[tc]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) { Yl[t] = yv[u]; Zl[t] = zv[u]; } }
+        }
+    }
+    // ---- ... then the LDS stores
+    if (tid < 64) { pq[tid] = p_own; pq[64 + tid] = q_own; }
+    vec4[tid] = vec_own;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int t = tid + u * FGW_THREADS;
+        if (t < NN) { const int i = t / N, j = t - i * N; C2l[i * P + j] = c2v[u]; if (!stage_yz) C1l[i * P + j] = c1v[u]; }
+    }
+    __syncthreads();
+    FGW_PROF(0);      // staging
+    const double qj = pq[64 + lane];                                    // b_j with j = lane (layout A)
+    const double pi_l = pq[lane];                                       // a_i with i = lane (layout B)
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int t = tid + u * FGW_THREADS;
+        if (t < NN) { const int i = t / N, j = t - i * N; Tl[i * P + j] = warm ? tv[u] : (float)(pq[i] * pq[64 + j]); }     // bregman.py:98-101
+    }
+    const double *r1v = vec4, *r2v = vec4 + 64, *y2v = vec4 + 128, *z2v = vec4 + 192;
+    // ---- dot(Y_i, Z_j) on MFMA -> Dl (C1's storage when Y, Z were staged; A otherwise)
+    double *Dl = stage_yz ? C1l : Al;
+    if (!y_zero) {
+        if (stage_yz)
+            mm_lds<FGW_WAVES, true>(N, N, d, Yl, d, Zl, d, [&](int i, int j, double v) { Dl[i * P + j] = v; }, border_prepare(N, N));
+        else
+            mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
+                   [&](int i, int j, double v) { Dl[i * P + j] = v; });
+    }
+    __syncthreads();
+    FGW_PROF(1);      // T0 + dot(Y, Z)
+    // ---- base = 2*alpha*constC + (1-alpha)*M  -> Bl                              (utils.py:39-43,154-171, bregman.py:124-125)
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int t = tid + u * FGW_THREADS;
+        if (t < NN) {
+            const int i = t / N, j = t - i * N;
+            double m = -2.0 * (y_zero ? 0.0 : Dl[i * P + j]); m += y2v[i]; m += z2v[j];
+            m = m > 0.0 ? m : 0.0;
+            Bl[i * P + j] = 2.0 * alpha * (r1v[i] + r2v[j]) + (1.0 - alpha) * m;      // (Z, staged here for the product, is dead since the barrier)
+        }
+    }
+    __syncthreads();
+    if (stage_yz) {                                                     // the product is consumed: C1 comes home from the registers
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int t = tid + u * FGW_THREADS;
+            if (t < NN) { const int i = t / N, j = t - i * N; C1l[i * P + j] = c1v[u]; }
+        }
+        __syncthreads();
+    }
+    FGW_PROF(2);      // base
+
+    const BorderIdx bnn = border_prepare(N, N);                          // border ownership of the N x N products below
+    int cpt = 0, sk_total = 0;
+    double err = 1.0;
+    while (err > (double)prm.inner_tol && cpt < prm.max_iter) {          // bregman.py:119
+        // ---- A = C1 @ T ; G = A @ (2 C2)^T                                (utils.py:48-64)
+        mm_lds<FGW_WAVES, false>(N, N, N, C1l, P, Tl, P, [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
+        __syncthreads();
+        FGW_PROF(3);  // A = C1 @ T
+        auto product_G = [&]() {
+            if constexpr (KL)
+                mm_f64(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return log((double)C2l[j * P + k] + 1e-15); },
+                       [&](int i, int j, double v) { Gl[i * P + j] = v; }, bnn);
+            else
+                mm_lds<FGW_WAVES, true>(N, N, N, Al, P, C2l, P, [&](int i, int j, double v) { Gl[i * P + j] = 2.0 * v; }, bnn);
+        };
+        product_G();
+        __syncthreads();
+        FGW_PROF(4);  // G = A @ (2 C2)^T
+        // ---- Mr = -(base - 2 alpha G)/eps (sinkhorn.py:388).  Padding entries (row/column >= N) are masked BY VALUE: Mr = -1e300, K = 0.
+        // The per-entry LDS offsets are derived from values the optimiser cannot see through, once per iteration: left alone it
+        // hoists all 4R of them (x 3 matrices) out of the loop and keeps them in registers across the products, which spills.
+        int lq = lane, wq = w;
+        asm volatile("" : "+v"(lq), "+v"(wq));
+        // Reads are clamped into the matrix and the value selected afterwards: no exec-mask branch per entry.
+        const int lc = lq < N ? lq : N - 1;
+        auto mrA = [&](int r) { const int q = wq + 4 * r, qc = q < N ? q : N - 1; const double m = -(Bl[qc * P + lc] - 2.0 * alpha * Gl[qc * P + lc]) * inv_eps; return (q < N && lane_ok) ? m : -1.0e300; };
+        auto mrB = [&](int r) { const int q = wq + 4 * r, qc = q < N ? q : N - 1; const double m = -(Bl[lc * P + qc] - 2.0 * alpha * Gl[lc * P + qc]) * inv_eps; return (q < N && lane_ok) ? m : -1.0e300; };
+        double kA[R], kB[R];                                            // the coupling in both layouts
+        int ii = 0;
+        bool exact = false;                                             // workgroup-uniform
+        {
+            // ---- first column step (u = v = 0): K = exp(Mr - ref_j), f_j = b_j / sum_i K.  The stabiliser is the column's DIAGONAL
+            // entry Mr_jj, which every wave reads for itself (no combine, no barrier); any reference within ~ +-600 of the column
+            // maximum keeps K inside the fp64 range, and the range check on the sums covers the rest.
+            const double ref_own = -(Bl[lc * P + lc] - 2.0 * alpha * Gl[lc * P + lc]) * inv_eps;      // Mr_jj, j = lane
+            fcp[lane] = ref_own;                                        // identical in every wave; a wave reads back what it wrote
+            double cs = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { kA[r] = exp_fast(mrA(r) - ref_own); cs += kA[r]; }
+            bufK[w * 64 + lane] = cs;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int q = wq + 4 * r; kB[r] = exp_fast(mrB(r) - fcp[q < N ? q : N - 1]); }
+            __syncthreads();
+            cs = ((bufK[lane] + bufK[64 + lane]) + bufK[128 + lane]) + bufK[192 + lane];
+            if (__any(lane_ok && !(cs > 1e-150 && cs < 1e150))) exact = true;
+            const double f = lane_ok ? qj * rcp_pos(cs) : 0.0;
+            gcp[lane] = f;                                              // (gcp: free until the first row step)
+#pragma unroll
+            for (int r = 0; r < R; ++r) { kA[r] *= f; kB[r] *= gcp[w + 4 * r]; }
+        }
+        FGW_PROF(5);  // K = exp(Mr - ref), first column step
+        double colsum = 0.0;                                            // column sums of the current state, when known
+        bool have_colsum = false;
+        for (; !exact && ii < prm.num_iter_max; ++ii) {
+            if (ii > 0) {
+                // ---- v update: T <- T diag(b / colsum(T))                                  (sinkhorn.py:415)
+                if (!have_colsum) {
+                    double cs = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cs += kA[r];
+                    bufC[w * 64 + lane] = cs;
+                    __syncthreads();
+                    colsum = ((bufC[lane] + bufC[64 + lane]) + bufC[128 + lane]) + bufC[192 + lane];
+                }
+                have_colsum = false;
+                if (__any(lane_ok && !(colsum > 1e-150 && colsum < 1e150))) { exact = true; break; }
+                const double f = lane_ok ? qj * rcp_pos(colsum) : 0.0;
+                fcp[lane] = f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { kA[r] *= f; kB[r] *= fcp[w + 4 * r]; }
+            }
+            // ---- u update: T <- diag(a / rowsum(T)) T                                       (sinkhorn.py:416)
+            double rs = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rs += kB[r];
+            bufR[w * 64 + lane] = rs;
+            __syncthreads();
+            rs = ((bufR[lane] + bufR[64 + lane]) + bufR[128 + lane]) + bufR[192 + lane];
+            if (__any(lane_ok && !(rs > 1e-150 && rs < 1e150))) { exact = true; break; }
+            const double g = lane_ok ? pi_l * rcp_pos(rs) : 0.0;
+            gcp[lane] = g;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { kB[r] *= g; kA[r] *= gcp[w + 4 * r]; }
+            if (ii % 10 == 0) {                                        // marginal violation (sinkhorn.py:418-433): ||colsum(T) - b||_2
+                double cs = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) cs += kA[r];
+                bufK[w * 64 + lane] = cs;
+                __syncthreads();
+                colsum = ((bufK[lane] + bufK[64 + lane]) + bufK[128 + lane]) + bufK[192 + lane];
+                have_colsum = true;                                    // the next v update starts from these sums
+                double df = lane_ok ? colsum - qj : 0.0;
+                df = wave_sum_d(df * df);                              // identical in every wave: the break is workgroup-uniform
+                if (sqrt(df) < (double)prm.stop_thr) { ++ii; break; }
+            }
+        }
+        if (exact) {
+            // ---- exact log-domain Sinkhorn (sinkhorn.py:393-433), restarted from u = v = 0.  Only reached when the scaling form
+            // would lose entries to underflow / overflow (never observed on conformer features).  Mr is re-formed from base and G at
+            // every use, so this path costs the scaling path no registers; its partial buffers share the scaling path's scratch.
+            __syncthreads();
+            double *xm = bufC, *xs = bufK, *uc = fcp, *vc = gcp;        // [4][64] max, [4][64] sum, [64] u, [64] v
+            const double loga = log(pi_l), logb = log(qj);
+            double u_l = 0.0, v_l = 0.0;
+            uc[lane] = 0.0;
+            for (ii = 0; ii < prm.num_iter_max; ++ii) {
+                // v_j = logb_j - logsumexp_i(Mr_ij + u_i): serial over my rows, then ONE 4-way combine of (partial max, partial
+                // sum) pairs: sum = sum_w s_w * exp(m_w - M)
+                double z[R];
+                double mx = -1.0e300;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { z[r] = mrA(r) + uc[w + 4 * r]; mx = fmax(z[r], mx); }
+                double sm = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) sm += exp_lse(z[r] - mx);
+                __syncthreads();                                       // previous readers of xm / xs are done
+                xm[w * 64 + lane] = mx; xs[w * 64 + lane] = sm;
+                __syncthreads();
+                {
+                    const double m0 = xm[lane], m1 = xm[64 + lane], m2 = xm[128 + lane], m3 = xm[192 + lane];
+                    const double M = fmax(fmax(m0, m1), fmax(m2, m3));
+                    sm = ((xs[lane] * exp_lse(m0 - M) + xs[64 + lane] * exp_lse(m1 - M)) + xs[128 + lane] * exp_lse(m2 - M)) +
+                         xs[192 + lane] * exp_lse(m3 - M);
+                    v_l = lane_ok ? logb - (log_acc(sm) + M) : 0.0;      // padding lanes keep a finite (zero) potential
+                }
+                vc[lane] = v_l;
+                // u_i = loga_i - logsumexp_j(Mr_ij + v_j)
+                mx = -1.0e300;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { z[r] = mrB(r) + vc[w + 4 * r]; mx = fmax(z[r], mx); }
+                sm = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) sm += exp_lse(z[r] - mx);
+                __syncthreads();
+                xm[w * 64 + lane] = mx; xs[w * 64 + lane] = sm;
+                __syncthreads();
+                {
+                    const double m0 = xm[lane], m1 = xm[64 + lane], m2 = xm[128 + lane], m3 = xm[192 + lane];
+                    const double M = fmax(fmax(m0, m1), fmax(m2, m3));
+                    sm = ((xs[lane] * exp_lse(m0 - M) + xs[64 + lane] * exp_lse(m1 - M)) + xs[128 + lane] * exp_lse(m2 - M)) +
+                         xs[192 + lane] * exp_lse(m3 - M);
+                    u_l = lane_ok ? loga - (log_acc(sm) + M) : 0.0;
+                }
+                uc[lane] = u_l;
+                if (ii % 10 == 0) {                                    // marginal violation (sinkhorn.py:418-433)
+                    double cs = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cs += exp_acc(mrA(r) + uc[w + 4 * r] + v_l);
+                    __syncthreads();
+                    xs[w * 64 + lane] = cs;
+                    __syncthreads();
+                    cs = ((xs[lane] + xs[64 + lane]) + xs[128 + lane]) + xs[192 + lane];
+                    double df = lane_ok ? cs - qj : 0.0;
+                    df = wave_sum_d(df * df);
+                    if (sqrt(df) < (double)prm.stop_thr) { ++ii; break; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) kA[r] = exp_acc(mrA(r) + uc[w + 4 * r] + v_l);      // sinkhorn.py:450
+        }
+        sk_total += ii;
+        FGW_PROF(6);  // Sinkhorn iterations
+        // ---- T = the scaled coupling (= exp(Mr + u + v), sinkhorn.py:450); err = ||T - Tprev||_F when cpt % 10 == 0 (bregman.py:144-147)
+        // Branch-free: padding entries are 0; their LDS traffic is redirected to a scratch word.
+        double e2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = wq + 4 * r;
+            const bool ok = lane_ok && i < N;
+            float *tp = ok ? &Tl[i * P + lq] : t_dummy;
+            const float tn = (float)kA[r];
+            const double df = ok ? (double)tn - (double)*tp : 0.0;
+            e2 += df * df;
+            *tp = tn;
+        }
+        if (cpt % 10 == 0) err = sqrt(block_sum_d(e2, red));
+        else __syncthreads();
+        ++cpt;
+        FGW_PROF(7);  // T store + err
+    }
+    __syncthreads();
+    for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); }
+    FGW_PROF(8);      // T -> global
+
+    // ---- contributions to the barycenter update while T is resident
+    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
+        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        if (z_lds) {                                                    // G's storage is idle again: Z through LDS, one coalesced pass
+            const int Nd = N * d;
+            for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
+                float zv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; zv[u] = Z[t < Nd ? t : Nd - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) Zl2[t] = zv[u]; }
+            }
+            __syncthreads();
+            mm_lds<FGW_WAVES, false>(N, d, N, Tl, P, Zl2, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; }, border_prepare(N, d));
+        } else {
+            mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
+                   [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        }
+    }
+    FGW_PROF(9);      // Ypart = T @ Z
+    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
+        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        if constexpr (KL)
+            mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
+                   [&](int k, int j) { const double cv = (double)C2l[k * P + j]; return log(cv > 1e-15 ? cv : 1e-15); },
+                   [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
+        else
+            mm_lds<FGW_WAVES, false>(N, N, N, Tl, P, C2l, P, [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
+        __syncthreads();
+        mm_lds<FGW_WAVES, true>(N, N, N, Al, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = v; }, bnn);
+    }
+    FGW_PROF(10);     // Cpart = T @ C2 @ T^T
+    FGW_PROF_FLUSH;
+}
+
+// Per-index vectors of the gradient's constant part (init_matrix, utils.py:39-43) and of the feature cost (utils.py:154-171).
+// out[0..N) = |y_i|^2, out[N..2N) = r1_i = sum_k f1(C[i,k]) p_k with f1(a) = a^2 (square loss) or a log(a + 1e-15) - a (kl).
+// LPI = NT / 64 lanes per index (N <= 64), strided partial sums combined by xor-shuffles: a fixed order, bitwise reproducible.
+template <int NT>
+__device__ __forceinline__ void molecule_vectors(const double *__restrict__ Y, const double *__restrict__ C, const float *__restrict__ p, int N,
+                                                 int d, bool kl, double *__restrict__ out) {
+    constexpr int LPI = NT / 64;
+    const int i = (int)threadIdx.x / LPI, sub = (int)threadIdx.x % LPI;
+    double y2 = 0.0, r1 = 0.0;
+    if (i < N) {
+        for (int c = sub; c < d; c += LPI) { const double v = Y[(size_t)i * d + c]; y2 += v * v; }
+        for (int k = sub; k < N; k += LPI) {
+            const double c1 = C[i * N + k], pk = p ? (double)p[k] : 1.0 / (double)N;
+            r1 += (kl ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * pk;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPI; o <<= 1) { y2 += __shfl_xor(y2, o, 64); r1 += __shfl_xor(r1, o, 64); }
+    if (i < N && sub == 0) { out[i] = y2; out[N + i] = r1; }
+}
+
+// One workgroup per (molecule, input graph): the static vectors |z_j|^2 and r2_j = sum_k q_k f2(C2[j,k]) (f2(b) = b^2, or b for kl),
+// and (s == 0) the molecule's initial |y_i|^2, r1_i.  Launched once per solve, after k_fgw_init.
+__global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps,
+                                                           const float *__restrict__ pb, FgwDims D, int kl, const double *__restrict__ Cw,
+                                                           const double *__restrict__ Yw, double *__restrict__ zvec, double *__restrict__ yvec) {
+    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    const int N = D.N, d = D.d;
+    const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
+    const float *C2 = Cs + ((size_t)b * D.K + s) * N * N;
+    const float *q = ps ? ps + ((size_t)b * D.K + s) * N : nullptr;
+    const int j = (int)threadIdx.x >> 2, sub = (int)threadIdx.x & 3;
+    double z2 = 0.0, r2 = 0.0;
+    if (j < N) {
+        for (int c = sub; c < d; c += 4) { const double v = (double)Z[(size_t)j * d + c]; z2 += v * v; }
+        for (int k = sub; k < N; k += 4) {
+            const double c2 = (double)C2[j * N + k], qk = q ? (double)q[k] : 1.0 / (double)N;
+            r2 += qk * (kl ? c2 : c2 * c2);
+        }
+    }
+    z2 += __shfl_xor(z2, 1, 64); z2 += __shfl_xor(z2, 2, 64);
+    r2 += __shfl_xor(r2, 1, 64); r2 += __shfl_xor(r2, 2, 64);
+    double *zo = zvec + ((size_t)b * D.K + s) * 2 * N;
+    if (j < N && sub == 0) { zo[j] = z2; zo[N + j] = r2; }
+    if (s == 0)
+        molecule_vectors<256>(Yw + (size_t)b * N * d, Cw + (size_t)b * N * N, pb ? pb + (size_t)b * N : nullptr, N, d, kl != 0, yvec + (size_t)b * 2 * N);
+}
+
+// Barycenter update from the per-graph contributions: elementwise, one workgroup per molecule.
+constexpr int UPD_THREADS = 1024;       // the kernel is a few dependent L2 round trips per molecule: more threads, fewer trips each
+__global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
+    const float *__restrict__ pb, const float *__restrict__ lambdas, FgwDims D, conan_fgw_params prm, int outer,
+    const double *__restrict__ Ypart, const double *__restrict__ Cpart, double *__restrict__ Cw, double *__restrict__ Yw,
+    int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout,
+    double *__restrict__ yvec) {
+    __shared__ double red[UPD_THREADS / 64 + 1];
+    const int b = blockIdx.x;
+    if (!active[b]) return;
+    const int N = D.N, d = D.d, K = D.K, NN = N * N, Nd = N * d;
+    const int tid = threadIdx.x;
+    double ef2 = 0.0, es2 = 0.0;
+    // The K contributions of U consecutive elements per thread are requested together (K * U loads in flight): the kernel is a
+    // handful of L2 round trips per molecule, so its time is the number of dependent trips, not the byte count.
+    constexpr int U = 4;
+    if (!prm.fixed_features) {
+        double *Yb = Yw + (size_t)b * Nd;
+        for (int t0 = tid; t0 < Nd; t0 += U * UPD_THREADS) {
+            double acc[U], old[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * UPD_THREADS;
+                acc[u] = 0.0; old[u] = 0.0;
+                if (t < Nd) {
+                    old[u] = Yb[t];
+                    for (int s = 0; s < K; ++s) {
+                        const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                        const int i = t / d;
+                        const double pinv = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
+                        acc[u] += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;          // utils.py:94
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * UPD_THREADS;
+                if (t < Nd) {
+                    const double df = acc[u] - old[u];
+                    ef2 += df * df;
+                    Yb[t] = acc[u];
+                    Yout[(size_t)b * Nd + t] = (float)acc[u];
+                }
+            }
+        }
+    }
+    if (!prm.fixed_structure) {
+        double *Cb = Cw + (size_t)b * NN;
+        for (int t0 = tid; t0 < NN; t0 += U * UPD_THREADS) {
+            double acc[U], old[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * UPD_THREADS;
+                acc[u] = 0.0; old[u] = 0.0;
+                if (t < NN) {
+                    old[u] = Cb[t];
+                    for (int s = 0; s < K; ++s) {
+                        const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                        acc[u] += lam * Cpart[((size_t)b * K + s) * NN + t];                 // utils.py:70
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * UPD_THREADS;
+                if (t < NN) {
+                    const int i = t / N, j = t - i * N;
+                    const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+                    const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
+                    const double cn = prm.loss_fun ? exp(acc[u] / (pi * pj)) : acc[u] / (pi * pj);     // :72-73 / :86-87
+                    const double df = cn - old[u];
+                    es2 += df * df;
+                    Cb[t] = cn;
+                    Cout[(size_t)b * NN + t] = (float)cn;
+                }
+            }
+        }
+    }
+    const double ef = sqrt(block_sum_d<UPD_THREADS / 64>(ef2, red));       // (its barriers also publish Yb / Cb to the whole workgroup)
+    const double es = sqrt(block_sum_d<UPD_THREADS / 64>(es2, red));
+    if (yvec) molecule_vectors<UPD_THREADS>(Yw + (size_t)b * Nd, Cw + (size_t)b * NN, pb ? pb + (size_t)b * N : nullptr, N, d, prm.loss_fun != 0,
+                                            yvec + (size_t)b * 2 * N);
+    if (tid == 0) {
+        errs[((size_t)b * 2 + 0) * prm.max_iter + outer] = (float)ef;
+        errs[((size_t)b * 2 + 1) * prm.max_iter + outer] = (float)es;
+        info[b * 4 + 0] = outer + 1;
+        active[b] = (ef > (double)prm.tol || es > (double)prm.tol) ? 1 : 0;           // barycenter.py:112
+    }
+}
+
+inline size_t small_lds(int N, int d) {
+    const size_t NP = (size_t)N * (N | 1);
+    (void)d; return NP * 8 * 4 + (256 + 128 + 8 + (NP >= (size_t)SK_SCRATCH_DOUBLES ? 0 : SK_SCRATCH_DOUBLES)) * 8 + NP * 4 * 2;
+}
+
+}  // namespace
+
+bool conan_fgw_small_supported(int N, int d) { return N <= 64 && small_lds(N, d) <= 160 * 1024; }
+
+size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
+    // Ypart [B,K,N,d] + Cpart [B,K,N,N] + zvec [B,K,2N] + yvec [B,2N], fp64
+    return ((size_t)B * K * N * d + (size_t)B * K * N * N + (size_t)B * K * 2 * N + (size_t)B * 2 * N) * 8 + 512;
+}
+
+void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
+                             const double *Cw, const double *Yw, double *zvec, double *yvec, hipStream_t s) {
+    k_fgw_small_vectors<<<D.B * D.K, 256, 0, s>>>(Ys, Cs, ps, pb, D, prm.loss_fun, Cw, Yw, zvec, yvec);
+}
+
+void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
+                              conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
+                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
+                              const double *yvec, hipStream_t s) {
+    const size_t lds = small_lds(D.N, D.d);
+    const int R = (D.N + 3) / 4;
+    const int grid = D.B * D.K;
+#define LAUNCH(RR)                                                                                                              \
+    do {                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR, KLV>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+        k_fgw_coupling_small<RR, KLV><<<grid, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, \
+                                                                info, Ypart, Cpart, zvec, yvec);                                \
+    } while (0)
+    if (prm.loss_fun) {
+        constexpr bool KLV = true;
+        if (R <= 6) LAUNCH(6);
+        else if (R <= 9) LAUNCH(9);
+        else if (R <= 12) LAUNCH(12);
+        else LAUNCH(16);
+    } else {
+        constexpr bool KLV = false;
+        if (R <= 6) LAUNCH(6);
+        else if (R <= 9) LAUNCH(9);
+        else if (R <= 12) LAUNCH(12);
+        else LAUNCH(16);
+    }
+#undef LAUNCH
+}
+
+void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
+                            const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
+                            float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s) {
+    k_fgw_update_parts<<<D.B, UPD_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout, yvec);
+}
