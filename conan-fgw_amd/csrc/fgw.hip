@@ -130,8 +130,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     // ---- base = alpha*2*constC + (1-alpha)*M,  M = clamp(|y_i|^2 + |z_j|^2 - 2 y_i.z_j, 0)   (utils.py:154-171, bregman.py:124-125)
     // dot(Y_i, Z_j) on fp64 MFMA straight from global memory (L2-resident), then the elementwise assembly
     if (!y_zero)
-        mm_f64<NW>(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
-               [&](int i, int j, double v) { base[i * P + j] = v; });
+        mm_f64_glb<NW, true>(N, N, d, Y, d, Z, d, [&](int i, int j, double v) { base[i * P + j] = v; });
     __syncthreads();
     FGW_PROF(1);      // dot(Y, Z)
     for (int t = tid; t < NN; t += NT) {
@@ -152,14 +151,16 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     while (err > (double)prm.inner_tol && cpt < prm.max_iter) {
         // A = C1 @ T ; G = A @ (2 C2)^T on fp64 MFMA ; tens = base - 2*alpha*G ; Mr = -tens/eps
         // (utils.py:48-64, bregman.py:124-125, sinkhorn.py:388)
-        mm_f64<NW>(N, N, N, [&](int i, int k) { return C1[i * N + k]; }, [&](int k, int j) { return (double)Tl[k * P + j]; },
-               [&](int i, int j, double v) { Al[i * P + j] = v; });
+        mm_f64_glb<NW, false>(N, N, N, C1, N, Tl, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
         FGW_PROF(3);  // A = C1 @ T
         auto form_mr = [&]() {
-            mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; },
-                   [&](int k, int j) { const double cv = (double)C2[j * N + k]; return KL ? log(cv + 1e-15) : 2.0 * cv; },
-                   [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
+            if constexpr (KL)
+                mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return log((double)C2[j * N + k] + 1e-15); },
+                       [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 2.0 * alpha * g) / eps; });
+            else
+                mm_f64_glb<NW, true>(N, N, N, Al, P, C2, N,
+                                     [&](int i, int j, double g) { Mr[i * P + j] = -(base[i * P + j] - 4.0 * alpha * g) / eps; });      // hC2 = 2 C2
         };
         form_mr();
         __syncthreads();
@@ -338,18 +339,19 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     // ---- contributions to the barycenter update (summed over s by k_fgw_update_parts)
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        mm_f64<NW>(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
-               [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        mm_f64_glb<NW, false>(N, d, N, Tl, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        mm_f64<NW>(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
-               [&](int k, int j) { const double cv = (double)C2[k * N + j]; return KL ? log(cv > 1e-15 ? cv : 1e-15) : cv; },
-               [&](int i, int j, double v) { Al[i * P + j] = v; });
+        if constexpr (KL)
+            mm_f64<NW>(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
+                   [&](int k, int j) { const double cv = (double)C2[k * N + j]; return log(cv > 1e-15 ? cv : 1e-15); },
+                   [&](int i, int j, double v) { Al[i * P + j] = v; });
+        else
+            mm_f64_glb<NW, false>(N, N, N, Tl, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64<NW>(N, N, N, [&](int i, int k) { return Al[i * P + k]; }, [&](int k, int j) { return (double)Tl[j * P + k]; },
-               [&](int i, int j, double v) { Cp[i * N + j] = v; });
+        mm_f64_glb<NW, true>(N, N, N, Al, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;

@@ -166,6 +166,59 @@ __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS
     }
 }
 
+// Padded-tile product for row-major operands in GLOBAL memory (the large-N kernel: L2-resident matrices).  X(i,k) = X[i*pX + k];
+// W(k,j) = W[k*pW + j] (WT = false) or W[j*pW + k] (WT = true).  Inside a 16-wide k-trip the MFMA step u takes k = k0 + 4*lk + u from
+// lane group lk (instead of k0 + 4*u + lk): every lane then owns FOUR CONSECUTIVE k of its row, i.e. one contiguous 32-byte
+// (fp64) / 16-byte (fp32) read per operand and trip instead of four scattered 8-byte ones.  The reader-lambda form issued
+// 8 wave-loads per trip that each touched 16 rows, and the products were bound by that.  Both operands use
+// the same permutation, so each k is still multiplied exactly once; the summation order inside a trip differs from mm_f64_pad.
+template <int NW, bool WT, typename TX, typename TW, class FS>
+__device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wave; t < Mq * Nq; t += NW) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool ra = ia < M, cb = jb < Nn;
+        const TX *xr = X + (size_t)(ra ? ia : M - 1) * pX;             // clamped rows: loads stay in range, values masked
+        const int jc = cb ? jb : Nn - 1;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kd; k0 += 16) {
+            const int kb = k0 + 4 * lk;                                 // this lane's four consecutive k
+            double a[4], b[4];
+            if (k0 + 16 <= Kd) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = (double)xr[kb + u];
+                if (WT) {
+                    const TW *wr = W + (size_t)jc * pW + kb;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[u] = (double)wr[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[u] = (double)W[(size_t)(kb + u) * pW + jc];
+                }
+            } else {                                                    // ragged last trip: clamp, then zero
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u, kc = k < Kd ? k : Kd - 1;
+                    const double av = (double)xr[kc], bv = (double)(WT ? W[(size_t)jc * pW + kc] : W[(size_t)kc * pW + jc]);
+                    a[u] = k < Kd ? av : 0.0; b[u] = k < Kd ? bv : 0.0;
+                }
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[0] : 0.0, cb ? b[0] : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[1] : 0.0, cb ? b[1] : 0.0, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[2] : 0.0, cb ? b[2] : 0.0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[3] : 0.0, cb ? b[3] : 0.0, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + lk + 4 * q;
+            if (i < M && cb) st(i, jb, acc[q] + acc2[q]);
+        }
+    }
+}
+
 // Variant for thin ragged borders: MFMA on the 16-aligned core, plain FMA loops for the few border rows/columns.
 // The border output owned by a thread (two passes of 64 outputs at most) depends only on (M, Nn): it is computed once per
 // kernel (two integer divisions per pass) and reused by every product of that shape.
