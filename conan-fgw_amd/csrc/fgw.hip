@@ -174,11 +174,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         int ii = 0;
         bool exact = false;
         auto bad = [](double x) { return !(x > 1e-150 && x < 1e150); };
-        auto any_bad = [&](bool mine) {                                   // workgroup-wide OR; every thread gets the result
-            const double tot = block_sum_d<NW>(mine ? 1.0 : 0.0, red);
-            return tot > 0.0;
-        };
+        double *bad_flag = red + 15;                                      // set by whoever sees a sum out of range; read after the next barrier
         for (int j = tid; j < N; j += NT) v[j] = Mr[j * P + j];          // column references (the diagonal), before K overwrites them
+        if (tid == 0) *bad_flag = 0.0;
         __syncthreads();
         for (int j = lane; j < N; j += 64) {                              // K = exp(Mr - ref_j), partial column sums
             const double ref = v[j];
@@ -187,17 +185,15 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
             psm[wave * N + j] = cs;
         }
         __syncthreads();
-        {
-            bool mine = false;
-            for (int j = tid; j < N; j += NT) {
-                double cs = 0.0;
+        for (int j = tid; j < N; j += NT) {
+            double cs = 0.0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
-                mine |= bad(cs);
-                v[j] = qb[j] / cs;                                        // f_j of the first v update (u = 0)
-            }
-            exact = any_bad(mine);                                        // (barriers inside: v[] is published)
+            for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
+            if (bad(cs)) *bad_flag = 1.0;
+            v[j] = qb[j] / cs;                                            // f_j of the first v update (u = 0)
         }
+        __syncthreads();
+        exact = *bad_flag != 0.0;                                         // workgroup-uniform: read after the barrier that published it
         FGW_PROF(5);  // K = exp(Mr - ref), first column step
         for (; !exact && ii < prm.num_iter_max; ++ii) {
             // K <- K diag(f); row sums                                                         (sinkhorn.py:415 applied, :416 prepared)
@@ -207,17 +203,15 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
                 pm[wave * N + i] = rs;
             }
             __syncthreads();
-            {
-                bool mine = false;
-                for (int i = tid; i < N; i += NT) {
-                    double rs = 0.0;
+            for (int i = tid; i < N; i += NT) {
+                double rs = 0.0;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) rs += pm[w * N + i];
-                    mine |= bad(rs);
-                    u[i] = pa[i] / rs;
-                }
-                if (any_bad(mine)) { exact = true; break; }
+                for (int w = 0; w < NW; ++w) rs += pm[w * N + i];
+                if (bad(rs)) *bad_flag = 1.0;
+                u[i] = pa[i] / rs;
             }
+            __syncthreads();
+            if (*bad_flag != 0.0) { exact = true; break; }
             // K <- diag(g) K; column sums = marginals of the iterate                           (sinkhorn.py:416 applied)
             for (int j = lane; j < N; j += 64) {
                 double cs = 0.0;
@@ -225,23 +219,23 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
                 psm[wave * N + j] = cs;
             }
             __syncthreads();
-            {
-                bool mine = false;
-                double e2 = 0.0;
-                for (int j = tid; j < N; j += NT) {
-                    double cs = 0.0;
+            double e2 = 0.0;
+            for (int j = tid; j < N; j += NT) {
+                double cs = 0.0;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
-                    mine |= bad(cs);
-                    const double df = cs - qb[j];
-                    e2 += df * df;
-                    v[j] = qb[j] / cs;                                    // f_j of the next v update
-                }
-                if (any_bad(mine)) { exact = true; break; }
-                if (ii % 10 == 0) {                                       // marginal violation, sinkhorn.py:418-433
-                    const double tot = block_sum_d<NW>(e2, red);
-                    if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
-                }
+                for (int w = 0; w < NW; ++w) cs += psm[w * N + j];
+                if (bad(cs)) *bad_flag = 1.0;
+                const double df = cs - qb[j];
+                e2 += df * df;
+                v[j] = qb[j] / cs;                                        // f_j of the next v update
+            }
+            if (ii % 10 == 0) {                                           // marginal violation, sinkhorn.py:418-433
+                const double tot = block_sum_d<NW>(e2, red);              // (its barriers publish v[] and the flag)
+                if (*bad_flag != 0.0) { exact = true; break; }
+                if (sqrt(tot) < (double)prm.stop_thr) { ++ii; break; }
+            } else {
+                __syncthreads();
+                if (*bad_flag != 0.0) { exact = true; break; }
             }
         }
         if (exact) {
