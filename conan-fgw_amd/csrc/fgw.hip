@@ -50,12 +50,16 @@ __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict
 // NW wavefronts per workgroup (8 = 512 threads): a workgroup's time is its dependent chain (tools/fgw_scaling.py), and at N ~ 80-110
 // the chain is made of serial loops over N/NW rows and of N^2/256/NW product tiles per wavefront, so twice the wavefronts shorten
 // it; residency is bound by LDS (the Sinkhorn cost, 2 workgroups per CU) either way.
-template <bool LDS_MODE, bool KL, int NW>      // KL: loss_fun = "kl_loss", see fgw_small.hip
+// MODE 2: the four matrices in LDS; 1: only the coupling (Mr / K) in LDS; 0: everything in the global scratch.  A template parameter,
+// not a runtime flag: a pointer chosen at run time between LDS and global memory compiles to flat_* accesses for every
+// element of the Sinkhorn passes.
+template <int MODE, bool KL, int NW>      // KL: loss_fun = "kl_loss", see fgw_small.hip
 __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
-    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch, int mr_lds,
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
     double *__restrict__ Ypart, double *__restrict__ Cpart) {
+    constexpr bool LDS_MODE = MODE == 2, MR_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     // rows and once by columns) stays in LDS when it fits (mr_lds); A, base and T live in an L2-resident global scratch.
     char *gs = scratch + (size_t)blockIdx.x * coupling_scratch_stride(NP);     // 16-byte aligned per workgroup
     char *ls = smem + (size_t)((6 + 2 * NW) * N + 16) * 8;
-    double *Mr = reinterpret_cast<double *>((LDS_MODE || mr_lds) ? ls : gs);
+    double *Mr = MR_LDS ? reinterpret_cast<double *>(ls) : reinterpret_cast<double *>(gs);
     double *Al = LDS_MODE ? Mr + NP : reinterpret_cast<double *>(gs) + NP;
     double *base = Al + NP;
     float *Tl = reinterpret_cast<float *>(base + NP);
@@ -566,37 +570,28 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, s);
     const size_t lc = coupling_lds(N);
     const bool c_lds = lc <= LDS_LIMIT;
-    if (c_lds && lc > 64 * 1024)
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, false, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<true, true, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
-    }
     const size_t vec_c = (size_t)((6 + 2 * GEN_NW) * N + 16) * 8;
     const size_t mr_bytes = NP * 8;
-    const int mr_lds = (!c_lds && vec_c + mr_bytes <= LDS_LIMIT) ? 1 : 0;
-    if (mr_lds)
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, false, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(vec_c + mr_bytes));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<false, true, GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(vec_c + mr_bytes));
-    }
+    const int mode = c_lds ? 2 : (vec_c + mr_bytes <= LDS_LIMIT ? 1 : 0);
+    const size_t lds_bytes = mode == 2 ? lc : vec_c + (mode == 1 ? mr_bytes : 0);
+#define CONAN_CPL(M, KLV)                                                                                                           \
+    do {                                                                                                                            \
+        if (lds_bytes > 64 * 1024)                                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<M, KLV, GEN_NW>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                  \
+        k_fgw_coupling<M, KLV, GEN_NW><<<B * K, 64 * GEN_NW, lds_bytes, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, \
+                                                                              info, sc_c, Ypart, Cpart);                            \
+    } while (0)
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         if (small)
             conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, s);
-        else if (c_lds && kl)
-            k_fgw_coupling<true, true, GEN_NW><<<B * K, 64 * GEN_NW, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
-        else if (c_lds)
-            k_fgw_coupling<true, false, GEN_NW><<<B * K, 64 * GEN_NW, lc, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, sc_c, 0, Ypart, Cpart);
-        else if (kl)
-            k_fgw_coupling<false, true, GEN_NW><<<B * K, 64 * GEN_NW, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
-                                                                                                     active, T, info, sc_c, mr_lds, Ypart, Cpart);
-        else
-            k_fgw_coupling<false, false, GEN_NW><<<B * K, 64 * GEN_NW, vec_c + (mr_lds ? mr_bytes : 0), s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw,
-                                                                                                      active, T, info, sc_c, mr_lds, Ypart, Cpart);
+        else if (mode == 2) { if (kl) CONAN_CPL(2, true); else CONAN_CPL(2, false); }
+        else if (mode == 1) { if (kl) CONAN_CPL(1, true); else CONAN_CPL(1, false); }
+        else { if (kl) CONAN_CPL(0, true); else CONAN_CPL(0, false); }
         conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, small ? yvec : nullptr, s);
     }
+#undef CONAN_CPL
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }
