@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
     for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
-        Tl[i * P + j] = (outer > 0 && prm.warmstart) ? Tg[t] : (float)(u[i] * v[j]);
+        const float t0 = (outer > 0 && prm.warmstart) ? Tg[t] : (float)(u[i] * v[j]);
+        Tl[i * P + j] = t0;
+        Mr[i * P + j] = (double)t0;     // the coupling also lives (fp64) where the Sinkhorn state K will: the products read it from there
     }
     // ---- init_matrix (utils.py:39-43): constC[i][j] = sum_k C1[i,k]^2 p_k + sum_k q_k C2[j,k]^2 ; squared feature norms
     double *y2a = Al, *z2a = Al + N;                            // Al is not live yet
@@ -155,7 +157,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     while (err > (double)prm.inner_tol && cpt < prm.max_iter) {
         // A = C1 @ T ; G = A @ (2 C2)^T on fp64 MFMA ; tens = base - 2*alpha*G ; Mr = -tens/eps
         // (utils.py:48-64, bregman.py:124-125, sinkhorn.py:388)
-        mm_f64_glb<NW, false>(N, N, N, C1, N, Tl, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        // W operand: the coupling as the Sinkhorn state left it in Mr's storage (LDS in modes 1 / 2; the fp32-rounded T in an
+        // fp64 container) instead of the fp32 copy in the global scratch: half of this product's memory accesses
+        mm_f64_glb<NW, false>(N, N, N, C1, N, Mr, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
         FGW_PROF(3);  // A = C1 @ T
         auto form_mr = [&]() {
@@ -324,6 +328,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
             const double df = (double)tn - (double)Tl[i * P + j];
             e2 += df * df;
             Tl[i * P + j] = tn;
+            Mr[i * P + j] = (double)tn;                             // the products read T from here: the same fp32-rounded values that are returned
         }
         if (cpt % 10 == 0) err = sqrt(block_sum_d<NW>(e2, red));
         else __syncthreads();
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     // ---- contributions to the barycenter update (summed over s by k_fgw_update_parts)
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        mm_f64_glb<NW, false>(N, d, N, Tl, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        mm_f64_glb<NW, false>(N, d, N, Mr, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
@@ -347,9 +352,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
                    [&](int k, int j) { const double cv = (double)C2[k * N + j]; return log(cv > 1e-15 ? cv : 1e-15); },
                    [&](int i, int j, double v) { Al[i * P + j] = v; });
         else
-            mm_f64_glb<NW, false>(N, N, N, Tl, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
+            mm_f64_glb<NW, false>(N, N, N, Mr, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64_glb<NW, true>(N, N, N, Al, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
+        mm_f64_glb<NW, true>(N, N, N, Al, P, Mr, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
