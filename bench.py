@@ -253,7 +253,7 @@ def run_rank(args):
         flat.zero()
         pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
         loss = torch.nn.functional.mse_loss(pred, y)
-        loss.backward()
+        flat.backward(loss)                        # = loss.backward() with the slab sums of all weight gradients batched into one launch
         loss_out.copy_(loss.detach())
 
     def eager_step():

@@ -27,6 +27,11 @@ class BatchLayout(ctypes.Structure):
                [(n, c_ll) for n in ("off_atom_off", "off_bond_off", "off_z", "off_pos", "off_x", "off_bsrc", "off_bdst", "off_battr", "off_y", "bytes")]
 
 
+class WgradJob(ctypes.Structure):
+    """Mirror of `conan_wgrad_job` (include/conan_fgw_hip.h)."""
+    _fields_ = [("ws", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("M", c_int), ("K", c_int), ("N", c_int)]
+
+
 # name -> (restype, argtypes); kept in the header's order.  tests/test_abi.py checks this table against the header.
 _P = c_void_p
 SIGNATURES = {
@@ -58,6 +63,10 @@ SIGNATURES = {
     "conan_unary_bwd": (c_int, [_P, _P, c_ll, c_int, _P, _P]),
     "conan_zero_tail": (c_int, [_P, _P, c_int, c_int, _P]),
     "conan_rbf_wgrad": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
+    "conan_wgrad_batchable": (c_int, [c_int, c_int]),
+    "conan_linear_wgrad_slabs": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_rbf_wgrad_slabs": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P]),
+    "conan_wgrad_reduce_batch": (c_int, [ctypes.POINTER(WgradJob), c_int, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),

@@ -494,6 +494,56 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce4(const float4 *__restrict_
     }
 }
 
+// Batched form: blockIdx.y selects one of up to WG_BATCH weight gradients (same per-job arithmetic and order as k_wgrad_reduce4), so
+// the slab reductions of a whole backward pass are ONE launch instead of one per Linear layer (24 per SchNet training step).
+constexpr int WG_BATCH = 32;
+struct WgradJobs {
+    const float4 *slabs[WG_BATCH];
+    const float4 *bias_slabs[WG_BATCH];
+    float4 *out[WG_BATCH];
+    float4 *bout[WG_BATCH];
+    int slices[WG_BATCH], NK4[WG_BATCH], N4[WG_BATCH];
+};
+__global__ void __launch_bounds__(256) k_wgrad_reduce4_batch(WgradJobs J) {
+    __shared__ float4 part[8][32];
+    const int job = blockIdx.y;
+    const int NK4 = J.NK4[job], N4 = J.N4[job], slices = J.slices[job];
+    float4 *bout = J.bout[job];
+    const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int idx = blockIdx.x * 32 + c;
+    if ((int)blockIdx.x * 32 >= NK4 + (bout ? N4 : 0)) return;           // workgroup-uniform: this job has fewer columns than the widest one
+    const bool is_w = idx < NK4, is_b = !is_w && bout && idx - NK4 < N4;
+    const float4 *src = is_w ? J.slabs[job] + idx : J.bias_slabs[job] + (idx - NK4);
+    const int stride = is_w ? NK4 : N4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (is_w || is_b) {
+        int s = g;
+        for (; s + 56 < slices; s += 64) {                    // 8 independent loads in flight per trip
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
+                a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+                a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w;
+                a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
+            }
+        }
+        for (; s < slices; s += 8) { const float4 v0 = src[(size_t)s * stride]; a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
+    }
+    a0.x += a2.x; a0.y += a2.y; a0.z += a2.z; a0.w += a2.w;
+    a1.x += a3.x; a1.y += a3.y; a1.z += a3.z; a1.w += a3.w;
+    part[g][c] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (g == 0 && (is_w || is_b)) {
+        float4 r = part[0][c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float4 v = part[q][c]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        if (is_w) J.out[job][idx] = r; else bout[idx - NK4] = r;
+    }
+}
+
 constexpr int WG_GROUPS = 16;
 
 static int wgrad_slices(int M, int K) {
@@ -590,6 +640,10 @@ static int wgrad_launch(const float *g, const float *x, int M, int K, int N, con
         }
     }
     const int NK = N * K;
+    if (!dW) {                                        // slabs only: the caller reduces them later (conan_wgrad_reduce_batch)
+        CONAN_LAUNCH_CHECK();
+        return CONAN_OK;
+    }
     if ((NK & 3) == 0 && (N & 3) == 0) {
         const int cols4 = NK / 4 + (dbias ? N / 4 : 0);
         k_wgrad_reduce4<<<(cols4 + 31) / 32, 256, 0, s>>>(reinterpret_cast<const float4 *>(slabs), reinterpret_cast<const float4 *>(bias_slabs), slices,
@@ -616,6 +670,46 @@ int conan_rbf_wgrad(const float *g, const float *dist, int M, const float *offse
                     const int *m_dev, float *dW, float *dbias, float *ws, void *stream) {
     if (!g || !dist || !offset || !dW || !ws || M < 0 || num_gaussians <= 0 || N <= 0) return CONAN_E_BADARG;
     return wgrad_launch(g, nullptr, M, num_gaussians, N, m_dev, dW, dbias, ws, as_stream(stream), dist, offset, coeff);
+}
+
+int conan_wgrad_batchable(int K, int N) { return (((long long)N * K) & 3) == 0 && (N & 3) == 0 ? 1 : 0; }
+
+int conan_linear_wgrad_slabs(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *ws, void *stream) {
+    if (!g || !x || !ws || M < 0 || K <= 0 || N <= 0 || !conan_wgrad_batchable(K, N)) return CONAN_E_BADARG;
+    return wgrad_launch(g, x, M, K, N, m_dev, nullptr, nullptr, ws, as_stream(stream), nullptr, nullptr, 0.f);
+}
+
+int conan_rbf_wgrad_slabs(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
+                          const int *m_dev, float *ws, void *stream) {
+    if (!g || !dist || !offset || !ws || M < 0 || num_gaussians <= 0 || N <= 0 || !conan_wgrad_batchable(num_gaussians, N)) return CONAN_E_BADARG;
+    return wgrad_launch(g, nullptr, M, num_gaussians, N, m_dev, nullptr, nullptr, ws, as_stream(stream), dist, offset, coeff);
+}
+
+int conan_wgrad_reduce_batch(const conan_wgrad_job *jobs, int num_jobs, void *stream) {
+    if (num_jobs < 0 || (num_jobs && !jobs)) return CONAN_E_BADARG;
+    hipStream_t s = as_stream(stream);
+    for (int j0 = 0; j0 < num_jobs; j0 += WG_BATCH) {
+        WgradJobs J;
+        const int nb = num_jobs - j0 < WG_BATCH ? num_jobs - j0 : WG_BATCH;
+        int max_cols4 = 0;
+        for (int q = 0; q < nb; ++q) {
+            const conan_wgrad_job &b = jobs[j0 + q];
+            if (!b.ws || !b.dW || b.M < 0 || b.K <= 0 || b.N <= 0 || !conan_wgrad_batchable(b.K, b.N)) return CONAN_E_BADARG;
+            const int slices = wgrad_slices(b.M, b.K);
+            const int NK = b.N * b.K;
+            J.slabs[q] = reinterpret_cast<const float4 *>(b.ws);
+            J.bias_slabs[q] = reinterpret_cast<const float4 *>(b.ws + (size_t)slices * NK);
+            J.out[q] = reinterpret_cast<float4 *>(b.dW);
+            J.bout[q] = reinterpret_cast<float4 *>(b.dbias);
+            J.slices[q] = slices; J.NK4[q] = NK / 4; J.N4[q] = b.N / 4;
+            const int cols4 = NK / 4 + (b.dbias ? b.N / 4 : 0);
+            if (cols4 > max_cols4) max_cols4 = cols4;
+        }
+        for (int q = nb; q < WG_BATCH; ++q) { J.slabs[q] = J.bias_slabs[q] = nullptr; J.out[q] = J.bout[q] = nullptr; J.slices[q] = J.NK4[q] = J.N4[q] = 0; }
+        k_wgrad_reduce4_batch<<<dim3((max_cols4 + 31) / 32, nb), 256, 0, s>>>(J);
+    }
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
 }
 
 }  // extern "C"

@@ -107,6 +107,92 @@ def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
     return out
 
 
+# ------------------------------------------------------------------------------------------------ deferred weight gradients
+# A weight gradient is produced in two stages: per-slice slabs (k_wgrad_lds) and their fixed-order sum.  Inside
+# `deferred_weight_gradients()` the second stage of every Linear layer of a backward pass is postponed and run as ONE launch
+# (conan_wgrad_reduce_batch) by `flush_weight_gradients()` — FlatGradients.pack() calls it — instead of 24 launches of ~6 us each.
+# The returned dW / db tensors are only valid after the flush; a weight that appears twice in one backward (autograd would add
+# the two results right away) flushes on the spot and takes the immediate path, so results never depend on the mode.
+_pending = None            # None: immediate mode; list of pending jobs (dicts) while deferring
+
+
+class deferred_weight_gradients:
+    def __enter__(self):
+        global _pending
+        self._outer = _pending
+        if _pending is None:
+            _pending = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending
+        if self._outer is None:
+            flush_weight_gradients()
+            _pending = None
+        return False
+
+
+def flush_weight_gradients():
+    """Reduce every pending slab set on the current stream (no-op when nothing is pending).  Returns {weight data_ptr: dW data_ptr}
+    of what was flushed, so that the owner of the parameters can check that autograd adopted those very tensors."""
+    global _pending
+    if not _pending:
+        return {}
+    import ctypes
+    from ._lib import WgradJob
+    jobs = (WgradJob * len(_pending))()
+    cur = torch.cuda.current_stream()
+    for st in {j["stream"] for j in _pending}:
+        if st != cur:
+            cur.wait_stream(st)                                   # slabs written on another stream (the covalent branch runs on one)
+    for q, j in enumerate(_pending):
+        jobs[q].ws, jobs[q].dW, jobs[q].dbias = ptr(j["ws"]), j["dw_ptr"], j["db_ptr"]
+        jobs[q].M, jobs[q].K, jobs[q].N = j["M"], j["K"], j["N"]
+    call("conan_wgrad_reduce_batch", jobs, len(_pending), stream_ptr())
+    done = {j["weight_ptr"]: j["dw_ptr"] for j in _pending}
+    for j in _pending:
+        j["ws"].record_stream(cur)
+    _pending.clear()
+    _flushed.update(done)
+    return done
+
+
+_flushed = {}              # weight data_ptr -> dW data_ptr of the last flushes (cleared by whoever verifies them)
+
+
+def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
+    """dW [N,K] (+ db [N]) = g^T x, or g^T rbf(dist) with rbf = (dist, offset, coeff).  Immediate, or slabs now + batched sum later.
+
+    Deferred mode hands autograd tensors whose values arrive at the flush.  That is only sound if autograd ADOPTS them (it does when it
+    holds the only reference and the parameter has no .grad yet; otherwise it copies on the spot), so the pending list keeps the raw
+    pointers and the storages — never the tensors — and FlatGradients.pack() verifies the adoption."""
+    dev = g.device
+    ws = torch.empty(int(lib().conan_linear_wgrad_ws(M, K, N)), dtype=f32, device=dev)
+    dw = torch.empty(N, K, dtype=f32, device=dev)
+    db = torch.empty(N, dtype=f32, device=dev) if has_bias else None
+    wptr = weight.data_ptr()
+    defer = _pending is not None and bool(lib().conan_wgrad_batchable(K, N))
+    if defer and any(j["weight_ptr"] == wptr for j in _pending):
+        flush_weight_gradients()                                  # second use of the same weight in this backward: autograd adds the two at once
+        defer = False
+    if rbf is None:
+        if defer:
+            call("conan_linear_wgrad_slabs", ptr(g), ptr(x), M, K, N, ptr(md), ptr(ws), stream_ptr())
+        else:
+            call("conan_linear_wgrad", ptr(g), ptr(x), M, K, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
+    else:
+        dist, offset, coeff = rbf
+        if defer:
+            call("conan_rbf_wgrad_slabs", ptr(g), ptr(dist), M, ptr(offset, f32), K, coeff, N, ptr(md), ptr(ws), stream_ptr())
+        else:
+            call("conan_rbf_wgrad", ptr(g), ptr(dist), M, ptr(offset, f32), K, coeff, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
+    if defer:
+        _pending.append(dict(ws=ws, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr() if db is not None else None,
+                             keep=(dw.untyped_storage(), db.untyped_storage() if db is not None else None),
+                             M=M, K=K, N=N, weight_ptr=wptr, stream=torch.cuda.current_stream()))
+    return dw, db
+
+
 # ------------------------------------------------------------------------------------------------ linear / activation
 class _LinearFn(torch.autograd.Function):
     @staticmethod
@@ -140,10 +226,7 @@ class _LinearFn(torch.autograd.Function):
             dx = empty_rows(x.shape[0], x.shape[1], x.device, md)
             call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
-            ws = torch.empty(int(lib().conan_linear_wgrad_ws(M, K, N)), dtype=f32, device=x.device)
-            dw = torch.empty_like(w)
-            db = torch.empty(N, dtype=f32, device=x.device) if ctx.has_b else None
-            call("conan_linear_wgrad", ptr(g), ptr(x), M, K, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
+            dw, db = _wgrad(g, x, M, K, N, md, w, ctx.has_b)
         return dx, dw, db, (dy if ctx.has_res else None), None, None
 
 
@@ -268,14 +351,10 @@ class _FilterFn(torch.autograd.Function):
         ME = g_.max_edges
         dev = dW.device
         g = _c(dW)                                   # already multiplied by C(d): cfconv(..., pre_cutoff_grad=True)
-        ws = torch.empty(int(max(lib().conan_linear_wgrad_ws(ME, F, F), lib().conan_linear_wgrad_ws(ME, Gs, F))), dtype=f32, device=dev)
-        dw2, db2 = torch.empty_like(w2), torch.empty(F, dtype=f32, device=dev)
-        call("conan_linear_wgrad", ptr(g), ptr(h1), ME, F, F, ptr(md), ptr(dw2), ptr(db2), ptr(ws), stream_ptr())
+        dw2, db2 = _wgrad(g, h1, ME, F, F, md, w2, True)
         dh1 = torch.empty_like(g)
         call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
-        dw1, db1 = torch.empty_like(w1), torch.empty(F, dtype=f32, device=dev)
-        call("conan_rbf_wgrad", ptr(dh1), ptr(dist), ME, ptr(_c(offset), f32), Gs, ctx.coeff, F, ptr(md), ptr(dw1), ptr(db1), ptr(ws),
-             stream_ptr())                            # rbf(dist) regenerated inside the GEMM
+        dw1, db1 = _wgrad(dh1, None, ME, Gs, F, md, w1, True, rbf=(dist, _c(offset), ctx.coeff))      # rbf(dist) regenerated inside the GEMM
         return None, None, None, dw1, db1, dw2, db2, None
 
 

@@ -100,7 +100,35 @@ class FlatGradients:
 
     def pack(self):
         """Gather the .grad tensors autograd produced into the flat buffer and alias them to it."""
+        self._flush_deferred()
         self._pack(self._order_idx, self.flat)
+
+    def _flush_deferred(self):
+        """Weight gradients whose slab reduction was deferred (ops.deferred_weight_gradients) become valid here, in one launch.
+        Deferral hands autograd tensors that are filled at this point, which is sound only if autograd adopted them as .grad: checked."""
+        if not self.flat.is_cuda:
+            return
+        from . import ops
+        ops.flush_weight_gradients()
+        if ops._flushed:
+            for p in self.params:
+                want = ops._flushed.get(p.data_ptr())
+                if want is not None and (p.grad is None or p.grad.data_ptr() != want):
+                    raise RuntimeError("a deferred weight gradient was copied by autograd before it was final (the parameter already had a "
+                                       ".grad, or something else held the tensor): call FlatGradients.zero() before backward, or do not "
+                                       "use deferred_weight_gradients here")
+            ops._flushed.clear()
+
+    def backward(self, loss: torch.Tensor):
+        """loss.backward() with the slab reductions of all weight gradients batched into one launch (flushed before any gradient is
+        packed or reduced).  Equivalent to `loss.backward()` in results."""
+        if self.flat.is_cuda:
+            from . import ops
+            with ops.deferred_weight_gradients():
+                loss.backward()
+            self._flush_deferred()                               # (the context flushed; this verifies the adoption)
+        else:
+            loss.backward()
 
     # ------------------------------------------------------------------------------------------------ overlap
     def enable_overlap(self, early_fraction: float = 0.5):
@@ -163,6 +191,7 @@ class FlatGradients:
             self._overlap, self._suspended = True, False
 
     def _fire_early(self):
+        self._flush_deferred()                                # the early bucket's weight gradients must be final before they travel
         idx = self._order_idx[: self._n_early]
         self._pack(idx, self.flat[: self._split])
         self._work = dist.all_reduce(self.flat[: self._split], op=dist.ReduceOp.SUM, async_op=True)

@@ -157,6 +157,22 @@ int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, cons
 int conan_rbf_wgrad(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
                     const int *m_dev, float *dW, float *dbias, float *ws, void *stream);
 
+/* Deferred form of the two weight gradients above: stage 1 only (the per-slice partial sums stay in ws, which must live until the
+ * reduction), and ONE launch that reduces the slabs of many weight gradients — a backward pass of the stage-2 model has 24
+ * Linear layers, i.e. 24 slab reductions of ~6 us each when done one by one.  Same arithmetic and summation order as the
+ * immediate form (bitwise-equal results).  Only for shapes with conan_wgrad_batchable(K, N) != 0 (N*K and N multiples of 4).
+ * `jobs` is a HOST array. */
+typedef struct conan_wgrad_job {
+    const float *ws;         /* the workspace the slabs were written to (conan_linear_wgrad_ws(M, K, N) floats) */
+    float *dW, *dbias;       /* outputs [N,K], [N] (dbias nullable) */
+    int M, K, N;             /* the shape the slabs were produced for */
+} conan_wgrad_job;
+int conan_wgrad_batchable(int K, int N);
+int conan_linear_wgrad_slabs(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *ws, void *stream);
+int conan_rbf_wgrad_slabs(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
+                          const int *m_dev, float *ws, void *stream);
+int conan_wgrad_reduce_batch(const conan_wgrad_job *jobs, int num_jobs, void *stream);
+
 /* rbf[e,k] = exp(coeff * (dist[e] - offset[k])^2): GaussianSmearing (PyG; schnet_no_sum.py:161,209).  `offset` is the
  * module's buffer (distance_expansion.offset), coeff = -0.5/(offset[1]-offset[0])^2.  num_edges_dev (nullable) = device
  * int with the edge count (rowptr[num_atoms]); at most max_edges rows are written. */

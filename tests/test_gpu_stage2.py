@@ -155,3 +155,39 @@ def test_stage2_with_visnet_backbone_matches_oracle():
         r = ref(t(b.z), t(b.pos).double(), t(b.batch), t(g.x), t(g.edge_index), t(g.edge_attr))
     assert y.shape == (b.num_molecules, 1)
     assert rel(y.cpu().double().numpy(), r.numpy()) < 1e-4
+
+
+def test_deferred_weight_gradients_are_bitwise_equal_to_immediate_ones():
+    """ops.deferred_weight_gradients / FlatGradients.backward: the slab reductions of all Linear layers in ONE launch, same sums in the
+    same order => every gradient bit-identical to the immediate path; a weight used twice in one backward is handled (flush + immediate)."""
+    from conan_fgw_amd import ops
+    from conan_fgw_amd.parallel import FlatGradients
+    dev, b, g, m, _ = _build(B=4, K=3, seed=31)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    batch = types.SimpleNamespace(z=t(b.z), pos=t(b.pos), x=t(g.x), edge_index=t(g.edge_index), edge_attr=t(g.edge_attr), batch=t(b.batch))
+    cidx = m.create_aggregation_index(b.num_graphs, dev)
+    tgt = t(b.y)[:, None]
+
+    def grads(deferred):
+        for p in m.parameters():
+            p.grad = None
+        loss = torch.nn.functional.mse_loss(m(batch, cidx, batch.batch), tgt)
+        if deferred:
+            flat = FlatGradients(m.parameters())
+            flat.backward(loss)
+            assert ops._pending is None                                   # context closed => everything flushed
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    a, c = grads(False), grads(True)
+    for k in a:
+        assert torch.equal(a[k], c[k]), k
+    # the same weight twice in one graph: y = lin(lin(x))
+    w = torch.randn(64, 64, device=dev, requires_grad=True); x = torch.randn(300, 64, device=dev)
+    ops.linear(ops.linear(x, w), w).sum().backward(); ref = w.grad.clone(); w.grad = None
+    with ops.deferred_weight_gradients():
+        ops.linear(ops.linear(x, w), w).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(w.grad, ref)
