@@ -432,13 +432,25 @@ __global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat,
     float *Cg = Cs + (size_t)g * N * N;
     for (int t = tid; t < N * N; t += 256) Cg[t] = 0.f;
     __syncthreads();
-    // edges of this graph: targets lo..lo+n-1 ; adj[src_local, tgt_local] += 1   (to_dense_adj accumulates)
-    for (int i = tid; i < n; i += 256) {
-        for (int e = rowptr[lo + i]; e < rowptr[lo + i + 1]; ++e) {
-            const int j = col[e] - lo;
-            if (j < N) Cg[j * N + i] += 1.0f;       // distinct (src, tgt) per thread: no race
+    // edges of this graph: targets lo..lo+n-1 ; adj[src_local, tgt_local] += 1   (to_dense_adj accumulates).  One thread per EDGE
+    // (a thread per target walked its ~20 edges through dependent loads); the target of an edge is found by bisection in the graph's
+    // row pointers, staged in LDS.  Counts are added atomically: a radius graph has no duplicate pairs, an arbitrary edge_index may,
+    // and sums of 1.0f are exact in any order.
+    __shared__ int rp[257];
+    const int e0 = rowptr[lo], e1 = rowptr[lo + n];
+    for (int i0 = 0; i0 < n; i0 += 256) {                                // graphs above 256 atoms: row pointers in chunks
+        const int m = min(256, n - i0);
+        __syncthreads();
+        for (int t = tid; t <= m; t += 256) rp[t] = rowptr[lo + i0 + t];
+        __syncthreads();
+        for (int e = rp[0] + tid; e < rp[m]; e += 256) {
+            int a = 0, b = m;                                            // rp[a] <= e < rp[b]
+            while (b - a > 1) { const int c = (a + b) >> 1; if (rp[c] <= e) a = c; else b = c; }
+            const int i = i0 + a, j = col[e] - lo;
+            if (j >= 0 && j < N) atomicAdd(&Cg[j * N + i], 1.0f);
         }
     }
+    (void)e0; (void)e1;
 }
 
 // Backward of the feature half: y = a + (x + shift - mn) * s / r, r = mx - mn, through min() and max() like autograd
