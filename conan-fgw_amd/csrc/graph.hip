@@ -74,6 +74,42 @@ __global__ void __launch_bounds__(RG_THREADS) k_radius(const float *__restrict__
     }
 }
 
+// Single-workgroup exclusive scan through LDS for n <= SCAN_LDS_MAX (every per-atom scan of a batch): the input is read with
+// coalesced loads into LDS, each thread scans its contiguous chunk there (odd chunk pitch: conflict-free), the thread totals are
+// scanned by shuffles, and the result leaves with coalesced stores.  The register variant below has every lane read its own
+// contiguous chunk from global memory — 25 wave-loads that each touch 64 cache lines for n = 25 k (16 us against ~6 us here).
+constexpr int SCAN_LDS_MAX = 36 * 1024;          // 144 KB of LDS
+__global__ void __launch_bounds__(1024) k_exclusive_scan_lds(const int *__restrict__ in, int n, int *__restrict__ out) {
+    extern __shared__ int sdat[];                 // [n] + [16] wavefront totals
+    int *wsum = sdat + n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i0 = t; i0 < n; i0 += 4 * 1024) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024; v[u] = in[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024; if (i < n) sdat[i] = v[u]; }
+    }
+    __syncthreads();
+    const int chunk = ((n + 1023) / 1024) | 1;    // odd pitch between the threads' chunks: conflict-free LDS walks
+    const int b = min(t * chunk, n), e = min(b + chunk, n);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += sdat[i];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int x = wsum[w]; if (w < wave) woff += x; total += x; }
+    int run = woff + inc - s;
+    for (int i = b; i < e; ++i) { const int x = sdat[i]; sdat[i] = run; run += x; }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) out[i] = sdat[i];
+    if (t == 0) out[n] = total;
+}
+
 // Single-workgroup exclusive scan, n up to a few million: out[0..n], out[n] = total.
 constexpr int SCAN_THREADS = 1024;
 __global__ void __launch_bounds__(SCAN_THREADS) k_exclusive_scan(const int *__restrict__ in, int n, int *__restrict__ out) {
@@ -109,6 +145,17 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_exclusive_scan(const int *__re
         for (int i = b; i < e; ++i) { const int x = in[i]; out[i] = run; run += x; }
     }
     if (t == 0) out[n] = total;
+}
+
+static void launch_exclusive_scan(const int *in, int n, int *out, hipStream_t s) {
+    if (n > 0 && n <= SCAN_LDS_MAX) {
+        const size_t lds = (size_t)(n + 16) * sizeof(int);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_exclusive_scan_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_exclusive_scan_lds<<<1, 1024, lds, s>>>(in, n, out);
+    } else {
+        k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(in, n, out);
+    }
 }
 
 // Multi-workgroup exclusive scan for long inputs (the pair flags: up to cap * num_atoms entries): per-block sums, a
@@ -153,7 +200,7 @@ static void scan_large(const int *in, int n, int *out, int *ws, hipStream_t s) {
     const int nblocks = (n + per - 1) / per;
     int *bsum = ws, *boff = ws + nblocks + 1;
     k_scan_block_sums<<<nblocks, SB_THREADS, 0, s>>>(in, n, bsum);
-    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(bsum, nblocks, boff);
+    launch_exclusive_scan(bsum, nblocks, boff, s);
     k_scan_block_apply<<<nblocks, SB_THREADS, 0, s>>>(in, n, boff, nblocks, out);
 }
 
@@ -335,7 +382,7 @@ int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms
     hipStream_t s = as_stream(stream);
     const float r2 = r * r;
     k_radius<0><<<num_graphs, RG_THREADS, 0, s>>>(pos, graph_ptr, r2, cap, loop, deg_ws, nullptr, nullptr, nullptr, nullptr);
-    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_ws, num_atoms, rowptr);
+    launch_exclusive_scan(deg_ws, num_atoms, rowptr, s);
     k_radius<1><<<num_graphs, RG_THREADS, 0, s>>>(pos, graph_ptr, r2, cap, loop, nullptr, rowptr, col, tgt, dist);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
@@ -377,8 +424,8 @@ int conan_bond_graph_csr(const int64_t *edge_index, int num_edges, int num_nodes
     if (hipMemsetAsync(ws, 0, sizeof(int) * 2 * (size_t)(num_nodes + 1), s) != hipSuccess) return CONAN_E_LAUNCH;
     const int eb = num_edges ? (num_edges + 255) / 256 : 1, nb = (num_nodes + 255) / 256;
     if (num_edges) k_bond_count<<<eb, 256, 0, s>>>(edge_index, num_edges, num_nodes, deg_t, deg_s);
-    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_t, num_nodes, rowptr);
-    k_exclusive_scan<<<1, SCAN_THREADS, 0, s>>>(deg_s, num_nodes, t_rowptr);
+    launch_exclusive_scan(deg_t, num_nodes, rowptr, s);
+    launch_exclusive_scan(deg_s, num_nodes, t_rowptr, s);
     if (num_edges) {
         if (hipMemsetAsync(ws, 0, sizeof(int) * 2 * (size_t)(num_nodes + 1), s) != hipSuccess) return CONAN_E_LAUNCH;
         k_bond_fill_t<<<eb, 256, 0, s>>>(edge_index, num_edges, num_nodes, rowptr, deg_t, col, eid);
