@@ -289,9 +289,10 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
                                                    const float *__restrict__ offset, float coeff) {
     constexpr int ROWS = 16, RG = ROWS / 8, W = 128 + KT, FRAGS = RG * W, NF = (FRAGS + 255) / 256;
     constexpr int TNB = KT == 128 ? 2 : 1;
+    static_assert(W % 64 == 0, "a wave's 64 fragments share one row group and one operand");
     __shared__ uint4 frag[2][3][RG][W];
     if (m_dev) M = min(M, *m_dev);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n0 = KT == 128 ? (wave >> 1) * 64 : wave * 32, k0 = KT == 128 ? (wave & 1) * 64 : 0;     // inside the tile
     const int nb = blockIdx.y * 128, kb = blockIdx.z * KT;
@@ -309,56 +310,63 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // producer role of this thread: fragments f = tid + 256 i  ->  (row group, column); fixed for the whole kernel.
-    // Loads are unconditional (row clamped into the slice, dead columns redirected to column 0) and masked afterwards,
-    // so a stage's 8 * NF loads issue back to back without branches.
-    int f_rg[NF], f_col[NF], f_ld[NF];
-    const float *f_ptr[NF];
+    // Producer roles.  Fragment f = 64 wave + 256 i + lane  ->  (row group, column); the 64 fragments of one wave share the
+    // row group and the operand (g or x), so row index, operand base and leading dimension are scalar registers and a load
+    // costs no vector ALU work: scalar base + per-lane column offset.  Dead columns read column 0 and are masked.
+    int f_rg[NF], f_col[NF];                         // wave-uniform row group, per-lane column inside [0, W)
+    unsigned f_ldc[NF];                              // per-lane column offset of the load
+    bool f_act[NF], f_isg[NF], f_all[NF], f_on[NF];
     float f_off[NF], bsum[NF];
-    bool f_on[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-        const int f = min(tid + 256 * i, FRAGS - 1);
-        f_rg[i] = f / W; f_col[i] = f - f_rg[i] * W;
-        bsum[i] = 0.f; f_off[i] = 0.f;
-        if (f_col[i] < 128) {
-            const int cc = nb + f_col[i];
-            f_on[i] = cc < N; f_ld[i] = N;
-            f_ptr[i] = g + (f_on[i] ? cc : 0);
-        } else {
-            const int cc = kb + f_col[i] - 128;
-            f_on[i] = cc < K;
-            if (RBF) { f_off[i] = f_on[i] ? offset[cc] : 0.f; f_ptr[i] = dist; f_ld[i] = 1; }
-            else { f_ptr[i] = x + (f_on[i] ? cc : 0); f_ld[i] = K; }
-        }
+        const int fb = 64 * wave + 256 * i;          // uniform
+        f_act[i] = fb < FRAGS;
+        f_rg[i] = fb / W;
+        const int cb = fb - f_rg[i] * W;             // uniform, multiple of 64
+        f_col[i] = cb + lane;
+        f_isg[i] = cb < 128;
+        const int cc = f_isg[i] ? nb + f_col[i] : kb + f_col[i] - 128;
+        f_on[i] = cc < (f_isg[i] ? N : K);
+        f_all[i] = __builtin_amdgcn_ballot_w64(f_on[i]) == ~0ull;
+        f_ldc[i] = f_on[i] ? (unsigned)cc : 0u;
+        f_off[i] = (RBF && !f_isg[i] && f_on[i]) ? offset[cc] : 0.f;
+        bsum[i] = 0.f;
     }
     float stA[NF][8], stB[NF][8];                // two stages of loads in flight
     auto fetch = [&](float (&st)[NF][8], int m0) {
+        const bool full = m0 + ROWS <= r_end;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
+            if (!f_act[i]) continue;
+            const int mr = m0 + 8 * f_rg[i];
+            if (RBF && !f_isg[i]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = min(m0 + 8 * f_rg[i] + j, r_end - 1);
-                st[i][j] = f_ptr[i][(size_t)m * f_ld[i]];
+                for (int j = 0; j < 8; ++j) st[i][j] = dist[full ? mr + j : min(mr + j, r_end - 1)];      // scalar loads
+            } else {
+                const float *src = f_isg[i] ? g : x;
+                const int ld = f_isg[i] ? N : K;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int m = full ? mr + j : min(mr + j, r_end - 1);
+                    st[i][j] = (src + (size_t)m * ld)[f_ldc[i]];
+                }
             }
         }
     };
     auto stash = [&](int buf, float (&st)[NF][8], int m0) {
+        const bool full = m0 + ROWS <= r_end;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            if (tid + 256 * i >= FRAGS) continue;
-            const bool is_g = f_col[i] < 128;
+            if (!f_act[i]) continue;
+            if (RBF && !f_isg[i]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool ok = f_on[i] && (m0 + 8 * f_rg[i] + j < r_end);
-                float v = st[i][j];
-                if (RBF && !is_g) { const float t = v - f_off[i]; v = expf(coeff * (t * t)); }
-                st[i][j] = ok ? v : 0.f;
+                for (int j = 0; j < 8; ++j) { const float t = st[i][j] - f_off[i]; st[i][j] = exp_neg_f(coeff * (t * t)); }
             }
-            if (is_g) {
+            if (!full || !f_all[i]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum[i] += st[i][j];
+                for (int j = 0; j < 8; ++j) st[i][j] = (f_on[i] && (m0 + 8 * f_rg[i] + j < r_end)) ? st[i][j] : 0.f;
             }
+            if (f_isg[i]) bsum[i] += ((st[i][0] + st[i][1]) + (st[i][2] + st[i][3])) + ((st[i][4] + st[i][5]) + (st[i][6] + st[i][7]));
             bf16x8 p1, p2, p3;
             wg_split3(st[i], p1, p2, p3);
             frag[buf][0][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p1);
@@ -375,12 +383,26 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
 #pragma unroll
             for (int b = 0; b < 2; ++b) q[b][pl] = __builtin_bit_cast(bf16x8, frag[buf][pl][h][128 + k0 + 32 * b + l31]);
         }
+        // the six partial products of a block are issued round-robin over the 2 * TNB accumulators: back-to-back MFMAs on
+        // ONE accumulator wait for each other's 16 passes, independent ones pipeline
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int a = 0; a < TNB; ++a)
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = wg_mma6(p[a][0], p[a][1], p[a][2], q[b][0], q[b][1], q[b][2], acc[a][b]);
+            for (int a = 0; a < TNB; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p[a][PA[t]], q[b][PB[t]], acc[a][b], 0, 0, 0);
     };
 
+#define WG_HALF(BUF, RA)                                                                                     \
+    {                                                                                                        \
+        compute(BUF);                                                                                        \
+        if (m + STEP < r_end) stash((BUF) ^ 1, RA, m + STEP);                                                \
+        if (m + 3 * STEP < r_end) fetch(RA, m + 3 * STEP);                                                   \
+        __syncthreads();                                                                                     \
+        m += STEP;                                                                                           \
+        if (m >= r_end) break;                                                                               \
+    }
     if (r_begin < r_end) {
         int m = r_begin;
         fetch(stA, m);
@@ -389,20 +411,10 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
         if (m + 2 * STEP < r_end) fetch(stB, m + 2 * STEP);
         __syncthreads();
         for (;;) {                                   // stage m is in buffer 0; stA holds the next stage, stB the one after
-            compute(0);
-            if (m + STEP < r_end) stash(1, stA, m + STEP);
-            if (m + 3 * STEP < r_end) fetch(stA, m + 3 * STEP);
-            __syncthreads();
-            m += STEP;
-            if (m >= r_end) break;
-            compute(1);
-            if (m + STEP < r_end) stash(0, stB, m + STEP);
-            if (m + 3 * STEP < r_end) fetch(stB, m + 3 * STEP);
-            __syncthreads();
-            m += STEP;
-            if (m >= r_end) break;
+            WG_HALF(0, stA) WG_HALF(1, stB)
         }
     }
+#undef WG_HALF
 
     float *slab = slabs + (size_t)slice * N * K;
 #pragma unroll
@@ -419,7 +431,7 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
         float *bp = reinterpret_cast<float *>(&frag[0][0][0][0]);            // [RG][128]; the stages are idle by now
 #pragma unroll
         for (int i = 0; i < NF; ++i)
-            if (tid + 256 * i < FRAGS && f_col[i] < 128) bp[f_rg[i] * 128 + f_col[i]] = bsum[i];
+            if (f_act[i] && f_isg[i]) bp[f_rg[i] * 128 + f_col[i]] = bsum[i];
         __syncthreads();
         if (tid < 128 && nb + tid < N) {
             float t = 0.f;
