@@ -29,7 +29,7 @@ class BatchLayout(ctypes.Structure):
 
 class WgradJob(ctypes.Structure):
     """Mirror of `conan_wgrad_job` (include/conan_fgw_hip.h)."""
-    _fields_ = [("ws", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("M", c_int), ("K", c_int), ("N", c_int)]
+    _fields_ = [("ws", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("M", c_int), ("K", c_int), ("N", c_int), ("slices", c_int)]
 
 
 # name -> (restype, argtypes); kept in the header's order.  tests/test_abi.py checks this table against the header.
@@ -67,6 +67,10 @@ SIGNATURES = {
     "conan_linear_wgrad_slabs": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_rbf_wgrad_slabs": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P]),
     "conan_wgrad_reduce_batch": (c_int, [ctypes.POINTER(WgradJob), c_int, _P]),
+    "conan_filter_bwd_supported": (c_int, [c_int, c_int]),
+    "conan_filter_bwd_slices": (c_int, [c_int]),
+    "conan_filter_bwd_ws": (c_ll, [c_int, c_int, c_int]),
+    "conan_filter_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),

@@ -1,0 +1,315 @@
+// Backward of the filter network  W = mlp2(ssp(mlp0(rbf(d))))  below its second Linear, in ONE pass over the edge rows:
+//
+//     dh1 = (g @ w2) * ssp'(h1)           (input gradient of mlp.2 times the activation derivative, from the saved h1)
+//     dw1 = dh1^T @ rbf(d),  db1 = colsum(dh1)      (weight / bias gradient of mlp.0; rbf regenerated from d)
+//
+// The composed form wrote dh1 [P,128] to HBM (k_linear_t16<128,128,2>) and read it back in the weight-gradient kernel
+// (k_wgrad_lds<64,true>): 2 x 132 MB per interaction at cfg2 that nobody else consumes.  Here dh1 never leaves registers.
+//
+// Mapping.  A wavefront owns 32 edge rows at a time.  The dx GEMM is oriented D[e][k] = sum_n g[e][n] w2[n][k] (A = g rows
+// straight from global memory, split into three bf16 planes in registers; B = the three bf16 images of w2 in LDS), so a
+// lane of the 32x32 accumulator block holds ONE channel k and 16 edge rows: e = (r&3) + 8(r>>2) + 4h for register r.  Eight
+// consecutive registers are then exactly an A fragment of the next product  dw1[k][j] += sum_e dh1[e][k] rbf[e][j]  (the
+// contraction index e may be permuted freely as long as both operands use the same order) — no transposition through LDS.
+// The rbf B fragments are generated for that edge order from the wave's 32 distances.  Column 63 of the rbf operand is the
+// constant 1, so dw1[:, 63] accumulates db1 for free (needs num_gaussians <= 63).
+//
+// Registers: the per-wave partial dw1 [128 x 64] is 128 accumulator registers, the dx block another 64; the kernel runs one
+// workgroup of 4 waves per CU (LDS: 102 KB of w2 images) = one wave per SIMD with the whole 512-entry register file, and
+// hides memory latency by loading the next tile's g rows and this tile's h1 rows before the MFMA chain of the current tile.
+// At the end the four waves add their partial sums in LDS (fixed order) and the workgroup writes one slab; the slabs of all
+// workgroups are reduced by the batched reducer of gemm.hip (bitwise reproducible, no float atomics).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int FB_THREADS = 256, FB_WAVES = 4;
+constexpr int FB_GRID_MAX = 256;
+
+__device__ __forceinline__ void fb_split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h1 = (__bf16)v[j];
+        const float r1 = v[j] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restrict__ g, const float *__restrict__ h1,
+                                                           const float *__restrict__ dist, const float *__restrict__ offset, int Gs,
+                                                           float coeff, const float *__restrict__ w2, int M,
+                                                           const int *__restrict__ m_dev, float *__restrict__ slabs,
+                                                           float *__restrict__ bias_slabs) {
+    constexpr int NB = F / 32;            // 32-wide blocks of the channel dimension
+    constexpr int S = F / 16;             // MFMA k-steps of the dx GEMM
+    constexpr int WS = F + 8;             // LDS pitch of a w2 image row (bf16 elements)
+    constexpr int JP = 64;                // Gaussians padded to two 32-wide blocks; column 63 = bias
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [3][k][WS]: image row k holds w2[n][k] for n = 0..F-1
+    float *DL = lds + (3 * F * WS) / 2;                         // [FB_WAVES][32] distances of the wave's tile
+    if (m_dev) M = min(M, *m_dev);
+    const int tiles = (M + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // ---- stage the three bf16 images of w2, transposed: a thread owns a 4(n) x 4(k) block (see gemm_t.hip) -------------
+    {
+        constexpr int PATCHES = (F / 16) * (F / 64), PERW = (PATCHES + FB_WAVES - 1) / FB_WAVES;
+        float4 wv[PERW][4];
+        const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
+#pragma unroll
+        for (int u = 0; u < PERW; ++u) {
+            const int pt = wave + u * FB_WAVES;
+            const int r0 = (pt / (F / 64)) * 16 + 4 * k4l, c0 = (pt % (F / 64)) * 64 + 4 * n4l;       // w2 rows r0.., columns c0..
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w2 + (size_t)(r0 + j) * F + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PERW; ++u) {
+            const int pt = wave + u * FB_WAVES;
+            if (pt >= PATCHES) continue;
+            const int r0 = (pt / (F / 64)) * 16 + 4 * k4l, c0 = (pt % (F / 64)) * 64 + 4 * n4l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                     // image row c0 + e: elements r0 .. r0 + 3
+                const float v4[4] = {e == 0 ? wv[u][0].x : e == 1 ? wv[u][0].y : e == 2 ? wv[u][0].z : wv[u][0].w,
+                                     e == 0 ? wv[u][1].x : e == 1 ? wv[u][1].y : e == 2 ? wv[u][1].z : wv[u][1].w,
+                                     e == 0 ? wv[u][2].x : e == 1 ? wv[u][2].y : e == 2 ? wv[u][2].z : wv[u][2].w,
+                                     e == 0 ? wv[u][3].x : e == 1 ? wv[u][3].y : e == 2 ? wv[u][3].z : wv[u][3].w};
+                bf16x4 q1, q2, q3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q1[j] = (__bf16)v4[j]; const float r1 = v4[j] - (float)q1[j];
+                    q2[j] = (__bf16)r1; q3[j] = (__bf16)(r1 - (float)q2[j]);
+                }
+                *reinterpret_cast<bf16x4 *>(&WB[(0 * F + c0 + e) * WS + r0]) = q1;
+                *reinterpret_cast<bf16x4 *>(&WB[(1 * F + c0 + e) * WS + r0]) = q2;
+                *reinterpret_cast<bf16x4 *>(&WB[(2 * F + c0 + e) * WS + r0]) = q3;
+            }
+        }
+    }
+    __syncthreads();
+
+    // Gaussian centres of this lane's two rbf columns; column 63 is the bias column, columns Gs..62 are dead.
+    float mu[2];
+    int jkind[2];                                              // 0 = Gaussian, 1 = zero, 2 = one
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const int j = 32 * jb + l31;
+        jkind[jb] = j < Gs ? 0 : (j == JP - 1 ? 2 : 1);
+        mu[jb] = j < Gs ? offset[j] : 0.f;
+    }
+
+    f32x16 dwacc[NB][2];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dwacc[kb][jb][r] = 0.f;
+
+    float *dl = DL + 32 * wave;
+    const int wave_stride = gridDim.x * FB_WAVES;
+    int tile = blockIdx.x * FB_WAVES + wave;
+    float4 xa[S], xb[S];
+    auto load_x = [&](int t) {
+        const int m = min((t << 5) + l31, M - 1);
+        const float *xr = g + (size_t)m * F + 8 * h;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                          // lane-half h owns n = 16s + 8h .. +7 of its row
+            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
+            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
+        }
+    };
+    if (tile < tiles) load_x(tile);
+#ifdef FB_PROF
+    long long tph[5] = {0, 0, 0, 0, 0}, tlast = clock64();
+#define FB_MARK(i) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define FB_MARK(i)
+#endif
+    for (; tile < tiles; tile += wave_stride) {
+        const int e0 = tile << 5;
+        FB_MARK(4)
+        // this tile's distances -> LDS (wave-private; LDS operations of one wave execute in order)
+        if (lane < 32) dl[lane] = dist[min(e0 + lane, M - 1)];
+        // this tile's h1 rows in accumulator layout: register r of block kb <-> edge row e0 + (r&3) + 8(r>>2) + 4h, channel 32kb + l31
+        float hv[NB][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = min(e0 + (r & 3) + 8 * (r >> 2) + 4 * h, M - 1);
+            const float *hr = h1 + (size_t)e * F + l31;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) hv[kb][r] = hr[32 * kb];
+        }
+        // ---- dx GEMM: acc[kb][r] = sum_n g[e][n] w2[n][32kb + l31] ---------------------------------------------------
+        f32x16 acc[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+        // MFMAs on ONE accumulator wait for each other (16 passes each): with a single wave per SIMD nothing else fills the
+        // gaps, so the six partial products are issued round-robin over two channel blocks (two independent chains).
+        constexpr int PQ[6] = {0, 1, 2, 0, 1, 0}, PP[6] = {2, 1, 0, 1, 0, 0};
+        const bool has_next = tile + wave_stride < tiles;
+        const float *xn = g + (size_t)min(((tile + wave_stride) << 5) + l31, M - 1) * F + 8 * h;
+        // Software pipeline over the 2 * S groups (k-step s, channel-block pair): the w2 fragments of group i + 1 are read from
+        // LDS and (at the first group of a k-step) the next k-step's slice of g is split while the 12 MFMAs of group i run —
+        // there is one wave per SIMD, nobody else covers an LDS round trip or a VALU burst.
+        bf16x8 q[2][3], p[2][2][3];
+        auto read_w = [&](bf16x8 (&dst)[2][3], int grp) {
+            const int s = grp >> 1, kb = (grp & 1) * 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[u][pl] = *reinterpret_cast<const bf16x8 *>(&WB[(pl * F + 32 * (kb + u) + l31) * WS + 16 * s + 8 * h]);
+        };
+        auto split_x = [&](bf16x8 (&dst)[3], int s) {
+            const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+            fb_split3(xv, dst[0], dst[1], dst[2]);
+            if (has_next) {                                    // this k-step's slice of g is consumed: reload it for the next tile
+                xa[s] = *reinterpret_cast<const float4 *>(xn + 16 * s);
+                xb[s] = *reinterpret_cast<const float4 *>(xn + 16 * s + 4);
+            }
+        };
+        split_x(q[0], 0);
+        read_w(p[0], 0);
+        FB_MARK(0)
+#pragma unroll
+        for (int grp = 0; grp < 2 * S; ++grp) {
+            const int s = grp >> 1, kb = (grp & 1) * 2;
+            if (grp + 1 < 2 * S) read_w(p[(grp + 1) & 1], grp + 1);
+            if ((grp & 1) == 0 && s + 1 < S) split_x(q[(s + 1) & 1], s + 1);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[kb + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[s & 1][PQ[t]], p[grp & 1][u][PP[t]], acc[kb + u], 0, 0, 0);
+            // per group: 12 MFMAs, 6 LDS reads, ~25 VALU (half of a split)  ->  { 1 DS read, 4 VALU, 2 MFMA } x 6
+#pragma unroll
+            for (int z = 0; z < 6; ++z) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        FB_MARK(1)
+        // ---- rbf B fragments of the tile: [e-step s2][column block jb], lane (column 32jb + l31, edge group h) ---------------
+        bf16x8 rb[2][2][3];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float4 da = *reinterpret_cast<const float4 *>(dl + 16 * s2 + 4 * h);
+            const float4 db = *reinterpret_cast<const float4 *>(dl + 16 * s2 + 4 * h + 8);
+            const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                float rv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = dv[j] - mu[jb];
+                    const float ex = exp_neg_f(coeff * (t * t));
+                    rv[j] = jkind[jb] == 0 ? ex : (jkind[jb] == 2 ? 1.0f : 0.0f);
+                }
+                fb_split3(rv, rb[s2][jb][0], rb[s2][jb][1], rb[s2][jb][2]);
+            }
+        }
+        FB_MARK(2)
+        constexpr int PP2[6] = {0, 1, 2, 0, 1, 0};             // (a3,b1) (a2,b2) (a1,b3) (a2,b1) (a1,b2) (a1,b1)
+        // ---- epilogue per channel block: dh1 = acc * ssp'(h1), then dw1[32kb.., :] += dh1^T rbf ----------------------------
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = 8 * s2 + j;
+                    const bool ok = e0 + (r & 3) + 8 * (r >> 2) + 4 * h < M;
+                    const float d = acc[kb][r] * (1.0f - 0.5f * __expf(-hv[kb][r]));      // ssp'(pre) from the saved output
+                    v[j] = ok ? d : 0.f;
+                }
+                bf16x8 a1, a2, a3;
+                fb_split3(v, a1, a2, a3);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+                        dwacc[kb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t < 3 ? (t == 0 ? a3 : t == 1 ? a2 : a1) : (t == 3 ? a2 : a1),
+                                                                                rb[s2][jb][PP2[t]], dwacc[kb][jb], 0, 0, 0);
+            }
+        }
+        FB_MARK(3)
+    }
+
+    // ---- the four waves' partial sums -> one slab per workgroup (waves added in the fixed order 0,1,2,3) -------------------
+    __syncthreads();                                           // every wave is done with the w2 images
+    float *RED = lds;                                          // [F][JP]
+    for (int w = 0; w < FB_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float *p = &RED[k * JP + 32 * jb + l31];
+                        *p = w == 0 ? dwacc[kb][jb][r] : *p + dwacc[kb][jb][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *slab = slabs + (size_t)blockIdx.x * F * Gs;
+    for (int idx = tid; idx < F * Gs; idx += FB_THREADS) {
+        const int k = idx / Gs, j = idx - k * Gs;
+        slab[idx] = RED[k * JP + j];
+    }
+    if (tid < F) bias_slabs[(size_t)blockIdx.x * F + tid] = RED[tid * JP + JP - 1];
+#ifdef FB_PROF
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < 5; ++i) bias_slabs[(size_t)blockIdx.x * F + wave * 8 + i] = (float)tph[i];
+#endif
+}
+
+}  // namespace
+
+int conan_wgrad_reduce_now(const float *slabs, const float *bias_slabs, int slices, int NK, int N, float *dW, float *dbias, hipStream_t s);   // gemm.hip
+
+extern "C" {
+
+int conan_filter_bwd_supported(int num_gaussians, int num_filters) { return num_filters == 128 && num_gaussians >= 1 && num_gaussians <= 63; }
+
+int conan_filter_bwd_slices(int M) {
+    const int tiles = (M + 31) / 32;
+    int grid = (tiles + FB_WAVES - 1) / FB_WAVES;
+    if (grid < 1) grid = 1;
+    return grid > FB_GRID_MAX ? FB_GRID_MAX : grid;
+}
+
+long long conan_filter_bwd_ws(int M, int num_gaussians, int num_filters) {
+    return (long long)conan_filter_bwd_slices(M) * ((long long)num_filters * num_gaussians + num_filters);
+}
+
+int conan_filter_bwd(const float *g, const float *h1, const float *dist, int M, const float *offset, int num_gaussians, float coeff,
+                     const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, void *stream) {
+    if (!g || !h1 || !dist || !offset || !w2 || !ws || M < 1) return CONAN_E_BADARG;
+    if (!conan_filter_bwd_supported(num_gaussians, num_filters)) return CONAN_E_UNSUPPORTED;
+    const int F = num_filters, Gs = num_gaussians, slices = conan_filter_bwd_slices(M);
+    hipStream_t s = as_stream(stream);
+    float *slabs = ws, *bias_slabs = ws + (size_t)slices * F * Gs;
+    const size_t lds = ((size_t)(3 * F * (F + 8)) / 2 + FB_WAVES * 32) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_bwd<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_filter_bwd<128><<<slices, FB_THREADS, lds, s>>>(g, h1, dist, offset, Gs, coeff, w2, M, m_dev, slabs, bias_slabs);
+    CONAN_LAUNCH_CHECK();
+    if (!dW1) return CONAN_OK;                        // slabs only: reduced later by conan_wgrad_reduce_batch (job.slices = conan_filter_bwd_slices(M))
+    return conan_wgrad_reduce_now(slabs, bias_slabs, slices, F * Gs, F, dW1, db1, s);
+}
+
+}  // extern "C"

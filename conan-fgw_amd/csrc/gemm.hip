@@ -684,6 +684,20 @@ int conan_rbf_wgrad(const float *g, const float *dist, int M, const float *offse
     return wgrad_launch(g, nullptr, M, num_gaussians, N, m_dev, dW, dbias, ws, as_stream(stream), dist, offset, coeff);
 }
 
+}  // extern "C"
+
+// slabs [slices][NK] + bias_slabs [slices][N] produced by another translation unit (filter_bwd.hip) -> dW, dbias; NK, N multiples of 4
+int conan_wgrad_reduce_now(const float *slabs, const float *bias_slabs, int slices, int NK, int N, float *dW, float *dbias, hipStream_t s) {
+    if ((NK & 3) || (N & 3)) return CONAN_E_UNSUPPORTED;
+    const int cols4 = NK / 4 + (dbias ? N / 4 : 0);
+    k_wgrad_reduce4<<<(cols4 + 31) / 32, 256, 0, s>>>(reinterpret_cast<const float4 *>(slabs), reinterpret_cast<const float4 *>(bias_slabs), slices,
+                                                     NK / 4, N / 4, reinterpret_cast<float4 *>(dW), reinterpret_cast<float4 *>(dbias));
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+extern "C" {
+
 int conan_wgrad_batchable(int K, int N) { return (((long long)N * K) & 3) == 0 && (N & 3) == 0 ? 1 : 0; }
 
 int conan_linear_wgrad_slabs(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *ws, void *stream) {
@@ -707,7 +721,7 @@ int conan_wgrad_reduce_batch(const conan_wgrad_job *jobs, int num_jobs, void *st
         for (int q = 0; q < nb; ++q) {
             const conan_wgrad_job &b = jobs[j0 + q];
             if (!b.ws || !b.dW || b.M < 0 || b.K <= 0 || b.N <= 0 || !conan_wgrad_batchable(b.K, b.N)) return CONAN_E_BADARG;
-            const int slices = wgrad_slices(b.M, b.K);
+            const int slices = b.slices > 0 ? b.slices : wgrad_slices(b.M, b.K);
             const int NK = b.N * b.K;
             J.slabs[q] = reinterpret_cast<const float4 *>(b.ws);
             J.bias_slabs[q] = reinterpret_cast<const float4 *>(b.ws + (size_t)slices * NK);

@@ -147,7 +147,7 @@ def flush_weight_gradients():
             cur.wait_stream(st)                                   # slabs written on another stream (the covalent branch runs on one)
     for q, j in enumerate(_pending):
         jobs[q].ws, jobs[q].dW, jobs[q].dbias = ptr(j["ws"]), j["dw_ptr"], j["db_ptr"]
-        jobs[q].M, jobs[q].K, jobs[q].N = j["M"], j["K"], j["N"]
+        jobs[q].M, jobs[q].K, jobs[q].N, jobs[q].slices = j["M"], j["K"], j["N"], j.get("slices", 0)
     call("conan_wgrad_reduce_batch", jobs, len(_pending), stream_ptr())
     done = {j["weight_ptr"]: j["dw_ptr"] for j in _pending}
     for j in _pending:
@@ -190,6 +190,28 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
         _pending.append(dict(ws=ws, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr() if db is not None else None,
                              keep=(dw.untyped_storage(), db.untyped_storage() if db is not None else None),
                              M=M, K=K, N=N, weight_ptr=wptr, stream=torch.cuda.current_stream()))
+    return dw, db
+
+
+def _filter_bwd(g, h1, dist, offset, coeff, w1, w2, M, md):
+    """dW1 [F,Gs], db1 [F] of the filter network's first Linear from the gradient g of its output, fused (conan_filter_bwd): the
+    input gradient of the second Linear times ssp'(h1) is formed tile by tile in registers and contracted with the regenerated
+    rbf(dist) on the spot.  Immediate, or slabs now + batched sum later (see _wgrad)."""
+    F, Gs = w1.shape
+    dev = g.device
+    ws = torch.empty(int(lib().conan_filter_bwd_ws(M, Gs, F)), dtype=f32, device=dev)
+    dw = torch.empty(F, Gs, dtype=f32, device=dev)
+    db = torch.empty(F, dtype=f32, device=dev)
+    wptr = w1.data_ptr()
+    defer = _pending is not None
+    if defer and any(j["weight_ptr"] == wptr for j in _pending):
+        flush_weight_gradients()
+        defer = False
+    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M, ptr(offset, f32), Gs, coeff, ptr(w2), F, ptr(md),
+         None if defer else ptr(dw), None if defer else ptr(db), ptr(ws), stream_ptr())
+    if defer:
+        _pending.append(dict(ws=ws, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr(), keep=(dw.untyped_storage(), db.untyped_storage()),
+                             M=M, K=Gs, N=F, slices=int(lib().conan_filter_bwd_slices(M)), weight_ptr=wptr, stream=torch.cuda.current_stream()))
     return dw, db
 
 
@@ -325,8 +347,8 @@ def cutoff_scale(w_raw: Tensor, graph: RadiusGraph) -> Tensor:
 
 class _FilterFn(torch.autograd.Function):
     """Fused filter generator (conan_filter_fwd).  Its output must be consumed by `cfconv(..., pre_cutoff_grad=True)`:
-    the incoming gradient g is then w.r.t. the un-scaled filter.  Backward is composed from the edge-level GEMM kernels:
-    dw2 = g^T h1 ; gpre = (g w2) * ssp'(h1) (fused epilogue) ; dw1 = gpre^T rbf  (rbf regenerated inside the GEMM: conan_rbf_wgrad)."""
+    the incoming gradient g is then w.r.t. the un-scaled filter.  Backward: dw2 = g^T h1 (conan_linear_wgrad), then ONE pass
+    (conan_filter_bwd) for gpre = (g w2) * ssp'(h1) and dw1 = gpre^T rbf, with gpre kept in registers and rbf regenerated."""
 
     @staticmethod
     def forward(ctx, graph, offset, coeff, w1, b1, w2, b2, use_pairs):
@@ -352,9 +374,12 @@ class _FilterFn(torch.autograd.Function):
         dev = dW.device
         g = _c(dW)                                   # already multiplied by C(d): cfconv(..., pre_cutoff_grad=True)
         dw2, db2 = _wgrad(g, h1, ME, F, F, md, w2, True)
-        dh1 = torch.empty_like(g)
-        call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
-        dw1, db1 = _wgrad(dh1, None, ME, Gs, F, md, w1, True, rbf=(dist, _c(offset), ctx.coeff))      # rbf(dist) regenerated inside the GEMM
+        if lib().conan_filter_bwd_supported(Gs, F):              # (g @ w2) * ssp'(h1) and its contraction with rbf(dist) in one pass
+            dw1, db1 = _filter_bwd(g, h1, dist, _c(offset), ctx.coeff, w1, _c(w2), ME, md)
+        else:
+            dh1 = torch.empty_like(g)
+            call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
+            dw1, db1 = _wgrad(dh1, None, ME, Gs, F, md, w1, True, rbf=(dist, _c(offset), ctx.coeff))      # rbf(dist) regenerated inside the GEMM
         return None, None, None, dw1, db1, dw2, db2, None
 
 

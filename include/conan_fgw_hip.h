@@ -166,12 +166,28 @@ typedef struct conan_wgrad_job {
     const float *ws;         /* the workspace the slabs were written to (conan_linear_wgrad_ws(M, K, N) floats) */
     float *dW, *dbias;       /* outputs [N,K], [N] (dbias nullable) */
     int M, K, N;             /* the shape the slabs were produced for */
+    int slices;              /* 0: slabs of conan_linear_wgrad_slabs / conan_rbf_wgrad_slabs (count derived from M, K);
+                                > 0: explicit slab count (conan_filter_bwd_slices(M) for conan_filter_bwd) */
 } conan_wgrad_job;
 int conan_wgrad_batchable(int K, int N);
 int conan_linear_wgrad_slabs(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *ws, void *stream);
 int conan_rbf_wgrad_slabs(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
                           const int *m_dev, float *ws, void *stream);
 int conan_wgrad_reduce_batch(const conan_wgrad_job *jobs, int num_jobs, void *stream);
+
+/* Backward of the filter network below its second Linear, fused (filter_bwd.hip):
+ *     dh1 = (g @ w2) * ssp'(h1) ;  dW1[F,Gs] = dh1^T rbf(dist) ;  db1[F] = colsum(dh1)
+ * i.e. conan_linear_fwd(g, w2, residual=h1, w_kn=1, act=2) followed by conan_rbf_wgrad, without dh1 [M,F] ever reaching HBM
+ * (schnet_no_sum.py InteractionBlock.mlp = Linear(Gs,F) - ShiftedSoftplus - Linear(F,F); autograd of mlp[2] input, the
+ * activation and mlp[0] weight).  g [M,F] is the gradient w.r.t. the mlp output, h1 [M,F] the saved ssp output
+ * (conan_filter_fwd h1_out), w2 [F,F] the forward weight of mlp[2].  ws holds conan_filter_bwd_ws(M, Gs, F) floats.
+ * dW1 == NULL: slabs only, to be reduced by conan_wgrad_reduce_batch with job.slices = conan_filter_bwd_slices(M), K = Gs, N = F.
+ * Supported: conan_filter_bwd_supported(Gs, F) (F = 128, Gs <= 63); otherwise CONAN_E_UNSUPPORTED (compose the two calls). */
+int conan_filter_bwd_supported(int num_gaussians, int num_filters);
+int conan_filter_bwd_slices(int M);
+long long conan_filter_bwd_ws(int M, int num_gaussians, int num_filters);
+int conan_filter_bwd(const float *g, const float *h1, const float *dist, int M, const float *offset, int num_gaussians, float coeff,
+                     const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, void *stream);
 
 /* rbf[e,k] = exp(coeff * (dist[e] - offset[k])^2): GaussianSmearing (PyG; schnet_no_sum.py:161,209).  `offset` is the
  * module's buffer (distance_expansion.offset), coeff = -0.5/(offset[1]-offset[0])^2.  num_edges_dev (nullable) = device

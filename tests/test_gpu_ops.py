@@ -191,6 +191,47 @@ def test_rbf_wgrad_matches_materialised_rbf(M, N, Gs):
     assert rel(db.double().cpu().numpy(), g[:M].double().sum(0).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,Gs", [(1, 50), (31, 50), (4133, 50), (40000, 50), (3000, 20), (2500, 63)])
+def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs):
+    """conan_filter_bwd (dh1 = (g w2) * ssp'(h1) kept in registers, dW1 = dh1^T rbf, db1 = colsum dh1) against the fp64 formula and
+    against the two kernels it replaces (conan_linear_fwd act=2 + conan_rbf_wgrad); rows beyond the device-side count are
+    masked; the slab form reduced through conan_wgrad_reduce_batch gives the same bits; repeat runs are bitwise equal."""
+    import ctypes
+    from conan_fgw_amd._lib import WgradJob, call, lib, ptr, stream_ptr
+    Fh, pad = 128, 37
+    assert lib().conan_filter_bwd_supported(Gs, Fh) == 1 and lib().conan_filter_bwd_supported(64, Fh) == 0 and lib().conan_filter_bwd_supported(50, 64) == 0
+    gen = torch.Generator().manual_seed(M + Gs)
+    g = torch.randn(M + pad, Fh, generator=gen).to(dev)
+    h1 = (torch.rand(M + pad, Fh, generator=gen) * 3 - 0.6).to(dev)                    # ssp output range (> -ln 2)
+    dist = (torch.rand(M + pad, generator=gen) * 10).to(dev)
+    w2 = (torch.randn(Fh, Fh, generator=gen) / 11).to(dev)
+    off = torch.linspace(0, 10, Gs).to(dev)
+    coeff = -0.5 / float(off[1] - off[0]) ** 2
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib().conan_filter_bwd_ws(M + pad, Gs, Fh)), device=dev)
+    dW, db = torch.empty(Fh, Gs, device=dev), torch.empty(Fh, device=dev)
+    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), ptr(dW), ptr(db), ptr(ws), stream_ptr())
+    dh = (g[:M].double() @ w2.double()) * (1 - 0.5 * torch.exp(-h1[:M].double()))
+    rbf = torch.exp(coeff * (dist[:M, None].double() - off[None].double()) ** 2)
+    assert rel(dW.double().cpu().numpy(), (dh.T @ rbf).cpu().numpy()) < 1e-5
+    assert rel(db.double().cpu().numpy(), dh.sum(0).cpu().numpy()) < 1e-5
+    # the composed pair
+    dh1 = torch.empty(M + pad, Fh, device=dev)
+    call("conan_linear_fwd", ptr(g), ptr(w2), None, ptr(h1), M + pad, Fh, Fh, 1, 2, ptr(md), ptr(dh1), stream_ptr())
+    dWc, dbc = torch.empty_like(dW), torch.empty_like(db)
+    wsc = torch.empty(int(lib().conan_linear_wgrad_ws(M + pad, Gs, Fh)), device=dev)
+    call("conan_rbf_wgrad", ptr(dh1), ptr(dist), M + pad, ptr(off), Gs, coeff, Fh, ptr(md), ptr(dWc), ptr(dbc), ptr(wsc), stream_ptr())
+    assert rel(dW.cpu().numpy(), dWc.cpu().numpy()) < 1e-5 and rel(db.cpu().numpy(), dbc.cpu().numpy()) < 1e-5
+    # slab form + batched reduction; bitwise reproducibility
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), None, None, ptr(ws), stream_ptr())
+    job = (WgradJob * 1)()
+    job[0].ws, job[0].dW, job[0].dbias = ws.data_ptr(), dW2.data_ptr(), db2.data_ptr()
+    job[0].M, job[0].K, job[0].N, job[0].slices = M + pad, Gs, Fh, int(lib().conan_filter_bwd_slices(M + pad))
+    call("conan_wgrad_reduce_batch", job, 1, stream_ptr())
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("M,K,N,act,w_kn", [(3000, 128, 384, 0, 0), (3000, 384, 128, 0, 1), (1777, 128, 256, 3, 0), (2048, 256, 128, 1, 1),
                                             (999, 512, 256, 1, 0), (640, 192, 320, 0, 0), (1500, 256, 256, 2, 1)])
 def test_linear_wide_layers_are_tiled_into_strided_chunks(M, K, N, act, w_kn):
