@@ -46,10 +46,11 @@ __global__ void __launch_bounds__(256) k_gat_node_alpha(const float *__restrict_
 // The row's edges are staged one per lane (source, <ea, v>, a_src[source]) — bonds: a handful per atom — so logits, max and
 // sum are wavefront reductions and the gather of the h_j rows is fed by cross-lane reads; rows longer than 64 edges take
 // the serial path below.
+template <int DT = GAT_MAXD>
 __device__ __forceinline__ float gat_dot(const float *__restrict__ ea, const float *vd, int D) {
     float dot = 0.f;
 #pragma unroll
-    for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dot += ea[d] * vd[d];
+    for (int d = 0; d < DT; ++d) if (d < D) dot += ea[d] * vd[d];
     return dot;
 }
 
@@ -120,6 +121,9 @@ constexpr int GAT_BW_WGS = 2048;
 constexpr int GAT_BW_WAVES = 4 * GAT_BW_WGS;
 
 // target side: dpre per edge / self loop, da_dst, partial dv
+// DT: size of the per-lane edge-attribute register arrays (4 for edge_dim <= 4, else DT): every entry costs wave-wide
+// reductions, and the generic 8-wide body was 34 % instruction-fetch stalls (SQ_WAIT_INST_ANY) on top of them.
+template <int DT>
 __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict__ h, const float *__restrict__ dout, const float *__restrict__ alpha,
                                                         const float *__restrict__ alpha_self, const float *__restrict__ a_src,
                                                         const float *__restrict__ a_dst, const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -128,9 +132,9 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
                                                         float *__restrict__ dpre_self, float *__restrict__ da_dst, float *__restrict__ part, int PW) {
     const int lane = threadIdx.x & 63;
     const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    float vd[GAT_MAXD], dvacc[GAT_MAXD];
+    float vd[DT], dvacc[DT];
 #pragma unroll
-    for (int d = 0; d < GAT_MAXD; ++d) { vd[d] = d < D ? v[d] : 0.f; dvacc[d] = 0.f; }
+    for (int d = 0; d < DT; ++d) { vd[d] = d < D ? v[d] : 0.f; dvacc[d] = 0.f; }
     for (int i = wg; i < n; i += GAT_BW_WAVES) {
         const int e0 = rowptr[i], e1 = rowptr[i + 1], deg = e1 - e0;
         const float ad = a_dst[i], as = alpha_self[i];
@@ -138,19 +142,19 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
         for (int c = lane; c < C; c += 64) dal_self += dout[(size_t)i * C + c] * h[(size_t)i * C + c];
         dal_self = wave_sum(dal_self);
         float dad = 0.f;
-        float mean_ea[GAT_MAXD];
+        float mean_ea[DT];
 #pragma unroll
-        for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] = 0.f;
+        for (int d = 0; d < DT; ++d) mean_ea[d] = 0.f;
         float mean_dot = 0.f, S = as * dal_self;
         if (deg <= 64) {
             const bool on = lane < deg;
             const int j = on ? col[e0 + lane] : i;
-            float ea[GAT_MAXD];
+            float ea[DT];
 #pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) ea[d] = (on && d < D) ? edge_attr[(size_t)eid[e0 + lane] * D + d] : 0.f;
+            for (int d = 0; d < DT; ++d) ea[d] = (on && d < D) ? edge_attr[(size_t)eid[e0 + lane] * D + d] : 0.f;
             float dot = 0.f;
 #pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) dot += ea[d] * vd[d];
+            for (int d = 0; d < DT; ++d) dot += ea[d] * vd[d];
             const float al = on ? alpha[e0 + lane] : 0.f;
             const float pre = on ? a_src[j] + ad + dot : 0.f;
             float dal = 0.f;                                   // <dout_i, h_j> of the edge owned by this lane
@@ -165,13 +169,13 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
             if (deg > 0) {
                 mean_dot = wave_sum(dot) / (float)deg;
 #pragma unroll
-                for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] = wave_sum(ea[d]) / (float)deg;
+                for (int d = 0; d < DT; ++d) mean_ea[d] = wave_sum(ea[d]) / (float)deg;
             }
             const float g = on ? al * (dal - S) * (pre > 0.f ? 1.f : slope) : 0.f;
             if (on) dpre[e0 + lane] = g;
             dad += wave_sum(g);
 #pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) dvacc[d] += wave_sum(g * ea[d]);
+            for (int d = 0; d < DT; ++d) dvacc[d] += wave_sum(g * ea[d]);
         } else {
             for (int p = e0; p < e1; ++p) {
                 const int j = col[p];
@@ -180,23 +184,23 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
                 S += alpha[p] * wave_sum(da);
                 const float *ea = edge_attr + (size_t)eid[p] * D;
 #pragma unroll
-                for (int d = 0; d < GAT_MAXD; ++d) if (d < D) { mean_ea[d] += ea[d]; mean_dot += ea[d] * vd[d]; }
+                for (int d = 0; d < DT; ++d) if (d < D) { mean_ea[d] += ea[d]; mean_dot += ea[d] * vd[d]; }
             }
             mean_dot /= (float)deg;
 #pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) mean_ea[d] /= (float)deg;
+            for (int d = 0; d < DT; ++d) mean_ea[d] /= (float)deg;
             for (int p = e0; p < e1; ++p) {
                 const int j = col[p];
                 float da = 0.f;
                 for (int c = lane; c < C; c += 64) da += dout[(size_t)i * C + c] * h[(size_t)j * C + c];
                 da = wave_sum(da);
                 const float *ea = edge_attr + (size_t)eid[p] * D;
-                const float pre = a_src[j] + ad + gat_dot(ea, vd, D);
+                const float pre = a_src[j] + ad + gat_dot<DT>(ea, vd, D);
                 const float g = alpha[p] * (da - S) * (pre > 0.f ? 1.f : slope);
                 if (lane == 0) dpre[p] = g;
                 dad += g;
 #pragma unroll
-                for (int d = 0; d < GAT_MAXD; ++d) if (d < D) dvacc[d] += g * ea[d];
+                for (int d = 0; d < DT; ++d) if (d < D) dvacc[d] += g * ea[d];
             }
         }
         {
@@ -205,13 +209,13 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
             if (lane == 0) dpre_self[i] = g;
             dad += g;
 #pragma unroll
-            for (int d = 0; d < GAT_MAXD; ++d) dvacc[d] += g * mean_ea[d];
+            for (int d = 0; d < DT; ++d) dvacc[d] += g * mean_ea[d];
         }
         if (lane == 0) da_dst[i] = dad;
     }
-    __shared__ float sm_dv[4][GAT_MAXD];
+    __shared__ float sm_dv[4][DT];
     if (lane == 0)
-        for (int d = 0; d < GAT_MAXD; ++d) sm_dv[threadIdx.x >> 6][d] = dvacc[d];
+        for (int d = 0; d < DT; ++d) sm_dv[threadIdx.x >> 6][d] = dvacc[d];
     __syncthreads();
     if (threadIdx.x < D)
         part[(size_t)blockIdx.x * PW + 3 * C + threadIdx.x] =
@@ -360,8 +364,12 @@ int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alph
     hipStream_t s = as_stream(stream);
     const int PW = 3 * channels + edge_dim;
     float *dpre_self = ws, *da_dst = ws + n, *dpre = ws + 2 * (size_t)n, *part = dpre + (num_edges > 0 ? num_edges : 1);
-    k_gat_bwd_target<<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
-                                                       channels, dpre, dpre_self, da_dst, part, PW);
+    if (edge_dim <= 4)
+        k_gat_bwd_target<4><<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
+                                                          channels, dpre, dpre_self, da_dst, part, PW);
+    else
+        k_gat_bwd_target<GAT_MAXD><<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v,
+                                                                 negative_slope, n, channels, dpre, dpre_self, da_dst, part, PW);
     k_gat_bwd_source<<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr, t_pos, t_tgt, n,
                                                        channels, dh, part, PW);
     k_gat_param_reduce<<<(PW + 31) / 32, 256, 0, s>>>(part, PW, dparams);

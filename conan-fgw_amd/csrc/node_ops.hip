@@ -35,14 +35,15 @@ __global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__
         zs[t] = (r >= 0 && r < rows) ? (int)r : -1;
     }
     __syncthreads();
-    if (c < H) {                            // loads issued 8 deep, then the (order-preserving) LDS accumulation
+    if (c < H) {                            // loads issued 32 deep (a batch costs one memory round trip), then the order-preserving LDS accumulation
+        constexpr int U = 32;
         int a = a0;
-        for (; a + 8 <= a1; a += 8) {
-            float v[8];
+        for (; a + U <= a1; a += U) {
+            float v[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = dout[(size_t)(a + u) * H + c];
+            for (int u = 0; u < U; ++u) v[u] = dout[(size_t)(a + u) * H + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int r = zs[a + u - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += v[u]; }
+            for (int u = 0; u < U; ++u) { const int r = zs[a + u - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += v[u]; }
         }
         for (; a < a1; ++a) { const int r = zs[a - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += dout[(size_t)a * H + c]; }
     }

@@ -1,0 +1,20 @@
+"""Probe for tools/ab.py: the large-N FGW barycenter solve (BACE / lipo shapes), timed per solve."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from conan_fgw_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1]:
+    _lib._SO = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else ""
+from conan_fgw_amd import ops
+dev = torch.device("cuda:0")
+out = []
+for name, B, K, N, d in (("bace B=64", 64, 5, 97, 64), ("lipo B=128", 128, 5, 85, 64), ("bace B=32", 32, 5, 97, 64)):
+    g = torch.Generator().manual_seed(0)
+    Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
+    A = (torch.rand(B, K, N, N, generator=g) < 0.1).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
+    for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): ops.fgw_barycenter_batched(Ys, Cs)
+    torch.cuda.synchronize(); out.append("%s N=%d: %.3f ms" % (name, N, (time.perf_counter() - t0) / 5 * 1e3))
+print(tag, "  ".join(out))
