@@ -15,8 +15,8 @@
 //                                match: no LDS round trip, no cross-lane traffic between the two GEMMs.
 // The A operands (the two weight matrices, <= 98 KB) are staged once per workgroup in LDS and read with conflict-free
 // ds_read_b128 (4 k-steps per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
-// MFMAs back to back: GEMM1 on v_mfma_f32_32x32x2_f32, GEMM2 as an exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16
-// (fp32-class accuracy; there is no other arithmetic mode and no environment switch).
+// MFMAs back to back, both GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy; there is no
+// other arithmetic mode and no environment switch).
 #include "common.h"
 
 namespace {
@@ -39,8 +39,8 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
     }
 }
 
-constexpr int GP = 56;        // gaussians padded to a multiple of 8 (zero weights beyond num_gaussians)
-constexpr int W1P = 60;       // LDS pitch of W1 rows  (60 = 4*15: 16 consecutive rows hit 16 distinct 16-B slots)
+constexpr int GP = 64;        // gaussians padded to four MFMA k-steps of 16 (zero weights beyond num_gaussians)
+constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (bf16 elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
 constexpr int FF_THREADS = 512;
 
 template <int F>
@@ -52,8 +52,9 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (bf16 elements; 16-B slots stay distinct)
     constexpr int W2WORDS = (3 * F * W2S) / 2;      // floats occupied by the three bf16 W2 images
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *W1L = lds;                     // [F][W1P]
-    float *W2L = W1L + F * W1P;           // 3 x bf16 [F][W2S], columns permuted per 16-group
+    constexpr int W1WORDS = (3 * F * W1S) / 2;      // floats occupied by the three bf16 W1 images
+    float *W1L = lds;                     // 3 x bf16 [F][W1S]
+    float *W2L = W1L + W1WORDS;           // 3 x bf16 [F][W2S], columns permuted per 16-group
     float *B1L = W2L + W2WORDS;           // [F]
     float *B2L = B1L + F;                 // [F]
     float *OFL = B2L + F;                 // [GP]
@@ -63,15 +64,25 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     if ((int)blockIdx.x * (FF_THREADS / 64) >= tiles) return;
 
     {
-        constexpr int PER1 = (F * W1P + FF_THREADS - 1) / FF_THREADS;
+        __bf16 *W1B = reinterpret_cast<__bf16 *>(W1L);
+        constexpr int PER1 = (F * GP + FF_THREADS - 1) / FF_THREADS;
         float wv[PER1];
 #pragma unroll
         for (int u = 0; u < PER1; ++u) {
-            const int t = tid + u * FF_THREADS, f = t / W1P, k = t - f * W1P;
-            wv[u] = (t < F * W1P && k < Gs) ? w1[(size_t)f * Gs + k] : 0.f;
+            const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
+            wv[u] = (t < F * GP && k < Gs) ? w1[(size_t)f * Gs + k] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < PER1; ++u) { const int t = tid + u * FF_THREADS; if (t < F * W1P) W1L[t] = wv[u]; }
+        for (int u = 0; u < PER1; ++u) {
+            const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
+            if (t >= F * GP) continue;
+            const float v = wv[u];
+            const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
+            const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
+            W1B[(0 * F + f) * W1S + k] = h1;
+            W1B[(1 * F + f) * W1S + k] = h2;
+            W1B[(2 * F + f) * W1S + k] = (__bf16)r2;
+        }
     }
     {
         // three bf16 images of W2; inside every group of 16 input channels the columns are stored in the order the B
@@ -117,34 +128,34 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[mb][r] = 0.f;
         {
-            // software pipeline: the A fragments of group g+1 are requested before the MFMAs of group g issue;
-            // sched_barrier keeps the compiler from hoisting every LDS read to the top (register blow-up).
-            float4 a_cur[MB], a_nxt[MB];
+            // both operands as exact 3-way bf16 splits (as GEMM2): the B fragment of k-step s is rbf_k(d_e) for k = 16s + 8h .. +7,
+            // evaluated and split in registers; the A fragments are the three W1 images.  6 x 32 cycles per 32x32x16 block instead
+            // of 8 x 64 on the fp32 MFMA.
+            const __bf16 *W1B = reinterpret_cast<const __bf16 *>(W1L);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a_cur[mb] = *reinterpret_cast<const float4 *>(&W1L[(32 * mb + l31) * W1P + 4 * h]);
+            for (int s = 0; s < GP / 16; ++s) {
+                const int kb = 16 * s + 8 * h;
+                const float4 o0 = *reinterpret_cast<const float4 *>(&OFL[kb]), o1 = *reinterpret_cast<const float4 *>(&OFL[kb + 4]);
+                const float of[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                float rb[8];
 #pragma unroll
-            for (int g = 0; g < GP / 8; ++g) {
-                const int kb = 8 * g + 4 * h;                    // this lane-half's 4 k indices of the group
-                if (g + 1 < GP / 8) {
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) a_nxt[mb] = *reinterpret_cast<const float4 *>(&W1L[(32 * mb + l31) * W1P + kb + 8]);
-                }
-                const float4 of = *reinterpret_cast<const float4 *>(&OFL[kb]);
-                float rb[4];
-                { float t0 = d - of.x; rb[0] = exp_neg_f(coeff * (t0 * t0)); }
-                { float t0 = d - of.y; rb[1] = exp_neg_f(coeff * (t0 * t0)); }
-                { float t0 = d - of.z; rb[2] = exp_neg_f(coeff * (t0 * t0)); }
-                { float t0 = d - of.w; rb[3] = exp_neg_f(coeff * (t0 * t0)); }
+                for (int j = 0; j < 8; ++j) { const float t0 = d - of[j]; rb[j] = exp_neg_f(coeff * (t0 * t0)); }
+                bf16x8 q1, q2, q3;
+                split3(rb, q1, q2, q3);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].x, rb[0], acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].y, rb[1], acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].z, rb[2], acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mb].w, rb[3], acc1[mb], 0, 0, 0);
+                    const int row = 32 * mb + l31;
+                    const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&W1B[(0 * F + row) * W1S + kb]);
+                    const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&W1B[(1 * F + row) * W1S + kb]);
+                    const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&W1B[(2 * F + row) * W1S + kb]);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc1[mb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) a_cur[mb] = a_nxt[mb];
             }
         }
         // bias + shifted softplus on the accumulators: register r of half h is channel 32mb + (r&3) + 8(r>>2) + 4h
@@ -228,7 +239,7 @@ template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    const size_t lds = ((size_t)F * W1P + (size_t)(3 * F * (F + 8)) / 2 + 2 * F + GP) * 4;
+    const size_t lds = ((size_t)(3 * F * W1S) / 2 + (size_t)(3 * F * (F + 8)) / 2 + 2 * F + GP) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;

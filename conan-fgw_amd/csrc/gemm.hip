@@ -406,12 +406,12 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
     if (r_begin < r_end) {
         int m = r_begin;
         fetch(stA, m);
+        if (m + STEP < r_end) fetch(stB, m + STEP);  // requested before the first wait: a slice of a node-level layer is only 8 stages
         stash(0, stA, m);
-        if (m + STEP < r_end) fetch(stA, m + STEP);
-        if (m + 2 * STEP < r_end) fetch(stB, m + 2 * STEP);
+        if (m + 2 * STEP < r_end) fetch(stA, m + 2 * STEP);
         __syncthreads();
-        for (;;) {                                   // stage m is in buffer 0; stA holds the next stage, stB the one after
-            WG_HALF(0, stA) WG_HALF(1, stB)
+        for (;;) {                                   // stage m is in buffer 0; stB holds the next stage, stA the one after
+            WG_HALF(0, stB) WG_HALF(1, stA)
         }
     }
 #undef WG_HALF

@@ -33,8 +33,8 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
 // ACT is a template parameter: the epilogue is straight-line code over 16*NB outputs per lane, and with a run-time
 // activation switch the kernel was 31 KB of code executed exactly once per wavefront at node-level sizes — rocprofv3
 // showed 45 % of the wave cycles waiting for instruction fetch (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).
-template <int K, int N, int ACT>
-__global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restrict__ x, const float *__restrict__ w,
+template <int K, int N, int ACT, int NT>
+__global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, const float *__restrict__ w,
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
                                                            int M, int w_kn, float *y,
                                                            const int *__restrict__ m_dev, int ldx, int ldw, int ldy,
@@ -53,21 +53,37 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
     if (m_dev) M = min(M, *m_dev);
     const int tiles = (M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x * (LT_THREADS / 64) >= tiles) return;
+    if ((int)blockIdx.x * (NT / 64) >= tiles) return;
+    // The wave's first tile of x is requested BEFORE the weights are staged (the two are independent): at node-level sizes a
+    // wave owns exactly one tile and the kernel is two serial memory round trips otherwise.  Later tiles are requested as soon
+    // as the MFMA loop has consumed the current one, i.e. they fly during the epilogue.
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_stride = gridDim.x * (NT / 64);
+    float4 xa[S], xb[S];
+    auto load_x = [&](int t) {
+        const int mr = min((t << 5) + l31, M - 1);
+        const float *xr = x + (size_t)mr * ldx + 8 * h;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                          // lane-half h owns k = 16s + 8h .. +7 of its row
+            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
+            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
+        }
+    };
+    if ((int)blockIdx.x * (NT / 64) + wave < tiles) load_x(blockIdx.x * (NT / 64) + wave);
     // Staging of the three bf16 images of W as [n][k]; all of a thread's loads are in flight before the first use.
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     if (!w_kn) {                                              // w is [N][K]: float4 = 4 consecutive k -> one 8-byte store per image
-        constexpr int V4 = N * K / 4, PER = (V4 + LT_THREADS - 1) / LT_THREADS;
+        constexpr int V4 = N * K / 4, PER = (V4 + NT - 1) / NT;
         float4 wv[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int q = tid + u * LT_THREADS;
+            const int q = tid + u * NT;
             const int n = (4 * q) / K, k = 4 * q - n * K;
             wv[u] = q < V4 ? *reinterpret_cast<const float4 *>(w + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int q = tid + u * LT_THREADS;
+            const int q = tid + u * NT;
             if (q >= V4) continue;
             const float v4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
             bf16x4 h1, h2, h3;
@@ -86,12 +102,12 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
         // four float4 loads along n, transposed in registers, 8-byte stores along k.  Inside a wavefront the blocks form a
         // 4(k4) x 16(n4) patch with lane = (n4 & 3) | (k4 << 2) | ((n4 >> 2) << 4): every 16-lane group then covers 4 rows x
         // 4 k-blocks = 16 distinct 8-byte bank slots (rows 4 apart sit 64 B apart modulo the 256-B bank cycle).
-        constexpr int PATCHES = (K / 16) * (N / 64), PERW = (PATCHES + LT_THREADS / 64 - 1) / (LT_THREADS / 64);
+        constexpr int PATCHES = (K / 16) * (N / 64), PERW = (PATCHES + NT / 64 - 1) / (NT / 64);
         float4 wv[PERW][4];
         const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
 #pragma unroll
         for (int u = 0; u < PERW; ++u) {
-            const int pt = wave + u * (LT_THREADS / 64);
+            const int pt = wave + u * (NT / 64);
             const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -99,7 +115,7 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
         }
 #pragma unroll
         for (int u = 0; u < PERW; ++u) {
-            const int pt = wave + u * (LT_THREADS / 64);
+            const int pt = wave + u * (NT / 64);
             if (pt >= PATCHES) continue;
             const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
 #pragma unroll
@@ -120,21 +136,12 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
             }
         }
     }
-    for (int t = tid; t < N; t += LT_THREADS) BL[t] = bias ? bias[t] : 0.f;
+    for (int t = tid; t < N; t += NT) BL[t] = bias ? bias[t] : 0.f;
     __syncthreads();
 
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wave_stride = gridDim.x * (LT_THREADS / 64);
-    for (int tile = blockIdx.x * (LT_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
+    for (int tile = blockIdx.x * (NT / 64) + wave; tile < tiles; tile += wave_stride) {
         const int m = (tile << 5) + l31;
         const bool valid = m < M;
-        const float *xr = x + (size_t)(valid ? m : M - 1) * ldx + 8 * h;
-        float4 xa[S], xb[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {                          // lane-half h owns k = 16s + 8h .. +7 of its row
-            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
-            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
-        }
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -161,6 +168,7 @@ __global__ void __launch_bounds__(LT_THREADS) k_linear_t16(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (tile + wave_stride < tiles) load_x(tile + wave_stride);
         if (!valid) continue;
         float *yr = y + (size_t)m * ldy + 4 * h;
         const float *rr = residual ? residual + (size_t)m * ldy + 4 * h : nullptr;
@@ -202,13 +210,24 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     if (ldw == 0) ldw = w_kn ? N : K;
     const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
     const int tiles16 = (M + 31) / 32;
-    int grid16 = (tiles16 + 7) / 8;
+    // 8 waves per workgroup (2 per SIMD cover each other's latencies) once every CU gets a full workgroup; below that 4-wave
+    // workgroups spread the tiles over twice as many CUs (node-level layers: 790 tiles -> 198 instead of 99 CUs).
+    const bool narrow = tiles16 < 8 * 256;
+    const int per = narrow ? 4 : 8;
+    int grid16 = (tiles16 + per - 1) / per;
     if (grid16 > 256) grid16 = 256;
 #define LAUNCH16(A)                                                                                                              \
     do {                                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds16);                                                                                   \
-        k_linear_t16<K, N, A><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out); \
+        if (narrow) {                                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A, 256>),                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);                                   \
+            k_linear_t16<K, N, A, 256><<<grid16, 256, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out); \
+        } else {                                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A, LT_THREADS>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);                                   \
+            k_linear_t16<K, N, A, LT_THREADS><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, \
+                                                                                pre_out);                                        \
+        }                                                                                                                        \
     } while (0)
     switch (act) {
         case 0: LAUNCH16(0); break;

@@ -201,11 +201,10 @@ int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edge
 
 /* Fused continuous-filter generator: for every edge e
  *   W[e,:] = ( mlp2( ssp( mlp0( rbf(dist[e]) ) ) ) ) * 0.5*(cos(dist[e]*pi/cutoff)+1)
- * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel, the first GEMM on the fp32 MFMA
- * (v_mfma_f32_32x32x2_f32), the second as an exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy,
- * see conan_linear_fwd), every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
+ * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel, both GEMMs as exact 3-way bf16 splits
+ * on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, see conan_linear_fwd), every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
  * are the torch Linear parameters of interactions.{i}.mlp.{0,2}.  h1_out (nullable) receives ssp(mlp0(rbf)) [E,F] for the
- * backward.  Supported shapes: conan_filter_fused_supported(Gs, F) (Gs <= 56, F in {32,64,128}); otherwise
+ * backward.  Supported shapes: conan_filter_fused_supported(Gs, F) (Gs <= 64, F in {32,64,128}); otherwise
  * CONAN_E_UNSUPPORTED and the caller composes conan_rbf_fwd / conan_linear_fwd / conan_cutoff_scale. */
 int conan_filter_fused_supported(int num_gaussians, int num_filters);
 int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int num_gaussians,

@@ -40,6 +40,16 @@ k2(); ref = g.double().t() @ h1.double(); e2 = float((dw.double() - ref).abs().m
 rb = torch.exp(coeff * (dist[:, None].double() - offset[None].double()) ** 2)
 k4(); ref = g.double().t() @ rb; e4 = float((dw1.double() - ref).abs().max() / ref.abs().max())
 eb = float((db.double() - g.double().sum(0)).abs().max() / g.double().sum(0).abs().max())
+# node-level sizes (25 k atoms): a 128 -> 128 Linear forward, its dx, and its weight gradient
+Mn = 25275
+xn = torch.randn(Mn, F, device=dev); yn = torch.empty(Mn, F, device=dev); bn = torch.randn(F, device=dev)
+wsn = torch.empty(_lib.lib().conan_linear_wgrad_ws(Mn, F, F), device=dev)
+def n1(): call("conan_linear_fwd", ptr(xn), ptr(w2), ptr(bn), None, Mn, F, F, 0, 0, None, ptr(yn), stream_ptr())
+def n2(): call("conan_linear_fwd", ptr(xn), ptr(w2), ptr(bn), None, Mn, F, F, 0, 1, None, ptr(yn), stream_ptr())
+def n3(): call("conan_linear_wgrad", ptr(xn), ptr(yn), Mn, F, F, None, ptr(dw), ptr(db), ptr(wsn), stream_ptr())
+tn1, tn2, tn3 = timed(n1, 50), timed(n2, 50), timed(n3, 50)
+n1(); en = float((yn.double() - (xn.double() @ w2.double().t() + bn.double())).abs().max())
+print(f"{tag} node-level (M={Mn}): linear {tn1:6.1f} us (abs err {en:.1e})  linear+ssp {tn2:6.1f} us  wgrad+reduce {tn3:6.1f} us")
 extra = ""
 if hasattr(_lib.lib(), "conan_filter_bwd"):
     ws2 = torch.empty(_lib.lib().conan_filter_bwd_ws(P, Gs, F), device=dev); dwf = torch.empty(F, Gs, device=dev); dbf = torch.empty(F, device=dev)
