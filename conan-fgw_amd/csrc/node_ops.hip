@@ -18,10 +18,10 @@ __global__ void k_embedding_fwd(const int64_t *__restrict__ z, const float *__re
     }
 }
 
-// Deterministic embedding gradient, two stages.  Stage 1: one workgroup per (chunk of 256 atoms, 128-column tile) keeps a
+// Deterministic embedding gradient, two stages.  Stage 1: one workgroup per (chunk of EMB_CHUNK atoms, 128-column tile) keeps a
 // [num_embeddings x 128] partial table in LDS; thread c owns column c, walks the chunk's atoms in order and adds
 // dout[a][c] into row z[a] (no atomics, fixed order).  Stage 2 sums the per-chunk tables in chunk order.
-constexpr int EMB_CHUNK = 256;
+constexpr int EMB_CHUNK = 128;      // atoms per workgroup: the chunk is walked serially (4 batches of 32 loads), 198 workgroups at 25 k atoms
 constexpr int EMB_ROWS_MAX = 100;     // torch.nn.Embedding(100, H): atomic numbers
 __global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__restrict__ z, const float *__restrict__ dout, int n, int H,
                                                               int rows, float *__restrict__ slabs) {

@@ -83,10 +83,7 @@ class _LinearSilu(torch.autograd.Function):
             dx = _tail0_shape(M, K, x.device, md)
             call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
-            ws = torch.empty(int(lib().conan_linear_wgrad_ws(M, K, N)), dtype=f32, device=x.device)
-            dw = torch.empty_like(w)
-            db = torch.empty(N, dtype=f32, device=x.device) if ctx.has_b else None
-            call("conan_linear_wgrad", ptr(g), ptr(x), M, K, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
+            dw, db = ops._wgrad(g, x, M, K, N, md, w, ctx.has_b)         # immediate, or slabs now + one batched reduction per backward pass
         return dx, dw, db, None
 
 
