@@ -19,6 +19,12 @@
 // hides memory latency by loading the next tile's g rows and this tile's h1 rows before the MFMA chain of the current tile.
 // At the end the four waves add their partial sums in LDS (fixed order) and the workgroup writes one slab; the slabs of all
 // workgroups are reduced by the batched reducer of gemm.hip (bitwise reproducible, no float atomics).
+//
+// Measured at cfg2 (259 k rows): 94 us against 106 + 71 us for the two kernels it replaces (264 MB instead of 704 MB of HBM
+// traffic).  rocprofv3 counters: 2.33 M MFMAs (35 % of the SIMD cycles), 14.6 M VALU instructions — 60 % of them the bf16
+// splitting of g, dh1 and rbf — and only a third of the MFMA cycles overlapped by VALU work; the kernel is bound by the sum of
+// the two, not by HBM (floor 61 us).  A variant with two waves per tile (half the channel blocks each, 96 accumulator
+// registers, 2 waves per SIMD) measured the same 94-98 us: what it gains in overlap it pays in duplicated splitting.
 #include "common.h"
 
 namespace {
@@ -128,15 +134,8 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
         }
     };
     if (tile < tiles) load_x(tile);
-#ifdef FB_PROF
-    long long tph[5] = {0, 0, 0, 0, 0}, tlast = clock64();
-#define FB_MARK(i) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
-#else
-#define FB_MARK(i)
-#endif
     for (; tile < tiles; tile += wave_stride) {
         const int e0 = tile << 5;
-        FB_MARK(4)
         // this tile's distances -> LDS (wave-private; LDS operations of one wave execute in order)
         if (lane < 32) dl[lane] = dist[min(e0 + lane, M - 1)];
         // this tile's h1 rows in accumulator layout: register r of block kb <-> edge row e0 + (r&3) + 8(r>>2) + 4h, channel 32kb + l31
@@ -181,7 +180,6 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
         };
         split_x(q[0], 0);
         read_w(p[0], 0);
-        FB_MARK(0)
 #pragma unroll
         for (int grp = 0; grp < 2 * S; ++grp) {
             const int s = grp >> 1, kb = (grp & 1) * 2;
@@ -200,7 +198,6 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
         }
-        FB_MARK(1)
         // ---- rbf B fragments of the tile: [e-step s2][column block jb], lane (column 32jb + l31, edge group h) ---------------
         bf16x8 rb[2][2][3];
 #pragma unroll
@@ -220,7 +217,6 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                 fb_split3(rv, rb[s2][jb][0], rb[s2][jb][1], rb[s2][jb][2]);
             }
         }
-        FB_MARK(2)
         constexpr int PP2[6] = {0, 1, 2, 0, 1, 0};             // (a3,b1) (a2,b2) (a1,b3) (a2,b1) (a1,b2) (a1,b1)
         // ---- epilogue per channel block: dh1 = acc * ssp'(h1), then dw1[32kb.., :] += dh1^T rbf ----------------------------
 #pragma unroll
@@ -245,7 +241,6 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                                                                                 rb[s2][jb][PP2[t]], dwacc[kb][jb], 0, 0, 0);
             }
         }
-        FB_MARK(3)
     }
 
     // ---- the four waves' partial sums -> one slab per workgroup (waves added in the fixed order 0,1,2,3) -------------------
@@ -272,11 +267,8 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
         slab[idx] = RED[k * JP + j];
     }
     if (tid < F) bias_slabs[(size_t)blockIdx.x * F + tid] = RED[tid * JP + JP - 1];
-#ifdef FB_PROF
-    __syncthreads();
-    if (lane == 0) for (int i = 0; i < 5; ++i) bias_slabs[(size_t)blockIdx.x * F + wave * 8 + i] = (float)tph[i];
-#endif
 }
+
 
 }  // namespace
 

@@ -58,9 +58,4 @@ if hasattr(_lib.lib(), "conan_filter_bwd"):
     dh = (g.double() @ w2.double()) * (1 - 0.5 * torch.exp(-h1.double()))
     rw, rbias = dh.t() @ rb, dh.sum(0)
     extra = f"   fused dx+dw1 {tf:7.1f} us (err {float((dwf.double() - rw).abs().max() / rw.abs().max()):.1e}, bias {float((dbf.double() - rbias).abs().max() / rbias.abs().max()):.1e})"
-if os.environ.get("FB_PROF") and extra:
-    sl = _lib.lib().conan_filter_bwd_slices(P); kf(); torch.cuda.synchronize()
-    bs = ws2[sl * F * Gs:].view(sl, F)[:, :32].view(sl, 4, 8)[:, :, :5].double()
-    tot = bs.sum(-1)
-    print("phase cycles per wave (mean over waves): wait-x/split0 %.0f  main GEMM %.0f  rbf %.0f  epilogue+dw1 %.0f  other %.0f   total %.0f (max %.0f)  tiles/wave %.2f" % (*bs.mean((0, 1)).tolist(), tot.mean(), tot.max(), (P + 31) // 32 / (sl * 4)))
 print(f"{tag} wgrad[128x128] {t2:7.1f} us (err {e2:.1e})   rbf wgrad[128x50] {t4:7.1f} us (err {e4:.1e}, bias {eb:.1e})   dx+ssp' {t3:7.1f} us{extra}")
