@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3      # dense fp32 matrix peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 matrix peak (MI355X_MICROARCH.md; 2:1-sparsity figures are never used)
 
 
 def parse(argv=None):
@@ -288,7 +289,7 @@ def run_rank(args):
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream())
     ev, ev_empty = [], []
-    ev_other = {"conan_filter_fwd": [], "conan_fgw_barycenter_fwd": []}
+    ev_other = {"conan_filter_fwd": [], "conan_filter_bwd": [], "conan_fgw_barycenter_fwd": []}
     with torch.cuda.stream(side):
         # ---- eager warm-up (also: gradient-order calibration for the overlapped all-reduce of the eager step)
         overlap = args.overlap and train and use_dist and world > 1      # opt-in: the default run keeps ONE collective per step on every path
@@ -461,9 +462,22 @@ def run_rank(args):
     if ev_other["conan_filter_fwd"]:
         t_ms = mean_ms(ev_other["conan_filter_fwd"])
         fl = P * 2.0 * (50 * 128 + 128 * 128)                       # (2*Gs*F + 2*F*F) per filter row; P rows (pairs)
-        other.append({"kernel": "k_filter_fused (rbf -> filter MLP -> cosine cutoff)", "bound": "mfma", "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2),
-                      "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), "avg_launch_ms": round(t_ms, 5),
-                      "note": "fp32-equivalent algorithmic FLOP vs the fp32 MFMA peak; the second GEMM runs as an exact 3-way bf16 split"})
+        issued = P * 6 * 2.0 * (64 * 128 + 128 * 128)              # what the matrix pipe executes: 6 bf16 partial products per fp32 product, Gs padded to 64
+        other.append({"kernel": "k_filter_fused (rbf -> filter MLP -> cosine cutoff)", "bound": "mfma", "achieved": round(issued / (t_ms * 1e-3) / 1e12, 1),
+                      "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(issued / (t_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4), "avg_launch_ms": round(t_ms, 5),
+                      "algorithmic_fp32_tflops": round(fl / (t_ms * 1e-3) / 1e12, 2),
+                      "note": "both GEMMs run as exact 3-way bf16 splits (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block): `achieved` counts the issued bf16 "
+                              "FLOP against the dense bf16 peak; algorithmic_fp32_tflops is the fp32-equivalent rate (2*(50*F + F*F) per row) for reference "
+                              "(fp32 MFMA peak 157.3 TF/s)"})
+    if ev_other["conan_filter_bwd"]:
+        t_ms = mean_ms(ev_other["conan_filter_bwd"])
+        byts = P * (2 * 4 * 128 + 4)                                # compulsory: g and h1 rows in, distances in; the [128 x 50] slabs are noise
+        issued = P * 6 * 2.0 * (128 * 128 + 64 * 128)               # dx GEMM + the dh1^T rbf contraction (Gs padded to 64), 6 bf16 partial products each
+        other.append({"kernel": "k_filter_bwd (filter-network backward: (g w2) * ssp'(h1) in registers, contracted with the regenerated rbf)", "bound": "hbm",
+                      "achieved": round(byts / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "avg_launch_ms": round(t_ms, 5), "issued_bf16_tflops": round(issued / (t_ms * 1e-3) / 1e12, 1),
+                      "note": "event bracket around kernel + slab write (the slab reduction is batched elsewhere); counters: MFMA 35 % + VALU 34 % of the SIMD "
+                              "cycles, 14 % of the MFMA cycles overlapped - bound by the sum of the two pipes (bf16 splitting), not by HBM"})
     if ev_other["conan_fgw_barycenter_fwd"]:
         t_ms = mean_ms(ev_other["conan_fgw_barycenter_fwd"])
         N_, d_ = b.max_nodes, 64

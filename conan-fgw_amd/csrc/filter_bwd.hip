@@ -21,10 +21,11 @@
 // workgroups are reduced by the batched reducer of gemm.hip (bitwise reproducible, no float atomics).
 //
 // Measured at cfg2 (259 k rows): 94 us against 106 + 71 us for the two kernels it replaces (264 MB instead of 704 MB of HBM
-// traffic).  rocprofv3 counters: 2.33 M MFMAs (35 % of the SIMD cycles), 14.6 M VALU instructions — 60 % of them the bf16
-// splitting of g, dh1 and rbf — and only a third of the MFMA cycles overlapped by VALU work; the kernel is bound by the sum of
-// the two, not by HBM (floor 61 us).  A variant with two waves per tile (half the channel blocks each, 96 accumulator
-// registers, 2 waves per SIMD) measured the same 94-98 us: what it gains in overlap it pays in duplicated splitting.
+// traffic).  rocprofv3 counters (2.17 GHz under this load): 2.33 M MFMAs = 35 % of the SIMD cycles, 18.2 M VALU instructions
+// = 34 % — more than half of them the bf16 splitting of g, dh1 and rbf — and only 14 % of the MFMA cycles have VALU work
+// running beside them: the kernel is bound by the SUM of the two pipes, not by HBM (floor 61 us).  A variant with two waves per
+// tile (half the channel blocks each, 96 accumulator registers, 2 waves per SIMD) overlapped more (31 %) but issued 24 M VALU
+// instructions for the duplicated splitting and measured the same 95-98 us.
 #include "common.h"
 
 namespace {
