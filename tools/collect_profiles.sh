@@ -10,13 +10,15 @@ $B --shape lipo --batch 128 --no-cpu-baseline > $O/bench_lipo.json 2>/dev/null
 $B --model visnet --shape bace --batch 64 --no-cpu-baseline > $O/bench_visnet_bace.json 2>/dev/null
 $B --shape freesolv --conformers 20 --batch 64 --no-cpu-baseline > $O/bench_freesolv_k20.json 2>/dev/null
 python3 $R/tools/cfconv_cold.py > $O/cfconv_cold.json 2>/dev/null
+python3 $R/tools/probe_stream_bw.py > $O/stream_bw.txt 2>/dev/null
+python3 $R/tools/probe_step.py "" fused conan_filter_bwd_supported 2>/dev/null | grep "step ms" > $O/ab_filter_bwd.txt
 for cfg in "train:" "lipo:--shape lipo --batch 128" "visnet_bace:--model visnet --shape bace --batch 64" "freesolv_k20:--shape freesolv --conformers 20 --batch 64"; do
   name=${cfg%%:*}; fl=${cfg#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o $name -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --eager $fl > /dev/null 2>&1
 done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > $O/pmc_sq.log 2>&1
 python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/r2_pmc_hbm.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_hbm.txt 2>&1
 python3 $R/tools/pmc_sq.py $O/pmc_sq $O/r2_pmc_mfma.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_sq.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head; ls $O

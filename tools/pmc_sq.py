@@ -40,13 +40,21 @@ def main():
         if dur.get(k):
             ns = sum(dur[k]) / len(dur[k])
             rec["avg_duration_us_under_pmc"] = round(ns / 1e3, 2)
+            # kernel cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs (it gives ~2.1-2.3 GHz under load on this part); without it the
+            # nominal 2.4 GHz is assumed, which understates every fraction below
+            cyc = rec["GRBM_GUI_ACTIVE"] / 8.0 if rec.get("GRBM_GUI_ACTIVE") else ns * CLOCK_GHZ
+            rec["clock_ghz"] = round(cyc / ns, 3)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in rec:
-                rec["mfma_busy_frac"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * ns * CLOCK_GHZ), 4)
+                rec["mfma_busy_frac"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 4)
+            if "SQ_INSTS_VALU" in rec:
+                rec["valu_issue_frac"] = round(4.0 * rec["SQ_INSTS_VALU"] / (SIMDS * cyc), 4)        # a wave64 VALU instruction occupies its SIMD for 4 cycles
+            if "SQ_VALU_MFMA_COEXEC_CYCLES" in rec and rec.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                rec["mfma_cycles_with_valu_beside"] = round(rec["SQ_VALU_MFMA_COEXEC_CYCLES"] / rec["SQ_VALU_MFMA_BUSY_CYCLES"], 4)
         kernels[k] = rec
     json.dump({"note": "rocprofv3 --kernel-trace --pmc <SQ counters> on `%s`; per-launch averages; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
-                       "(1024 SIMDs x duration x 2.4 GHz)" % cmd, "kernels": kernels}, open(out, "w"), indent=1)
-    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:12]:
-        print(f"{k:40s} {v['launches']:4d}  mfma_busy_frac={v.get('mfma_busy_frac')}  dur={v.get('avg_duration_us_under_pmc')} us")
+                       "(1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_issue_frac = 4 x SQ_INSTS_VALU / the same" % cmd, "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:14]:
+        print(f"{k:40s} {v['launches']:4d}  mfma_busy={v.get('mfma_busy_frac')}  valu_issue={v.get('valu_issue_frac')}  clock={v.get('clock_ghz')} GHz  dur={v.get('avg_duration_us_under_pmc')} us")
 
 
 if __name__ == "__main__":
