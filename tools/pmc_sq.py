@@ -42,7 +42,7 @@ def main():
             rec["avg_duration_us_under_pmc"] = round(ns / 1e3, 2)
             # kernel cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs (it gives ~2.1-2.3 GHz under load on this part); without it the
             # nominal 2.4 GHz is assumed, which understates every fraction below
-            cyc = rec["GRBM_GUI_ACTIVE"] / 8.0 if rec.get("GRBM_GUI_ACTIVE") else ns * CLOCK_GHZ
+            cyc = min(rec["GRBM_GUI_ACTIVE"] / 8.0, ns * CLOCK_GHZ) if rec.get("GRBM_GUI_ACTIVE") else ns * CLOCK_GHZ     # (the counter also runs a little before / after a short kernel)
             rec["clock_ghz"] = round(cyc / ns, 3)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in rec:
                 rec["mfma_busy_frac"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 4)
