@@ -98,3 +98,30 @@ def test_backward_matches_oracle_autograd(H, shape, B, K):
         assert rel(p.grad.detach().cpu().numpy(), q.grad.numpy()) < 2e-3, name
         checked += 1
     assert checked > 100
+
+
+def test_edge_buffer_tails_are_never_read():
+    """The worst-case-sized edge buffers are handed out uninitialised (visnet_ops._tail0_shape): outputs and every parameter gradient
+    must be bitwise independent of what the allocator's recycled blocks contain — the same forward + backward is run after the
+    caching allocator's free blocks were filled with zeros and after they were filled with NaNs."""
+    b = make_batch("bace", 2, 3, seed=31)                        # cap-32 truncation active: max_edges is well above the edge count
+    z, pos, batch = torch.from_numpy(b.z).to(dev), torch.from_numpy(b.pos).to(dev), torch.from_numpy(b.batch).to(dev)
+    torch.manual_seed(9)
+    m = ViSNet(dev, hidden_channels=64).to(dev)
+
+    def run(fill):
+        junk = [torch.full((1 << 22,), fill, device=dev) for _ in range(24)]           # 384 MiB of recycled blocks in many sizes' pools
+        junk += [torch.full((n,), fill, device=dev) for n in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20) for _ in range(8)]
+        del junk
+        for p in m.parameters():
+            p.grad = None
+        h3, hb = m.forward_w_barycenter(z, pos, 3, batch)
+        (h3.sum() + hb.sum()).backward()
+        torch.cuda.synchronize()
+        return [h3.detach().clone(), hb.detach().clone()] + [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]
+
+    a, c = run(0.0), run(float("nan"))
+    assert len(a) == len(c) and len(a) > 50
+    for u, v in zip(a, c):
+        assert torch.isfinite(v).all()
+        assert torch.equal(u, v)
