@@ -32,6 +32,11 @@ class WgradJob(ctypes.Structure):
     _fields_ = [("ws", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("M", c_int), ("K", c_int), ("N", c_int), ("slices", c_int)]
 
 
+class WgradSlabJob(ctypes.Structure):
+    """Mirror of `conan_wgrad_slab_job` (include/conan_fgw_hip.h)."""
+    _fields_ = [("g", c_void_p), ("x", c_void_p), ("m_dev", c_void_p), ("ws", c_void_p), ("M", c_int), ("K", c_int), ("N", c_int), ("slices", c_int)]
+
+
 # name -> (restype, argtypes); kept in the header's order.  tests/test_abi.py checks this table against the header.
 _P = c_void_p
 SIGNATURES = {
@@ -67,6 +72,7 @@ SIGNATURES = {
     "conan_linear_wgrad_slabs": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_rbf_wgrad_slabs": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P]),
     "conan_wgrad_reduce_batch": (c_int, [ctypes.POINTER(WgradJob), c_int, _P]),
+    "conan_linear_wgrad_slabs_batch": (c_int, [ctypes.POINTER(WgradSlabJob), c_int, _P]),
     "conan_filter_bwd_supported": (c_int, [c_int, c_int]),
     "conan_filter_bwd_slices": (c_int, [c_int]),
     "conan_filter_bwd_ws": (c_ll, [c_int, c_int, c_int]),

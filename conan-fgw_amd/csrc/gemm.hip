@@ -246,7 +246,6 @@ __global__ void k_ssp_bwd(const float *__restrict__ dy, const float *__restrict_
 // Stage 1: the rows are cut into slices, one workgroup per (slice, 128x128 tile of dW), partial slabs written per slice.
 // Stage 2: the per-slice slabs are summed in a fixed order => bitwise reproducible, no float atomics.
 constexpr int WG_SLICES_MAX = 768;      // 3 workgroups per CU
-constexpr int WG_U = 16;            // row pairs in flight
 
 
 // bf16-split arithmetic of the weight gradient: 16 rows per MFMA step; an operand fragment (8 consecutive rows of one
@@ -282,11 +281,13 @@ __device__ __forceinline__ f32x16 wg_mma6(const bf16x8 &a1, const bf16x8 &a2, co
 // KT = 128: 2x2 waves of 64x64;  KT = 64: 4 waves of 32(n) x 64(k).
 // RBF = true: the x operand is the Gaussian expansion of dist[] (GaussianSmearing) generated by the producers instead of
 // loaded — the backward of the first filter layer then reads no [P, 50] buffer at all.
+// `slice` of `num_slices` row slices, 128-row tile `tile_n` of N, KT-wide tile `tile_k` of K: blockIdx / gridDim of the plain launch,
+// decoded from a job table by the batched one.
 template <int KT, bool RBF>
-__global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
-                                                   int rows_per_slice, float *__restrict__ slabs, float *__restrict__ bias_slabs,
-                                                   const int *__restrict__ m_dev, const float *__restrict__ dist,
-                                                   const float *__restrict__ offset, float coeff) {
+__device__ __forceinline__ void wgrad_lds_body(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
+                                               float *__restrict__ slabs, float *__restrict__ bias_slabs,
+                                               const int *__restrict__ m_dev, const float *__restrict__ dist,
+                                               const float *__restrict__ offset, float coeff, int slice, int num_slices, int tile_n, int tile_k) {
     constexpr int ROWS = 16, RG = ROWS / 8, W = 128 + KT, FRAGS = RG * W, NF = (FRAGS + 255) / 256;
     constexpr int TNB = KT == 128 ? 2 : 1;
     static_assert(W % 64 == 0, "a wave's 64 fragments share one row group and one operand");
@@ -295,13 +296,11 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n0 = KT == 128 ? (wave >> 1) * 64 : wave * 32, k0 = KT == 128 ? (wave & 1) * 64 : 0;     // inside the tile
-    const int nb = blockIdx.y * 128, kb = blockIdx.z * KT;
-    const int slice = blockIdx.x;
+    const int nb = tile_n * 128, kb = tile_k * KT;
     // stages are dealt round-robin: slice s owns rows [16 t, 16 t + 16) for t = s, s + slices, ...  At any moment the
     // resident workgroups then stream one contiguous window of g and x (all HBM channels busy) instead of `slices`
     // streams a power-of-two stride apart.
-    const int r_begin = slice * ROWS, r_end = M, STEP = (int)gridDim.x * ROWS;
-    (void)rows_per_slice;
+    const int r_begin = slice * ROWS, r_end = M, STEP = num_slices * ROWS;
     f32x16 acc[TNB][2];
 #pragma unroll
     for (int a = 0; a < TNB; ++a)
@@ -427,7 +426,7 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
                 const int k = kb + k0 + b * 32 + l31;
                 if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
             }
-    if (blockIdx.z == 0) {                       // bias gradient = column sums of g, combined over the row groups in LDS
+    if (tile_k == 0) {                           // bias gradient = column sums of g, combined over the row groups in LDS
         float *bp = reinterpret_cast<float *>(&frag[0][0][0][0]);            // [RG][128]; the stages are idle by now
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -440,6 +439,38 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
             bias_slabs[(size_t)slice * N + nb + tid] = t;
         }
     }
+}
+
+template <int KT, bool RBF>
+__global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
+                                                   float *__restrict__ slabs, float *__restrict__ bias_slabs,
+                                                   const int *__restrict__ m_dev, const float *__restrict__ dist,
+                                                   const float *__restrict__ offset, float coeff) {
+    wgrad_lds_body<KT, RBF>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
+// Many weight gradients in ONE launch.  A node-level layer (25 k rows) is a latency chain of 8 stages in 198 workgroups — 16-21 us
+// with most of the chip idle — and a backward pass of the stage-2 model has 22 of them, all independent of each other once their
+// g and x exist.  Workgroup b belongs to the job whose [first, first + count) range contains it and is decoded into (slice, n tile,
+// k tile) there; per-job arithmetic and slab layout are exactly those of the plain launch (bitwise-equal results).
+constexpr int WGS_BATCH = 24;
+struct WgradSlabJobs {
+    const float *g[WGS_BATCH], *x[WGS_BATCH];
+    const int *m_dev[WGS_BATCH];
+    float *slabs[WGS_BATCH], *bias_slabs[WGS_BATCH];
+    int M[WGS_BATCH], K[WGS_BATCH], N[WGS_BATCH], slices[WGS_BATCH], tiles_n[WGS_BATCH], first[WGS_BATCH + 1];
+    int count;
+};
+template <int KT>
+__global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds_batch(const WgradSlabJobs J) {
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < J.count && b >= J.first[j + 1]) ++j;            // uniform scan over <= 24 entries held in scalar registers
+    const int local = b - J.first[j];
+    const int slice = local % J.slices[j], rest = local / J.slices[j];
+    const int tile_n = rest % J.tiles_n[j], tile_k = rest / J.tiles_n[j];
+    wgrad_lds_body<KT, false>(J.g[j], J.x[j], J.M[j], J.K[j], J.N[j], J.slabs[j], J.bias_slabs[j], J.m_dev[j], nullptr, nullptr, 0.f, slice,
+                              J.slices[j], tile_n, tile_k);
 }
 
 // slabs [slices][NK] (+ bias_slabs [slices][N]) -> out[g][NK] (+ bout[g][N]) for slice group g = blockIdx.y; fixed order.
@@ -637,18 +668,16 @@ static int wgrad_launch(const float *g, const float *x, int M, int K, int N, con
                         hipStream_t s, const float *dist, const float *offset, float coeff) {
     const bool rbf = dist != nullptr;
     const int slices = wgrad_slices(M, K);
-    int rows = (M + slices - 1) / slices;
-    rows = ((rows + 2 * WG_U - 1) / (2 * WG_U)) * (2 * WG_U);
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * N * K;
     {
         const int KT = K > 64 ? 128 : 64;
         dim3 grid(slices, (N + 127) / 128, (K + KT - 1) / KT);
         if (KT == 128) {
-            if (rbf) k_wgrad_lds<128, true><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
-            else k_wgrad_lds<128, false><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            if (rbf) k_wgrad_lds<128, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            else k_wgrad_lds<128, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
         } else {
-            if (rbf) k_wgrad_lds<64, true><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
-            else k_wgrad_lds<64, false><<<grid, 256, 0, s>>>(g, x, M, K, N, rows, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            if (rbf) k_wgrad_lds<64, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            else k_wgrad_lds<64, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
         }
     }
     const int NK = N * K;
@@ -709,6 +738,40 @@ int conan_rbf_wgrad_slabs(const float *g, const float *dist, int M, const float 
                           const int *m_dev, float *ws, void *stream) {
     if (!g || !dist || !offset || !ws || M < 0 || num_gaussians <= 0 || N <= 0 || !conan_wgrad_batchable(num_gaussians, N)) return CONAN_E_BADARG;
     return wgrad_launch(g, nullptr, M, num_gaussians, N, m_dev, nullptr, nullptr, ws, as_stream(stream), dist, offset, coeff);
+}
+
+int conan_linear_wgrad_slabs_batch(const conan_wgrad_slab_job *jobs, int num_jobs, void *stream) {
+    if (num_jobs < 0 || (num_jobs && !jobs)) return CONAN_E_BADARG;
+    hipStream_t s = as_stream(stream);
+    for (int j = 0; j < num_jobs; ++j) {
+        const conan_wgrad_slab_job &b = jobs[j];
+        if (!b.g || !b.x || !b.ws || b.M < 0 || b.K <= 0 || b.N <= 0 || b.slices < 0 || !conan_wgrad_batchable(b.K, b.N)) return CONAN_E_BADARG;
+    }
+    for (int wide = 0; wide < 2; ++wide) {                  // one launch sequence per k-tile width (two template instantiations)
+        WgradSlabJobs J;
+        J.count = 0; J.first[0] = 0;
+        auto flush = [&]() {
+            if (!J.count) return;
+            if (wide) k_wgrad_lds_batch<128><<<J.first[J.count], 256, 0, s>>>(J);
+            else k_wgrad_lds_batch<64><<<J.first[J.count], 256, 0, s>>>(J);
+            J.count = 0; J.first[0] = 0;
+        };
+        for (int j = 0; j < num_jobs; ++j) {
+            const conan_wgrad_slab_job &b = jobs[j];
+            if ((b.K > 64) != (wide != 0) || b.M == 0) continue;
+            const int KT = wide ? 128 : 64, q = J.count;
+            const int dflt = wgrad_slices(b.M, b.K), slices = (b.slices > 0 && b.slices <= dflt) ? b.slices : dflt;
+            const int tn = (b.N + 127) / 128, tk = (b.K + KT - 1) / KT;
+            J.g[q] = b.g; J.x[q] = b.x; J.m_dev[q] = b.m_dev;
+            J.slabs[q] = b.ws; J.bias_slabs[q] = b.ws + (size_t)slices * b.N * b.K;
+            J.M[q] = b.M; J.K[q] = b.K; J.N[q] = b.N; J.slices[q] = slices; J.tiles_n[q] = tn;
+            J.first[q + 1] = J.first[q] + slices * tn * tk;
+            if (++J.count == WGS_BATCH) flush();
+        }
+        flush();
+    }
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
 }
 
 int conan_wgrad_reduce_batch(const conan_wgrad_job *jobs, int num_jobs, void *stream) {

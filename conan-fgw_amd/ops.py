@@ -112,7 +112,9 @@ def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
 # `deferred_weight_gradients()` the second stage of every Linear layer of a backward pass is postponed and run as ONE launch
 # (conan_wgrad_reduce_batch) by `flush_weight_gradients()` — FlatGradients.pack() calls it — instead of 24 launches of ~6 us each.
 # The returned dW / db tensors are only valid after the flush; a weight that appears twice in one backward (autograd would add
-# the two results right away) flushes on the spot and takes the immediate path, so results never depend on the mode.
+# the two results right away) flushes on the spot and takes the immediate path.  Node-level layers postpone their slab kernel as well
+# (one batched launch, 256-row slices): their sums differ from the immediate mode's by the fp32 summation order only; each mode is
+# bitwise reproducible.
 _pending = None            # None: immediate mode; list of pending jobs (dicts) while deferring
 
 
@@ -139,12 +141,24 @@ def flush_weight_gradients():
     if not _pending:
         return {}
     import ctypes
-    from ._lib import WgradJob
+    from ._lib import WgradJob, WgradSlabJob
     jobs = (WgradJob * len(_pending))()
     cur = torch.cuda.current_stream()
     for st in {j["stream"] for j in _pending}:
         if st != cur:
             cur.wait_stream(st)                                   # slabs written on another stream (the covalent branch runs on one)
+    late = [j for j in _pending if "operands" in j]               # node-level layers: stage 1 was postponed as well (see _wgrad)
+    if late:
+        sj = (WgradSlabJob * len(late))()
+        for q, j in enumerate(late):
+            g, x, md = j["operands"]
+            sj[q].g, sj[q].x, sj[q].m_dev, sj[q].ws = ptr(g), ptr(x), ptr(md), ptr(j["ws"])
+            sj[q].M, sj[q].K, sj[q].N, sj[q].slices = j["M"], j["K"], j["N"], j["slices"]
+        call("conan_linear_wgrad_slabs_batch", sj, len(late), stream_ptr())
+        for j in late:
+            for t in j.pop("operands"):
+                if t is not None:
+                    t.record_stream(cur)
     for q, j in enumerate(_pending):
         jobs[q].ws, jobs[q].dW, jobs[q].dbias = ptr(j["ws"]), j["dw_ptr"], j["db_ptr"]
         jobs[q].M, jobs[q].K, jobs[q].N, jobs[q].slices = j["M"], j["K"], j["N"], j.get("slices", 0)
@@ -157,6 +171,7 @@ def flush_weight_gradients():
     return done
 
 
+_LATE_STAGE1_ROWS = 65536   # below this row count a weight gradient's slab kernel is postponed to the batched launch
 _flushed = {}              # weight data_ptr -> dW data_ptr of the last flushes (cleared by whoever verifies them)
 
 
@@ -175,8 +190,14 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
     if defer and any(j["weight_ptr"] == wptr for j in _pending):
         flush_weight_gradients()                                  # second use of the same weight in this backward: autograd adds the two at once
         defer = False
+    # Node-level layers (a few ten thousand rows) are latency chains that leave most of the chip idle: in deferred mode their slab
+    # kernels are postponed too and all of them run as ONE launch at the flush (conan_linear_wgrad_slabs_batch).  g and x stay alive
+    # until then (a node-level pair is 26 MB); edge-level layers already fill the chip and keep their immediate stage 1.
+    late = defer and rbf is None and M <= _LATE_STAGE1_ROWS
     if rbf is None:
-        if defer:
+        if late:
+            pass
+        elif defer:
             call("conan_linear_wgrad_slabs", ptr(g), ptr(x), M, K, N, ptr(md), ptr(ws), stream_ptr())
         else:
             call("conan_linear_wgrad", ptr(g), ptr(x), M, K, N, ptr(md), ptr(dw), ptr(db), ptr(ws), stream_ptr())
@@ -190,6 +211,8 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
         _pending.append(dict(ws=ws, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr() if db is not None else None,
                              keep=(dw.untyped_storage(), db.untyped_storage() if db is not None else None),
                              M=M, K=K, N=N, weight_ptr=wptr, stream=torch.cuda.current_stream()))
+        if late:                                                   # 256 rows per slice instead of 128: half the slab volume, the batch keeps the chip busy
+            _pending[-1]["operands"], _pending[-1]["slices"] = (g, x, md), max(1, (M + 255) // 256)
     return dw, db
 
 

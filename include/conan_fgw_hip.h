@@ -174,6 +174,20 @@ int conan_linear_wgrad_slabs(const float *g, const float *x, int M, int K, int N
 int conan_rbf_wgrad_slabs(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,
                           const int *m_dev, float *ws, void *stream);
 int conan_wgrad_reduce_batch(const conan_wgrad_job *jobs, int num_jobs, void *stream);
+/* Stage 1 of MANY weight gradients in one launch (per k-tile width): job j is exactly conan_linear_wgrad_slabs(g, x, M, K, N, m_dev, ws)
+ * — same slabs, same bits — but the jobs' workgroups share one grid.  A node-level layer alone (25 k rows) is 198 latency-bound
+ * workgroups on a 256-CU chip; the 22 of a stage-2 backward pass, postponed until their g and x all exist, fill it.  The caller keeps
+ * g, x and ws alive until the launch has run; the slabs are then reduced with conan_wgrad_reduce_batch as usual. */
+typedef struct {
+    const float *g, *x;      /* [M,N], [M,K] */
+    const int *m_dev;        /* nullable device-side row count */
+    float *ws;               /* conan_linear_wgrad_ws(M, K, N) floats */
+    int M, K, N;
+    int slices;              /* 0: as conan_linear_wgrad_slabs; > 0: this many row slices (<= the default count; the same value then goes
+                                into conan_wgrad_job.slices).  With many jobs in flight fewer, longer slices keep the chip just as
+                                busy and shrink the slab volume the reducer has to read. */
+} conan_wgrad_slab_job;
+int conan_linear_wgrad_slabs_batch(const conan_wgrad_slab_job *jobs, int num_jobs, void *stream);
 
 /* Backward of the filter network below its second Linear, fused (filter_bwd.hip):
  *     dh1 = (g @ w2) * ssp'(h1) ;  dW1[F,Gs] = dh1^T rbf(dist) ;  db1[F] = colsum(dh1)

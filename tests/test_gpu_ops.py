@@ -191,6 +191,51 @@ def test_rbf_wgrad_matches_materialised_rbf(M, N, Gs):
     assert rel(db.double().cpu().numpy(), g[:M].double().sum(0).cpu().numpy()) < 1e-5
 
 
+def test_wgrad_slabs_batch_equals_the_per_job_launches():
+    """conan_linear_wgrad_slabs_batch: many weight gradients' stage 1 in one launch per k-tile width.  With default slice counts the slabs
+    (hence the reduced dW / db) are bit-identical to conan_linear_wgrad_slabs job by job; with fewer, longer slices the result agrees with
+    the fp64 product to fp32 rounding; a device-side row count masks the tail; M = 0 jobs are skipped."""
+    from conan_fgw_amd._lib import WgradJob, WgradSlabJob, call, lib, ptr, stream_ptr
+    shapes = [(3000, 128, 128), (2500, 64, 128), (777, 64, 64), (5000, 128, 64), (1, 128, 128), (300, 32, 128), (4000, 256, 128)]
+    gen = torch.Generator().manual_seed(7)
+    gs = [torch.randn(M + 9, N, generator=gen).to(dev) for M, K, N in shapes]
+    xs = [torch.randn(M + 9, K, generator=gen).to(dev) for M, K, N in shapes]
+    mds = [torch.tensor([M], dtype=torch.int32, device=dev) if i % 2 else None for i, (M, K, N) in enumerate(shapes)]
+    rows = [M if mds[i] is not None else M + 9 for i, (M, K, N) in enumerate(shapes)]
+
+    def reduce(wss, slices):
+        jobs = (WgradJob * len(shapes))()
+        out = []
+        for q, (M, K, N) in enumerate(shapes):
+            dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+            jobs[q].ws, jobs[q].dW, jobs[q].dbias = wss[q].data_ptr(), dW.data_ptr(), db.data_ptr()
+            jobs[q].M, jobs[q].K, jobs[q].N, jobs[q].slices = M + 9, K, N, slices[q]
+            out.append((dW, db))
+        call("conan_wgrad_reduce_batch", jobs, len(shapes), stream_ptr())
+        return out
+
+    def batch(slices):
+        wss = [torch.empty(int(lib().conan_linear_wgrad_ws(M + 9, K, N)), device=dev) for M, K, N in shapes]
+        sj = (WgradSlabJob * len(shapes))()
+        for q, (M, K, N) in enumerate(shapes):
+            sj[q].g, sj[q].x, sj[q].m_dev, sj[q].ws = gs[q].data_ptr(), xs[q].data_ptr(), mds[q].data_ptr() if mds[q] is not None else None, wss[q].data_ptr()
+            sj[q].M, sj[q].K, sj[q].N, sj[q].slices = M + 9, K, N, slices[q]
+        call("conan_linear_wgrad_slabs_batch", sj, len(shapes), stream_ptr())
+        return reduce(wss, slices)
+
+    wss = [torch.empty(int(lib().conan_linear_wgrad_ws(M + 9, K, N)), device=dev) for M, K, N in shapes]
+    for q, (M, K, N) in enumerate(shapes):
+        call("conan_linear_wgrad_slabs", ptr(gs[q]), ptr(xs[q]), M + 9, K, N, ptr(mds[q]), ptr(wss[q]), stream_ptr())
+    one_by_one = reduce(wss, [0] * len(shapes))
+    batched = batch([0] * len(shapes))
+    long_slices = batch([max(1, (M + 9 + 255) // 256) for M, K, N in shapes])
+    for q, (M, K, N) in enumerate(shapes):
+        ref = gs[q][:rows[q]].double().T @ xs[q][:rows[q]].double()
+        assert torch.equal(batched[q][0], one_by_one[q][0]) and torch.equal(batched[q][1], one_by_one[q][1]), shapes[q]
+        assert rel(long_slices[q][0].double().cpu().numpy(), ref.cpu().numpy()) < 1e-5, shapes[q]
+        assert rel(long_slices[q][1].double().cpu().numpy(), gs[q][:rows[q]].double().sum(0).cpu().numpy()) < 1e-5, shapes[q]
+
+
 @pytest.mark.parametrize("M,Gs", [(1, 50), (31, 50), (4133, 50), (40000, 50), (3000, 20), (2500, 63)])
 def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs):
     """conan_filter_bwd (dh1 = (g w2) * ssp'(h1) kept in registers, dW1 = dh1^T rbf, db1 = colsum dh1) against the fp64 formula and

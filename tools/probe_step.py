@@ -42,16 +42,21 @@ def block(n=20):
 
 
 L = _lib.lib()
+py_off = [o for o in off if o == "late_stage1"]            # python-level switch: node-level slab kernels immediate instead of batched
+off = [o for o in off if o not in py_off]
 saved = {name: getattr(L, name) for name in off}
+late_rows = ops._LATE_STAGE1_ROWS
 side = torch.cuda.Stream(device=dev); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(5): step()
     res = {"on": [], "off": []}
     for rep in range(4):
         res["on"].append(block())
-        if off:
+        if off or py_off:
             for name in off: setattr(L, name, lambda *a: 0)
+            if py_off: ops._LATE_STAGE1_ROWS = 0
             block(3); res["off"].append(block())
             for name in off: setattr(L, name, saved[name])
+            ops._LATE_STAGE1_ROWS = late_rows
             block(3)
-print(tag, "step ms:", " ".join("%.3f" % t for t in res["on"]), ("| with %s off: " % ",".join(off) + " ".join("%.3f" % t for t in res["off"])) if off else "")
+print(tag, "step ms:", " ".join("%.3f" % t for t in res["on"]), ("| with %s off: " % ",".join(off + py_off) + " ".join("%.3f" % t for t in res["off"])) if (off or py_off) else "")
