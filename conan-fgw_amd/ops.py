@@ -113,8 +113,7 @@ def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
 # (conan_wgrad_reduce_batch) by `flush_weight_gradients()` — FlatGradients.pack() calls it — instead of 24 launches of ~6 us each.
 # The returned dW / db tensors are only valid after the flush; a weight that appears twice in one backward (autograd would add
 # the two results right away) flushes on the spot and takes the immediate path.  Node-level layers postpone their slab kernel as well
-# (one batched launch, 256-row slices): their sums differ from the immediate mode's by the fp32 summation order only; each mode is
-# bitwise reproducible.
+# (one batched launch, same slices): results never depend on the mode, bit for bit.
 _pending = None            # None: immediate mode; list of pending jobs (dicts) while deferring
 
 
@@ -153,7 +152,7 @@ def flush_weight_gradients():
         for q, j in enumerate(late):
             g, x, md = j["operands"]
             sj[q].g, sj[q].x, sj[q].m_dev, sj[q].ws = ptr(g), ptr(x), ptr(md), ptr(j["ws"])
-            sj[q].M, sj[q].K, sj[q].N, sj[q].slices = j["M"], j["K"], j["N"], j["slices"]
+            sj[q].M, sj[q].K, sj[q].N, sj[q].slices = j["M"], j["K"], j["N"], 0      # default slice count: same slabs, same bits as the immediate form (256- and 512-row slices measured no faster)
         call("conan_linear_wgrad_slabs_batch", sj, len(late), stream_ptr())
         for j in late:
             for t in j.pop("operands"):
@@ -211,8 +210,8 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
         _pending.append(dict(ws=ws, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr() if db is not None else None,
                              keep=(dw.untyped_storage(), db.untyped_storage() if db is not None else None),
                              M=M, K=K, N=N, weight_ptr=wptr, stream=torch.cuda.current_stream()))
-        if late:                                                   # 256 rows per slice instead of 128: half the slab volume, the batch keeps the chip busy
-            _pending[-1]["operands"], _pending[-1]["slices"] = (g, x, md), max(1, (M + 255) // 256)
+        if late:
+            _pending[-1]["operands"] = (g, x, md)
     return dw, db
 
 
