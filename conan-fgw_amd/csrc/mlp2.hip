@@ -1,0 +1,296 @@
+// Two chained node-level Linear layers in ONE launch:
+//
+//     forward :  h = ssp(x W1^T + b1) ;  y  = h W2^T + b2 (+ residual)                 (InteractionBlock: conv.lin2 -> act -> lin, + x)
+//     backward:  dh = (dy W2) * ssp'(h) ;  dx = dh W1                                   (the two input-gradient GEMMs and the activation
+//                                                                                        derivative between them; h is the saved output)
+//
+// At node level (25 k rows) a Linear launch is mostly fixed cost — 8.4 us of 13.5 us are weight staging, one tile per wave, the
+// launch itself — and the layers of an interaction form a serial chain, so the only way to shorten it is to have fewer links.
+// Mapping (as filter_fused.hip): the row index lives on the MFMA column (= lane), the channel on the MFMA row.  A wave owns one
+// 32-row tile: GEMM1's B operand are its x rows straight from global memory (requested before the weights are staged), GEMM2's B
+// operand IS GEMM1's accumulator after the element-wise step (register r of lane-half h = channel 32nb + (r&3) + 8(r>>2) + 4h, so
+// the second weight is staged with the matching column permutation) — nothing crosses lanes or LDS between the two GEMMs.  Both
+// products are exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-class).  The LDS weight buffer is reused: stage W1,
+// barrier, GEMM1, barrier, stage W2, barrier, GEMM2.  `mid` (h forward, dh backward) is also written out: the weight gradients
+// of the two layers need it.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int M2_THREADS = 256, M2_WAVES = 4;
+
+__device__ __forceinline__ void m2_split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h1 = (__bf16)v[j];
+        const float r1 = v[j] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
+    }
+}
+
+// Three bf16 images of a weight as [n][k] (pitch KD + 8), staged by all threads in two steps so that the global loads of BOTH weights can
+// be in flight from the start of the kernel: m2_fetch (float4 loads into registers) and m2_park (split + 8-byte LDS stores).
+// src is [n][k] (TRANS = false: forward; a float4 = 4 consecutive k of one row) or [k][n] (TRANS = true: the backward reads the forward
+// weights transposed; a thread owns a 4(k) x 4(n) block, transposed in registers — lane mapping as gemm_t.hip: every 16-lane group covers
+// 16 distinct 8-byte bank slots).  PERM: inside every group of 16 k's the columns are stored in the order in which a lane-half
+// enumerates the accumulator registers of the previous GEMM (position 8h + j <-> (j&3) + 8(j>>2) + 4h); four consecutive, 4-aligned k's
+// stay consecutive under that permutation, so the 8-byte stores survive it.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int m2_perm4(int k, bool perm) {
+    if (!perm) return k;
+    const int a = (k & 15) >> 2;
+    return (k & ~15) + 8 * (a & 1) + 4 * (a >> 1);
+}
+__device__ __forceinline__ void m2_store4(__bf16 *WB, int NO, int WS, int n, int kp, const float *v4) {
+    bf16x4 h1, h2, h3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h1[e] = (__bf16)v4[e]; const float r1 = v4[e] - (float)h1[e];
+        h2[e] = (__bf16)r1; h3[e] = (__bf16)(r1 - (float)h2[e]);
+    }
+    *reinterpret_cast<bf16x4 *>(&WB[(0 * NO + n) * WS + kp]) = h1;
+    *reinterpret_cast<bf16x4 *>(&WB[(1 * NO + n) * WS + kp]) = h2;
+    *reinterpret_cast<bf16x4 *>(&WB[(2 * NO + n) * WS + kp]) = h3;
+}
+template <int NO, int KD, bool TRANS>
+struct M2Weight {
+    static constexpr int V4 = NO * KD / 4, PER = (V4 + M2_THREADS - 1) / M2_THREADS;                       // plain layout: float4s per thread
+    static constexpr int PATCHES = (KD / 16) * (NO / 64), PERW = (PATCHES + M2_WAVES - 1) / M2_WAVES;      // transposed layout: 16(k) x 64(n) patches per wave
+    float4 v[TRANS ? PERW * 4 : PER];
+    __device__ __forceinline__ void fetch(const float *__restrict__ w, int tid) {
+        const int lane = tid & 63, wave = tid >> 6;
+        if (!TRANS) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int q = tid + u * M2_THREADS;
+                v[u] = q < V4 ? *reinterpret_cast<const float4 *>(w + 4 * (size_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
+#pragma unroll
+            for (int u = 0; u < PERW; ++u) {
+                const int pt = wave + u * M2_WAVES;
+                const int k0 = (pt / (NO / 64)) * 16 + 4 * k4l, n0 = (pt % (NO / 64)) * 64 + 4 * n4l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[4 * u + j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * NO + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void park(__bf16 *__restrict__ WB, int tid, bool perm) const {
+        constexpr int WS = KD + 8;
+        const int lane = tid & 63, wave = tid >> 6;
+        if (!TRANS) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int q = tid + u * M2_THREADS;
+                if (q >= V4) continue;
+                const int n = (4 * q) / KD, k = 4 * q - n * KD;
+                const float v4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                m2_store4(WB, NO, WS, n, m2_perm4(k, perm), v4);
+            }
+        } else {
+            const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
+#pragma unroll
+            for (int u = 0; u < PERW; ++u) {
+                const int pt = wave + u * M2_WAVES;
+                if (pt >= PATCHES) continue;
+                const int k0 = (pt / (NO / 64)) * 16 + 4 * k4l, n0 = (pt % (NO / 64)) * 64 + 4 * n4l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                     // row n0 + e of the image: k0 .. k0 + 3
+                    const float v4[4] = {e == 0 ? v[4 * u].x : e == 1 ? v[4 * u].y : e == 2 ? v[4 * u].z : v[4 * u].w,
+                                         e == 0 ? v[4 * u + 1].x : e == 1 ? v[4 * u + 1].y : e == 2 ? v[4 * u + 1].z : v[4 * u + 1].w,
+                                         e == 0 ? v[4 * u + 2].x : e == 1 ? v[4 * u + 2].y : e == 2 ? v[4 * u + 2].z : v[4 * u + 2].w,
+                                         e == 0 ? v[4 * u + 3].x : e == 1 ? v[4 * u + 3].y : e == 2 ? v[4 * u + 3].z : v[4 * u + 3].w};
+                    m2_store4(WB, NO, WS, n0 + e, m2_perm4(k0, perm), v4);
+                }
+            }
+        }
+    }
+};
+
+// KA -> NA -> NB.  BWD = false: mid = ssp(acc1 + bA), y = acc2 + bB (+ residual).  BWD = true: mid = acc1 * ssp'(aux) with aux the saved
+// ssp output, y = acc2; weights read transposed, no biases.
+template <int KA, int NA, int NB, bool BWD>
+__global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x, const float *__restrict__ wA, const float *__restrict__ bA,
+                                                     const float *__restrict__ wB, const float *__restrict__ bB, const float *__restrict__ aux,
+                                                     const float *__restrict__ residual, int M, float *__restrict__ mid_out, float *__restrict__ y) {
+    constexpr int SA = KA / 16, SB = NA / 16, MBA = NA / 32, MBB = NB / 32;
+    constexpr int WSA = KA + 8, WSB = NA + 8;
+    constexpr int WORDS_A = (3 * NA * WSA) / 2, WORDS_B = (3 * NB * WSB) / 2, WORDS = WORDS_A > WORDS_B ? WORDS_A : WORDS_B;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);
+    float *BL = lds + WORDS;                                   // [NA + NB] biases
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * M2_WAVES + wave;
+    const int m = (tile << 5) + l31;
+    const bool valid = m < M;
+    const int mr = valid ? m : M - 1;
+
+    // the wave's x rows and (backward) the saved activations are requested before any weight is staged
+    float4 xa[SA], xb[SA];
+    {
+        const float *xr = x + (size_t)mr * KA + 8 * h;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) {
+            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
+            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
+        }
+    }
+    float4 av[MBA][4];
+    if (BWD) {
+        const float *ar = aux + (size_t)mr * NA + 4 * h;
+#pragma unroll
+        for (int nb = 0; nb < MBA; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[nb][q] = *reinterpret_cast<const float4 *>(ar + 32 * nb + 8 * q);
+    }
+    M2Weight<NA, KA, BWD> stA;
+    M2Weight<NB, NA, BWD> stB;
+    stA.fetch(wA, tid);
+    stB.fetch(wB, tid);                                        // in flight during the first GEMM
+    stA.park(WB, tid, false);
+    for (int t = tid; t < NA + NB; t += M2_THREADS) BL[t] = BWD ? 0.f : (t < NA ? bA[t] : bB[t - NA]);
+    __syncthreads();
+
+    // ---------------- GEMM1^T: acc1[nb] = WA[32nb.., :] . x^T
+    f32x16 acc1[MBA];
+#pragma unroll
+    for (int nb = 0; nb < MBA; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SA; ++s) {
+        const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+        bf16x8 q1, q2, q3;
+        m2_split3(xv, q1, q2, q3);
+        const int colp = 16 * s + 8 * h;
+#pragma unroll
+        for (int nb = 0; nb < MBA; ++nb) {
+            const int row = 32 * nb + l31;
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&WB[(0 * NA + row) * WSA + colp]);
+            const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&WB[(1 * NA + row) * WSA + colp]);
+            const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&WB[(2 * NA + row) * WSA + colp]);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc1[nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // element-wise step on the accumulators (register r of half h is channel 32nb + (r&3) + 8(r>>2) + 4h) and the `mid` output
+#pragma unroll
+    for (int nb = 0; nb < MBA; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+            if (BWD) {
+                const float a4[4] = {av[nb][q].x, av[nb][q].y, av[nb][q].z, av[nb][q].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = acc1[nb][4 * q + u] * (1.0f - 0.5f * __expf(-a4[u]));      // * ssp'(pre) from the saved output
+            } else {
+                const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
+                v[0] = ssp_f(acc1[nb][4 * q + 0] + bb.x); v[1] = ssp_f(acc1[nb][4 * q + 1] + bb.y);
+                v[2] = ssp_f(acc1[nb][4 * q + 2] + bb.z); v[3] = ssp_f(acc1[nb][4 * q + 3] + bb.w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc1[nb][4 * q + u] = v[u];
+            if (mid_out && valid)
+                *reinterpret_cast<float4 *>(mid_out + (size_t)m * NA + 32 * nb + 8 * q + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    __syncthreads();                                           // every wave is done with the first weight
+    stB.park(WB, tid, true);
+    float4 rv[MBB][4];
+    if (!BWD && residual) {
+        const float *rr = residual + (size_t)mr * NB + 4 * h;
+#pragma unroll
+        for (int nb = 0; nb < MBB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
+    }
+    __syncthreads();
+
+    // ---------------- GEMM2^T: acc2[nb] = WB[32nb.., :] . mid^T, B operand = acc1 (k order of the A fragments permuted to match)
+    f32x16 acc2[MBB];
+#pragma unroll
+    for (int nb = 0; nb < MBB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+#pragma unroll
+    for (int ms = 0; ms < SB; ++ms) {
+        const int mb = ms >> 1, sgrp = ms & 1;
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
+        bf16x8 q1, q2, q3;
+        m2_split3(hv, q1, q2, q3);
+        const int colp = 32 * mb + 16 * sgrp + 8 * h;
+#pragma unroll
+        for (int nb = 0; nb < MBB; ++nb) {
+            const int row = 32 * nb + l31;
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&WB[(0 * NB + row) * WSB + colp]);
+            const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&WB[(1 * NB + row) * WSB + colp]);
+            const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&WB[(2 * NB + row) * WSB + colp]);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc2[nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < MBB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4 *>(&BL[NA + 32 * nb + 8 * q + 4 * h]);
+            float4 o = make_float4(acc2[nb][4 * q] + bb.x, acc2[nb][4 * q + 1] + bb.y, acc2[nb][4 * q + 2] + bb.z, acc2[nb][4 * q + 3] + bb.w);
+            if (!BWD && residual) { o.x += rv[nb][q].x; o.y += rv[nb][q].y; o.z += rv[nb][q].z; o.w += rv[nb][q].w; }
+            *reinterpret_cast<float4 *>(y + (size_t)m * NB + 32 * nb + 8 * q + 4 * h) = o;
+        }
+}
+
+template <int KA, int NA, int NB, bool BWD>
+int m2_launch(const float *x, const float *wA, const float *bA, const float *wB, const float *bB, const float *aux, const float *residual, int M,
+              float *mid_out, float *y, hipStream_t s) {
+    constexpr int WA = (3 * NA * (KA + 8)) / 2, WBw = (3 * NB * (NA + 8)) / 2;
+    const size_t lds = ((size_t)(WA > WBw ? WA : WBw) + NA + NB) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp2<KA, NA, NB, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (M + 31) / 32;
+    k_mlp2<KA, NA, NB, BWD><<<(tiles + M2_WAVES - 1) / M2_WAVES, M2_THREADS, lds, s>>>(x, wA, bA, wB, bB, aux, residual, M, mid_out, y);
+    return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int conan_mlp2_supported(int M, int K, int N1, int N2) { return (K == 128 && N1 == 128 && N2 == 128 && M >= 1 && M <= 65536) ? 1 : 0; }
+
+int conan_mlp2_fwd(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *residual, int M, int K, int N1,
+                   int N2, float *mid_out, float *y, void *stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    if (!conan_mlp2_supported(M, K, N1, N2)) return CONAN_E_UNSUPPORTED;
+    return m2_launch<128, 128, 128, false>(x, w1, b1, w2, b2, nullptr, residual, M, mid_out, y, as_stream(stream));
+}
+
+int conan_mlp2_bwd(const float *dy, const float *w2, const float *w1, const float *mid, int M, int K, int N1, int N2, float *dmid_out, float *dx,
+                   void *stream) {
+    if (!dy || !w1 || !w2 || !mid || !dx || M < 0) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    if (!conan_mlp2_supported(M, K, N1, N2)) return CONAN_E_UNSUPPORTED;
+    // dy [M,N2] -> (W2 read as [N2][N1]: contraction over n2) -> dmid [M,N1] -> (W1 read as [N1][K]) -> dx [M,K]
+    return m2_launch<128, 128, 128, true>(dy, w2, nullptr, w1, nullptr, mid, nullptr, M, dmid_out, dx, as_stream(stream));
+}
+
+}  // extern "C"

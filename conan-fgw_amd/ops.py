@@ -280,6 +280,46 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: bool =
     return _LinearFn.apply(x, weight, bias, residual, 1 if act else 0, m_dev)
 
 
+class _Mlp2Fn(torch.autograd.Function):
+    """y = ssp(x w1^T + b1) w2^T + b2 (+ residual) in one launch; backward: one launch for both input-gradient GEMMs and the
+    activation derivative between them, then the two weight gradients (conan_mlp2_fwd / conan_mlp2_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        M, K = x.shape
+        N1, N2 = w1.shape[0], w2.shape[0]
+        need = any(ctx.needs_input_grad[:5])
+        mid = torch.empty(M, N1, dtype=f32, device=x.device) if need else None
+        y = torch.empty(M, N2, dtype=f32, device=x.device)
+        call("conan_mlp2_fwd", ptr(x, f32), ptr(w1, f32), ptr(_c(b1), f32), ptr(w2, f32), ptr(_c(b2), f32),
+             ptr(_c(residual)) if residual is not None else None, M, K, N1, N2, ptr(mid), ptr(y), stream_ptr())
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, w1, w2, mid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, mid = ctx.saved_tensors
+        dy = _c(dy)
+        M, K = x.shape
+        N1, N2 = w1.shape[0], w2.shape[0]
+        dmid = torch.empty(M, N1, dtype=f32, device=x.device)
+        dx = torch.empty(M, K, dtype=f32, device=x.device)
+        call("conan_mlp2_bwd", ptr(dy), ptr(w2), ptr(w1), ptr(mid), M, K, N1, N2, ptr(dmid), ptr(dx), stream_ptr())
+        dw2, db2 = _wgrad(dy, mid, M, N1, N2, None, w2, True)
+        dw1, db1 = _wgrad(dmid, x, M, K, N1, None, w1, True)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
+
+
+def mlp2(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+    """ssp(x w1^T + b1) w2^T + b2 (+ residual).  One launch where conan_mlp2_supported (node-level rows, 128-wide layers), else the two
+    linear kernels."""
+    if x.is_cuda and b1 is not None and b2 is not None and lib().conan_mlp2_supported(x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]):
+        return _Mlp2Fn.apply(x, w1, b1, w2, b2, residual)
+    return linear(linear(x, w1, b1, act=True), w2, b2, residual=residual)
+
+
 class _UnaryFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, op):

@@ -122,8 +122,8 @@ class InteractionBlock(torch.nn.Module):
     def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf: Tensor) -> Tensor:
         """Returns x + lin(ssp(conv(x)))  — the residual of schnet_no_sum.py:164 is fused into the last linear."""
         m = self.conv(x, graph, rbf)
-        m = ops.linear(m, self.conv.lin2.weight, self.conv.lin2.bias, act=True)           # conv.lin2 + InteractionBlock.act
-        return ops.linear(m, self.lin.weight, self.lin.bias, residual=x)                  # lin, + x
+        # conv.lin2 + InteractionBlock.act, then lin + x: one launch at node-level sizes (ops.mlp2), two linear kernels otherwise
+        return ops.mlp2(m, self.conv.lin2.weight, self.conv.lin2.bias, self.lin.weight, self.lin.bias, residual=x)
 
 
 class SchNetNoSum(torch.nn.Module):

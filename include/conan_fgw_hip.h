@@ -213,6 +213,20 @@ int conan_rbf_fwd(const float *dist, const int *num_edges_dev, int max_edges, co
 int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edges, int width, float cutoff,
                        const float *in, float *out, void *stream);
 
+/* Two chained node-level Linear layers in one launch (mlp2.hip):
+ *   forward : mid = ssp(x w1^T + b1) [M,N1];  y = mid w2^T + b2 (+ residual) [M,N2]
+ *             = InteractionBlock's  conv.lin2 -> act -> lin (+ x)  (schnet_no_sum.py:164 with PyG's InteractionBlock.forward)
+ *   backward: dmid = (dy w2) * ssp'(mid) [M,N1];  dx = dmid w1 [M,K]   (mid = the forward's saved output; the weight gradients are
+ *             conan_linear_wgrad(dy, mid) and conan_linear_wgrad(dmid, x))
+ * Same arithmetic as two conan_linear_fwd calls (exact 3-way bf16 split, fp32-class).  mid_out / dmid_out nullable.
+ * Supported: conan_mlp2_supported(M, K, N1, N2) (K = N1 = N2 = 128, M <= 65536: one 32-row tile per wavefront, weights staged twice per
+ * workgroup — a node-level kernel); otherwise CONAN_E_UNSUPPORTED (compose the two calls). */
+int conan_mlp2_supported(int M, int K, int N1, int N2);
+int conan_mlp2_fwd(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *residual, int M, int K, int N1,
+                   int N2, float *mid_out, float *y, void *stream);
+int conan_mlp2_bwd(const float *dy, const float *w2, const float *w1, const float *mid, int M, int K, int N1, int N2, float *dmid_out, float *dx,
+                   void *stream);
+
 /* Fused continuous-filter generator: for every edge e
  *   W[e,:] = ( mlp2( ssp( mlp0( rbf(dist[e]) ) ) ) ) * 0.5*(cos(dist[e]*pi/cutoff)+1)
  * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel, both GEMMs as exact 3-way bf16 splits

@@ -191,6 +191,42 @@ def test_rbf_wgrad_matches_materialised_rbf(M, N, Gs):
     assert rel(db.double().cpu().numpy(), g[:M].double().sum(0).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M", [1, 33, 1000, 25275])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_mlp2_fused_pair_of_linears_fwd_bwd(M, with_res):
+    """ops.mlp2 (conan_mlp2_fwd / conan_mlp2_bwd: lin2 -> ssp -> lin (+ x) of an InteractionBlock in one launch each way) against the fp64
+    formula with torch autograd, and against the two-kernel composition it replaces."""
+    gen = torch.Generator().manual_seed(M)
+    Fh = 128
+    x = torch.randn(M, Fh, generator=gen).to(dev).requires_grad_(True)
+    res = torch.randn(M, Fh, generator=gen).to(dev).requires_grad_(True) if with_res else None
+    w1 = (torch.randn(Fh, Fh, generator=gen) / 11).to(dev).requires_grad_(True); b1 = (torch.randn(Fh, generator=gen) / 5).to(dev).requires_grad_(True)
+    w2 = (torch.randn(Fh, Fh, generator=gen) / 11).to(dev).requires_grad_(True); b2 = (torch.randn(Fh, generator=gen) / 5).to(dev).requires_grad_(True)
+    gy = torch.randn(M, Fh, generator=gen).to(dev)
+    leaves = [x, w1, b1, w2, b2] + ([res] if with_res else [])
+    from conan_fgw_amd._lib import lib
+    assert lib().conan_mlp2_supported(M, Fh, Fh, Fh) == 1 and lib().conan_mlp2_supported(70000, Fh, Fh, Fh) == 0 and lib().conan_mlp2_supported(M, 64, Fh, Fh) == 0
+
+    def grads(fn):
+        for t in leaves:
+            t.grad = None
+        y = fn()
+        (y * gy).sum().backward()
+        return [y.detach()] + [t.grad.detach().clone() for t in leaves]
+
+    fused = grads(lambda: ops.mlp2(x, w1, b1, w2, b2, residual=res))
+    comp = grads(lambda: ops.linear(ops.linear(x, w1, b1, act=True), w2, b2, residual=res))
+    d = [t.detach().double() for t in leaves]
+    for t in d:
+        t.requires_grad_(True)
+    yd = _ssp(d[0] @ d[1].T + d[2]) @ d[3].T + d[4] + (d[5] if with_res else 0.0)
+    (yd * gy.double()).sum().backward()
+    ref = [yd.detach()] + [t.grad for t in d]
+    for a, c, r in zip(fused, comp, ref):
+        assert rel(a.double().cpu().numpy(), r.cpu().numpy()) < 2e-6
+        assert rel(a.cpu().numpy(), c.cpu().numpy()) < 2e-6
+
+
 def test_wgrad_slabs_batch_equals_the_per_job_launches():
     """conan_linear_wgrad_slabs_batch: many weight gradients' stage 1 in one launch per k-tile width.  With default slice counts the slabs
     (hence the reduced dW / db) are bit-identical to conan_linear_wgrad_slabs job by job; with fewer, longer slices the result agrees with
