@@ -79,6 +79,9 @@ SIGNATURES = {
     "conan_filter_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "conan_stage2_head_supported": (c_int, [c_int]),
+    "conan_stage2_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "conan_stage2_head_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_mlp2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "conan_mlp2_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_mlp2_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -1,0 +1,134 @@
+// Stage-2 aggregation head in one launch each way (schnet_based_models.py:163-171 of the reference, `EmbeddingsWithGATAggregationBaryCenter`):
+//
+//     x   = Lin3d(x3) + xc + agg_weight * Linbary(xb)          [G, D]   (xc = Lin_cov(GAT) arrives transformed from the side stream)
+//     out = Linreg( mean over the K conformers of a molecule of x )    [G/K, 1]
+//
+// Everything is linear, so the conformer mean is taken FIRST (three D-vectors per molecule) and the two D x D layers act on the means:
+// out_b = wreg . (W3 m3_b + b3 + mc_b + aw (Wb mb_b + bb)) + breg.  As separate launches this was 8 kernels forward and 9 backward of
+// 5-15 us each on 1 280 x 64 operands — pure launch cost in a 3.2 ms step.  D <= 64 (one lane per channel), one wavefront per molecule.
+// Backward: blocks [0, nmol/4) write the input gradients (broadcast over K), the remaining blocks form the parameter gradients with a
+// fixed-order loop over the molecules (bitwise reproducible, no atomics): 2 x D/4 blocks of 4 rows of dW3 / dWb, one block for the vectors.
+#include "common.h"
+
+namespace {
+
+constexpr int HD_THREADS = 256, HD_WAVES = 4, HD_MAXD = 64, HD_PITCH = HD_MAXD + 1;
+
+__global__ void __launch_bounds__(HD_THREADS) k_stage2_head_fwd(const float *__restrict__ x3, const float *__restrict__ xc, const float *__restrict__ xb,
+                                                                const float *__restrict__ W3, const float *__restrict__ b3,
+                                                                const float *__restrict__ Wb, const float *__restrict__ bb,
+                                                                const float *__restrict__ wreg, const float *__restrict__ breg, float aw, int nmol, int K,
+                                                                int D, float *__restrict__ out, float *__restrict__ m3s, float *__restrict__ mbs,
+                                                                float *__restrict__ ts) {
+    __shared__ float W3L[HD_MAXD * HD_PITCH], WbL[HD_MAXD * HD_PITCH], vec[HD_WAVES][2][HD_MAXD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = tid; t < D * D; t += HD_THREADS) { const int c = t / D, j = t - c * D; W3L[c * HD_PITCH + j] = W3[t]; WbL[c * HD_PITCH + j] = Wb[t]; }
+    const int b = blockIdx.x * HD_WAVES + wave;
+    const bool on = b < nmol && lane < D;
+    float m3 = 0.f, mc = 0.f, mb = 0.f;
+    if (on) {
+        const size_t base = (size_t)b * K * D + lane;
+        for (int k = 0; k < K; ++k) { m3 += x3[base + (size_t)k * D]; mc += xc[base + (size_t)k * D]; mb += xb[base + (size_t)k * D]; }
+        const float inv = 1.0f / (float)K;
+        m3 *= inv; mc *= inv; mb *= inv;
+    }
+    vec[wave][0][lane] = m3; vec[wave][1][lane] = mb;
+    __syncthreads();
+    float t = 0.f, o = 0.f;
+    if (on) {
+        float a = b3[lane], c = bb[lane];
+        for (int j = 0; j < D; ++j) { a += W3L[lane * HD_PITCH + j] * vec[wave][0][j]; c += WbL[lane * HD_PITCH + j] * vec[wave][1][j]; }
+        t = a + mc + aw * c;
+        o = wreg[lane] * t;
+        m3s[(size_t)b * D + lane] = m3; mbs[(size_t)b * D + lane] = mb; ts[(size_t)b * D + lane] = t;
+    }
+    o = wave_sum(o);
+    if (b < nmol && lane == 0) out[b] = o + breg[0];
+}
+
+__global__ void __launch_bounds__(HD_THREADS) k_stage2_head_bwd(const float *__restrict__ dout, const float *__restrict__ W3, const float *__restrict__ Wb,
+                                                                const float *__restrict__ wreg, const float *__restrict__ m3s,
+                                                                const float *__restrict__ mbs, const float *__restrict__ ts, float aw, int nmol, int K, int D,
+                                                                float *__restrict__ dx3, float *__restrict__ dxc, float *__restrict__ dxb,
+                                                                float *__restrict__ dW3, float *__restrict__ db3, float *__restrict__ dWb,
+                                                                float *__restrict__ dbb, float *__restrict__ dwreg, float *__restrict__ dbreg) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk_x = (nmol + HD_WAVES - 1) / HD_WAVES, rows4 = (D + 3) / 4;
+    if ((int)blockIdx.x < nblk_x) {
+        // ---- input gradients of the molecules of this block: u = dout_b * wreg, then u W3 / u / aw u Wb, all divided by K
+        __shared__ float W3L[HD_MAXD * HD_PITCH], WbL[HD_MAXD * HD_PITCH], u[HD_WAVES][HD_MAXD];
+        for (int t = tid; t < D * D; t += HD_THREADS) { const int c = t / D, j = t - c * D; W3L[c * HD_PITCH + j] = W3[t]; WbL[c * HD_PITCH + j] = Wb[t]; }
+        const int b = blockIdx.x * HD_WAVES + wave;
+        const bool on = b < nmol && lane < D;
+        const float uo = on ? dout[b] * wreg[lane] : 0.f;
+        u[wave][lane] = uo;
+        __syncthreads();
+        if (on) {
+            float g3 = 0.f, gb = 0.f;
+            for (int c = 0; c < D; ++c) { g3 += u[wave][c] * W3L[c * HD_PITCH + lane]; gb += u[wave][c] * WbL[c * HD_PITCH + lane]; }
+            const float inv = 1.0f / (float)K;
+            g3 *= inv; gb *= aw * inv;
+            const float gc = uo * inv;
+            const size_t base = (size_t)b * K * D + lane;
+            for (int k = 0; k < K; ++k) { dx3[base + (size_t)k * D] = g3; dxc[base + (size_t)k * D] = gc; dxb[base + (size_t)k * D] = gb; }
+        }
+        return;
+    }
+    const int pb = blockIdx.x - nblk_x;
+    if (pb < 2 * rows4) {
+        // ---- 4 rows of dW3 (pb < rows4) or dWb: dW[c][j] = sum_b dout_b wreg[c] m_b[j] (x aw for the barycenter layer), molecules in order
+        const bool bary = pb >= rows4;
+        const int c = 4 * (bary ? pb - rows4 : pb) + wave, j = lane;
+        if (c >= D || j >= D) return;
+        const float *ms = bary ? mbs : m3s;
+        const float wc = wreg[c];
+        float acc = 0.f;
+        for (int b = 0; b < nmol; ++b) acc += (dout[b] * wc) * ms[(size_t)b * D + j];
+        (bary ? dWb : dW3)[c * D + j] = bary ? aw * acc : acc;
+        return;
+    }
+    // ---- vectors: db3 = sum_b u_b, dbb = aw db3, dwreg = sum_b dout_b t_b, dbreg = sum_b dout_b   (wave 0: lane = channel)
+    if (wave == 0) {
+        float su = 0.f, sw = 0.f, sd = 0.f;
+        if (lane < D) {
+            const float wc = wreg[lane];
+            for (int b = 0; b < nmol; ++b) { const float d = dout[b]; su += d * wc; sw += d * ts[(size_t)b * D + lane]; sd += d; }
+            db3[lane] = su; dbb[lane] = aw * su; dwreg[lane] = sw;
+        }
+        if (lane == 0) dbreg[0] = sd;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int conan_stage2_head_supported(int D) { return (D >= 1 && D <= HD_MAXD) ? 1 : 0; }
+
+int conan_stage2_head_fwd(const float *x3, const float *xc, const float *xb, const float *W3, const float *b3, const float *Wb, const float *bb,
+                          const float *wreg, const float *breg, float agg_weight, int num_molecules, int K, int D, float *out, float *m3, float *mb,
+                          float *t, void *stream) {
+    if (!x3 || !xc || !xb || !W3 || !b3 || !Wb || !bb || !wreg || !breg || !out || !m3 || !mb || !t || num_molecules < 0 || K <= 0) return CONAN_E_BADARG;
+    if (!conan_stage2_head_supported(D)) return CONAN_E_UNSUPPORTED;
+    if (num_molecules == 0) return CONAN_OK;
+    k_stage2_head_fwd<<<(num_molecules + HD_WAVES - 1) / HD_WAVES, HD_THREADS, 0, as_stream(stream)>>>(x3, xc, xb, W3, b3, Wb, bb, wreg, breg, agg_weight,
+                                                                                                       num_molecules, K, D, out, m3, mb, t);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_stage2_head_bwd(const float *dout, const float *W3, const float *Wb, const float *wreg, const float *m3, const float *mb, const float *t,
+                          float agg_weight, int num_molecules, int K, int D, float *dx3, float *dxc, float *dxb, float *dW3, float *db3, float *dWb,
+                          float *dbb, float *dwreg, float *dbreg, void *stream) {
+    if (!dout || !W3 || !Wb || !wreg || !m3 || !mb || !t || !dx3 || !dxc || !dxb || !dW3 || !db3 || !dWb || !dbb || !dwreg || !dbreg ||
+        num_molecules <= 0 || K <= 0)
+        return CONAN_E_BADARG;
+    if (!conan_stage2_head_supported(D)) return CONAN_E_UNSUPPORTED;
+    const int blocks = (num_molecules + HD_WAVES - 1) / HD_WAVES + 2 * ((D + 3) / 4) + 1;
+    k_stage2_head_bwd<<<blocks, HD_THREADS, 0, as_stream(stream)>>>(dout, W3, Wb, wreg, m3, mb, t, agg_weight, num_molecules, K, D, dx3, dxc, dxb, dW3,
+                                                                    db3, dWb, dbb, dwreg, dbreg);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+}  // extern "C"

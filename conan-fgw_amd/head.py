@@ -115,16 +115,20 @@ class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
         x_3d, x_bary = self.node_embeddings_model.forward_w_barycenter(
             z=batch.z, pos=batch.pos, num_conformers=K, batch=node_index, max_iter=self.numItermax, epsilon=self.epsilon,
             **({"num_graphs": num_graphs, "max_nodes": max_nodes} if num_graphs is not None else {}))             # :153-160
-        x_bary = ops.linear(x_bary, self.transformation_matrix_bary.weight, self.transformation_matrix_bary.bias)  # :163
-        x_3d = ops.linear(x_3d, self.transformation_matrix_3d.weight, self.transformation_matrix_3d.bias)          # :164
-        main.wait_stream(side)
-        x_cov.record_stream(main)
-        x = x_3d + x_cov + self.agg_weight * x_bary                                                                   # :169
-        G, d = x.shape
+        G, d = x_3d.shape
         # conformers_mean_aggr(x, conformers_index): the index is K consecutive copies of every molecule id, so the mean is a
         # reshape (checked, because the reference's aggregation accepts any sorted index)
         if conformers_index is not None and conformers_index.numel() != G:
             raise ValueError("conformers_index must have one entry per conformer graph")
+        main.wait_stream(side)
+        x_cov.record_stream(main)
+        if isinstance(self.molecular_regression_lin, Linear) and ops.stage2_head_supported(d):
+            # :163-171 in one launch (all of it is linear: the conformer mean is taken first); 17 launches of 5-15 us otherwise
+            return ops.stage2_head(x_3d, x_cov, x_bary, self.transformation_matrix_3d, self.transformation_matrix_bary,
+                                   self.molecular_regression_lin, self.agg_weight, K)
+        x_bary = ops.linear(x_bary, self.transformation_matrix_bary.weight, self.transformation_matrix_bary.bias)  # :163
+        x_3d = ops.linear(x_3d, self.transformation_matrix_3d.weight, self.transformation_matrix_3d.bias)          # :164
+        x = x_3d + x_cov + self.agg_weight * x_bary                                                                   # :169
         x = x.view(G // K, K, d).mean(dim=1)                                                                          # :170
         return ops.linear(x.contiguous(), self.molecular_regression_lin.weight, self.molecular_regression_lin.bias)   # :171
 

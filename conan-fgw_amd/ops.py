@@ -320,6 +320,46 @@ def mlp2(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Op
     return linear(linear(x, w1, b1, act=True), w2, b2, residual=residual)
 
 
+class _Stage2HeadFn(torch.autograd.Function):
+    """out = Linreg(mean_K(Lin3d(x3) + xc + aw * Linbary(xb))): one launch each way (conan_stage2_head_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x3, xc, xb, W3, b3, Wb, bb, wreg, breg, aw, K):
+        x3, xc, xb = _c(x3), _c(xc), _c(xb)
+        G, D = x3.shape
+        B = G // K
+        dev = x3.device
+        out = torch.empty(B, 1, dtype=f32, device=dev)
+        m3, mb, t = (torch.empty(B, D, dtype=f32, device=dev) for _ in range(3))
+        call("conan_stage2_head_fwd", ptr(x3, f32), ptr(xc, f32), ptr(xb, f32), ptr(_c(W3), f32), ptr(_c(b3), f32), ptr(_c(Wb), f32), ptr(_c(bb), f32),
+             ptr(_c(wreg), f32), ptr(_c(breg), f32), float(aw), B, K, D, ptr(out), ptr(m3), ptr(mb), ptr(t), stream_ptr())
+        ctx.save_for_backward(W3, Wb, wreg, m3, mb, t)
+        ctx.dims, ctx.aw = (B, K, D), float(aw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        W3, Wb, wreg, m3, mb, t = ctx.saved_tensors
+        B, K, D = ctx.dims
+        dev = dout.device
+        dx3, dxc, dxb = (torch.empty(B * K, D, dtype=f32, device=dev) for _ in range(3))
+        dW3, dWb = torch.empty(D, D, dtype=f32, device=dev), torch.empty(D, D, dtype=f32, device=dev)
+        db3, dbb = torch.empty(D, dtype=f32, device=dev), torch.empty(D, dtype=f32, device=dev)
+        dwreg, dbreg = torch.empty(1, D, dtype=f32, device=dev), torch.empty(1, dtype=f32, device=dev)
+        call("conan_stage2_head_bwd", ptr(_c(dout)), ptr(_c(W3)), ptr(_c(Wb)), ptr(_c(wreg)), ptr(m3), ptr(mb), ptr(t), ctx.aw, B, K, D,
+             ptr(dx3), ptr(dxc), ptr(dxb), ptr(dW3), ptr(db3), ptr(dWb), ptr(dbb), ptr(dwreg), ptr(dbreg), stream_ptr())
+        return dx3, dxc, dxb, dW3, db3, dWb, dbb, dwreg, dbreg, None, None
+
+
+def stage2_head(x3: Tensor, xc: Tensor, xb: Tensor, lin3d, linbary, linreg, agg_weight: float, K: int) -> Tensor:
+    """[G,D] x 3 -> [G/K, 1]: Linreg(mean over the K conformers of (Lin3d(x3) + xc + agg_weight * Linbary(xb)))."""
+    return _Stage2HeadFn.apply(x3, xc, xb, lin3d.weight, lin3d.bias, linbary.weight, linbary.bias, linreg.weight, linreg.bias, agg_weight, K)
+
+
+def stage2_head_supported(D: int) -> bool:
+    return bool(lib().conan_stage2_head_supported(int(D)))
+
+
 class _UnaryFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, op):

@@ -213,6 +213,20 @@ int conan_rbf_fwd(const float *dist, const int *num_edges_dev, int max_edges, co
 int conan_cutoff_scale(const float *dist, const int *num_edges_dev, int max_edges, int width, float cutoff,
                        const float *in, float *out, void *stream);
 
+/* Stage-2 aggregation head (head.hip; schnet_based_models.py:163-171): for conformer-graph rows x3, xc, xb [G = num_molecules*K, D]
+ *   out[b] = wreg . mean_k( x3 W3^T + b3 + xc + agg_weight (xb Wb^T + bb) ) + breg            [num_molecules]
+ * = transformation_matrix_3d / _bary (xc is transformation_matrix_cov's output), the weighted sum, conformers_mean_aggr and
+ * molecular_regression_lin (Linear(D, 1)) in ONE launch; the conformer mean is taken first (all of it is linear).  The forward also
+ * returns the per-molecule means m3, mb and the pre-regression vector t [num_molecules, D] for the backward, which writes the three input
+ * gradients [G, D] and all six parameter gradients (fixed summation order over the molecules: bitwise reproducible).  D <= 64. */
+int conan_stage2_head_supported(int D);
+int conan_stage2_head_fwd(const float *x3, const float *xc, const float *xb, const float *W3, const float *b3, const float *Wb, const float *bb,
+                          const float *wreg, const float *breg, float agg_weight, int num_molecules, int K, int D, float *out, float *m3, float *mb,
+                          float *t, void *stream);
+int conan_stage2_head_bwd(const float *dout, const float *W3, const float *Wb, const float *wreg, const float *m3, const float *mb, const float *t,
+                          float agg_weight, int num_molecules, int K, int D, float *dx3, float *dxc, float *dxb, float *dW3, float *db3, float *dWb,
+                          float *dbb, float *dwreg, float *dbreg, void *stream);
+
 /* Two chained node-level Linear layers in one launch (mlp2.hip):
  *   forward : mid = ssp(x w1^T + b1) [M,N1];  y = mid w2^T + b2 (+ residual) [M,N2]
  *             = InteractionBlock's  conv.lin2 -> act -> lin (+ x)  (schnet_no_sum.py:164 with PyG's InteractionBlock.forward)

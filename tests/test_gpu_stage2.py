@@ -192,3 +192,37 @@ def test_deferred_weight_gradients_are_bitwise_equal_to_immediate_ones():
         ops.linear(ops.linear(x, w), w).sum().backward()
     torch.cuda.synchronize()
     assert torch.equal(w.grad, ref)
+
+
+@pytest.mark.parametrize("B,K,D", [(1, 1, 64), (7, 5, 64), (256, 5, 64), (33, 20, 32)])
+def test_stage2_head_fused_matches_the_composed_modules(B, K, D):
+    """ops.stage2_head (conan_stage2_head_fwd / _bwd: transformation_matrix_3d / _bary, weighted sum, conformer mean and the regression
+    layer in one launch each way) against the same expression in fp64 torch with autograd: output, the three input gradients and all six
+    parameter gradients; repeat runs are bitwise equal."""
+    from conan_fgw_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(B * 100 + K)
+    G = B * K
+    mk = lambda *s: torch.randn(*s, generator=gen).to(dev).requires_grad_(True)
+    x3, xc, xb = mk(G, D), mk(G, D), mk(G, D)
+    l3, lb, lr = torch.nn.Linear(D, D).to(dev), torch.nn.Linear(D, D).to(dev), torch.nn.Linear(D, 1).to(dev)
+    gy = torch.randn(B, 1, generator=gen).to(dev)
+    leaves = [x3, xc, xb, l3.weight, l3.bias, lb.weight, lb.bias, lr.weight, lr.bias]
+
+    def run():
+        for t in leaves:
+            t.grad = None
+        out = ops.stage2_head(x3, xc, xb, l3, lb, lr, 0.2, K)
+        (out * gy).sum().backward()
+        return [out.detach().clone()] + [t.grad.detach().clone() for t in leaves]
+
+    a, a2 = run(), run()
+    d = [t.detach().double().requires_grad_(True) for t in leaves]
+    x = (d[0] @ d[3].T + d[4]) + d[1] + 0.2 * (d[2] @ d[5].T + d[6])
+    out = x.view(B, K, D).mean(1) @ d[7].T + d[8]
+    (out * gy.double()).sum().backward()
+    ref = [out.detach()] + [t.grad for t in d]
+    assert a[0].shape == (B, 1)
+    for u, v, r in zip(a, a2, ref):
+        assert torch.equal(u, v)
+        assert rel(u.double().cpu().numpy(), r.cpu().numpy()) < 2e-6
