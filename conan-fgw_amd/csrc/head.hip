@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int HD_THREADS = 256, HD_WAVES = 4, HD_MAXD = 64, HD_PITCH = HD_MAXD + 1;
+constexpr int HD_THREADS = 256, HD_WAVES = 4, HD_MAXD = 64, HD_PITCH = HD_MAXD + 1, HD_U = 16;
 
 __global__ void __launch_bounds__(HD_THREADS) k_stage2_head_fwd(const float *__restrict__ x3, const float *__restrict__ xc, const float *__restrict__ xb,
                                                                 const float *__restrict__ W3, const float *__restrict__ b3,
@@ -83,7 +83,15 @@ __global__ void __launch_bounds__(HD_THREADS) k_stage2_head_bwd(const float *__r
         const float *ms = bary ? mbs : m3s;
         const float wc = wreg[c];
         float acc = 0.f;
-        for (int b = 0; b < nmol; ++b) acc += (dout[b] * wc) * ms[(size_t)b * D + j];
+        int b = 0;
+        for (; b + HD_U <= nmol; b += HD_U) {                       // HD_U loads in flight, summed in molecule order (a serial loop is one L2 round trip per molecule)
+            float dv[HD_U], mv[HD_U];
+#pragma unroll
+            for (int q = 0; q < HD_U; ++q) { dv[q] = dout[b + q]; mv[q] = ms[(size_t)(b + q) * D + j]; }
+#pragma unroll
+            for (int q = 0; q < HD_U; ++q) acc += (dv[q] * wc) * mv[q];
+        }
+        for (; b < nmol; ++b) acc += (dout[b] * wc) * ms[(size_t)b * D + j];
         (bary ? dWb : dW3)[c * D + j] = bary ? aw * acc : acc;
         return;
     }
@@ -92,7 +100,15 @@ __global__ void __launch_bounds__(HD_THREADS) k_stage2_head_bwd(const float *__r
         float su = 0.f, sw = 0.f, sd = 0.f;
         if (lane < D) {
             const float wc = wreg[lane];
-            for (int b = 0; b < nmol; ++b) { const float d = dout[b]; su += d * wc; sw += d * ts[(size_t)b * D + lane]; sd += d; }
+            int b = 0;
+            for (; b + HD_U <= nmol; b += HD_U) {
+                float dv[HD_U], tv[HD_U];
+#pragma unroll
+                for (int q = 0; q < HD_U; ++q) { dv[q] = dout[b + q]; tv[q] = ts[(size_t)(b + q) * D + lane]; }
+#pragma unroll
+                for (int q = 0; q < HD_U; ++q) { su += dv[q] * wc; sw += dv[q] * tv[q]; sd += dv[q]; }
+            }
+            for (; b < nmol; ++b) { const float d = dout[b]; su += d * wc; sw += d * ts[(size_t)b * D + lane]; sd += d; }
             db3[lane] = su; dbb[lane] = aw * su; dwreg[lane] = sw;
         }
         if (lane == 0) dbreg[0] = sd;
