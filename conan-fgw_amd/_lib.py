@@ -85,6 +85,9 @@ SIGNATURES = {
     "conan_mlp2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "conan_mlp2_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_mlp2_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_mlp2_outact_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "conan_mlp2_outact_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_mlp2_outact_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),

@@ -4,6 +4,10 @@
 //     backward:  dh = (dy W2) * ssp'(h) ;  dx = dh W1                                   (the two input-gradient GEMMs and the activation
 //                                                                                        derivative between them; h is the saved output)
 //
+// The same kernel with the activation moved behind the second layer serves the per-atom heads (lin1 -> lin2 -> act, schnet_no_sum.py:176-178,
+// 225-231): forward  mid = x W1^T + b1 ;  y = ssp(mid W2^T + b2),  backward  g = dy * ssp'(y) (applied to the input rows and written out for
+// the weight gradient) ; dmid = g W2 ; dx = dmid W1.
+//
 // At node level (25 k rows) a Linear launch is mostly fixed cost — 8.4 us of 13.5 us are weight staging, one tile per wave, the
 // launch itself — and the layers of an interaction form a serial chain, so the only way to shorten it is to have fewer links.
 // Mapping (as filter_fused.hip): the row index lives on the MFMA column (= lane), the channel on the MFMA row.  A wave owns one
@@ -113,12 +117,15 @@ struct M2Weight {
     }
 };
 
-// KA -> NA -> NB.  BWD = false: mid = ssp(acc1 + bA), y = acc2 + bB (+ residual).  BWD = true: mid = acc1 * ssp'(aux) with aux the saved
-// ssp output, y = acc2; weights read transposed, no biases.
-template <int KA, int NA, int NB, bool BWD>
+// KA -> NA -> NB.  MODE 0: mid = ssp(acc1 + bA), y = acc2 + bB (+ residual).  MODE 1 (its backward): mid = acc1 * ssp'(aux) with aux the saved
+// ssp output [M,NA], y = acc2; weights read transposed, no biases.  MODE 2: mid = acc1 + bA, y = ssp(acc2 + bB).  MODE 3 (its backward):
+// the input rows are scaled by ssp'(aux), aux = the saved output [M,KA], and written to in_out; mid = acc1, y = acc2; transposed weights.
+template <int KA, int NA, int NB, int MODE>
 __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x, const float *__restrict__ wA, const float *__restrict__ bA,
                                                      const float *__restrict__ wB, const float *__restrict__ bB, const float *__restrict__ aux,
-                                                     const float *__restrict__ residual, int M, float *__restrict__ mid_out, float *__restrict__ y) {
+                                                     const float *__restrict__ residual, int M, float *__restrict__ mid_out, float *__restrict__ y,
+                                                     float *__restrict__ in_out) {
+    constexpr bool BWD = (MODE & 1) != 0;
     constexpr int SA = KA / 16, SB = NA / 16, MBA = NA / 32, MBB = NB / 32;
     constexpr int WSA = KA + 8, WSB = NA + 8;
     constexpr int WORDS_A = (3 * NA * WSA) / 2, WORDS_B = (3 * NB * WSB) / 2, WORDS = WORDS_A > WORDS_B ? WORDS_A : WORDS_B;
@@ -142,13 +149,22 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
             xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
         }
     }
-    float4 av[MBA][4];
-    if (BWD) {
+    float4 av[MODE == 1 ? MBA : 1][4];
+    if (MODE == 1) {
         const float *ar = aux + (size_t)mr * NA + 4 * h;
 #pragma unroll
         for (int nb = 0; nb < MBA; ++nb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) av[nb][q] = *reinterpret_cast<const float4 *>(ar + 32 * nb + 8 * q);
+    }
+    float4 ya[MODE == 3 ? SA : 1], yb[MODE == 3 ? SA : 1];
+    if (MODE == 3) {
+        const float *ar = aux + (size_t)mr * KA + 8 * h;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) {
+            ya[s] = *reinterpret_cast<const float4 *>(ar + 16 * s);
+            yb[s] = *reinterpret_cast<const float4 *>(ar + 16 * s + 4);
+        }
     }
     M2Weight<NA, KA, BWD> stA;
     M2Weight<NB, NA, BWD> stB;
@@ -156,6 +172,20 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     stB.fetch(wB, tid);                                        // in flight during the first GEMM
     stA.park(WB, tid, false);
     for (int t = tid; t < NA + NB; t += M2_THREADS) BL[t] = BWD ? 0.f : (t < NA ? bA[t] : bB[t - NA]);
+    if (MODE == 3) {                                           // g = dy * ssp'(pre) from the saved output, in place and out for the weight gradient
+#pragma unroll
+        for (int s = 0; s < SA; ++s) {
+            xa[s].x *= 1.0f - 0.5f * __expf(-ya[s].x); xa[s].y *= 1.0f - 0.5f * __expf(-ya[s].y);
+            xa[s].z *= 1.0f - 0.5f * __expf(-ya[s].z); xa[s].w *= 1.0f - 0.5f * __expf(-ya[s].w);
+            xb[s].x *= 1.0f - 0.5f * __expf(-yb[s].x); xb[s].y *= 1.0f - 0.5f * __expf(-yb[s].y);
+            xb[s].z *= 1.0f - 0.5f * __expf(-yb[s].z); xb[s].w *= 1.0f - 0.5f * __expf(-yb[s].w);
+            if (in_out && valid) {
+                float *gr = in_out + (size_t)m * KA + 8 * h + 16 * s;
+                *reinterpret_cast<float4 *>(gr) = xa[s];
+                *reinterpret_cast<float4 *>(gr + 4) = xb[s];
+            }
+        }
+    }
     __syncthreads();
 
     // ---------------- GEMM1^T: acc1[nb] = WA[32nb.., :] . x^T
@@ -191,14 +221,18 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float v[4];
-            if (BWD) {
+            if (MODE == 1) {
                 const float a4[4] = {av[nb][q].x, av[nb][q].y, av[nb][q].z, av[nb][q].w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = acc1[nb][4 * q + u] * (1.0f - 0.5f * __expf(-a4[u]));      // * ssp'(pre) from the saved output
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = acc1[nb][4 * q + u];
             } else {
                 const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
-                v[0] = ssp_f(acc1[nb][4 * q + 0] + bb.x); v[1] = ssp_f(acc1[nb][4 * q + 1] + bb.y);
-                v[2] = ssp_f(acc1[nb][4 * q + 2] + bb.z); v[3] = ssp_f(acc1[nb][4 * q + 3] + bb.w);
+                const float p4[4] = {acc1[nb][4 * q + 0] + bb.x, acc1[nb][4 * q + 1] + bb.y, acc1[nb][4 * q + 2] + bb.z, acc1[nb][4 * q + 3] + bb.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = MODE == 0 ? ssp_f(p4[u]) : p4[u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc1[nb][4 * q + u] = v[u];
@@ -207,8 +241,8 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
         }
     __syncthreads();                                           // every wave is done with the first weight
     stB.park(WB, tid, true);
-    float4 rv[MBB][4];
-    if (!BWD && residual) {
+    float4 rv[MODE == 0 ? MBB : 1][4];
+    if (MODE == 0 && residual) {
         const float *rr = residual + (size_t)mr * NB + 4 * h;
 #pragma unroll
         for (int nb = 0; nb < MBB; ++nb)
@@ -254,19 +288,20 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
         for (int q = 0; q < 4; ++q) {
             const float4 bb = *reinterpret_cast<const float4 *>(&BL[NA + 32 * nb + 8 * q + 4 * h]);
             float4 o = make_float4(acc2[nb][4 * q] + bb.x, acc2[nb][4 * q + 1] + bb.y, acc2[nb][4 * q + 2] + bb.z, acc2[nb][4 * q + 3] + bb.w);
-            if (!BWD && residual) { o.x += rv[nb][q].x; o.y += rv[nb][q].y; o.z += rv[nb][q].z; o.w += rv[nb][q].w; }
+            if (MODE == 0 && residual) { o.x += rv[nb][q].x; o.y += rv[nb][q].y; o.z += rv[nb][q].z; o.w += rv[nb][q].w; }
+            if (MODE == 2) { o.x = ssp_f(o.x); o.y = ssp_f(o.y); o.z = ssp_f(o.z); o.w = ssp_f(o.w); }
             *reinterpret_cast<float4 *>(y + (size_t)m * NB + 32 * nb + 8 * q + 4 * h) = o;
         }
 }
 
-template <int KA, int NA, int NB, bool BWD>
+template <int KA, int NA, int NB, int MODE>
 int m2_launch(const float *x, const float *wA, const float *bA, const float *wB, const float *bB, const float *aux, const float *residual, int M,
-              float *mid_out, float *y, hipStream_t s) {
+              float *mid_out, float *y, float *in_out, hipStream_t s) {
     constexpr int WA = (3 * NA * (KA + 8)) / 2, WBw = (3 * NB * (NA + 8)) / 2;
     const size_t lds = ((size_t)(WA > WBw ? WA : WBw) + NA + NB) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp2<KA, NA, NB, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp2<KA, NA, NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (M + 31) / 32;
-    k_mlp2<KA, NA, NB, BWD><<<(tiles + M2_WAVES - 1) / M2_WAVES, M2_THREADS, lds, s>>>(x, wA, bA, wB, bB, aux, residual, M, mid_out, y);
+    k_mlp2<KA, NA, NB, MODE><<<(tiles + M2_WAVES - 1) / M2_WAVES, M2_THREADS, lds, s>>>(x, wA, bA, wB, bB, aux, residual, M, mid_out, y, in_out);
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
@@ -281,7 +316,7 @@ int conan_mlp2_fwd(const float *x, const float *w1, const float *b1, const float
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0) return CONAN_E_BADARG;
     if (M == 0) return CONAN_OK;
     if (!conan_mlp2_supported(M, K, N1, N2)) return CONAN_E_UNSUPPORTED;
-    return m2_launch<128, 128, 128, false>(x, w1, b1, w2, b2, nullptr, residual, M, mid_out, y, as_stream(stream));
+    return m2_launch<128, 128, 128, 0>(x, w1, b1, w2, b2, nullptr, residual, M, mid_out, y, nullptr, as_stream(stream));
 }
 
 int conan_mlp2_bwd(const float *dy, const float *w2, const float *w1, const float *mid, int M, int K, int N1, int N2, float *dmid_out, float *dx,
@@ -290,7 +325,26 @@ int conan_mlp2_bwd(const float *dy, const float *w2, const float *w1, const floa
     if (M == 0) return CONAN_OK;
     if (!conan_mlp2_supported(M, K, N1, N2)) return CONAN_E_UNSUPPORTED;
     // dy [M,N2] -> (W2 read as [N2][N1]: contraction over n2) -> dmid [M,N1] -> (W1 read as [N1][K]) -> dx [M,K]
-    return m2_launch<128, 128, 128, true>(dy, w2, nullptr, w1, nullptr, mid, nullptr, M, dmid_out, dx, as_stream(stream));
+    return m2_launch<128, 128, 128, 1>(dy, w2, nullptr, w1, nullptr, mid, nullptr, M, dmid_out, dx, nullptr, as_stream(stream));
+}
+
+int conan_mlp2_outact_supported(int M, int K, int N1, int N2) { return (K == 128 && N1 == 64 && N2 == 64 && M >= 1 && M <= 65536) ? 1 : 0; }
+
+int conan_mlp2_outact_fwd(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int M, int K, int N1, int N2,
+                          float *mid_out, float *y, void *stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    if (!conan_mlp2_outact_supported(M, K, N1, N2)) return CONAN_E_UNSUPPORTED;
+    return m2_launch<128, 64, 64, 2>(x, w1, b1, w2, b2, nullptr, nullptr, M, mid_out, y, nullptr, as_stream(stream));
+}
+
+int conan_mlp2_outact_bwd(const float *dy, const float *y, const float *w2, const float *w1, int M, int K, int N1, int N2, float *g_out,
+                          float *dmid_out, float *dx, void *stream) {
+    if (!dy || !y || !w1 || !w2 || !dx || M < 0) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    if (!conan_mlp2_outact_supported(M, K, N1, N2)) return CONAN_E_UNSUPPORTED;
+    // g = dy * ssp'(y) [M,N2] -> (W2 read as [N2][N1]) -> dmid [M,N1] -> (W1 read as [N1][K]) -> dx [M,K]
+    return m2_launch<64, 64, 128, 3>(dy, w2, nullptr, w1, nullptr, y, nullptr, M, dmid_out, dx, g_out, as_stream(stream));
 }
 
 }  // extern "C"

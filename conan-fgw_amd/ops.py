@@ -320,6 +320,46 @@ def mlp2(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Op
     return linear(linear(x, w1, b1, act=True), w2, b2, residual=residual)
 
 
+class _Mlp2OutActFn(torch.autograd.Function):
+    """y = ssp((x w1^T + b1) w2^T + b2) in one launch; backward: dy * ssp'(y), both input-gradient GEMMs in one launch, then the two weight
+    gradients (conan_mlp2_outact_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        M, K = x.shape
+        N1, N2 = w1.shape[0], w2.shape[0]
+        need = any(ctx.needs_input_grad)
+        mid = torch.empty(M, N1, dtype=f32, device=x.device) if need else None
+        y = torch.empty(M, N2, dtype=f32, device=x.device)
+        call("conan_mlp2_outact_fwd", ptr(x, f32), ptr(w1, f32), ptr(_c(b1), f32), ptr(w2, f32), ptr(_c(b2), f32), M, K, N1, N2, ptr(mid), ptr(y),
+             stream_ptr())
+        ctx.save_for_backward(x, w1, w2, mid, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, mid, y = ctx.saved_tensors
+        dy = _c(dy)
+        M, K = x.shape
+        N1, N2 = w1.shape[0], w2.shape[0]
+        dev = x.device
+        g = torch.empty(M, N2, dtype=f32, device=dev)
+        dmid = torch.empty(M, N1, dtype=f32, device=dev)
+        dx = torch.empty(M, K, dtype=f32, device=dev)
+        call("conan_mlp2_outact_bwd", ptr(dy), ptr(y), ptr(w2), ptr(w1), M, K, N1, N2, ptr(g), ptr(dmid), ptr(dx), stream_ptr())
+        dw2, db2 = _wgrad(g, mid, M, N1, N2, None, w2, True)
+        dw1, db1 = _wgrad(dmid, x, M, K, N1, None, w1, True)
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp2_outact(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """ssp((x w1^T + b1) w2^T + b2).  One launch where conan_mlp2_outact_supported (node-level rows, 128 -> 64 -> 64), else two linear kernels."""
+    if x.is_cuda and b1 is not None and b2 is not None and lib().conan_mlp2_outact_supported(x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]):
+        return _Mlp2OutActFn.apply(x, w1, b1, w2, b2)
+    return linear(linear(x, w1, b1), w2, b2, act=True)
+
+
 class _Stage2HeadFn(torch.autograd.Function):
     """out = Linreg(mean_K(Lin3d(x3) + xc + aw * Linbary(xb))): one launch each way (conan_stage2_head_fwd / _bwd)."""
 

@@ -193,8 +193,7 @@ class SchNetNoSum(torch.nn.Module):
         return h
 
     def _head(self, h: Tensor, lin1: Linear, lin2: Linear) -> Tensor:
-        h = ops.linear(h, lin1.weight, lin1.bias)
-        return ops.linear(h, lin2.weight, lin2.bias, act=True)
+        return ops.mlp2_outact(h, lin1.weight, lin1.bias, lin2.weight, lin2.bias)      # lin1 -> lin2 -> act: one launch at node level
 
     # ---------------------------------------------------------------------------------------------- reference API
     def forward(self, z: Tensor, pos: Tensor, batch: OptTensor = None, data_batch=None, num_graphs: Optional[int] = None) -> Tensor:
@@ -216,8 +215,10 @@ class SchNetNoSum(torch.nn.Module):
         return h, h_bary
 
     def _compute_barycenter(self, node_feature: Tensor, edge_index, batch: Tensor, batch_size: int, num_conformers: int,
-                            max_nodes: Optional[int] = None):
-        """schnet_no_sum.py:234-315.  `edge_index` may be the reference's int64 [2,E] tensor or an ops.RadiusGraph."""
+                            max_nodes: Optional[int] = None, _want_node_out: bool = True):
+        """schnet_no_sum.py:234-315.  `edge_index` may be the reference's int64 [2,E] tensor or an ops.RadiusGraph.
+        `_want_node_out=False` (forward_w_barycenter, which discards it like the reference does at :346) skips the readout of the
+        node features: the first return value is then None."""
         K = num_conformers
         G = batch_size * K
         if isinstance(edge_index, ops.RadiusGraph):
@@ -232,7 +233,7 @@ class SchNetNoSum(torch.nn.Module):
         Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), Cs.view(batch_size, K, N, N))   # :259-306
         self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs, Ys=Ys, Cs=Cs)
         F_bary_batch = ops.fgw_readout(Y, K, self.READOUT_MODE)                            # :308-312
-        node_out = ops.segment_sum(node_feature, graph.graph_ptr, G)                       # :314
+        node_out = ops.segment_sum(node_feature, graph.graph_ptr, G) if _want_node_out else None    # :314
         return node_out, F_bary_batch
 
     def forward_w_barycenter(self, z: Tensor, pos: Tensor, num_conformers: int, batch: OptTensor = None, data_batch=None,
@@ -243,7 +244,8 @@ class SchNetNoSum(torch.nn.Module):
         batch, gptr, graph, G = self._graphs(z, pos, batch, num_graphs)
         h_3d, h_bary = self.forward_3d_bary(z, pos, batch, _graph=graph)                   # :341
         batch_size = G // num_conformers                                                  # :345
-        _, h_bary = self._compute_barycenter(h_bary, graph, batch, batch_size, num_conformers, max_nodes=max_nodes)   # :346-352
+        _, h_bary = self._compute_barycenter(h_bary, graph, batch, batch_size, num_conformers, max_nodes=max_nodes,
+                                             _want_node_out=False)                            # :346-352 (its first result is dropped there too)
         h_3d = ops.segment_sum(h_3d, gptr, G)                                              # :353
         return h_3d, h_bary
 

@@ -240,6 +240,16 @@ int conan_mlp2_fwd(const float *x, const float *w1, const float *b1, const float
                    int N2, float *mid_out, float *y, void *stream);
 int conan_mlp2_bwd(const float *dy, const float *w2, const float *w1, const float *mid, int M, int K, int N1, int N2, float *dmid_out, float *dx,
                    void *stream);
+/* Same kernel with the activation behind the second layer — the per-atom heads lin1 -> lin2 -> act (schnet_no_sum.py:176-178, 225-231):
+ *   forward : mid = x w1^T + b1 [M,N1];  y = ssp(mid w2^T + b2) [M,N2]
+ *   backward: g = dy * ssp'(y) [M,N2] (written to g_out);  dmid = g w2 [M,N1];  dx = dmid w1 [M,K]
+ *             (weight gradients: conan_linear_wgrad(g, mid) and conan_linear_wgrad(dmid, x))
+ * Supported: conan_mlp2_outact_supported(M, K, N1, N2) (K = 128, N1 = N2 = 64, M <= 65536). */
+int conan_mlp2_outact_supported(int M, int K, int N1, int N2);
+int conan_mlp2_outact_fwd(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int M, int K, int N1, int N2,
+                          float *mid_out, float *y, void *stream);
+int conan_mlp2_outact_bwd(const float *dy, const float *y, const float *w2, const float *w1, int M, int K, int N1, int N2, float *g_out,
+                          float *dmid_out, float *dx, void *stream);
 
 /* Fused continuous-filter generator: for every edge e
  *   W[e,:] = ( mlp2( ssp( mlp0( rbf(dist[e]) ) ) ) ) * 0.5*(cos(dist[e]*pi/cutoff)+1)

@@ -227,6 +227,37 @@ def test_mlp2_fused_pair_of_linears_fwd_bwd(M, with_res):
         assert rel(a.cpu().numpy(), c.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("M", [1, 33, 1000, 25275])
+def test_mlp2_outact_fused_head_fwd_bwd(M):
+    """ops.mlp2_outact (lin1 -> lin2 -> ssp of the per-atom heads in one launch each way, 128 -> 64 -> 64) against the fp64 formula with torch
+    autograd and against the two-kernel composition."""
+    gen = torch.Generator().manual_seed(M + 5)
+    x = torch.randn(M, 128, generator=gen).to(dev).requires_grad_(True)
+    w1 = (torch.randn(64, 128, generator=gen) / 11).to(dev).requires_grad_(True); b1 = (torch.randn(64, generator=gen) / 5).to(dev).requires_grad_(True)
+    w2 = (torch.randn(64, 64, generator=gen) / 8).to(dev).requires_grad_(True); b2 = (torch.randn(64, generator=gen) / 5).to(dev).requires_grad_(True)
+    gy = torch.randn(M, 64, generator=gen).to(dev)
+    leaves = [x, w1, b1, w2, b2]
+    from conan_fgw_amd._lib import lib
+    assert lib().conan_mlp2_outact_supported(M, 128, 64, 64) == 1 and lib().conan_mlp2_outact_supported(M, 128, 128, 128) == 0
+
+    def grads(fn):
+        for t in leaves:
+            t.grad = None
+        y = fn()
+        (y * gy).sum().backward()
+        return [y.detach()] + [t.grad.detach().clone() for t in leaves]
+
+    fused = grads(lambda: ops.mlp2_outact(x, w1, b1, w2, b2))
+    comp = grads(lambda: ops.linear(ops.linear(x, w1, b1), w2, b2, act=True))
+    d = [t.detach().double().requires_grad_(True) for t in leaves]
+    yd = _ssp((d[0] @ d[1].T + d[2]) @ d[3].T + d[4])
+    (yd * gy.double()).sum().backward()
+    ref = [yd.detach()] + [t.grad for t in d]
+    for a, c, r in zip(fused, comp, ref):
+        assert rel(a.double().cpu().numpy(), r.cpu().numpy()) < 2e-6
+        assert rel(a.cpu().numpy(), c.cpu().numpy()) < 2e-6
+
+
 def test_wgrad_slabs_batch_equals_the_per_job_launches():
     """conan_linear_wgrad_slabs_batch: many weight gradients' stage 1 in one launch per k-tile width.  With default slice counts the slabs
     (hence the reduced dW / db) are bit-identical to conan_linear_wgrad_slabs job by job; with fewer, longer slices the result agrees with
