@@ -274,6 +274,45 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.has_res else None), None, None
 
 
+class _LinearTapFn(torch.autograd.Function):
+    """(x W^T, x): a bias-free Linear that also hands its input through.  The second output is for a residual connection taken from the
+    same x further down: its gradient then arrives HERE, together with the gradient of the product, and the backward forms
+    dx = dy W + d_tap in the epilogue of the one input-gradient GEMM instead of leaving a separate add of two [M,K] tensors to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _c(x), _c(w)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=f32, device=x.device)
+        call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), None, None, M, K, N, 0, 0, None, ptr(y), stream_ptr())
+        ctx.save_for_backward(x, w)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dtap):
+        x, w = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dw = None
+        if dy is None:                                             # only the tap was used downstream
+            return dtap, None
+        dy = _c(dy)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=f32, device=x.device)
+            call("conan_linear_fwd", ptr(dy), ptr(w), None, ptr(_c(dtap)) if dtap is not None else None, M, N, K, 1, 0, None, ptr(dx), stream_ptr())
+        elif dtap is not None:
+            dx = dtap
+        if ctx.needs_input_grad[1]:
+            dw, _ = _wgrad(dy, x, M, K, N, None, w, False)
+        return dx, dw
+
+
+def linear_tap(x: Tensor, weight: Tensor):
+    """Returns (x @ weight.T, x'): x' is x, to be used for a residual connection downstream (see _LinearTapFn)."""
+    return _LinearTapFn.apply(x, weight)
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: bool = False, residual: Optional[Tensor] = None,
            m_dev: Optional[Tensor] = None) -> Tensor:
     """act(x @ weight.T + bias) (+ residual) with act = shifted softplus.  `m_dev`: device int32 row count (edge-level)."""

@@ -86,7 +86,7 @@ class CFConv(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
 
-    def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf) -> Tensor:
+    def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf, tap: bool = False):
         if isinstance(rbf, Tensor):                                                       # generic path: any (Gs, F)
             md = graph.num_edges_dev
             h1 = ops.linear(rbf, self.nn[0].weight, self.nn[0].bias, act=True, m_dev=md)   # mlp[0] + ssp
@@ -95,10 +95,14 @@ class CFConv(torch.nn.Module):
         else:                                                                             # fused: rbf -> mlp -> * C(d) in one kernel
             offset, coeff = rbf
             W = ops.filter_generate(graph, offset, coeff, self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias)
-        x = ops.linear(x, self.lin1.weight)                                               # lin1 (no bias)
+        x_in = None
+        if tap:                                                                           # lin1 (no bias), handing x through for the residual
+            x, x_in = ops.linear_tap(x, self.lin1.weight)
+        else:
+            x = ops.linear(x, self.lin1.weight)
         fused = not isinstance(rbf, Tensor)            # fused path: one filter row per undirected pair (W_ij = W_ji)
         x = ops.cfconv(x, W, graph, pre_cutoff_grad=fused, use_pairs=fused)               # propagate: gather * W, scatter-add
-        return x                                                                          # lin2 applied by the caller (fused with ssp)
+        return (x, x_in) if tap else x                                                    # lin2 applied by the caller (fused with ssp)
 
 
 class InteractionBlock(torch.nn.Module):
@@ -121,7 +125,8 @@ class InteractionBlock(torch.nn.Module):
 
     def forward(self, x: Tensor, graph: ops.RadiusGraph, rbf: Tensor) -> Tensor:
         """Returns x + lin(ssp(conv(x)))  — the residual of schnet_no_sum.py:164 is fused into the last linear."""
-        m = self.conv(x, graph, rbf)
+        # the residual's x is taken from conv.lin1's second output: its gradient then meets lin1's input gradient inside one GEMM
+        m, x = self.conv(x, graph, rbf, tap=True)
         # conv.lin2 + InteractionBlock.act, then lin + x: one launch at node-level sizes (ops.mlp2), two linear kernels otherwise
         return ops.mlp2(m, self.conv.lin2.weight, self.conv.lin2.bias, self.lin.weight, self.lin.bias, residual=x)
 
