@@ -511,7 +511,13 @@ __global__ void __launch_bounds__(64) k_readout_fwd(const float *__restrict__ Y,
     }
     for (int c = threadIdx.x; c < d; c += 64) {
         float sum = 0.f, sq = 0.f;
-        for (int i = 0; i < N; ++i) { const float y = has_nan ? 0.f : Yb[i * d + c]; sum += y; sq += y * y; }
+        for (int i0 = 0; i0 < N; i0 += 8) {                     // 8 loads in flight (clamped), summed in node order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Yb[min(i0 + u, N - 1) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float y = (has_nan || i0 + u >= N) ? 0.f : v[u]; sum += y; sq += y * y; }
+        }
         float r = mode == 1 ? sum / sqrtf(sq) : sum;       // sum_i Y_ic / ||Y_:c||_2   (division by zero -> NaN, as the reference)
         for (int k = 0; k < K; ++k) out[((size_t)b * K + k) * d + c] = r;
     }

@@ -74,7 +74,21 @@ __global__ void __launch_bounds__(64) k_segment_sum(const float *__restrict__ x,
     const int lo = gptr[g], hi = gptr[g + 1];
     for (int c = threadIdx.x; c < W; c += 64) {
         float s = 0.f;
-        for (int a = lo; a < hi; ++a) s += x[(size_t)a * W + c];
+        int a = lo;
+        for (; a + 8 <= hi; a += 8) {                            // 8 loads in flight, summed in atom order (a serial loop is one round trip per atom)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(a + u) * W + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        if (a < hi) {                                            // tail: clamped loads, masked adds
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)min(a + u, hi - 1) * W + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += a + u < hi ? v[u] : 0.f;
+        }
         out[(size_t)g * W + c] = s;
     }
 }
