@@ -758,7 +758,7 @@ int conan_linear_wgrad_slabs_batch(const conan_wgrad_slab_job *jobs, int num_job
         };
         for (int j = 0; j < num_jobs; ++j) {
             const conan_wgrad_slab_job &b = jobs[j];
-            if ((b.K > 64) != (wide != 0) || b.M == 0) continue;
+            if ((b.K > 64) != (wide != 0)) continue;              // (a job with M = 0 still runs: its one slice writes zero slabs for the reducer)
             const int KT = wide ? 128 : 64, q = J.count;
             const int dflt = wgrad_slices(b.M, b.K), slices = (b.slices > 0 && b.slices <= dflt) ? b.slices : dflt;
             const int tn = (b.N + 127) / 128, tk = (b.K + KT - 1) / KT;

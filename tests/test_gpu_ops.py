@@ -261,9 +261,9 @@ def test_mlp2_outact_fused_head_fwd_bwd(M):
 def test_wgrad_slabs_batch_equals_the_per_job_launches():
     """conan_linear_wgrad_slabs_batch: many weight gradients' stage 1 in one launch per k-tile width.  With default slice counts the slabs
     (hence the reduced dW / db) are bit-identical to conan_linear_wgrad_slabs job by job; with fewer, longer slices the result agrees with
-    the fp64 product to fp32 rounding; a device-side row count masks the tail; M = 0 jobs are skipped."""
+    the fp64 product to fp32 rounding; a device-side row count masks the tail; a job whose device-side count is 0 yields zeros."""
     from conan_fgw_amd._lib import WgradJob, WgradSlabJob, call, lib, ptr, stream_ptr
-    shapes = [(3000, 128, 128), (2500, 64, 128), (777, 64, 64), (5000, 128, 64), (1, 128, 128), (300, 32, 128), (4000, 256, 128)]
+    shapes = [(3000, 128, 128), (2500, 64, 128), (777, 64, 64), (5000, 128, 64), (1, 128, 128), (300, 32, 128), (4000, 256, 128), (0, 128, 128)]
     gen = torch.Generator().manual_seed(7)
     gs = [torch.randn(M + 9, N, generator=gen).to(dev) for M, K, N in shapes]
     xs = [torch.randn(M + 9, K, generator=gen).to(dev) for M, K, N in shapes]
