@@ -121,9 +121,16 @@ class ViSNetBlock(torch.nn.Module):
         md = g.num_edges_dev
         xl = vo.layernorm(x, L.layernorm)
         vl = vo.scale_channels(vec, L.vec_layernorm.weight)
-        q, k, v = vo.lin(xl, L.q_proj), vo.lin(xl, L.k_proj), vo.lin(xl, L.v_proj)
-        dk, dv = vo.lin(f, L.dk_proj, True, md), vo.lin(f, L.dv_proj, True, md)
-        vp = vo.lin(vl.view(3 * n, H), L.vec_proj)                                 # [3n, 3H] = [vec1|vec2|vec3]
+        q, k, v = vo.multi_lin(xl, [L.q_proj, L.k_proj, L.v_proj])
+        # dk / dv / f_proj read the same f: one autograd node, so that the three input gradients are summed inside the backward GEMMs
+        if L.last_layer:
+            dk, dv = vo.multi_lin(f, [L.dk_proj, L.dv_proj], True, md)
+        else:
+            dk, dv, t = vo.multi_lin(f, [L.dk_proj, L.dv_proj, L.f_proj], True, md)
+        if L.last_layer:
+            vp = vo.lin(vl.view(3 * n, H), L.vec_proj)                             # [3n, 3H] = [vec1|vec2|vec3]
+        else:                                                                      # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node
+            vp, wt, ws = vo.multi_lin(vl.view(3 * n, H), [L.vec_proj, L.w_trg_proj, L.w_src_proj])
         vdot = vo.vecdot(vp, n, H)
         vmsg, xagg = vo.attn_message(q, k, v, dk, dv, g, L.cutoff, L.num_heads)
         sact = vo.lin(vmsg, L.s_proj, True, md)                                    # [E, 2H] = [s1|s2]
@@ -132,8 +139,7 @@ class ViSNetBlock(torch.nn.Module):
         xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
         if L.last_layer:
             return xo, veco, f
-        wt, ws = vo.lin(vl.view(3 * n, H), L.w_trg_proj), vo.lin(vl.view(3 * n, H), L.w_src_proj)   # node-level: Linear commutes with the gather
-        t = vo.lin(f, L.f_proj, True, md)
+        # (wt, ws: node-level — Linear commutes with the gather)
         return xo, veco, vo.edge_update(wt, ws, t, dvec, f, g)
 
 

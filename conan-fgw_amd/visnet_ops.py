@@ -86,6 +86,75 @@ class _LinearSilu(torch.autograd.Function):
         return dx, dw, db, None
 
 
+_MULTI_LINEAR = True
+
+
+class _MultiLinear(torch.autograd.Function):
+    """Several Linear layers (optionally + SiLU) of the SAME input: y_i = act(x W_i^T + b_i).  Forward: one launch per layer as before.
+    Backward: the input gradient sum_i g_i W_i is accumulated by the GEMMs themselves (each launch adds the running sum in its epilogue)
+    instead of leaving len - 1 element-wise adds of [M,K] tensors to autograd — at edge level (dk / dv / f_proj of `f`) an add costs as much
+    traffic as a GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, m_dev, act, *wb):
+        x = _c(x)
+        M, K = x.shape
+        n = len(wb) // 2
+        ws, bs = [_c(w) for w in wb[:n]], list(wb[n:])
+        need = x.requires_grad or any(w.requires_grad for w in ws)
+        ys, pres = [], []
+        for w, b in zip(ws, bs):
+            N = w.shape[0]
+            y = _tail0_shape(M, N, x.device, m_dev)
+            if act and need:
+                pre = torch.empty(M, N, dtype=f32, device=x.device)
+                call("conan_linear_act_fwd", ptr(x, f32), ptr(w, f32), ptr(b), M, K, N, 3, ptr(m_dev), ptr(y), ptr(pre), stream_ptr())
+                pres.append(pre)
+            else:
+                call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), None, M, K, N, 0, 3 if act else 0, ptr(m_dev), ptr(y), stream_ptr())
+            ys.append(y)
+        ctx.save_for_backward(x, *ws, *pres)
+        ctx.n, ctx.act, ctx.m_dev, ctx.has_b = n, act, m_dev, [b is not None for b in bs]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, md = ctx.n, ctx.m_dev
+        saved = ctx.saved_tensors
+        x, ws, pres = saved[0], saved[1:1 + n], saved[1 + n:]
+        M, K = x.shape
+        dx = None
+        dws, dbs = [None] * n, [None] * n
+        for i in range(n):
+            if dys[i] is None:
+                continue
+            w, N = ws[i], ws[i].shape[0]
+            if ctx.act:
+                g = _tail0(pres[i], md)
+                call("conan_silu_bwd", ptr(pres[i]), ptr(_c(dys[i])), M, N, ptr(md), ptr(g), stream_ptr())
+            else:
+                g = _c(dys[i])
+            if ctx.needs_input_grad[0]:
+                first = dx is None
+                if first:
+                    dx = _tail0_shape(M, K, x.device, md)
+                if first or N <= 128:
+                    call("conan_linear_fwd", ptr(g), ptr(w), None, None if first else ptr(dx), M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())   # dx (+)= g W
+                else:           # a contraction wider than one 128-chunk accumulates in place over several launches: it cannot also read dx as its residual
+                    tmp = _tail0_shape(M, K, x.device, md)
+                    call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(tmp), stream_ptr())
+                    dx = dx + tmp
+            dws[i], dbs[i] = ops._wgrad(g, x, M, K, N, md, w, ctx.has_b[i])
+        return (dx, None, None) + tuple(dws) + tuple(dbs)
+
+
+def multi_lin(x: Tensor, mods, act_silu: bool = False, m_dev=None):
+    """[act(Linear_i(x)) for Linear_i in mods] with the input gradients accumulated inside the backward GEMMs (see _MultiLinear)."""
+    if _MULTI_LINEAR and all(x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0 for m in mods):
+        return _MultiLinear.apply(x, m_dev, act_silu, *[m.weight for m in mods], *[m.bias for m in mods])
+    return tuple(lin(x, m, act_silu, m_dev) for m in mods)
+
+
 def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Tensor:
     if act_silu and x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0:
         return _LinearSilu.apply(x, m.weight, m.bias, m_dev)
