@@ -104,10 +104,10 @@ SIGNATURES = {
     "conan_layernorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "conan_scale_channels": (c_int, [_P, _P, c_ll, c_int, _P, _P]),
     "conan_visnet_vecdot": (c_int, [_P, c_int, c_int, _P, _P]),
-    "conan_visnet_attn_message": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
-    "conan_visnet_vec_aggregate": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_visnet_attn_message": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_vec_aggregate": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "conan_visnet_node_update": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
-    "conan_visnet_edge_update": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_edge_update": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_visnet_spatial_norm": (c_int, [_P, c_int, c_int, _P, _P]),
     "conan_visnet_gate": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_visnet_prior": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
@@ -120,10 +120,10 @@ SIGNATURES = {
     "conan_layernorm_bwd_ws": (c_ll, [c_int, c_int]),
     "conan_layernorm_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "conan_visnet_vecdot_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
-    "conan_visnet_attn_message_bwd": (c_int, [_P] * 13 + [c_float, c_int, c_int, c_int] + [_P] * 6),
-    "conan_visnet_vec_aggregate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "conan_visnet_attn_message_bwd": (c_int, [_P] * 13 + [c_float, c_int, c_int, c_int, c_int] + [_P] * 6),
+    "conan_visnet_vec_aggregate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_visnet_node_update_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
-    "conan_visnet_edge_update_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "conan_visnet_edge_update_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "conan_visnet_spatial_norm_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_visnet_gate_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_fgw_densify": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),

@@ -109,7 +109,7 @@ template <int CPL>
 __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                   const float *__restrict__ dk, const float *__restrict__ dv, const int *__restrict__ rowptr,
                                                   const int *__restrict__ col, const float *__restrict__ dist, float cutoff, int n, int H,
-                                                  int lph, float *__restrict__ vmsg, float *__restrict__ xagg) {
+                                                  int lph, int pre, float *__restrict__ vmsg, float *__restrict__ xagg) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = lane * CPL;
@@ -124,8 +124,9 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
 #pragma unroll
             for (int u = 0; u < CPL; ++u) {
                 const float kj = on ? k[(size_t)j * H + c0 + u] : 0.f;
-                const float dke = on ? dk[(size_t)e * H + c0 + u] : 0.f;
+                float dke = on ? dk[(size_t)e * H + c0 + u] : 0.f;
                 dvv[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
+                if (pre) { dke = silu_f(dke); dvv[u] = silu_f(dvv[u]); }      // dk / dv arrive as the projections' pre-activations
                 vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f;
                 part += qi[u] * kj * dke;
             }
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
 
 // Vector message + aggregation (:646-653, :672): vagg_i[sp] = sum_e vec_j[sp]*s1_e + s2_e*d_e[sp],  s = [s1|s2] in [E,2H]
 __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__ vec, const float *__restrict__ s, const float *__restrict__ dvec,
-                                                       const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H,
+                                                       const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int pre,
                                                        float *__restrict__ vagg) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
@@ -155,7 +156,8 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
                 const int j = col[e];
-                const float s1 = s[(size_t)e * 2 * H + c], s2 = s[(size_t)e * 2 * H + H + c];
+                float s1 = s[(size_t)e * 2 * H + c], s2 = s[(size_t)e * 2 * H + H + c];
+                if (pre) { s1 = silu_f(s1); s2 = silu_f(s2); }                 // s arrives as s_proj's pre-activation
                 const float *vj = vec + (size_t)j * 3 * H;
                 a0 += vj[c] * s1 + s2 * dvec[e * 3];
                 a1 += vj[H + c] * s1 + s2 * dvec[e * 3 + 1];
@@ -187,7 +189,7 @@ __global__ void k_node_update(const float *__restrict__ x, const float *__restri
 // wt = w_trg_proj(vec), ws = w_src_proj(vec) are node-level [n,3,H]; t = SiLU(f_proj(f_ij)) [E,H]
 __global__ void k_edge_update(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t, const float *__restrict__ dvec,
                               const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H,
-                              const float *__restrict__ f, float *__restrict__ fo) {
+                              int pre, const float *__restrict__ f, float *__restrict__ fo) {
     const int E = min(*ne_dev, max_edges);
     const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
@@ -199,7 +201,8 @@ __global__ void k_edge_update(const float *__restrict__ wt, const float *__restr
         const float pb = b0 * (-d0) + b1 * (-d1) + b2 * (-d2);        // vec . (-d)
         const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
         const float w20 = b0 - pb * (-d0), w21 = b1 - pb * (-d1), w22 = b2 - pb * (-d2);
-        fo[q] = f[q] + t[q] * (w10 * w20 + w11 * w21 + w12 * w22);
+        const float tv = pre ? silu_f(t[q]) : t[q];                  // t arrives as f_proj's pre-activation
+        fo[q] = f[q] + tv * (w10 * w20 + w11 * w21 + w12 * w22);
     }
 }
 
@@ -284,8 +287,8 @@ int conan_visnet_vecdot(const float *vp, int n, int H, float *out, void *stream)
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_attn_message(const float *q, const float *k, const float *v, const float *dk, const float *dv, const int *rowptr,
-                              const int *col, const float *dist, float cutoff, int n, int H, int num_heads, float *vmsg, float *xagg,
-                              void *stream) {
+                              const int *col, const float *dist, float cutoff, int n, int H, int num_heads, int pre_act, float *vmsg,
+                              float *xagg, void *stream) {
     VN_CHECK(q && k && v && dk && dv && rowptr && col && dist && vmsg && xagg && n >= 0 && H > 0 && num_heads > 0 && H % num_heads == 0);
     const int hd = H / num_heads;
     const int cpl = H > 64 ? (H + 63) / 64 : 1;
@@ -293,15 +296,15 @@ int conan_visnet_attn_message(const float *q, const float *k, const float *v, co
     const int lph = hd / cpl;
     if (lph & (lph - 1)) return CONAN_E_UNSUPPORTED;
     if (n == 0) return CONAN_OK;
-    if (cpl == 2) k_attn_msg<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, vmsg, xagg);
-    else k_attn_msg<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, vmsg, xagg);
+    if (cpl == 2) k_attn_msg<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
+    else k_attn_msg<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_vec_aggregate(const float *vec, const float *s, const float *dvec, const int *rowptr, const int *col, int n, int H,
-                               float *vagg, void *stream) {
+                               int pre_act, float *vagg, void *stream) {
     VN_CHECK(vec && s && dvec && rowptr && col && vagg && n >= 0 && H > 0);
     if (n == 0) return CONAN_OK;
-    k_vec_aggregate<<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, vagg);
+    k_vec_aggregate<<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_node_update(const float *x, const float *vec, const float *vdot, const float *o, const float *vp, const float *vagg, int n,
@@ -311,9 +314,9 @@ int conan_visnet_node_update(const float *x, const float *vec, const float *vdot
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_edge_update(const float *wt, const float *ws, const float *t, const float *dvec, const int *col, const int *tgt,
-                             const int *num_edges_dev, int max_edges, int H, const float *f, float *f_out, void *stream) {
+                             const int *num_edges_dev, int max_edges, int H, int pre_act, const float *f, float *f_out, void *stream) {
     VN_CHECK(wt && ws && t && dvec && col && tgt && num_edges_dev && f && f_out && H > 0);
-    k_edge_update<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, f, f_out);
+    k_edge_update<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_spatial_norm(const float *v, int n, int H, float *out, void *stream) {

@@ -151,7 +151,7 @@ template <int CPL>
 __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                          const float *__restrict__ dk, const float *__restrict__ dv, const float *__restrict__ dvmsg,
                                                          const float *__restrict__ dxagg, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                         const float *__restrict__ dist, float cutoff, int n, int H, int lph,
+                                                         const float *__restrict__ dist, float cutoff, int n, int H, int lph, int pre,
                                                          float *__restrict__ dq, float *__restrict__ ddk, float *__restrict__ ddv) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
@@ -163,18 +163,20 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
         for (int u = 0; u < CPL; ++u) { qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f; gx[u] = on ? dxagg[(size_t)i * H + c0 + u] : 0.f; acc[u] = 0.f; }
         for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
             const int j = col[e];
-            float kj[CPL], vj[CPL], dke[CPL], dve[CPL], dm[CPL];
+            float kj[CPL], vj[CPL], dke[CPL], dve[CPL], dm[CPL], sk[CPL], sv[CPL];
 #pragma unroll
             for (int u = 0; u < CPL; ++u) {
                 kj[u] = on ? k[(size_t)j * H + c0 + u] : 0.f; vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f;
                 dke[u] = on ? dk[(size_t)e * H + c0 + u] : 0.f; dve[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
+                sk[u] = 1.f; sv[u] = 1.f;
+                if (pre) { sk[u] = dsilu_f(dke[u]); sv[u] = dsilu_f(dve[u]); dke[u] = silu_f(dke[u]); dve[u] = silu_f(dve[u]); }   // pre-activations in, gradients w.r.t. them out
                 dm[u] = on ? dvmsg[(size_t)e * H + c0 + u] + gx[u] : 0.f;
             }
             float attn, da;
             attn_edge<CPL>(qi, kj, vj, dke, dve, dm, cos_cutoff(dist[e], cutoff), lph, attn, da);
 #pragma unroll
             for (int u = 0; u < CPL; ++u) {
-                if (on) { ddv[(size_t)e * H + c0 + u] = dm[u] * vj[u] * attn; ddk[(size_t)e * H + c0 + u] = da * qi[u] * kj[u]; }
+                if (on) { ddv[(size_t)e * H + c0 + u] = dm[u] * vj[u] * attn * sv[u]; ddk[(size_t)e * H + c0 + u] = da * qi[u] * kj[u] * sk[u]; }
                 acc[u] += da * kj[u] * dke[u];
             }
         }
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
                                                          const float *__restrict__ dk, const float *__restrict__ dv, const float *__restrict__ dvmsg,
                                                          const float *__restrict__ dxagg, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                          const int *__restrict__ tgt, const float *__restrict__ dist, float cutoff, int n, int H, int lph,
-                                                         float *__restrict__ dkn, float *__restrict__ dvn) {
+                                                         int pre, float *__restrict__ dkn, float *__restrict__ dvn) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = lane * CPL;
@@ -205,6 +207,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
             for (int u = 0; u < CPL; ++u) {
                 qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f;
                 dke[u] = on ? dk[(size_t)e * H + c0 + u] : 0.f; dve[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
+                if (pre) { dke[u] = silu_f(dke[u]); dve[u] = silu_f(dve[u]); }
                 dm[u] = on ? dvmsg[(size_t)e * H + c0 + u] + dxagg[(size_t)i * H + c0 + u] : 0.f;
             }
             float attn, da;
@@ -222,20 +225,23 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
 // ds[e] = [ sum_sp dvagg[tgt,sp]*vec[src,sp] | sum_sp dvagg[tgt,sp]*d_e[sp] ]
 __global__ void k_vec_aggregate_bwd_s(const float *__restrict__ vec, const float *__restrict__ dvagg, const float *__restrict__ dvec3,
                                       const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges,
-                                      int H, float *__restrict__ ds) {
+                                      int H, const float *__restrict__ s_pre, float *__restrict__ ds) {
     const int E = min(*ne_dev, max_edges);
     const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
         const int e = (int)(t / H), c = (int)(t - (long long)e * H);
         const float *g = dvagg + (size_t)tgt[e] * 3 * H, *vj = vec + (size_t)col[e] * 3 * H;
         const float g0 = g[c], g1 = g[H + c], g2 = g[2 * H + c];
-        ds[(size_t)e * 2 * H + c] = g0 * vj[c] + g1 * vj[H + c] + g2 * vj[2 * H + c];
-        ds[(size_t)e * 2 * H + H + c] = g0 * dvec3[e * 3] + g1 * dvec3[e * 3 + 1] + g2 * dvec3[e * 3 + 2];
+        float r1 = g0 * vj[c] + g1 * vj[H + c] + g2 * vj[2 * H + c];
+        float r2 = g0 * dvec3[e * 3] + g1 * dvec3[e * 3 + 1] + g2 * dvec3[e * 3 + 2];
+        if (s_pre) { r1 *= dsilu_f(s_pre[(size_t)e * 2 * H + c]); r2 *= dsilu_f(s_pre[(size_t)e * 2 * H + H + c]); }   // gradient w.r.t. the pre-activation
+        ds[(size_t)e * 2 * H + c] = r1;
+        ds[(size_t)e * 2 * H + H + c] = r2;
     }
 }
 // dvec[j,sp] = sum_{e in srclist(j)} dvagg[tgt_e,sp] * s1_e
 __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__restrict__ s, const float *__restrict__ dvagg, const int *__restrict__ t_rowptr,
-                                                             const int *__restrict__ t_eid, const int *__restrict__ tgt, int n, int H,
+                                                             const int *__restrict__ t_eid, const int *__restrict__ tgt, int n, int H, int pre,
                                                              float *__restrict__ dvec) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__rest
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int q = t_rowptr[j]; q < t_rowptr[j + 1]; ++q) {
                 const int e = t_eid[q];
-                const float s1 = s[(size_t)e * 2 * H + c];
+                const float s1 = pre ? silu_f(s[(size_t)e * 2 * H + c]) : s[(size_t)e * 2 * H + c];
                 const float *g = dvagg + (size_t)tgt[e] * 3 * H;
                 a0 += g[c] * s1; a1 += g[H + c] * s1; a2 += g[2 * H + c] * s1;
             }
@@ -282,7 +288,7 @@ __global__ void k_node_update_bwd(const float *__restrict__ dxo, const float *__
 // target pass: dwt[i] = sum_{e in row(i)} P_d (g * w2), and dt[e] = dfo * (w1.w2)   with g = dfo * t, P_d u = u - (u.d)d
 __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t,
                                                            const float *__restrict__ dvec3, const float *__restrict__ dfo, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ col, int n, int H, float *__restrict__ dwt, float *__restrict__ dt) {
+                                                           const int *__restrict__ col, int n, int H, int pre, float *__restrict__ dwt, float *__restrict__ dt) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
@@ -298,8 +304,9 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restri
                 const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
                 const float w20 = b0 - pb * d0, w21 = b1 - pb * d1, w22 = b2 - pb * d2;
                 const float gf = dfo[(size_t)e * H + c];
-                dt[(size_t)e * H + c] = gf * (w10 * w20 + w11 * w21 + w12 * w22);
-                const float g = gf * t[(size_t)e * H + c];
+                const float tr = t[(size_t)e * H + c];
+                dt[(size_t)e * H + c] = gf * (w10 * w20 + w11 * w21 + w12 * w22) * (pre ? dsilu_f(tr) : 1.0f);
+                const float g = gf * (pre ? silu_f(tr) : tr);
                 const float u0 = g * w20, u1 = g * w21, u2 = g * w22;
                 const float pu = u0 * d0 + u1 * d1 + u2 * d2;
                 s0 += u0 - pu * d0; s1 += u1 - pu * d1; s2 += u2 - pu * d2;
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restri
 // source pass: dws[j] = sum_{e in srclist(j)} P_d (g * w1)
 __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restrict__ wt, const float *__restrict__ t, const float *__restrict__ dvec3,
                                                            const float *__restrict__ dfo, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
-                                                           const int *__restrict__ tgt, int n, int H, float *__restrict__ dws) {
+                                                           const int *__restrict__ tgt, int n, int H, int pre, float *__restrict__ dws) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
@@ -324,7 +331,7 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restri
                 const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c];
                 const float pa = a0 * d0 + a1 * d1 + a2 * d2;
                 const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
-                const float g = dfo[(size_t)e * H + c] * t[(size_t)e * H + c];
+                const float g = dfo[(size_t)e * H + c] * (pre ? silu_f(t[(size_t)e * H + c]) : t[(size_t)e * H + c]);
                 const float u0 = g * w10, u1 = g * w11, u2 = g * w12;
                 const float pu = u0 * d0 + u1 * d1 + u2 * d2;
                 s0 += u0 - pu * d0; s1 += u1 - pu * d1; s2 += u2 - pu * d2;
@@ -429,8 +436,8 @@ int conan_visnet_vecdot_bwd(const float *vp, const float *dout, int n, int H, fl
 }
 int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v, const float *dk, const float *dv, const float *dvmsg,
                                   const float *dxagg, const int *rowptr, const int *col, const int *tgt, const int *t_rowptr,
-                                  const int *t_eid, const float *dist, float cutoff, int n, int H, int num_heads, float *dq, float *dkn,
-                                  float *dvn, float *ddk, float *ddv, void *stream) {
+                                  const int *t_eid, const float *dist, float cutoff, int n, int H, int num_heads, int pre_act, float *dq,
+                                  float *dkn, float *dvn, float *ddk, float *ddv, void *stream) {
     VB_CHECK(q && k && v && dk && dv && dvmsg && dxagg && rowptr && col && tgt && t_rowptr && t_eid && dist && dq && dkn && dvn && ddk && ddv);
     VB_CHECK(n >= 0 && H > 0 && num_heads > 0 && H % num_heads == 0);
     const int hd = H / num_heads, cpl = H > 64 ? (H + 63) / 64 : 1;
@@ -441,21 +448,21 @@ int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v
     hipStream_t s = as_stream(stream);
     const int g = nblk((long long)n * 64);
     if (cpl == 2) {
-        k_attn_bwd_target<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, dq, ddk, ddv);
-        k_attn_bwd_source<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, dkn, dvn);
+        k_attn_bwd_target<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, pre_act, dq, ddk, ddv);
+        k_attn_bwd_source<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, pre_act, dkn, dvn);
     } else {
-        k_attn_bwd_target<1><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, dq, ddk, ddv);
-        k_attn_bwd_source<1><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, dkn, dvn);
+        k_attn_bwd_target<1><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, pre_act, dq, ddk, ddv);
+        k_attn_bwd_source<1><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, pre_act, dkn, dvn);
     }
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float *dvec3, const float *dvagg, const int *col, const int *tgt,
-                                   const int *t_rowptr, const int *t_eid, const int *num_edges_dev, int max_edges, int n, int H, float *ds,
-                                   float *dvec, void *stream) {
+                                   const int *t_rowptr, const int *t_eid, const int *num_edges_dev, int max_edges, int n, int H, int pre_act,
+                                   float *ds, float *dvec, void *stream) {
     VB_CHECK(vec && s && dvec3 && dvagg && col && tgt && t_rowptr && t_eid && num_edges_dev && ds && dvec && H > 0);
     hipStream_t st = as_stream(stream);
-    k_vec_aggregate_bwd_s<<<nblk((long long)max_edges * H), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, ds);
-    if (n > 0) k_vec_aggregate_bwd_v<<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, dvec);
+    k_vec_aggregate_bwd_s<<<nblk((long long)max_edges * H), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
+    if (n > 0) k_vec_aggregate_bwd_v<<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp, int n, int H,
@@ -465,13 +472,13 @@ int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const flo
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_edge_update_bwd(const float *wt, const float *ws, const float *t, const float *dvec3, const float *dfo, const int *rowptr,
-                                 const int *col, const int *tgt, const int *t_rowptr, const int *t_eid, int n, int H, float *dwt, float *dws,
-                                 float *dt, void *stream) {
+                                 const int *col, const int *tgt, const int *t_rowptr, const int *t_eid, int n, int H, int pre_act, float *dwt,
+                                 float *dws, float *dt, void *stream) {
     VB_CHECK(wt && ws && t && dvec3 && dfo && rowptr && col && tgt && t_rowptr && t_eid && dwt && dws && dt && n >= 0 && H > 0);
     if (n == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
-    k_edge_update_bwd_t<<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, dwt, dt);
-    k_edge_update_bwd_s<<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, dws);
+    k_edge_update_bwd_t<<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
+    k_edge_update_bwd_s<<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_spatial_norm_bwd(const float *v, const float *dout, int n, int H, float *dv, void *stream) {

@@ -123,24 +123,25 @@ class ViSNetBlock(torch.nn.Module):
         vl = vo.scale_channels(vec, L.vec_layernorm.weight)
         q, k, v = vo.multi_lin(xl, [L.q_proj, L.k_proj, L.v_proj])
         # dk / dv / f_proj read the same f: one autograd node, so that the three input gradients are summed inside the backward GEMMs
+        # dk / dv stay PRE-activations: act (SiLU) is applied inside the attention kernels as they load them
         if L.last_layer:
-            dk, dv = vo.multi_lin(f, [L.dk_proj, L.dv_proj], True, md)
+            dk, dv = vo.multi_lin(f, [L.dk_proj, L.dv_proj], False, md)
         else:
-            dk, dv, t = vo.multi_lin(f, [L.dk_proj, L.dv_proj, L.f_proj], True, md)
+            dk, dv, t = vo.multi_lin(f, [L.dk_proj, L.dv_proj, L.f_proj], False, md)      # t too: act applied inside edge_update
         if L.last_layer:
             vp = vo.lin(vl.view(3 * n, H), L.vec_proj)                             # [3n, 3H] = [vec1|vec2|vec3]
         else:                                                                      # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node
             vp, wt, ws = vo.multi_lin(vl.view(3 * n, H), [L.vec_proj, L.w_trg_proj, L.w_src_proj])
         vdot = vo.vecdot(vp, n, H)
-        vmsg, xagg = vo.attn_message(q, k, v, dk, dv, g, L.cutoff, L.num_heads)
-        sact = vo.lin(vmsg, L.s_proj, True, md)                                    # [E, 2H] = [s1|s2]
-        vagg = vo.vec_aggregate(vl, sact, dvec, g)
+        vmsg, xagg = vo.attn_message(q, k, v, dk, dv, g, L.cutoff, L.num_heads, pre_act=True)
+        sact = vo.lin(vmsg, L.s_proj, False, md)                                   # [E, 2H] = pre-activation of [s1|s2]; act applied inside vec_aggregate
+        vagg = vo.vec_aggregate(vl, sact, dvec, g, pre_act=True)
         o = vo.lin(xagg, L.o_proj)
         xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
         if L.last_layer:
             return xo, veco, f
         # (wt, ws: node-level — Linear commutes with the gather)
-        return xo, veco, vo.edge_update(wt, ws, t, dvec, f, g)
+        return xo, veco, vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True)
 
 
 def ne_cutoff(block: ViSNetBlock) -> float:

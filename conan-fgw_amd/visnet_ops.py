@@ -305,15 +305,15 @@ def vecdot(vp, n, H):
 
 class _AttnMessage(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, dk, dv, graph, cutoff, heads):
+    def forward(ctx, q, k, v, dk, dv, graph, cutoff, heads, pre_act):
         q, k, v, dk, dv = (_c(t) for t in (q, k, v, dk, dv))
         n, H = q.shape
         vmsg = _tail0_shape(graph.max_edges, H, q.device, graph.num_edges_dev)
         xagg = _new(q, n, H)
         call("conan_visnet_attn_message", ptr(q, f32), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(graph.rowptr), ptr(graph.col), ptr(graph.dist),
-             float(cutoff), n, H, heads, ptr(vmsg), ptr(xagg), stream_ptr())
+             float(cutoff), n, H, heads, int(pre_act), ptr(vmsg), ptr(xagg), stream_ptr())
         ctx.save_for_backward(q, k, v, dk, dv)
-        ctx.graph, ctx.cutoff, ctx.heads = graph, float(cutoff), heads
+        ctx.graph, ctx.cutoff, ctx.heads, ctx.pre = graph, float(cutoff), heads, int(pre_act)
         return vmsg, xagg
 
     @staticmethod
@@ -325,23 +325,27 @@ class _AttnMessage(torch.autograd.Function):
         dq, dkn, dvn = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ddk, ddv = _tail0(dk, g.num_edges_dev), _tail0(dv, g.num_edges_dev)
         call("conan_visnet_attn_message_bwd", ptr(q), ptr(k), ptr(v), ptr(dk), ptr(dv), ptr(_c(dvmsg)), ptr(_c(dxagg)), ptr(g.rowptr), ptr(g.col),
-             ptr(g.tgt), ptr(tr), ptr(te), ptr(g.dist), ctx.cutoff, n, H, ctx.heads, ptr(dq), ptr(dkn), ptr(dvn), ptr(ddk), ptr(ddv), stream_ptr())
-        return dq, dkn, dvn, ddk, ddv, None, None, None
+             ptr(g.tgt), ptr(tr), ptr(te), ptr(g.dist), ctx.cutoff, n, H, ctx.heads, ctx.pre, ptr(dq), ptr(dkn), ptr(dvn), ptr(ddk), ptr(ddv),
+             stream_ptr())
+        return dq, dkn, dvn, ddk, ddv, None, None, None, None
 
 
-def attn_message(q, k, v, dk, dv, graph, cutoff, heads):
-    return _AttnMessage.apply(q, k, v, dk, dv, graph, cutoff, heads)
+def attn_message(q, k, v, dk, dv, graph, cutoff, heads, pre_act=False):
+    """pre_act=True: dk / dv are the projections' pre-activations; SiLU is applied inside the kernels as they are loaded (and the gradients
+    returned for them are w.r.t. the pre-activations), so the activated [E,H] tensors and the stand-alone SiLU backward passes never exist."""
+    return _AttnMessage.apply(q, k, v, dk, dv, graph, cutoff, heads, pre_act)
 
 
 class _VecAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, vec, s, dvec3, graph):
+    def forward(ctx, vec, s, dvec3, graph, pre_act):
         vec, s = _c(vec), _c(s)
         n, _, H = vec.shape
         vagg = torch.empty_like(vec)
-        call("conan_visnet_vec_aggregate", ptr(vec, f32), ptr(s, f32), ptr(dvec3), ptr(graph.rowptr), ptr(graph.col), n, H, ptr(vagg), stream_ptr())
+        call("conan_visnet_vec_aggregate", ptr(vec, f32), ptr(s, f32), ptr(dvec3), ptr(graph.rowptr), ptr(graph.col), n, H, int(pre_act), ptr(vagg),
+             stream_ptr())
         ctx.save_for_backward(vec, s, dvec3)
-        ctx.graph = graph
+        ctx.graph, ctx.pre = graph, int(pre_act)
         return vagg
 
     @staticmethod
@@ -352,12 +356,13 @@ class _VecAggregate(torch.autograd.Function):
         n, _, H = vec.shape
         ds, dvec = _tail0(s, g.num_edges_dev), torch.empty_like(vec)
         call("conan_visnet_vec_aggregate_bwd", ptr(vec), ptr(s), ptr(dvec3), ptr(_c(dvagg)), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
-             ptr(g.num_edges_dev), g.max_edges, n, H, ptr(ds), ptr(dvec), stream_ptr())
-        return dvec, ds, None, None
+             ptr(g.num_edges_dev), g.max_edges, n, H, ctx.pre, ptr(ds), ptr(dvec), stream_ptr())
+        return dvec, ds, None, None, None
 
 
-def vec_aggregate(vec, s, dvec3, graph):
-    return _VecAggregate.apply(vec, s, dvec3, graph)
+def vec_aggregate(vec, s, dvec3, graph, pre_act=False):
+    """pre_act=True: s is s_proj's pre-activation (SiLU applied on load, gradient returned w.r.t. it; see attn_message)."""
+    return _VecAggregate.apply(vec, s, dvec3, graph, pre_act)
 
 
 class _NodeUpdate(torch.autograd.Function):
@@ -386,14 +391,14 @@ def node_update(x, vec, vdot, o, vp, vagg):
 
 class _EdgeUpdate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, wt, ws, t, dvec3, f, graph):
+    def forward(ctx, wt, ws, t, dvec3, f, graph, pre_act):
         wt, ws, t, f = (_c(a) for a in (wt, ws, t, f))
         H = f.shape[1]
         fo = _tail0(f, graph.num_edges_dev)
         call("conan_visnet_edge_update", ptr(wt, f32), ptr(ws), ptr(t), ptr(dvec3), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev),
-             graph.max_edges, H, ptr(f), ptr(fo), stream_ptr())
+             graph.max_edges, H, int(pre_act), ptr(f), ptr(fo), stream_ptr())
         ctx.save_for_backward(wt, ws, t, dvec3)
-        ctx.graph = graph
+        ctx.graph, ctx.pre = graph, int(pre_act)
         return fo
 
     @staticmethod
@@ -405,12 +410,13 @@ class _EdgeUpdate(torch.autograd.Function):
         dfo = _c(dfo)
         dwt, dws, dt = torch.empty_like(wt), torch.empty_like(ws), _tail0(t, g.num_edges_dev)
         call("conan_visnet_edge_update_bwd", ptr(wt), ptr(ws), ptr(t), ptr(dvec3), ptr(dfo), ptr(g.rowptr), ptr(g.col), ptr(g.tgt), ptr(tr), ptr(te),
-             n, H, ptr(dwt), ptr(dws), ptr(dt), stream_ptr())
-        return dwt, dws, dt, None, dfo, None
+             n, H, ctx.pre, ptr(dwt), ptr(dws), ptr(dt), stream_ptr())
+        return dwt, dws, dt, None, dfo, None, None
 
 
-def edge_update(wt, ws, t, dvec3, f, graph):
-    return _EdgeUpdate.apply(wt, ws, t, dvec3, f, graph)
+def edge_update(wt, ws, t, dvec3, f, graph, pre_act=False):
+    """pre_act=True: t is f_proj's pre-activation (SiLU applied on load, gradient returned w.r.t. it; see attn_message)."""
+    return _EdgeUpdate.apply(wt, ws, t, dvec3, f, graph, pre_act)
 
 
 class _SpatialNorm(torch.autograd.Function):

@@ -314,21 +314,25 @@ int conan_scale_channels(const float *v, const float *w, long long rows, int H, 
 /* vec_dot[a,c] = sum_sp vp[a,sp,c] * vp[a,sp,H+c], vp = vec_proj(vec) [n,3,3H] (:605-607). */
 int conan_visnet_vecdot(const float *vp, int n, int H, float *out, void *stream);
 /* ViS_MP.message (scalar half) + aggregate (:632-645, :671): attn_h = SiLU(sum_{c in head} q_i k_j dk_e) * C(r_e);
- * vmsg[e,:] = v_j * dv_e * attn_h;  xagg[i,:] = sum_{e in row i} vmsg[e,:].  H <= 64 or H == 128. */
+ * vmsg[e,:] = v_j * dv_e * attn_h;  xagg[i,:] = sum_{e in row i} vmsg[e,:].  H <= 64 or H == 128.
+ * pre_act != 0: dk / dv are the PRE-activations of dk_proj / dv_proj (:623-624) and act (SiLU) is applied as they are loaded — the
+ * activated [E,H] tensors then never exist in HBM (the backward returns the gradients w.r.t. the pre-activations, likewise). */
 int conan_visnet_attn_message(const float *q, const float *k, const float *v, const float *dk, const float *dv,
                               const int *rowptr, const int *col, const float *dist, float cutoff, int n, int H,
-                              int num_heads, float *vmsg, float *xagg, void *stream);
+                              int num_heads, int pre_act, float *vmsg, float *xagg, void *stream);
 /* ViS_MP.message (vector half) + aggregate (:646-653, :672): vagg[i,sp,:] = sum_e vec[src,sp,:]*s1_e + s2_e*d_e[sp], s=[s1|s2]. */
+/* pre_act != 0 (here and in conan_visnet_edge_update and the two backward entry points): s / t are the PRE-activations of s_proj /
+ * f_proj; SiLU is applied as they are loaded and the gradients returned for them are w.r.t. the pre-activations (see conan_visnet_attn_message). */
 int conan_visnet_vec_aggregate(const float *vec, const float *s, const float *dvec, const int *rowptr, const int *col,
-                               int n, int H, float *vagg, void *stream);
+                               int n, int H, int pre_act, float *vagg, void *stream);
 /* Residual node update (:621-625, :873-881): x' = x + vec_dot*o2 + o3; vec' = vec + vec3*o1 + vagg; o=[o1|o2|o3], vec3=vp[:,:,2H:]. */
 int conan_visnet_node_update(const float *x, const float *vec, const float *vdot, const float *o, const float *vp,
                              const float *vagg, int n, int H, float *x_out, float *vec_out, void *stream);
 /* ViS_MP.edge_update (:655-661) with the node-side projections hoisted: wt = w_trg_proj(vec), ws = w_src_proj(vec) [n,3,H],
  * t = SiLU(f_proj(f)) [E,H]:  f'[e] = f[e] + t[e] * sum_sp rej(wt[tgt],d)[sp] * rej(ws[src],-d)[sp]. */
 int conan_visnet_edge_update(const float *wt, const float *ws, const float *t, const float *dvec, const int *col,
-                             const int *tgt, const int *num_edges_dev, int max_edges, int H, const float *f, float *f_out,
-                             void *stream);
+                             const int *tgt, const int *num_edges_dev, int max_edges, int H, int pre_act, const float *f,
+                             float *f_out, void *stream);
 /* GatedEquivariantBlock pieces (:942-960): |v|_2 over the spatial axis; gated split of update_net's output. */
 int conan_visnet_spatial_norm(const float *v, int n, int H, float *out, void *stream);
 int conan_visnet_gate(const float *u, const float *v2, int n, int out_channels, int scalar_activation, float *x_out,
@@ -361,20 +365,20 @@ int conan_visnet_vecdot_bwd(const float *vp, const float *dout, int n, int H, fl
 int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v, const float *dk, const float *dv,
                                   const float *dvmsg, const float *dxagg, const int *rowptr, const int *col,
                                   const int *tgt, const int *t_rowptr, const int *t_eid, const float *dist, float cutoff,
-                                  int n, int H, int num_heads, float *dq, float *dkn, float *dvn, float *ddk, float *ddv,
-                                  void *stream);
+                                  int n, int H, int num_heads, int pre_act, float *dq, float *dkn, float *dvn, float *ddk,
+                                  float *ddv, void *stream);
 /* Vector aggregate: ds [E,2H], dvec [n,3,H] from dvagg [n,3,H]. */
 int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float *dvec3, const float *dvagg,
                                    const int *col, const int *tgt, const int *t_rowptr, const int *t_eid,
-                                   const int *num_edges_dev, int max_edges, int n, int H, float *ds, float *dvec,
-                                   void *stream);
+                                   const int *num_edges_dev, int max_edges, int n, int H, int pre_act, float *ds,
+                                   float *dvec, void *stream);
 /* Node update: dvdot [n,H], do [n,3H], dvp [n,3,3H] = [0|0|dvec_out*o1] (dx = dx_out, dvec = dvagg = dvec_out). */
 int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp,
                                  int n, int H, float *dvdot, float *dout_o, float *dvp, void *stream);
 /* Edge update: dwt, dws [n,3,H] and dt [E,H] from df_out (df = df_out). */
 int conan_visnet_edge_update_bwd(const float *wt, const float *ws, const float *t, const float *dvec3, const float *dfo,
                                  const int *rowptr, const int *col, const int *tgt, const int *t_rowptr, const int *t_eid,
-                                 int n, int H, float *dwt, float *dws, float *dt, void *stream);
+                                 int n, int H, int pre_act, float *dwt, float *dws, float *dt, void *stream);
 int conan_visnet_spatial_norm_bwd(const float *v, const float *dout, int n, int H, float *dv, void *stream);
 int conan_visnet_gate_bwd(const float *u, const float *v2, const float *dxo, const float *dvo, int n, int out_channels,
                           int scalar_activation, float *du, float *dv2, void *stream);
