@@ -8,7 +8,8 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v * sigmoid(v) with the hardware reciprocal (1 ulp) instead of an IEEE division: the message kernels apply it per loaded element now
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float cos_cutoff(float d, float cutoff) {      // CosineCutoff, :33-46
     return d < cutoff ? 0.5f * (cosf(__fdiv_rn(d * 3.14159265358979323846f, cutoff)) + 1.0f) : 0.0f;
 }

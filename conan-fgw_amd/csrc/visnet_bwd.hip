@@ -6,7 +6,7 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }      // hardware reciprocal, 1 ulp
 __device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f(v); }
 __device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f(v); return s * (1.0f + v * (1.0f - s)); }
 __device__ __forceinline__ float cos_cutoff(float d, float cutoff) {
