@@ -127,7 +127,8 @@ class ViSNetBlock(torch.nn.Module):
         if L.last_layer:
             dk, dv = vo.multi_lin(f, [L.dk_proj, L.dv_proj], False, md)
         else:
-            dk, dv, t = vo.multi_lin(f, [L.dk_proj, L.dv_proj, L.f_proj], False, md)      # t too: act applied inside edge_update
+            # (t too: act applied inside edge_update; f itself is handed through for edge_update's residual, see _MultiLinear)
+            dk, dv, t, f = vo.multi_lin(f, [L.dk_proj, L.dv_proj, L.f_proj], False, md, tap=True)
         if L.last_layer:
             vp = vo.lin(vl.view(3 * n, H), L.vec_proj)                             # [3n, 3H] = [vec1|vec2|vec3]
         else:                                                                      # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node

@@ -96,7 +96,7 @@ class _MultiLinear(torch.autograd.Function):
     traffic as a GEMM."""
 
     @staticmethod
-    def forward(ctx, x, m_dev, act, *wb):
+    def forward(ctx, x, m_dev, act, tap, *wb):
         x = _c(x)
         M, K = x.shape
         n = len(wb) // 2
@@ -114,8 +114,10 @@ class _MultiLinear(torch.autograd.Function):
                 call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), None, M, K, N, 0, 3 if act else 0, ptr(m_dev), ptr(y), stream_ptr())
             ys.append(y)
         ctx.save_for_backward(x, *ws, *pres)
-        ctx.n, ctx.act, ctx.m_dev, ctx.has_b = n, act, m_dev, [b is not None for b in bs]
-        return tuple(ys)
+        ctx.n, ctx.act, ctx.m_dev, ctx.has_b, ctx.tap = n, act, m_dev, [b is not None for b in bs], bool(tap)
+        # tap: x handed through as one more output, for a consumer that uses the same x as a residual (edge_update's f): the gradient of
+        # that use then arrives here and seeds the running sum of the input-gradient GEMMs instead of being added by autograd afterwards
+        return tuple(ys) + ((x.view_as(x),) if tap else ())
 
     @staticmethod
     def backward(ctx, *dys):
@@ -123,6 +125,7 @@ class _MultiLinear(torch.autograd.Function):
         saved = ctx.saved_tensors
         x, ws, pres = saved[0], saved[1:1 + n], saved[1 + n:]
         M, K = x.shape
+        seed = _c(dys[n]) if (ctx.tap and dys[n] is not None) else None      # gradient of the handed-through x: seeds the running sum
         dx = None
         dws, dbs = [None] * n, [None] * n
         for i in range(n):
@@ -135,24 +138,29 @@ class _MultiLinear(torch.autograd.Function):
             else:
                 g = _c(dys[i])
             if ctx.needs_input_grad[0]:
-                first = dx is None
-                if first:
-                    dx = _tail0_shape(M, K, x.device, md)
-                if first or N <= 128:
-                    call("conan_linear_fwd", ptr(g), ptr(w), None, None if first else ptr(dx), M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())   # dx (+)= g W
+                if dx is None:
+                    dx, res = _tail0_shape(M, K, x.device, md), seed
+                    seed = None
+                else:
+                    res = dx
+                if res is None or N <= 128:
+                    call("conan_linear_fwd", ptr(g), ptr(w), None, ptr(res), M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())      # dx = g W (+ running sum)
                 else:           # a contraction wider than one 128-chunk accumulates in place over several launches: it cannot also read dx as its residual
                     tmp = _tail0_shape(M, K, x.device, md)
                     call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(tmp), stream_ptr())
-                    dx = dx + tmp
+                    dx = res + tmp
             dws[i], dbs[i] = ops._wgrad(g, x, M, K, N, md, w, ctx.has_b[i])
-        return (dx, None, None) + tuple(dws) + tuple(dbs)
+        if dx is None and seed is not None:
+            dx = seed
+        return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
-def multi_lin(x: Tensor, mods, act_silu: bool = False, m_dev=None):
-    """[act(Linear_i(x)) for Linear_i in mods] with the input gradients accumulated inside the backward GEMMs (see _MultiLinear)."""
+def multi_lin(x: Tensor, mods, act_silu: bool = False, m_dev=None, tap: bool = False):
+    """[act(Linear_i(x)) for Linear_i in mods] (+ [x] with tap=True) with the input gradients accumulated inside the backward GEMMs (see
+    _MultiLinear)."""
     if _MULTI_LINEAR and all(x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0 for m in mods):
-        return _MultiLinear.apply(x, m_dev, act_silu, *[m.weight for m in mods], *[m.bias for m in mods])
-    return tuple(lin(x, m, act_silu, m_dev) for m in mods)
+        return _MultiLinear.apply(x, m_dev, act_silu, tap, *[m.weight for m in mods], *[m.bias for m in mods])
+    return tuple(lin(x, m, act_silu, m_dev) for m in mods) + ((x,) if tap else ())
 
 
 def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Tensor:
