@@ -267,6 +267,7 @@ int conan_linear_t_try(const float *x, const float *w, const float *bias, const 
     if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 128, 0, 64, nullptr, pre_out); return 1; }
     if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 64, nullptr, pre_out); return 1; }
     if (K == 64 && N == 128) { *rc = launch_t<64, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 128, nullptr, pre_out); return 1; }
+    if (K == 32 && N == 128 && !w_kn) { *rc = launch_t<32, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 32, 0, 128, nullptr, pre_out); return 1; }   // ViSNet's rbf projections (32 -> 128, edge level)
     if ((K % 64) || (N % 64) || K > 1024 || N > 1024) return 0;
     const bool k128 = (K % 128) == 0, n128 = (N % 128) == 0;
     if (k128 && n128) *rc = chunk_launch<128, 128>(x, w, bias, residual, M, K, N, w_kn, act, y, m_dev, s, pre_out);

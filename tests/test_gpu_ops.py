@@ -20,7 +20,7 @@ def _ssp(x):
     return F.softplus(x) - math.log(2.0)
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 50, 128), (63, 128, 128), (64, 128, 64), (1000, 64, 64), (257, 50, 32), (3210, 128, 128), (130, 10, 256)])
+@pytest.mark.parametrize("M,K,N", [(1, 50, 128), (63, 128, 128), (64, 128, 64), (1000, 64, 64), (257, 50, 32), (3210, 128, 128), (130, 10, 256), (5000, 32, 128)])
 @pytest.mark.parametrize("act", [False, True])
 def test_linear_fwd_bwd(M, K, N, act):
     g = torch.Generator().manual_seed(M + K + N)
