@@ -86,9 +86,6 @@ class _LinearSilu(torch.autograd.Function):
         return dx, dw, db, None
 
 
-_MULTI_LINEAR = True
-
-
 class _MultiLinear(torch.autograd.Function):
     """Several Linear layers (optionally + SiLU) of the SAME input: y_i = act(x W_i^T + b_i).  Forward: one launch per layer as before.
     Backward: the input gradient sum_i g_i W_i is accumulated by the GEMMs themselves (each launch adds the running sum in its epilogue)
@@ -158,7 +155,7 @@ class _MultiLinear(torch.autograd.Function):
 def multi_lin(x: Tensor, mods, act_silu: bool = False, m_dev=None, tap: bool = False):
     """[act(Linear_i(x)) for Linear_i in mods] (+ [x] with tap=True) with the input gradients accumulated inside the backward GEMMs (see
     _MultiLinear)."""
-    if _MULTI_LINEAR and all(x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0 for m in mods):
+    if all(x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0 for m in mods):
         return _MultiLinear.apply(x, m_dev, act_silu, tap, *[m.weight for m in mods], *[m.bias for m in mods])
     return tuple(lin(x, m, act_silu, m_dev) for m in mods) + ((x,) if tap else ())
 
