@@ -13,8 +13,8 @@
 //   GEMM2^T  W^T  = W2 . H1    : the B operand IS the accumulator of GEMM1 (after bias + ssp), register r of lane-half h
 //                                being row 32mb + (r&3) + 8(r>>2) + 4h, so the k order of the A fragments is permuted to
 //                                match: no LDS round trip, no cross-lane traffic between the two GEMMs.
-// The A operands (the two weight matrices, <= 98 KB) are staged once per workgroup in LDS and read with conflict-free
-// ds_read_b128 (4 k-steps per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
+// The A operands (the two weight matrices as three bf16 images each: 54 + 102 KB at F = 128, of the CU's 160 KB) are staged once per
+// workgroup in LDS and read with conflict-free ds_read_b128 (one 16-wide k-step of one image per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
 // MFMAs back to back, both GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy; there is no
 // other arithmetic mode and no environment switch).
 #include "common.h"
