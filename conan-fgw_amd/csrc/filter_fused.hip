@@ -174,8 +174,13 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4 *>(h1_out + (size_t)e * F + 32 * mb + 8 * q + 4 * h) =
-                        make_float4(acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]);
+                {
+                    // streaming stores: h1 is not read again before the backward pass, W is read by the very next kernel — without the hint
+                    // the two 132 MB streams together overflow the 256 MiB Infinity Cache and the gather finds none of W there
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4 hv4 = {acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]};
+                    __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)e * F + 32 * mb + 8 * q + 4 * h));
+                }
         }
 
         // ---------------- GEMM2^T in groups of NG output row-blocks (bounds the live accumulators: 16*(MB + NG) registers)
