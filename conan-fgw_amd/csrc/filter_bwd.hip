@@ -123,10 +123,14 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
 
     float *dl = DL + 32 * wave;
     const int wave_stride = gridDim.x * FB_WAVES;
+    // Rows are walked from the END: the weight-gradient kernel that ran just before streamed g and h1 (264 MB) front to back through the
+    // 256 MiB Infinity Cache, so their tails are what it still holds — read in the same direction every line would be evicted just before it
+    // is needed (step -0.06 ms in a same-job A/B).  Logical tile t is physical tile tiles - 1 - t.
+#define FB_PHYS(t) max(tiles - 1 - (t), 0)
     int tile = blockIdx.x * FB_WAVES + wave;
     float4 xa[S], xb[S];
     auto load_x = [&](int t) {
-        const int m = min((t << 5) + l31, M - 1);
+        const int m = min((FB_PHYS(t) << 5) + l31, M - 1);
         const float *xr = g + (size_t)m * F + 8 * h;
 #pragma unroll
         for (int s = 0; s < S; ++s) {                          // lane-half h owns n = 16s + 8h .. +7 of its row
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
     };
     if (tile < tiles) load_x(tile);
     for (; tile < tiles; tile += wave_stride) {
-        const int e0 = tile << 5;
+        const int e0 = FB_PHYS(tile) << 5;
         // this tile's distances -> LDS (wave-private; LDS operations of one wave execute in order)
         if (lane < 32) dl[lane] = dist[min(e0 + lane, M - 1)];
         // this tile's h1 rows in accumulator layout: register r of block kb <-> edge row e0 + (r&3) + 8(r>>2) + 4h, channel 32kb + l31
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
         // gaps, so the six partial products are issued round-robin over two channel blocks (two independent chains).
         constexpr int PQ[6] = {0, 1, 2, 0, 1, 0}, PP[6] = {2, 1, 0, 1, 0, 0};
         const bool has_next = tile + wave_stride < tiles;
-        const float *xn = g + (size_t)min(((tile + wave_stride) << 5) + l31, M - 1) * F + 8 * h;
+        const float *xn = g + (size_t)min((FB_PHYS(tile + wave_stride) << 5) + l31, M - 1) * F + 8 * h;
         // Software pipeline over the 2 * S groups (k-step s, channel-block pair): the w2 fragments of group i + 1 are read from
         // LDS and (at the first group of a k-step) the next k-step's slice of g is split while the 12 MFMAs of group i run —
         // there is one wave per SIMD, nobody else covers an LDS round trip or a VALU burst.
