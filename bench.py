@@ -46,10 +46,15 @@ def parse(argv=None):
     ap.add_argument("--conformers", type=int, default=5)
     ap.add_argument("--shape", default="esol")
     ap.add_argument("--model", choices=["schnet", "visnet"], default="schnet", help="backbone (BASELINE.json configs[3] = visnet + bace)")
+    ap.add_argument("--head", choices=["regression", "classification"], default="regression",
+                    help="classification = EmbeddingsWithGATAggregationClassificationBaryCenter (sigmoid head, BCE): SURVEY 8(d) cfg4 with --model visnet --shape bace")
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each (value = the median block; min / max are printed beside it)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the world > 1 step at any world size: graph A -> all_reduce of the flat gradient buffer -> graph B (1-GPU test of the RCCL path)")
     ap.add_argument("--eager", action="store_true", help="time the eager Python step instead of the HIP-graph replay")
     ap.add_argument("--overlap", action="store_true", help="eager step: reduce the early gradient bucket while backward still runs (parallel.FlatGradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall-clock budget of the whole CPU-baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=48.0, help="wall-clock budget of the whole CPU-baseline leg")
     ap.add_argument("--cpu-full", action="store_true", help="SURVEY 8(d) protocol in full: 3 warm-up + 10 timed batches per leg")
     return ap.parse_args(argv)
 
@@ -155,23 +160,30 @@ def cpu_baseline(args, gpu_model=None):
     for nt in configs:
         torch.set_num_threads(nt)
         for name, fn in legs:
-            warm, timed = (3, 10) if args.cpu_full else (1, 10)
+            timed = 10
             t0 = time.perf_counter()
             ts = []
-            for w in range(warm):
+            t1 = time.perf_counter()
+            fn()
+            cold = time.perf_counter() - t1
+            # 3 warm-up + 10 timed.  A leg whose batch is short enough for the full protocol inside its share of the
+            # budget gets it; a longer one keeps 1 warm-up and as many timed batches as fit (recorded per leg).
+            full = args.cpu_full or cold * 13.5 <= budget
+            warm = 3 if full else 1
+            for w in range(warm - 1):
                 t1 = time.perf_counter()
                 fn()
                 cold = time.perf_counter() - t1
-            if not args.cpu_full and time.perf_counter() - t0 > budget:
+            if not full and time.perf_counter() - t0 > budget:
                 ts = [cold]                      # one batch already spends this leg's budget: it is the sample (noted as un-warmed)
             else:
                 for _ in range(timed):
                     t1 = time.perf_counter()
                     fn()
                     ts.append(time.perf_counter() - t1)
-                    if not args.cpu_full and time.perf_counter() - t0 > budget:
+                    if not full and time.perf_counter() - t0 > budget:
                         break
-            table[f"{name}@{nt}t"] = {"molecules_per_s": round(nb / float(np.median(ts)), 2), "timed_batches": len(ts),
+            table[f"{name}@{nt}t"] = {"molecules_per_s": round(nb / float(np.median(ts)), 2), "timed_batches": len(ts), "warmups": warm,
                                       "warmed": not (len(ts) == 1 and ts[0] == cold)}
             print(f"[cpu_baseline] {name}@{nt}t: {table[f'{name}@{nt}t']}  ({time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
     torch.set_num_threads(default_threads)
@@ -182,7 +194,9 @@ def cpu_baseline(args, gpu_model=None):
            "sample": f"{args.shape.upper()}-shaped batch of {nb} molecules (BASELINE configs[0]), K={K}: median of {table[key]['timed_batches']} "
                      f"{'training steps' if args.mode == 'train' else 'forwards'} of the CPU oracle in fp32 (SchNet trunk in torch, FGW = scalar C restatement, "
                      f"GAT + head), {best} torch thread(s) (the faster of {configs}) on {all_cores} host cores; legs = SURVEY 8(d) (i)-(iii) + training step",
-           "protocol": "3 warm-up + 10 timed, median" if args.cpu_full else f"1 warm-up + 1..10 timed per leg inside a {args.cpu_seconds:.0f} s budget, median",
+           "protocol": "3 warm-up + 10 timed, median" if args.cpu_full else
+                       f"per leg inside a {args.cpu_seconds:.0f} s budget: 3 warm-up + 10 timed where that fits the leg's share (legs[*].warmups == 3), "
+                       "else 1 warm-up + as many timed batches as fit; median",
            "legs": table, "host_cores": all_cores, "wall_s": round(time.perf_counter() - t_start, 1)}
     if gpu_model is not None and args.model == "schnet":
         # the same sample through the HIP path and through the fp64 oracle with the HIP model's current weights
@@ -209,6 +223,9 @@ def cpu_baseline(args, gpu_model=None):
 
 # ---------------------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
+    # dmabuf IPC for RCCL across processes on this driver: set before the first GPU call of THIS process, whichever launcher started it
+    # (spawn_ranks sets it for its children too; ranks that arrive through `python -m torch.distributed.run ... bench.py` only pass here)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -242,25 +259,32 @@ def run_rank(args):
     y = torch.from_numpy(b.y).to(dev)[:, None]
     torch.manual_seed(5)                                                          # train_val.py:223
     # the reference's stage-2 model: backbone (common.py:524-529 / :542-546) + GAT branch + aggregation head
-    model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=args.model).to(dev)
+    classify = args.head == "classification"
+    if classify:                                                                  # schnet_based_models.py:308-369 (SURVEY 8(d) cfg4 with ViSNet-128)
+        from conan_fgw_amd.head import EmbeddingsWithGATAggregationClassificationBaryCenter
+        model = EmbeddingsWithGATAggregationClassificationBaryCenter(K, dev, model_name=args.model, feat_dim=128 if args.model == "visnet" else 512).to(dev)
+        y = (y > 0).to(torch.float32)                                             # synthetic binary labels
+    else:
+        model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=args.model).to(dev)
     cidx = model.create_aggregation_index(b.num_graphs, dev)
     flat = FlatGradients(model.parameters())
     opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True, capturable=True)
     loss_out = torch.zeros((), device=dev)
     train = args.mode == "train"
     inv_world = 1.0 / world
+    collective = train and use_dist and (world > 1 or args.force_collective)      # the step contains the RCCL all-reduce
 
     def fwd_bwd():
         flat.zero()
         pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-        loss = torch.nn.functional.mse_loss(pred, y)
+        loss = torch.nn.functional.binary_cross_entropy(pred, y) if classify else torch.nn.functional.mse_loss(pred, y)   # common.py: BCE / MSE
         flat.backward(loss)                        # = loss.backward() with the slab sums of all weight gradients batched into one launch
         loss_out.copy_(loss.detach())
 
     def eager_step():
         if train:
             fwd_bwd()
-            flat.all_reduce_mean()                 # pack + (world > 1) RCCL all-reduce(s) + mean
+            flat.all_reduce_mean(force=args.force_collective)      # pack + (world > 1 or forced) RCCL all-reduce(s) + mean
             opt.step()
         else:
             with torch.no_grad():
@@ -303,7 +327,9 @@ def run_rank(args):
 
         # ---- eager rate (always measured; it is `value` only with --eager)
         n_eager = args.steps if args.eager else max(3, min(args.steps, 10))
-        dt_eager = timed(eager_step, n_eager)
+        dt_eager_blocks = [timed(eager_step, n_eager) for _ in range(max(1, args.blocks) if args.eager else 1)]
+        dt_eager = float(np.median(dt_eager_blocks))
+        dt_blocks = dt_eager_blocks
         loss_eager = float(loss_out)
 
         # ---- HIP-graph capture of the same step: A = forward + backward + pack | all-reduce (eager RCCL call between the two
@@ -324,19 +350,20 @@ def run_rank(args):
                 if train:
                     gB = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gB, stream=side, pool=gA.pool()):
-                        if world > 1:
+                        if collective:
                             flat.flat.mul_(inv_world)
                         opt.step()
 
                 def graph_step():
                     gA.replay()
                     if train:
-                        if world > 1:
+                        if collective:
                             dist.all_reduce(flat.flat, op=dist.ReduceOp.SUM)
                         gB.replay()
                 for _ in range(max(2, args.warmup)):
                     graph_step()
-                dt_graph = timed(graph_step, args.steps)
+                dt_blocks = [timed(graph_step, args.steps) for _ in range(max(1, args.blocks))]
+                dt_graph = float(np.median(dt_blocks))
             except Exception as e:                                   # capture is an optimisation of the launch path, never a requirement
                 graph_err = f"{type(e).__name__}: {e}"[:300]
                 torch.cuda.synchronize()
@@ -494,6 +521,9 @@ def run_rank(args):
         out = {
             "metric": "molecules/s (K=5 conformers)", "value": round(mol / dt, 1), "unit": "molecules/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / steps, 4),
+            "blocks": {"n": len(dt_blocks), "steps_each": steps, "ms_per_step": [round(1e3 * t / steps, 4) for t in dt_blocks],
+                       "min": round(1e3 * min(dt_blocks) / steps, 4), "max": round(1e3 * max(dt_blocks) / steps, 4),
+                       "note": "each block = exactly --steps steps between barrier + synchronize, max over ranks; value / ms_per_step = the median block"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
@@ -502,7 +532,8 @@ def run_rank(args):
                        "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "allreduce_us": None if ar_us is None else round(ar_us, 1),
-            "allreduce": {"payload_bytes": int(flat.flat.numel()) * 4, "calls_per_step": (1 if world > 1 else 0) if use_graph else flat.last_allreduce_launches,
+            "allreduce": {"payload_bytes": int(flat.flat.numel()) * 4, "calls_per_step": (1 if collective else 0) if use_graph else flat.last_allreduce_launches,
+                          "in_timed_step": bool(collective), "forced": bool(args.force_collective and world == 1),
                           "eager_overlap_buckets": list(buckets)},
             "eager": {"molecules_per_s": round(args.batch * world * n_eager / dt_eager, 1), "ms_per_step": round(1e3 * dt_eager / n_eager, 4), "steps": n_eager},
             "with_input_pipeline": pipe,

@@ -10,6 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libconan_fgw_hip.so")
 _LIB = None
+ABI_VERSION = 3            # == CONAN_FGW_ABI_VERSION of include/conan_fgw_hip.h (tests/test_abi.py compares the two)
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 
@@ -43,7 +44,7 @@ SIGNATURES = {
     "conan_abi_version": (c_int, []),
     "conan_collate_layout": (c_int, [c_int, c_int, _P, _P, c_int, c_int, ctypes.POINTER(BatchLayout)]),
     "conan_collate_pack": (c_int, [ctypes.POINTER(BatchLayout), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "conan_collate_unpack": (c_int, [_P, ctypes.POINTER(BatchLayout), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "conan_collate_unpack": (c_int, [_P, ctypes.POINTER(BatchLayout), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_graph_ptr_from_batch": (c_int, [_P, c_int, c_int, _P, _P]),
     "conan_radius_graph_csr": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "conan_csr_transpose": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
@@ -130,7 +131,7 @@ SIGNATURES = {
     "conan_fgw_densify_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P]),
     "conan_fgw_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
     "conan_fgw_barycenter_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(FgwParams),
-                                         _P, _P, _P, _P, _P, _P, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_fgw_barycenter_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "conan_fgw_readout_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "conan_fgw_readout_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
@@ -163,8 +164,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.conan_abi_version() != 1:
-            raise RuntimeError("libconan_fgw_hip.so: ABI version mismatch")
+        if L.conan_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libconan_fgw_hip.so: ABI version {L.conan_abi_version()} != {ABI_VERSION} expected by _lib.py (stale build: "
+                               "make -C conan-fgw_amd/csrc)")
         _LIB = L
     return _LIB
 

@@ -57,7 +57,7 @@ class ConformerMolecule:
 
 class DeviceBatch(types.SimpleNamespace):
     """The collated batch on the device: `z, pos, batch, x, edge_index, edge_attr, y, smiles` (the PyG `Batch` fields the models
-    read, schnet_based_models.py:135-173) + `batch_node_index` (== `batch`), `conformers_index`, `graph_ptr` and the host-known
+    read, schnet_based_models.py:135-173) + `conf_node_batch` (datasets.py:197) + `batch_node_index` (== `batch`), `conformers_index`, `graph_ptr` and the host-known
     `num_graphs`, `max_nodes`, `num_molecules`.  `ready` is recorded on the copy stream behind the unpack kernel."""
 
     def wait(self, stream: Optional[torch.cuda.Stream] = None):
@@ -150,7 +150,7 @@ class DeviceCollator:
                  batch=torch.empty(A, dtype=torch.int64, device=dev), x=torch.empty(A, L.x_dim, dtype=torch.float32, device=dev),
                  edge_index=torch.empty(2, E, dtype=torch.int64, device=dev), edge_attr=torch.empty(E, L.ea_dim, dtype=torch.float32, device=dev),
                  y=torch.empty(G, dtype=torch.float32, device=dev), graph_ptr=torch.empty(G + 1, dtype=torch.int32, device=dev),
-                 conformers_index=torch.empty(G, dtype=torch.int64, device=dev))
+                 conformers_index=torch.empty(G, dtype=torch.int64, device=dev), conf_node_batch=torch.empty(A, dtype=torch.int64, device=dev))
         if self.static:
             self._out = o
         return o
@@ -159,11 +159,12 @@ class DeviceCollator:
         L, pinned, smiles = self.pack(batch_items)
         slot = self._slot
         self._slot = (slot + 1) % self.depth
-        if self._staged[slot] is None or self._staged[slot].numel() < L.bytes:
-            self._staged[slot] = torch.empty(pinned.numel(), dtype=torch.uint8, device=self.device)
-        staged = self._staged[slot]
         cs = self.copy_stream
         main = torch.cuda.current_stream(self.device)
+        if self._staged[slot] is None or self._staged[slot].numel() < L.bytes:
+            with torch.cuda.stream(cs):                      # allocated on the stream that writes it: the caching allocator orders a
+                self._staged[slot] = torch.empty(pinned.numel(), dtype=torch.uint8, device=self.device)      # reused block behind its last use there
+        staged = self._staged[slot]
         with torch.cuda.stream(cs):
             staged[: L.bytes].copy_(pinned[: L.bytes], non_blocking=True)      # overlaps whatever the caller's stream is running
         if self.static and self._out is not None:
@@ -172,7 +173,7 @@ class DeviceCollator:
             o = self._outputs(L)
             call("conan_collate_unpack", ptr(staged), ctypes.byref(L), ptr(o["z"]), ptr(o["pos"]), ptr(o["batch"]), ptr(o["x"]) if L.x_dim else None,
                  ptr(o["edge_index"]) if L.num_bond_edges else None, ptr(o["edge_attr"]) if (L.num_bond_edges and L.ea_dim) else None,
-                 ptr(o["y"]), ptr(o["graph_ptr"]), ptr(o["conformers_index"]), stream_ptr())
+                 ptr(o["y"]), ptr(o["graph_ptr"]), ptr(o["conformers_index"]), ptr(o["conf_node_batch"]), stream_ptr())
             ev = torch.cuda.Event()
             ev.record(cs)
         self._events[slot] = ev

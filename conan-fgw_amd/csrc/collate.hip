@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(128) k_collate_unpack(const char *__restrict__
                                                         float *__restrict__ pos, int64_t *__restrict__ batch, float *__restrict__ x,
                                                         int64_t *__restrict__ edge_index, float *__restrict__ edge_attr,
                                                         float *__restrict__ y, int *__restrict__ graph_ptr,
-                                                        int64_t *__restrict__ conformers_index) {
+                                                        int64_t *__restrict__ conformers_index, int64_t *__restrict__ conf_node_batch) {
     const int g = blockIdx.x, m = g / L.K, k = g - m * L.K;
     const int *aoff = reinterpret_cast<const int *>(packed + L.off_atom_off);      // [B+1] atoms of the molecules before m (one conformer each)
     const int *boff = reinterpret_cast<const int *>(packed + L.off_bond_off);      // [B+1]
@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(128) k_collate_unpack(const char *__restrict__
     const float *ba = reinterpret_cast<const float *>(packed + L.off_battr) + (size_t)b0 * L.ea_dim;
     const int t = threadIdx.x;
     for (int i = t; i < n; i += 128) { z[node0 + i] = zs[i]; batch[node0 + i] = g; }
+    // data_batch.conf_node_batch (datasets.py:177,191,197): (arange(n) + atoms of the molecules before m), repeated for each conformer
+    if (conf_node_batch) for (int i = t; i < n; i += 128) conf_node_batch[node0 + i] = a0 + i;
     for (int i = t; i < n * 3; i += 128) pos[(size_t)node0 * 3 + i] = ps[i];
     for (int i = t; i < n * L.x_dim; i += 128) x[(size_t)node0 * L.x_dim + i] = xs[i];
     for (int i = t; i < e; i += 128) {
@@ -115,11 +117,12 @@ int conan_collate_pack(const conan_batch_layout *L, const int *n_atoms, const in
 }
 
 int conan_collate_unpack(const void *packed_dev, const conan_batch_layout *L, int64_t *z, float *pos, int64_t *batch, float *x,
-                         int64_t *edge_index, float *edge_attr, float *y, int *graph_ptr, int64_t *conformers_index, void *stream) {
+                         int64_t *edge_index, float *edge_attr, float *y, int *graph_ptr, int64_t *conformers_index,
+                         int64_t *conf_node_batch, void *stream) {
     if (!packed_dev || !L || !z || !pos || !batch || !y || !graph_ptr || !conformers_index || L->num_graphs <= 0) return CONAN_E_BADARG;
     if ((L->x_dim && !x) || (L->num_bond_edges && (!edge_index || (L->ea_dim && !edge_attr)))) return CONAN_E_BADARG;
     k_collate_unpack<<<L->num_graphs, 128, 0, as_stream(stream)>>>(static_cast<const char *>(packed_dev), *L, z, pos, batch, x, edge_index,
-                                                                   edge_attr, y, graph_ptr, conformers_index);
+                                                                   edge_attr, y, graph_ptr, conformers_index, conf_node_batch);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

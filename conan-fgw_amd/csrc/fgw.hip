@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         int ii = 0;
         bool exact = false;
         auto bad = [](double x) { return !(x > 1e-150 && x < 1e150); };
+        static_assert(NW < 15, "red[15] is the range flag: block_sum_d<NW> must not reach it");
         double *bad_flag = red + 15;                                      // set by whoever sees a sum out of range; read after the next barrier
         for (int j = tid; j < N; j += NT) v[j] = Mr[j * P + j];          // column references (the diagonal), before K overwrites them
         if (tid == 0) *bad_flag = 0.0;
@@ -566,8 +567,8 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d) {
 
 int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
                              const float *init_C, const float *init_Y, int B, int K, int N, int d,
-                             const conan_fgw_params *params, float *Y, float *C, float *T, int *info, float *errs,
-                             void *workspace, void *stream) {
+                             const conan_fgw_params *params, float *Y, float *C, float *T, float *T_iter, int *info,
+                             float *errs, void *workspace, void *stream) {
     if (!Ys || !Cs || !params || !Y || !C || !T || !info || !errs || !workspace || B <= 0 || K <= 0 || N <= 0 || d <= 0)
         return CONAN_E_BADARG;
     if (params->max_iter <= 0 || params->num_iter_max <= 0) return CONAN_E_BADARG;
@@ -612,6 +613,8 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
         else if (mode == 2) { if (kl) CONAN_CPL(2, true); else CONAN_CPL(2, false); }
         else if (mode == 1) { if (kl) CONAN_CPL(1, true); else CONAN_CPL(1, false); }
         else { if (kl) CONAN_CPL(0, true); else CONAN_CPL(0, false); }
+        if (T_iter)      // log["Ts_iter"] (barycenter.py:196): a snapshot per outer iteration, only when the caller asks for the log
+            (void)hipMemcpyAsync(T_iter + (size_t)outer * B * K * NN, T, (size_t)B * K * NN * sizeof(float), hipMemcpyDeviceToDevice, s);
         conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, small ? yvec : nullptr, s);
     }
 #undef CONAN_CPL

@@ -361,7 +361,7 @@ __global__ void k_bond_fill_s(const int *__restrict__ rowptr, const int *__restr
 
 extern "C" {
 
-int conan_abi_version(void) { return 1; }
+int conan_abi_version(void) { return CONAN_FGW_ABI_VERSION; }
 
 int conan_graph_ptr_from_batch(const int64_t *batch, int num_atoms, int num_graphs, int *graph_ptr, void *stream) {
     if (num_atoms < 0 || num_graphs < 0 || !graph_ptr) return CONAN_E_BADARG;

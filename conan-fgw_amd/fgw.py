@@ -64,17 +64,26 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
     lam = None
     if lambdas is not None:
         lam = torch.as_tensor(lambdas, dtype=torch.float32, device=Ys_t.device)
-    Y, C, T, info, errs = ops.fgw_barycenter_batched(
+    res = ops.fgw_barycenter_batched(
         Ys_t.view(1, K, N, d), Cs_t.view(1, K, N, N), ps=ps_t, p=p_t, lambdas=lam,
         init_C=init_C.to(torch.float32).view(1, N, N), init_Y=None if init_Y is None else init_Y.to(torch.float32).view(1, N, d),
         alpha=alpha, epsilon=epsilon, max_iter=max_iter, tol=tol, inner_tol=1e-4, num_iter_max=num_iter_max, stop_thr=stop_thr,
-        fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT, loss_fun=loss_fun)
+        fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT, loss_fun=loss_fun, keep_iterates=bool(log))
+    Y, C, T, info, errs = res[:5]
     if not log:
         return Y[0], C[0]
     outer = int(info[0, 0].item())
+    T_iter = res[5]
+    # log["Ms"] (barycenter.py:82,177,220): the feature costs dist(Y, Ys[s]) of the returned barycenter — clamped squared
+    # euclidean distances (utils.py:154-171); a by-product for the caller's inspection, formed here from the outputs
+    Yd = Y[0]
+    y2 = (Yd * Yd).sum(1)
+    Ms = [torch.clamp(y2[:, None] + (Ys_t[s] * Ys_t[s]).sum(1)[None, :] - 2.0 * (Yd @ Ys_t[s].T), min=0) for s in range(K)]
     log_ = {"err_feature": [errs[0, 0, i] for i in range(outer)], "err_structure": [errs[0, 1, i] for i in range(outer)],
+            "Ts_iter": [[T_iter[i, 0, s] for s in range(K)] for i in range(outer)],           # barycenter.py:196
             "T": [T[0, s] for s in range(K)],
             "p": p if p is not None else torch.ones(N, device=Y.device) / N,
+            "Ms": Ms,
             "n_outer": outer, "n_pgd": int(info[0, 1].item()), "n_sinkhorn": int(info[0, 2].item())}
     return Y[0], C[0], log_
 

@@ -169,15 +169,19 @@ class EmbeddingsWithGATAggregationClassificationBaryCenter(EmbeddingsWithGATAggr
     ReLU MLP of `build_mlp_class(is_complex=True)` (:31-45) and a sigmoid (:367).  Sub-module names as in the reference
     (`molecular_regression_lin.{0,2,4}`, `self_attention.*`)."""
 
-    def __init__(self, num_conformers: int, device=None, agg_weight: float = 0.2, gat_in_channels: int = 9):
+    def __init__(self, num_conformers: int, device=None, agg_weight: float = 0.2, gat_in_channels: int = 9, model_name: str = "schnet",
+                 feat_dim: int = 512):
+        """`model_name` as in the reference's constructor (schnet_based_models.py:313 -> common.py:444-446): "schnet" (512 / 256 / 10
+        gaussians) or "visnet" (`get_model("visnet", feat_dim=...)` ignores the cutoff keyword and keeps 5 A, common.py:542-546).
+        `feat_dim` is the reference's literal 512; SURVEY.md 8(d) cfg4 (BACE + ViSNet-128 + sigmoid head) passes 128."""
         torch.nn.Module.__init__(self)
         from .gat import GATBased
         self.num_conformers = num_conformers
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.node_embeddings_model = EquivModelsHolder.get_model("schnet", device, feat_dim=512, cutoff=10.0)   # common.py:444-446
+        self.node_embeddings_model = EquivModelsHolder.get_model(model_name, device, feat_dim=feat_dim, cutoff=10.0)   # common.py:444-446
         out_channels = self.node_embeddings_model.hidden_channels // 2                      # 256
-        self.gat_embeddings_model = (EquivModelsHolder.get_model("gat", device, feat_dim=512) if gat_in_channels == 9
-                                     else GATBased(out_channels=512 // 2, in_channels=gat_in_channels))
+        self.gat_embeddings_model = (EquivModelsHolder.get_model("gat", device, feat_dim=feat_dim) if gat_in_channels == 9      # :330 (512)
+                                     else GATBased(out_channels=feat_dim // 2, in_channels=gat_in_channels))
         self.transformation_matrix_3d = Linear(out_channels, out_channels)
         self.transformation_matrix_cov = Linear(out_channels, out_channels)
         self.transformation_matrix_bary = Linear(out_channels, out_channels)

@@ -134,8 +134,10 @@ class deferred_weight_gradients:
 
 
 def flush_weight_gradients():
-    """Reduce every pending slab set on the current stream (no-op when nothing is pending).  Returns {weight data_ptr: dW data_ptr}
-    of what was flushed, so that the owner of the parameters can check that autograd adopted those very tensors."""
+    """Reduce every pending slab set on the current stream (no-op when nothing is pending).  Returns {weight data_ptr: (dW data_ptr,
+    db data_ptr | None)} of what was flushed, so that the owner of the parameters can check that autograd adopted those very tensors
+    (FlatGradients._flush_deferred does, for dW and db).  The deferred mode is only sound behind that check: use it through
+    FlatGradients.backward(), not as a bare `with deferred_weight_gradients(): loss.backward()`."""
     global _pending
     if not _pending:
         return {}
@@ -162,7 +164,7 @@ def flush_weight_gradients():
         jobs[q].ws, jobs[q].dW, jobs[q].dbias = ptr(j["ws"]), j["dw_ptr"], j["db_ptr"]
         jobs[q].M, jobs[q].K, jobs[q].N, jobs[q].slices = j["M"], j["K"], j["N"], j.get("slices", 0)
     call("conan_wgrad_reduce_batch", jobs, len(_pending), stream_ptr())
-    done = {j["weight_ptr"]: j["dw_ptr"] for j in _pending}
+    done = {j["weight_ptr"]: (j["dw_ptr"], j["db_ptr"]) for j in _pending}
     for j in _pending:
         j["ws"].record_stream(cur)
     _pending.clear()
@@ -171,7 +173,7 @@ def flush_weight_gradients():
 
 
 _LATE_STAGE1_ROWS = 65536   # below this row count a weight gradient's slab kernel is postponed to the batched launch
-_flushed = {}              # weight data_ptr -> dW data_ptr of the last flushes (cleared by whoever verifies them)
+_flushed = {}              # weight data_ptr -> (dW data_ptr, db data_ptr | None) of the last flushes (cleared by whoever verifies them)
 
 
 def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
@@ -406,6 +408,8 @@ class _Stage2HeadFn(torch.autograd.Function):
     def forward(ctx, x3, xc, xb, W3, b3, Wb, bb, wreg, breg, aw, K):
         x3, xc, xb = _c(x3), _c(xc), _c(xb)
         G, D = x3.shape
+        if G % K != 0:
+            raise ValueError(f"stage2_head: {G} conformer graphs are not a multiple of num_conformers={K}")
         B = G // K
         dev = x3.device
         out = torch.empty(B, 1, dtype=f32, device=dev)
@@ -692,16 +696,20 @@ class _FgwBarycenterFn(torch.autograd.Function):
         Y = torch.empty(B, N, d, dtype=f32, device=dev)
         C = torch.empty(B, N, N, dtype=f32, device=dev)
         T = torch.empty(B, K, N, N, dtype=f32, device=dev)
+        T_iter = torch.empty(prm.max_iter, B, K, N, N, dtype=f32, device=dev) if params.get("keep_iterates") else None
         info = torch.empty(B, 4, dtype=i32, device=dev)
         errs = torch.empty(B, 2, prm.max_iter, dtype=f32, device=dev)
         ws = torch.empty(int(lib().conan_fgw_workspace_bytes(B, K, N, d)), dtype=torch.uint8, device=dev)
         import ctypes
         call("conan_fgw_barycenter_fwd", ptr(Ys, f32), ptr(Cs, f32), ptr(ps), ptr(p), ptr(lambdas), ptr(init_C), ptr(init_Y),
-             B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(info), ptr(errs), ptr(ws), stream_ptr())
+             B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(T_iter), ptr(info), ptr(errs), ptr(ws), stream_ptr())
         ctx.save_for_backward(T, p, lambdas)
         ctx.dims = (B, K, N, d)
-        ctx.mark_non_differentiable(C, T, info, errs)
-        return Y, C, T, info, errs
+        if T_iter is None:
+            ctx.mark_non_differentiable(C, T, info, errs)
+            return Y, C, T, info, errs
+        ctx.mark_non_differentiable(C, T, info, errs, T_iter)
+        return Y, C, T, info, errs, T_iter
 
     @staticmethod
     def backward(ctx, dY, *_):
@@ -715,7 +723,8 @@ class _FgwBarycenterFn(torch.autograd.Function):
 def fgw_barycenter_batched(Ys: Tensor, Cs: Tensor, ps: Optional[Tensor] = None, p: Optional[Tensor] = None,
                            lambdas: Optional[Tensor] = None, init_C: Optional[Tensor] = None, init_Y: Optional[Tensor] = None,
                            **params):
-    """B independent FGW barycenters.  Ys [B,K,N,d], Cs [B,K,N,N] -> Y [B,N,d], C [B,N,N], T [B,K,N,N], info [B,4], errs [B,2,max_iter].
+    """B independent FGW barycenters.  Ys [B,K,N,d], Cs [B,K,N,N] -> Y [B,N,d], C [B,N,N], T [B,K,N,N], info [B,4], errs [B,2,max_iter]
+    (+ T_iter [max_iter,B,K,N,N] with keep_iterates=True: the couplings after every outer iteration, barycenter.py:196).
     Gradient flows to Ys only (through the final couplings as constants), like the reference."""
     prm = dict(PROD_FGW)
     prm.update(params)

@@ -57,6 +57,7 @@ class FlatGradients:
         self._overlap = False
         self._order: Optional[list] = None          # calibration record: (param index, produced on the calling stream?)
         self._pending = 0
+        self._fired: set = set()
         self._work = None
         self.last_allreduce_launches = 0
 
@@ -80,6 +81,7 @@ class FlatGradients:
         for p in self.params:
             p.grad = None
         self._pending = self._n_early if self._overlap else 0
+        self._fired = set()
         self._work = None
 
     # ------------------------------------------------------------------------------------------------ pack
@@ -103,21 +105,35 @@ class FlatGradients:
         self._flush_deferred()
         self._pack(self._order_idx, self.flat)
 
-    def _flush_deferred(self):
+    def _flush_deferred(self, only=None):
         """Weight gradients whose slab reduction was deferred (ops.deferred_weight_gradients) become valid here, in one launch.
-        Deferral hands autograd tensors that are filled at this point, which is sound only if autograd adopted them as .grad: checked."""
+        Deferral hands autograd tensors that are filled at this point, which is sound only if autograd adopted them as .grad: checked.
+
+        `only` (a set of parameter indices): verify just those parameters and leave the other flushed entries for the next call.
+        The early-bucket hook uses it: it runs inside the post-accumulate hook of the LAST early parameter, when sibling outputs
+        of the same autograd node (the other weights of a fused two-layer function, a bias whose hook order differs) may not have
+        been accumulated yet — their .grad is still None, which is not a copy.  They are verified at the end of backward."""
         if not self.flat.is_cuda:
             return
         from . import ops
         ops.flush_weight_gradients()
         if ops._flushed:
-            for p in self.params:
-                want = ops._flushed.get(p.data_ptr())
-                if want is not None and (p.grad is None or p.grad.data_ptr() != want):
+            grads = {p.grad.data_ptr() for p in self.params if p.grad is not None}
+            for i, p in enumerate(self.params):
+                key = p.data_ptr()
+                want = ops._flushed.get(key)
+                if want is None or (only is not None and i not in only):
+                    continue
+                dw_ptr, db_ptr = want
+                if only is not None and db_ptr is not None and db_ptr not in grads and p.grad is not None and p.grad.data_ptr() == dw_ptr:
+                    continue                                   # the bias of this layer has not been accumulated yet: checked at the end
+                if p.grad is None or p.grad.data_ptr() != dw_ptr or (db_ptr is not None and db_ptr not in grads):
                     raise RuntimeError("a deferred weight gradient was copied by autograd before it was final (the parameter already had a "
                                        ".grad, or something else held the tensor): call FlatGradients.zero() before backward, or do not "
                                        "use deferred_weight_gradients here")
-            ops._flushed.clear()
+                del ops._flushed[key]
+            if only is None:
+                ops._flushed.clear()
 
     def backward(self, loss: torch.Tensor):
         """loss.backward() with the slab reductions of all weight gradients batched into one launch (flushed before any gradient is
@@ -132,9 +148,13 @@ class FlatGradients:
 
     # ------------------------------------------------------------------------------------------------ overlap
     def enable_overlap(self, early_fraction: float = 0.5):
-        """Start recording the gradient production order; call `calibrate()` after one backward."""
+        """Start recording the gradient production order; call `calibrate()` after one backward.  May be called again to re-cut the
+        buffer at another fraction (the hooks are registered once)."""
         self._frac = float(early_fraction)
         self._order = []
+        self._overlap = False
+        if self._hooks:
+            return
         main = torch.cuda.current_stream() if self.flat.is_cuda else None
         index = {id(p): i for i, p in enumerate(self.params)}
 
@@ -144,6 +164,7 @@ class FlatGradients:
                 on_main = (not self.flat.is_cuda) or torch.cuda.current_stream() == main
                 self._order.append((i, on_main))
             elif self._overlap and i in self._early:
+                self._fired.add(i)
                 self._pending -= 1
                 if self._pending == 0:
                     self._fire_early()
@@ -191,13 +212,17 @@ class FlatGradients:
             self._overlap, self._suspended = True, False
 
     def _fire_early(self):
-        self._flush_deferred()                                # the early bucket's weight gradients must be final before they travel
+        # the early bucket's weight gradients must be final before they travel; only parameters whose hook has fired are verified
+        # here (an unfired sibling of the same autograd node has .grad None until its own AccumulateGrad runs)
+        self._flush_deferred(only=self._fired)
         idx = self._order_idx[: self._n_early]
         self._pack(idx, self.flat[: self._split])
         self._work = dist.all_reduce(self.flat[: self._split], op=dist.ReduceOp.SUM, async_op=True)
 
     # ------------------------------------------------------------------------------------------------ reduce
-    def all_reduce_mean(self):
+    def all_reduce_mean(self, force: bool = False):
+        """Pack, sum across ranks, divide by the world size.  `force`: issue the collective even in a 1-rank group (the same RCCL
+        call the multi-rank step makes; used to exercise the path on one GPU)."""
         world = _world()
         self.last_allreduce_launches = 0
         if self._overlap and self._work is not None:
@@ -209,7 +234,7 @@ class FlatGradients:
             self.flat.mul_(1.0 / world)
             return
         self.pack()
-        if world > 1:
+        if world > 1 or (force and dist.is_available() and dist.is_initialized()):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.last_allreduce_launches = 1
             self.flat.mul_(1.0 / world)

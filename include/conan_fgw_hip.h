@@ -34,7 +34,10 @@ extern "C" {
 #define CONAN_E_LAUNCH (-2)
 #define CONAN_E_UNSUPPORTED (-3)
 
-/* Library / device probe.  Returns the ABI version (1). */
+/* Library / device probe.  Returns CONAN_FGW_ABI_VERSION of the build.  The version changes whenever an existing export changes its
+ * signature or meaning (v2: num_embeddings / pre_act arguments of round 2; v3: round-3 signatures), so a consumer compiled against
+ * this header can detect a stale library: compare the return value with the macro. */
+#define CONAN_FGW_ABI_VERSION 3
 int conan_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- batch assembly */
@@ -70,11 +73,12 @@ int conan_collate_pack(const conan_batch_layout *layout, const int *n_atoms, con
 /* (device) Expand a packed batch (already copied to the device) into the flat tensors of the reference's model API:
  * z[A] int64, pos[A,3], batch[A] int64 (= batch_node_index = data_batch.batch), x[A,x_dim], edge_index[2,E] int64 with node
  * offsets (Batch.from_data_list), edge_attr[E,ea_dim], y[G] (every conformer Data carries its molecule's target),
- * graph_ptr[G+1] int32 and conformers_index[G] int64 (create_aggregation_index, common.py:414-423).  `layout` is a HOST
- * pointer (passed to the kernel by value). */
+ * graph_ptr[G+1] int32, conformers_index[G] int64 (create_aggregation_index, common.py:414-423) and, when not NULL,
+ * conf_node_batch[A] int64 (data_batch.conf_node_batch, datasets.py:177,191,197: the molecule-level atom number of every
+ * conformer atom; nothing in the reference reads it).  `layout` is a HOST pointer (passed to the kernel by value). */
 int conan_collate_unpack(const void *packed_dev, const conan_batch_layout *layout, int64_t *z, float *pos, int64_t *batch,
                          float *x, int64_t *edge_index, float *edge_attr, float *y, int *graph_ptr, int64_t *conformers_index,
-                         void *stream);
+                         int64_t *conf_node_batch, void *stream);
 
 /* ---------------------------------------------------------------------------------------------- graph construction */
 
@@ -88,6 +92,10 @@ int conan_graph_ptr_from_batch(const int64_t *batch, int num_atoms, int num_grap
  * candidate.  Per target the first `limit` candidates in ascending source index are kept, limit = loop ? cap : cap + 1
  * (torch-cluster 1.6.1: radius_graph calls radius(x, x, r, batch, batch, cap if loop else cap + 1)), then the self pair is
  * dropped unless `loop`: a target with >= cap + 1 lower-index candidates keeps cap + 1 edges, any other truncated one cap.
+ * WHICH neighbours survive a truncated row (more than `limit` atoms in range: conformers of > 33 atoms) follows torch-cluster's
+ * CUDA kernel (radius_cuda.cu: linear scan in ascending index); its CPU path (nanoflann KD-tree, unsorted result) keeps an
+ * implementation-defined subset of the same size, so on truncated rows "bit-exact neighbour indices" means equal to the CUDA
+ * scan order, not to a CPU run.  Untruncated rows (every ESOL / FreeSolv-sized conformer) are the same set either way.
  * Outputs: rowptr[num_atoms+1]; col/tgt/dist sized for (loop ? cap : cap + 1)*num_atoms entries (rowptr[num_atoms] are written);
  * dist[e] = sqrt(d2) = the reference's edge_weight.  `deg_ws[num_atoms+1]` is scratch. */
 int conan_radius_graph_csr(const float *pos, const int *graph_ptr, int num_atoms, int num_graphs, float r, int cap,
@@ -418,13 +426,15 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d);
  * Ys[B,K,N,d], Cs[B,K,N,N], ps[B,K,N] or NULL (uniform), p[B,N] or NULL (uniform), lambdas[K] or NULL (1/K),
  * init_C[B,N,N] or NULL (= Cs[b,0], schnet_no_sum.py:303), init_Y[B,N,d] or NULL (zeros).
  * Outputs: Y[B,N,d], C[B,N,N], T[B,K,N,N] (final couplings, saved for the backward),
+ * T_iter[max_iter,B,K,N,N] or NULL: the couplings after every outer iteration (the reference's log["Ts_iter"], barycenter.py:196;
+ * a molecule that stopped early keeps its last couplings in the later slots),
  * info[B,4] int32 = {outer iterations, total PGD iterations, total Sinkhorn iterations, flags},
  * errs[B,2,max_iter] fp32 = err_feature / err_structure per outer iteration (NaN where not executed).
  * Internal arithmetic is fp64 (DESIGN.md section "FGW numerics"); I/O is fp32. */
 int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
                              const float *init_C, const float *init_Y, int B, int K, int N, int d,
-                             const conan_fgw_params *params /* (host) */, float *Y, float *C, float *T, int *info,
-                             float *errs, void *workspace, void *stream);
+                             const conan_fgw_params *params /* (host) */, float *Y, float *C, float *T, float *T_iter,
+                             int *info, float *errs, void *workspace, void *stream);
 
 /* dYs[b,s,j,:] = lambdas[s] * sum_i T[b,s,i,j] * (1/p[b,i]) * dY[b,i,:]  — the whole backward of the block given the
  * saved couplings (the reference solves them under torch.no_grad(), barycenter.py:120). */

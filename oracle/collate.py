@@ -10,8 +10,8 @@ import numpy as np
 
 
 def collate(items, K):
-    z, pos, x, batch, ei, ea, y, smiles, bni = [], [], [], [], [], [], [], [], []
-    node0, mol_id = 0, -1
+    z, pos, x, batch, ei, ea, y, smiles, bni, cnb = [], [], [], [], [], [], [], [], [], []
+    node0, mol_id, node_count = 0, -1, 0
     for it in items:                                   # datasets.py:180-184: one id per conformer graph, molecule-major
         n = len(it.z)
         for k in range(K):
@@ -21,9 +21,11 @@ def collate(items, K):
             ei.append(np.asarray(it.edge_index, np.int64) + node0); ea.append(np.asarray(it.edge_attr, np.float32))
             y.append(np.float32(it.y)); smiles.append(it.smiles)
             node0 += n
+        cnb.append(np.tile(np.arange(n, dtype=np.int64) + node_count, K))      # datasets.py:189-192: (arange(n) + node_count).repeat(num_confs)
+        node_count += n
     cat = lambda a, ax=0: np.concatenate(a, axis=ax)
     return dict(z=cat(z), pos=cat(pos), x=cat(x), batch=cat(batch), batch_node_index=cat(bni), edge_index=cat(ei, 1), edge_attr=cat(ea),
-                y=np.asarray(y, np.float32), smiles=smiles)
+                y=np.asarray(y, np.float32), smiles=smiles, conf_node_batch=cat(cnb))
 
 
 def aggregation_index(smiles, K):

@@ -58,16 +58,21 @@ class Stage2ClassificationOracle(nn.Module):
     """EmbeddingsWithGATAggregationClassificationBaryCenter.forward (schnet_based_models.py:350-369): SchNet 512 / 256 filters /
     10 gaussians (common.py:513-522), 256-wide branches, build_mlp_class(is_complex=True) (:31-45), sigmoid."""
 
-    def __init__(self, num_conformers: int, agg_weight: float = 0.2, gat_in_channels: int = 9):
+    def __init__(self, num_conformers: int, agg_weight: float = 0.2, gat_in_channels: int = 9, model_name: str = "schnet", feat_dim: int = 512):
         super().__init__()
         self.num_conformers, self.agg_weight = num_conformers, agg_weight
-        self.node_embeddings_model = SchNetNoSumOracle(512, 256, 3, num_gaussians=10, cutoff=10.0)
-        self.gat_embeddings_model = GATBasedOracle(256, 3, gat_in_channels)
-        self.transformation_matrix_3d = nn.Linear(256, 256)
-        self.transformation_matrix_cov = nn.Linear(256, 256)
-        self.transformation_matrix_bary = nn.Linear(256, 256)
-        self.molecular_regression_lin = nn.Sequential(nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 1))
-        self.self_attention = nn.ModuleDict({"query": nn.Linear(256, 256), "key": nn.Linear(256, 256), "value": nn.Linear(256, 256)})
+        if model_name == "visnet":                                  # get_model("visnet", feat_dim=...), common.py:444-446 -> :542-546
+            from .visnet import ViSNetOracle
+            self.node_embeddings_model = ViSNetOracle(feat_dim)
+        else:
+            self.node_embeddings_model = SchNetNoSumOracle(feat_dim, 256, 3, num_gaussians=10, cutoff=10.0)
+        c = feat_dim // 2
+        self.gat_embeddings_model = GATBasedOracle(c, 3, gat_in_channels)
+        self.transformation_matrix_3d = nn.Linear(c, c)
+        self.transformation_matrix_cov = nn.Linear(c, c)
+        self.transformation_matrix_bary = nn.Linear(c, c)
+        self.molecular_regression_lin = nn.Sequential(nn.Linear(c, c), nn.ReLU(), nn.Linear(c, c // 2), nn.ReLU(), nn.Linear(c // 2, 1))
+        self.self_attention = nn.ModuleDict({"query": nn.Linear(c, c), "key": nn.Linear(c, c), "value": nn.Linear(c, c)})
 
     def forward(self, z, pos, node_index, x, edge_index, edge_attr):
         K = self.num_conformers

@@ -40,7 +40,10 @@ def test_library_exports_every_declared_symbol(built):
     L = ctypes.CDLL(built.library_path())
     for name in _declared():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
-    assert L.conan_abi_version() == 1
+    hdr = open(HEADER).read()
+    want = int(re.search(r"#define\s+CONAN_FGW_ABI_VERSION\s+(\d+)", hdr).group(1))
+    from conan_fgw_amd import _lib
+    assert L.conan_abi_version() == want == _lib.ABI_VERSION
 
 
 def test_ctypes_table_matches_header(built):

@@ -50,6 +50,13 @@ def test_pack_layout_and_contents():
     # the synthetic flat batch and the oracle's collate of its items agree (edge order inside a graph is the item's own)
     assert np.array_equal(ref["z"], cb.z) and np.array_equal(ref["pos"], cb.pos) and np.array_equal(ref["batch"], cb.batch)
     assert np.array_equal(ocoll.aggregation_index(ref["smiles"], K), np.repeat(np.arange(5), K))
+    # conf_node_batch written out as the reference's torch expression (datasets.py:177,189-192,197)
+    import torch
+    cnb, node_count = [], 0
+    for it in items:
+        cnb.extend((torch.arange(len(it.z)) + node_count).repeat(K))
+        node_count += len(it.z)
+    assert np.array_equal(ref["conf_node_batch"], torch.LongTensor(cnb).numpy())
 
 
 def test_pack_rejects_a_bond_that_leaves_its_molecule():

@@ -19,7 +19,7 @@ def test_collate_matches_reference_semantics(shape, B, K):
     ref = ocoll.collate(items, K)
     data, node_index = collate_fn(items, dev)
     torch.cuda.synchronize()
-    for k in ("z", "pos", "x", "batch", "edge_index", "edge_attr", "y"):
+    for k in ("z", "pos", "x", "batch", "edge_index", "edge_attr", "y", "conf_node_batch"):
         got = getattr(data, k).cpu().numpy()
         assert got.dtype == ref[k].dtype and np.array_equal(got, ref[k]), k                 # bit-exact: integer and copied float data
     assert np.array_equal(node_index.cpu().numpy(), ref["batch_node_index"])

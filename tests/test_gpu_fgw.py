@@ -81,6 +81,14 @@ def test_cfm_log_known_answer(golden_dir):
     np.testing.assert_allclose([float(e) for e in log["err_feature"]], g["err_feature"], rtol=2e-4)
     assert log["n_outer"] == 5
     assert rel(torch.stack(log["T"]).cpu().numpy(), g["T"]) < 2e-3
+    # the rest of the reference's log (barycenter.py:196,218-223): couplings after every outer iteration and the final feature costs
+    assert len(log["Ts_iter"]) == 5 and all(len(ts) == 10 for ts in log["Ts_iter"])
+    ti = torch.stack([torch.stack(ts) for ts in log["Ts_iter"]]).cpu().numpy()
+    assert rel(ti[0], g["Ts_iter"][0]) < 1e-5                                # first outer iteration: no accumulated chaos yet
+    assert rel(ti, g["Ts_iter"]) < 2e-3
+    assert np.array_equal(ti[-1], torch.stack(log["T"]).cpu().numpy())      # the last snapshot IS the returned coupling
+    assert rel(torch.stack(log["Ms"]).cpu().numpy(), g["Ms"]) < 1e-4
+    assert torch.equal(log["p"].cpu(), torch.ones(22) / 22)
 
 
 def test_batched_equals_single_and_is_deterministic():

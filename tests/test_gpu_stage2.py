@@ -157,6 +157,37 @@ def test_stage2_with_visnet_backbone_matches_oracle():
     assert rel(y.cpu().double().numpy(), r.numpy()) < 1e-4
 
 
+def test_classification_head_on_visnet_backbone_cfg4():
+    """BACE-shaped conformers + ViSNet-128 + the classification (sigmoid) head — `model_name="visnet"` of
+    EmbeddingsWithGATAggregationClassificationBaryCenter (schnet_based_models.py:308-369, common.py:444-446 -> :542-546)."""
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationClassificationBaryCenter
+    from oracle.head import Stage2ClassificationOracle
+    dev = torch.device("cuda:0")
+    K = 2
+    b = make_batch("bace", 2, K, seed=71)
+    g = make_bond_graph(b, seed=72)
+    torch.manual_seed(6)
+    m = EmbeddingsWithGATAggregationClassificationBaryCenter(K, dev, model_name="visnet", feat_dim=128).to(dev)
+    ref = Stage2ClassificationOracle(K, model_name="visnet", feat_dim=128).double()
+    res = ref.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    t = lambda a: torch.from_numpy(a)
+    batch = types.SimpleNamespace(z=t(b.z).to(dev), pos=t(b.pos).to(dev), x=t(g.x).to(dev), edge_index=t(g.edge_index).to(dev),
+                                  edge_attr=t(g.edge_attr).to(dev), batch=t(b.batch).to(dev))
+    p = m(batch, m.create_aggregation_index(b.num_graphs, dev), batch.batch)
+    r = ref(t(b.z), t(b.pos).double(), t(b.batch), t(g.x), t(g.edge_index), t(g.edge_attr))
+    assert p.shape == (b.num_molecules, 1) and 0.0 < float(p.detach().min()) and float(p.detach().max()) < 1.0
+    assert rel(p.detach().cpu().double().numpy(), r.detach().numpy()) < 1e-4
+    lab = torch.tensor([[1.0], [0.0]])
+    torch.nn.functional.binary_cross_entropy(p, lab.to(dev)).backward()
+    torch.nn.functional.binary_cross_entropy(r, lab.double()).backward()
+    gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
+    gmax = max(float(q.grad.norm()) for q in rp.values() if q.grad is not None)
+    for k in ["molecular_regression_lin.2.weight", "transformation_matrix_3d.weight", "transformation_matrix_bary.weight"]:
+        err = float((gp[k].grad.cpu().double() - rp[k].grad).norm())
+        assert err <= 1e-4 * float(rp[k].grad.norm()) + 1e-6 * gmax, (k, err, float(rp[k].grad.norm()))
+
+
 def test_deferred_weight_gradients_are_bitwise_equal_to_immediate_ones():
     """ops.deferred_weight_gradients / FlatGradients.backward: the slab reductions of all Linear layers in ONE launch and the slab kernels
     of the node-level layers in one launch too — same slices, same sums in the same order => every gradient bit-identical to the
