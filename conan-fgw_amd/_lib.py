@@ -19,7 +19,7 @@ class FgwParams(ctypes.Structure):
     """Mirror of `conan_fgw_params` (include/conan_fgw_hip.h)."""
     _fields_ = [("alpha", c_float), ("epsilon", c_float), ("max_iter", c_int), ("tol", c_float), ("inner_tol", c_float),
                 ("num_iter_max", c_int), ("stop_thr", c_float), ("fixed_structure", c_int), ("fixed_features", c_int),
-                ("warmstart", c_int), ("loss_fun", c_int)]
+                ("warmstart", c_int), ("loss_fun", c_int), ("cs_small_int", c_int)]
 
 
 class BatchLayout(ctypes.Structure):

@@ -586,6 +586,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     double *Cpart = Ypart + (size_t)B * K * N * d;
     double *zvec = Cpart + (size_t)B * K * NN;              // [B,K,2N]  |z_j|^2, r2_j      (register-resident path)
     double *yvec = zvec + (size_t)B * K * 2 * N;            // [B,2N]    |y_i|^2, r1_i
+    int *redo = reinterpret_cast<int *>(yvec + (size_t)B * 2 * N);      // [B,K]  couplings the round-3 kernel hands back to the exact path
     const bool small = conan_fgw_small_supported(N, d);
     const bool kl = params->loss_fun != 0;
     if (params->loss_fun != 0 && params->loss_fun != 1) return CONAN_E_BADARG;
@@ -609,7 +610,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         if (small)
-            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, s);
+            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, redo, s);
         else if (mode == 2) { if (kl) CONAN_CPL(2, true); else CONAN_CPL(2, false); }
         else if (mode == 1) { if (kl) CONAN_CPL(1, true); else CONAN_CPL(1, false); }
         else { if (kl) CONAN_CPL(0, true); else CONAN_CPL(0, false); }

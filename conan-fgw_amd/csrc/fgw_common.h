@@ -227,14 +227,14 @@ struct BorderIdx {
     bool on[2];
 };
 template <int NW = FGW_WAVES>
-__device__ __forceinline__ BorderIdx border_prepare(int M, int Nn) {
+__device__ __forceinline__ BorderIdx border_prepare(int M, int Nn, const int tid = threadIdx.x) {
     BorderIdx bi;
     const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4;
     const int nb1 = (M - Mc) * Nn, nb2 = Mc * (Nn - Nc);
     bi.count = nb1 + nb2;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int t = p * (NW * 16) + ((int)threadIdx.x >> 2);
+        const int t = p * (NW * 16) + (tid >> 2);
         bi.on[p] = t < bi.count;
         bi.i[p] = 0; bi.j[p] = 0;
         if (bi.on[p]) {
@@ -333,8 +333,10 @@ __device__ __forceinline__ double mm_w_at(const TW *W, int pW, int k, int j) { r
 
 template <int NW = FGW_WAVES, bool WT, typename TX, typename TW, class FS>
 __device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
-                                       const BorderIdx &bi) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                       const BorderIdx &bi, const int tid = threadIdx.x) {
+    // `tid`: callers inside a long loop pass a copy of threadIdx.x laundered through an empty asm, so that the per-lane pointers and
+    // tile indices below are re-derived per call instead of being hoisted out of the loop and kept (spilled) across it
+    const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const bool border = border_path<NW>(M, Nn);
     const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;
@@ -452,6 +454,158 @@ __device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restri
     }
 }
 
+// mm_lds with the results HELD in registers until `mid()` has run: every wavefront finishes reading its operands, then mid() (a
+// workgroup barrier), then the stores — so that the output may overwrite an operand (A -> K in place) or a staging area that shares
+// storage with the output (the prologue's Y / Z against base).  Same tiling, fragment layout, summation order and border rule as
+// mm_lds: bitwise-equal results.  MAXT = compile-time bound on the tiles per wavefront (ceil(Mq * Nq / NW)).
+template <int NW, int MAXT, bool WT, typename TX, typename TW, class FM, class FS>
+__device__ __forceinline__ void mm_lds_hold(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FM mid,
+                                            FS st, const int tid = threadIdx.x) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool border = border_path<NW>(M, Nn);
+    const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;
+    const int kfull = Kd & ~3;
+    const int wstep = WT ? 4 : 4 * pW;
+    f64x4 res[MAXT];
+#pragma unroll
+    for (int tt = 0; tt < MAXT; ++tt) {
+        const int t = wave + tt * NW;
+        res[tt] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (t < Mq * Nq) {                                        // wave-uniform
+            const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+            const int ia = i0 + li, jb = j0 + li;
+            const bool ra = ia < M, cb = jb < Nn;
+            const TX *xp = X + (ra ? ia : M - 1) * pX + lk;
+            const TW *wp = WT ? W + (cb ? jb : Nn - 1) * pW + lk : W + lk * pW + (cb ? jb : Nn - 1);
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+            int k0 = 0;
+            for (; k0 + 16 <= kfull; k0 += 16) {
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = (double)xp[4 * u]; b[u] = (double)wp[u * wstep]; }
+                xp += 16; wp += 4 * wstep;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[0] : 0.0, cb ? b[0] : 0.0, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[1] : 0.0, cb ? b[1] : 0.0, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[2] : 0.0, cb ? b[2] : 0.0, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[3] : 0.0, cb ? b[3] : 0.0, acc2, 0, 0, 0);
+            }
+            for (; k0 < kfull; k0 += 4) {
+                const double a = (double)xp[0], b = (double)wp[0];
+                xp += 4; wp += wstep;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a : 0.0, cb ? b : 0.0, acc, 0, 0, 0);
+            }
+            if (k0 < Kd) {
+                const bool kin = k0 + lk < Kd;
+                const int back = kin ? 0 : lk;
+                const double a = (double)xp[-back], b = (double)(WT ? wp[-back] : wp[-back * pW]);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc2, 0, 0, 0);
+            }
+            res[tt] = acc + acc2;
+        }
+    }
+    // border outputs (see mm_lds): thin border = three lanes per output in one pass, else four lanes per output in up to two passes
+    const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4, nb1 = (M - Mc) * Nn;
+    const int bcount = border ? nb1 + Mc * (Nn - Nc) : 0;
+    const bool thin = bcount <= NW * 21;
+    double bval[2] = {0.0, 0.0};
+    int b_i[2] = {0, 0}, b_j[2] = {0, 0};
+    bool b_on[2] = {false, false};
+    if (border && thin) {
+        const int o = wave * 21 + lane / 3, sub3 = lane % 3;
+        const bool on = lane < 63 && o < bcount;
+        if (on) {
+            if (o < nb1) { b_i[0] = Mc + o / Nn; b_j[0] = o % Nn; }
+            else { const int q = o - nb1; b_i[0] = q / (Nn - Nc); b_j[0] = Nc + q % (Nn - Nc); }
+        }
+        double acc = 0.0;
+        if (on) {
+            const int ws3 = WT ? 3 : 3 * pW;
+            const TX *xp = X + b_i[0] * pX + sub3;
+            const TW *wp = WT ? W + b_j[0] * pW + sub3 : W + sub3 * pW + b_j[0];
+            int k = sub3;
+            for (; k + 9 < Kd; k += 12) {
+                double xa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xa[u] = (double)xp[3 * u]; wb[u] = (double)wp[u * ws3]; }
+                xp += 12; wp += 4 * ws3;
+                acc += (xa[0] * wb[0] + xa[2] * wb[2]) + (xa[1] * wb[1] + xa[3] * wb[3]);
+            }
+            if (k < Kd) {
+                double xa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int uu = k + 3 * u < Kd ? u : 0;
+                    xa[u] = (double)xp[3 * uu]; wb[u] = (double)wp[uu * ws3];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += (k + 3 * u < Kd) ? xa[u] * wb[u] : 0.0;
+            }
+        }
+        const double a1 = __shfl(acc, lane + 1, 64), a2 = __shfl(acc, lane + 2, 64);
+        bval[0] = acc + a1 + a2;
+        b_on[0] = on && sub3 == 0;
+    } else if (border) {
+        const int sub = tid & 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (p * (NW * 16) >= bcount) break;
+            const int t = p * (NW * 16) + (tid >> 2);
+            const bool on = t < bcount;
+            if (on) {
+                if (t < nb1) { b_i[p] = Mc + t / Nn; b_j[p] = t % Nn; }
+                else { const int q = t - nb1; b_i[p] = q / (Nn - Nc); b_j[p] = Nc + q % (Nn - Nc); }
+            }
+            double acc = 0.0;
+            if (on) {
+                const TX *xp = X + b_i[p] * pX + sub;
+                const TW *wp = WT ? W + b_j[p] * pW + sub : W + sub * pW + b_j[p];
+                int k = sub;
+                for (; k + 28 < Kd; k += 32) {
+                    double xa[8], wb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { xa[u] = (double)xp[4 * u]; wb[u] = (double)wp[u * wstep]; }
+                    xp += 32; wp += 8 * wstep;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += xa[u] * wb[u];
+                }
+                if (k < Kd) {
+                    double xa[8], wb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int uu = k + 4 * u < Kd ? u : 0;
+                        xa[u] = (double)xp[4 * uu]; wb[u] = (double)wp[uu * wstep];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += (k + 4 * u < Kd) ? xa[u] * wb[u] : 0.0;
+                }
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            bval[p] = acc;
+            b_on[p] = on && sub == 0;
+        }
+    }
+    mid();
+#pragma unroll
+    for (int tt = 0; tt < MAXT; ++tt) {
+        const int t = wave + tt * NW;
+        if (t < Mq * Nq) {
+            const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4, jb = j0 + li;
+            if (jb < Nn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + lk + 4 * q;
+                    if (i < M) st(i, jb, res[tt][q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (b_on[p]) st(b_i[p], b_j[p], bval[p]);
+}
+
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
 bool conan_fgw_small_supported(int N, int d);
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
@@ -460,7 +614,7 @@ void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, 
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
                               const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
-                              const double *yvec, hipStream_t s);
+                              const double *yvec, int *redo, hipStream_t s);
 // yvec (nullable): the register-resident path's per-molecule vectors, refreshed after every update
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
                             const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,

@@ -38,10 +38,11 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
-    double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec) {
+    double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, const int *__restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
+    if (only && !only[blockIdx.x]) return;      // second pass behind k_fgw_coupling_fast: only the couplings it handed back
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -389,6 +390,345 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     FGW_PROF_FLUSH;
 }
 
+// ================================================================================================================================
+// Round-3 coupling kernel (square loss): same algorithm and mapping as k_fgw_coupling_small above, re-cut for RESIDENCY and fewer
+// vector instructions.  At cfg2 (N = 33) the kernel above holds 46.7 KB of LDS and 151 VGPRs: three workgroups per CU, 1 280
+// couplings on 768 slots = 1.67 rounds of a ~100-phase dependent chain with the vector ALU issuing in 39 % of the cycles.  Here:
+//   * Sinkhorn iterates on the SCALING VECTORS with the kernel matrix fixed: K = exp(Mr - ref_j) is formed ONCE per projected-
+//     gradient iteration, in the accumulator layout of the product that produces G (one exp per entry instead of one per entry and
+//     register layout), and every half-iteration is a matrix-vector product against it, f = b / (K^T g), g = a / (K f)
+//     (sinkhorn.py:415-416 with f = e^v, g = e^u): 9 FMAs per thread instead of 9 adds + 18 multiplies; the marginal check
+//     (:418-433) is f * (K^T g), whose K^T g is the next iteration's column product.  The returned coupling (:450) is g_i K_ij f_j.
+//   * LDS: A and K share one matrix (the product that turns A into K holds its results in registers until every wavefront has
+//     read its operands, mm_lds_hold), the adjacency C2 is kept as bytes when its entries are small integers (the model's
+//     to_dense_adj output always is; conan_fgw_params.cs_small_int), the per-index vectors and the Sinkhorn partial sums overlay
+//     matrices that are dead while they live: 31.0 KB at N = 33 => FIVE workgroups per CU (160 KB / 5) and <= 96 VGPRs,
+//     i.e. all 1 280 couplings of cfg2 resident at once.
+//   * Integer work: (row, column) of the staging loops advance incrementally (one division per thread instead of one per entry),
+//     the column reference of K is base's diagonal (read where the entry is formed; no combine, no barrier).
+// What it does NOT contain is the exact log-domain fallback: a row / column sum outside [1e-150, 1e150] (never observed on conformer
+// features) makes the workgroup give up WITHOUT writing anything and raise redo[b, s]; the launcher then runs the kernel above —
+// which carries the exact path — on the flagged couplings only (an early-exit launch otherwise).
+// ================================================================================================================================
+template <int R> struct FastCfg {
+    static constexpr int OCC = R <= 9 ? 5 : (R <= 12 ? 2 : 1);       // workgroups per CU the register budget is cut for
+};
+// tiles per wavefront of an N x N product (the dispatch rule of mm_lds): a template parameter of the kernel, because the products that
+// hold their results in registers unroll over it — N = 32..34 (one 16 x 16 tile per wavefront + a thin border) must not pay the
+// registers of N = 36 (nine padded tiles: three per wavefront)
+inline int fast_tiles_per_wave(int N) {
+    const int Mc = (N >> 4) << 4;
+    const bool border = (N - Mc) * N + Mc * (N - Mc) <= FGW_WAVES * 32 && Mc > 0;
+    const int q = border ? N >> 4 : (N + 15) >> 4;
+    return (q * q + FGW_WAVES - 1) / FGW_WAVES;
+}
+constexpr int FAST_VEC_DOUBLES = 128 + 256;                          // p, q [2][64] + r1, r2, |y|^2, |z|^2 [4][64]
+constexpr int FAST_SK_DOUBLES = 2 * 256 + 2 * 64;                    // column / row partial sums [4][64] each + f, g [64] each
+
+struct FastLds {
+    int npa;                 // doubles per fp64 matrix slot (N * P rounded up to even: 16-byte aligned slots)
+    size_t off_t, off_c2, off_red, off_vec, off_sk, bytes;
+    bool vec_alias, sk_alias;
+};
+template <typename C2T>
+__host__ __device__ inline FastLds fast_lds(int N) {
+    FastLds L;
+    const int NP = N * (N | 1);
+    L.npa = (NP + 1) & ~1;
+    size_t o = (size_t)3 * L.npa * 8;                                // C1 | AK | base
+    L.off_t = o; o += ((size_t)NP * 4 + 15) & ~(size_t)15;           // T (fp32)
+    L.off_c2 = o; o += ((size_t)NP * sizeof(C2T) + 15) & ~(size_t)15;
+    L.off_red = o; o += 64;
+    L.vec_alias = (size_t)NP * 4 >= FAST_VEC_DOUBLES * 8;            // vectors overlay T until T0 is written
+    L.sk_alias = L.npa >= FAST_SK_DOUBLES;                           // Sinkhorn scratch overlays AK once K sits in registers
+    L.off_vec = L.vec_alias ? L.off_t : o; if (!L.vec_alias) o += FAST_VEC_DOUBLES * 8;
+    L.off_sk = L.sk_alias ? (size_t)L.npa * 8 : o; if (!L.sk_alias) o += FAST_SK_DOUBLES * 8;
+    L.bytes = o;
+    return L;
+}
+
+template <int R, int MAXT, typename C2T>
+__global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_fast(
+    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
+    FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
+    double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    if (!active[b]) return;
+    const int N = D.N, P = D.P, d = D.d;
+    const int NN = N * N;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool lane_ok = lane < N;
+    FGW_PROF_DECL;
+
+    const FastLds L = fast_lds<C2T>(N);
+    double *C1l = reinterpret_cast<double *>(smem);                  // [N,P]  barycenter structure C
+    double *AKl = C1l + L.npa;                                       // [N,P]  A = C1 @ T, then K = exp(Mr - ref); Sinkhorn scratch; T @ C2
+    double *Bl = AKl + L.npa;                                        // [N,P]  base = 2 alpha constC + (1 - alpha) M
+    float *Tl = reinterpret_cast<float *>(smem + L.off_t);           // [N,P]
+    C2T *C2l = reinterpret_cast<C2T *>(smem + L.off_c2);             // [N,P]
+    double *red = reinterpret_cast<double *>(smem + L.off_red);      // [8]
+    float *t_dummy = reinterpret_cast<float *>(red + 7);
+    double *pq = reinterpret_cast<double *>(smem + L.off_vec);       // [2][64] p, q   (prologue only)
+    double *vec4 = pq + 128;                                         // [4][64] r1_i, r2_j, |y_i|^2, |z_j|^2   (prologue only)
+    double *bufC = reinterpret_cast<double *>(smem + L.off_sk);      // [4][64] column partial sums
+    double *bufR = bufC + 256;                                       // [4][64] row partial sums
+    double *fvP = bufR + 256;                                        // [4][16] column factors f, index (j & 3) * 16 + (j >> 2)
+    double *gvP = fvP + 64;                                          // [4][16] row factors g, same permutation
+    double *Yl = AKl;                                                // prologue: Y (fp64 [N,d]) over AK | base
+    float *Zl = reinterpret_cast<float *>(C1l);                      // prologue / epilogue: Z (fp32 [N,d]) over C1
+    const bool yz_lds = d <= 2 * P;
+
+    const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
+    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
+    const double *C1 = Cw + (size_t)b * NN;
+    const double *Y = Yw + (size_t)b * N * d;
+    float *Tg = Tw + ((size_t)b * D.K + s) * NN;
+    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
+
+    // ---- loads first: every global load of the prologue is in flight before the first LDS store.  (row, column) of a thread's
+    // matrix entries: ONE division, then steps of 256 entries (the staging loops below walk them incrementally).
+    constexpr int EPT = (16 * R * R + FGW_THREADS - 1) / FGW_THREADS;      // matrix entries per thread (N <= 4R)
+    const int e_dq = FGW_THREADS / N, e_dr = FGW_THREADS - e_dq * N;
+    const int e_i0 = tid / N, e_j0 = tid - e_i0 * N;
+    auto for_entries = [&](auto fn) {                                     // fn(u, i * P + j) for this thread's entries t = tid + 256 u < N * N
+        int i = e_i0, j = e_j0;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            if (tid + u * FGW_THREADS < NN) fn(u, i * P + j);
+            j += e_dr; i += e_dq;
+            if (j >= N) { j -= N; ++i; }
+        }
+    };
+    const bool warm = outer > 0 && prm.warmstart;
+    const bool stage_yz = d <= 2 * P && !y_zero;                          // Y / Z through LDS for the prologue's dot(Y, Z)
+    float c2v[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) { const int t = tid + u * FGW_THREADS; c2v[u] = C2[t < NN ? t : NN - 1]; }
+    // C1 (and the warm-start coupling) cannot go to LDS before the dot product has consumed Z, which is staged over C1's storage: they
+    // are requested when the product's MFMAs are done (below) instead of being parked in registers across it.
+    double c1v[EPT];
+    float tv[EPT];
+    auto load_c1_t = [&]() {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int t = tid + u * FGW_THREADS, tc = t < NN ? t : NN - 1;
+            c1v[u] = C1[tc]; tv[u] = warm ? Tg[tc] : 0.f;
+        }
+    };
+    if (!stage_yz) load_c1_t();
+    const double p_own = tid < N ? (pb ? (double)pb[(size_t)b * N + tid] : 1.0 / (double)N) : 1.0;
+    const double q_own = tid < N ? (ps ? (double)ps[((size_t)b * D.K + s) * N + tid] : 1.0 / (double)N) : 1.0;
+    double vec_own;
+    {
+        const int v = tid >> 6, i = tid & 63;
+        const double *src = (v == 0 || v == 2) ? yvec + (size_t)b * 2 * N + (v == 0 ? N : 0) : zvec + ((size_t)b * D.K + s) * 2 * N + (v == 1 ? N : 0);
+        vec_own = src[i < N ? i : N - 1];
+        vec_own = i < N ? vec_own : 0.0;
+    }
+    if (stage_yz) {
+        const int Nd = N * d;
+        for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
+            double yv[4]; float zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS, tc = t < Nd ? t : Nd - 1; yv[u] = Y[tc]; zv[u] = Z[tc]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) { Yl[t] = yv[u]; Zl[t] = zv[u]; } }
+        }
+    }
+    if (tid < 64) { pq[tid] = p_own; pq[64 + tid] = q_own; }
+    vec4[tid] = vec_own;
+    for_entries([&](int u, int o) { C2l[o] = (C2T)c2v[u]; if (!stage_yz) C1l[o] = c1v[u]; });
+    __syncthreads();
+    FGW_PROF(0);      // staging
+    const double qj = pq[64 + lane];                                    // b_j with j = lane (layout A)
+    const double pi_l = pq[lane];                                       // a_i with i = lane (layout B)
+    const double *r1v = vec4, *r2v = vec4 + 64, *y2v = vec4 + 128, *z2v = vec4 + 192;
+    auto base_of = [&](int i, int j, double dot) {                      // utils.py:39-43,154-171, bregman.py:124-125
+        double m = -2.0 * dot; m += y2v[i]; m += z2v[j];
+        m = m > 0.0 ? m : 0.0;
+        return 2.0 * alpha * (r1v[i] + r2v[j]) + (1.0 - alpha) * m;
+    };
+    // ---- base = 2 alpha constC + (1 - alpha) M, M from dot(Y_i, Z_j) on MFMA.  With Y / Z staged over AK | base and C1, the products are
+    // held in registers until every wavefront has read its operands (base lands on Y's second half).
+    if (y_zero) {
+        int i = e_i0, j = e_j0;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            if (tid + u * FGW_THREADS < NN) Bl[i * P + j] = base_of(i, j, 0.0);
+            j += e_dr; i += e_dq;
+            if (j >= N) { j -= N; ++i; }
+        }
+    } else if (stage_yz) {
+        mm_lds_hold<FGW_WAVES, MAXT, true>(N, N, d, Yl, d, Zl, d, [&]() { load_c1_t(); __syncthreads(); },
+                                           [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
+        for_entries([&](int u, int o) { C1l[o] = c1v[u]; });            // Z is consumed (the barrier inside the product): C1 takes its place
+    } else {
+        mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
+               [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
+    }
+    // ---- T0 = G0 (warm start) or p q^T (bregman.py:98-101), written over the vectors once nobody reads them any more
+    double pA[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int q = w + 4 * r; pA[r] = pq[q < N ? q : N - 1]; }
+    __syncthreads();
+    FGW_PROF(1);      // dot(Y, Z) + base
+    if (warm) {
+        for_entries([&](int u, int o) { Tl[o] = tv[u]; });
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N && lane_ok) Tl[i * P + lane] = (float)(pA[r] * qj); }
+    }
+    __syncthreads();
+    FGW_PROF(2);      // T0
+
+    int cpt = 0, sk_total = 0;
+    double err = 1.0;
+    bool bail = false;                                                  // workgroup-uniform
+    while (err > (double)prm.inner_tol && cpt < prm.max_iter) {          // bregman.py:119
+        // Everything per-lane below (LDS offsets, tile indices, fragment pointers) is derived from THIS copy of the thread index, which the
+        // optimiser cannot see through: left alone it hoists some sixty loop-invariant offsets out of the loop and spills them.
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lq = tq & 63, wq = tq >> 6;
+        const bool lq_ok = lq < N;
+        const BorderIdx bnn = border_prepare(N, N, tq);                 // (only the thick-border branch of mm_lds reads it)
+        // ---- A = C1 @ T                                                        (utils.py:48-53)
+        mm_lds<FGW_WAVES, false>(N, N, N, C1l, P, Tl, P, [&](int i, int j, double v) { AKl[i * P + j] = v; }, bnn, tq);
+        __syncthreads();
+        FGW_PROF(3);  // A = C1 @ T
+        // ---- G = A @ (2 C2)^T, Mr = -(base - 2 alpha G) / eps (utils.py:62-64, sinkhorn.py:388), K = exp(Mr - ref_j) with the column
+        // reference ref_j = -base_jj / eps: formed where the product leaves its result, written over A once every wavefront has read A.
+        mm_lds_hold<FGW_WAVES, MAXT, true>(N, N, N, AKl, P, C2l, P, [&]() { __syncthreads(); }, [&](int i, int j, double v) {
+            const double x = ((Bl[j * P + j] - Bl[i * P + j]) + 4.0 * alpha * v) * inv_eps;      // Mr_ij - ref_j, G = 2 v
+            AKl[i * P + j] = exp_fast(x);
+        }, tq);
+        __syncthreads();
+        FGW_PROF(4);  // G, K
+        // ---- K into registers in both layouts: kA[r] = K[w + 4r][lane] (lane <-> column), kB[r] = K[lane][w + 4r] (lane <-> row)
+        double kA[R], kB[R];
+        {
+            const int lc = lq_ok ? lq : N - 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int q = wq + 4 * r, qc = q < N ? q : N - 1;
+                const double a = AKl[qc * P + lc], bb = AKl[lc * P + qc];
+                const bool ok = q < N && lq_ok;
+                kA[r] = ok ? a : 0.0; kB[r] = ok ? bb : 0.0;
+            }
+        }
+        __syncthreads();                                                // K is in registers: its storage becomes the Sinkhorn scratch
+        FGW_PROF(5);  // K -> registers
+        // ---- Sinkhorn on the scaling vectors (sinkhorn.py:413-433): f_j = b_j / sum_i K_ij g_i ; g_i = a_i / sum_j K_ij f_j
+        const int permL = (lq & 3) * 16 + (lq >> 2);                    // slot of this lane's factor in fvP / gvP
+        double *bufCw = bufC + wq * 64 + lq, *bufRw = bufR + wq * 64 + lq;
+        const double *fw = fvP + wq * 16, *gw = gvP + wq * 16;
+        int ii = 0;
+        double f = 0.0, g = 0.0, colp = 0.0;
+        bool have_colp = false;
+        for (; ii < prm.num_iter_max; ++ii) {
+            if (!have_colp) {                                           // v update (:415): column products against the current g (1 at ii = 0)
+                double pc = 0.0;
+                if (ii == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) pc += kA[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) pc = fma(kA[r], gw[r], pc);
+                }
+                *bufCw = pc;
+                __syncthreads();
+                colp = ((bufC[lq] + bufC[64 + lq]) + bufC[128 + lq]) + bufC[192 + lq];
+            }
+            have_colp = false;
+            if (__any(lq_ok && !(colp > 1e-150 && colp < 1e150))) { bail = true; break; }
+            f = lq_ok ? qj * rcp_pos(colp) : 0.0;
+            fvP[permL] = f;                                             // every wavefront writes the same 64 values and reads back its own
+            double pr = 0.0;                                            // u update (:416)
+#pragma unroll
+            for (int r = 0; r < R; ++r) pr = fma(kB[r], fw[r], pr);
+            *bufRw = pr;
+            __syncthreads();
+            const double rs = ((bufR[lq] + bufR[64 + lq]) + bufR[128 + lq]) + bufR[192 + lq];
+            if (__any(lq_ok && !(rs > 1e-150 && rs < 1e150))) { bail = true; break; }
+            g = lq_ok ? pi_l * rcp_pos(rs) : 0.0;
+            gvP[permL] = g;
+            if (ii % 10 == 0) {                                         // marginal violation (:418-433): || f * (K^T g) - b ||_2
+                double pc = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) pc = fma(kA[r], gw[r], pc);
+                *bufCw = pc;
+                __syncthreads();
+                colp = ((bufC[lq] + bufC[64 + lq]) + bufC[128 + lq]) + bufC[192 + lq];
+                have_colp = true;                                       // the next v update starts from these products
+                double df = lq_ok ? f * colp - qj : 0.0;
+                df = wave_sum_d(df * df);                              // identical in every wavefront: the break is workgroup-uniform
+                if (sqrt(df) < (double)prm.stop_thr) { ++ii; break; }
+            }
+        }
+        if (bail) break;
+        sk_total += ii;
+        FGW_PROF(6);  // Sinkhorn iterations
+        // ---- T = diag(g) K diag(f) (= exp(Mr + u + v), sinkhorn.py:450); err = ||T - Tprev||_F when cpt % 10 == 0 (bregman.py:144-147)
+        double e2 = 0.0;
+        {
+            float *trow = Tl + wq * P + lq;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool ok = lq_ok && wq + 4 * r < N;
+                float *tp = ok ? trow + 4 * r * P : t_dummy;
+                const float tn = (float)((gw[r] * kA[r]) * f);
+                const double df = ok ? (double)tn - (double)*tp : 0.0;
+                e2 += df * df;
+                *tp = tn;
+            }
+        }
+        if (cpt % 10 == 0) err = sqrt(block_sum_d(e2, red));
+        else __syncthreads();
+        ++cpt;
+        FGW_PROF(7);  // T store + err
+    }
+    if (bail) {                                                         // nothing has been written: the launcher re-runs this coupling on the exact path
+        if (tid == 0) redo[blockIdx.x] = 1;
+        return;
+    }
+    __syncthreads();
+    for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[blockIdx.x] = 0; }
+    FGW_PROF(8);      // T -> global
+
+    // ---- contributions to the barycenter update while T is resident
+    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
+        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        if (yz_lds) {                                                   // C1 is dead: Z through its storage, one coalesced pass
+            const int Nd = N * d;
+            for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
+                float zv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; zv[u] = Z[t < Nd ? t : Nd - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) Zl[t] = zv[u]; }
+            }
+            __syncthreads();
+            mm_lds<FGW_WAVES, false>(N, d, N, Tl, P, Zl, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; }, border_prepare(N, d));
+        } else {
+            mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
+                   [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        }
+    }
+    FGW_PROF(9);      // Ypart = T @ Z
+    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
+        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        const BorderIdx bnn = border_prepare(N, N);
+        mm_lds<FGW_WAVES, false>(N, N, N, Tl, P, C2l, P, [&](int i, int j, double v) { AKl[i * P + j] = v; }, bnn);
+        __syncthreads();
+        mm_lds<FGW_WAVES, true>(N, N, N, AKl, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = v; }, bnn);
+    }
+    FGW_PROF(10);     // Cpart = T @ C2 @ T^T
+    FGW_PROF_FLUSH;
+}
+
 // Per-index vectors of the gradient's constant part (init_matrix, utils.py:39-43) and of the feature cost (utils.py:154-171).
 // out[0..N) = |y_i|^2, out[N..2N) = r1_i = sum_k f1(C[i,k]) p_k with f1(a) = a^2 (square loss) or a log(a + 1e-15) - a (kl).
 // LPI = NT / 64 lanes per index (N <= 64), strided partial sums combined by xor-shuffles: a fixed order, bitwise reproducible.
@@ -537,8 +877,8 @@ inline size_t small_lds(int N, int d) {
 bool conan_fgw_small_supported(int N, int d) { return N <= 64 && small_lds(N, d) <= 160 * 1024; }
 
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
-    // Ypart [B,K,N,d] + Cpart [B,K,N,N] + zvec [B,K,2N] + yvec [B,2N], fp64
-    return ((size_t)B * K * N * d + (size_t)B * K * N * N + (size_t)B * K * 2 * N + (size_t)B * 2 * N) * 8 + 512;
+    // Ypart [B,K,N,d] + Cpart [B,K,N,N] + zvec [B,K,2N] + yvec [B,2N], fp64; redo [B,K] int32
+    return ((size_t)B * K * N * d + (size_t)B * K * N * N + (size_t)B * K * 2 * N + (size_t)B * 2 * N) * 8 + (size_t)B * K * 4 + 512;
 }
 
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
@@ -546,20 +886,67 @@ void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, 
     k_fgw_small_vectors<<<D.B * D.K, 256, 0, s>>>(Ys, Cs, ps, pb, D, prm.loss_fun, Cw, Yw, zvec, yvec);
 }
 
+template <int R, int MAXT, typename C2T>
+static void launch_fast_t(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm, int outer, int y_zero,
+                        const double *Cw, const double *Yw, const int *active, float *Tw, int *info, double *Ypart, double *Cpart,
+                        const double *zvec, const double *yvec, int *redo, hipStream_t s) {
+    const size_t lds = fast_lds<C2T>(D.N).bytes;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_fast<R, MAXT, C2T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    k_fgw_coupling_fast<R, MAXT, C2T><<<D.B * D.K, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart,
+                                                                          Cpart, zvec, yvec, redo);
+}
+template <int R, typename C2T>
+static void launch_fast(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm, int outer, int y_zero,
+                        const double *Cw, const double *Yw, const int *active, float *Tw, int *info, double *Ypart, double *Cpart,
+                        const double *zvec, const double *yvec, int *redo, hipStream_t s) {
+    const int tpw = fast_tiles_per_wave(D.N);                          // <= ceil(ceil(4R / 16)^2 / 4)
+#define ARGS Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s
+    if constexpr (R <= 6) launch_fast_t<R, 1, C2T>(ARGS);
+    else if constexpr (R <= 12) { if (tpw <= 1) launch_fast_t<R, 1, C2T>(ARGS); else launch_fast_t<R, 3, C2T>(ARGS); }
+    else { if (tpw <= 1) launch_fast_t<R, 1, C2T>(ARGS); else if (tpw <= 3) launch_fast_t<R, 3, C2T>(ARGS); else launch_fast_t<R, 4, C2T>(ARGS); }
+#undef ARGS
+}
+
+bool conan_fgw_fast_supported(int N, int d, int small_int) {
+    if (N > 64 || N < 4) return false;
+    const size_t lds = small_int ? fast_lds<unsigned char>(N).bytes : fast_lds<float>(N).bytes;
+    return lds <= 160 * 1024 && d >= 1;
+}
+
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
                               const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
-                              const double *yvec, hipStream_t s) {
+                              const double *yvec, int *redo, hipStream_t s) {
     const size_t lds = small_lds(D.N, D.d);
     const int R = (D.N + 3) / 4;
     const int grid = D.B * D.K;
+    // Square loss: the round-3 kernel first; whatever it hands back (redo[b, s] = 1: a Sinkhorn sum left the fp64-safe range) is solved
+    // by the kernel with the exact log-domain path, launched over the same grid with an early exit for everything else.
+    const int *only = nullptr;
+#ifndef CONAN_FGW_NO_FAST      // (A/B switch of tools/ab.py: the round-2 kernel alone)
+    if (!prm.loss_fun && redo && conan_fgw_fast_supported(D.N, D.d, prm.cs_small_int)) {
+#define FAST(RR)                                                                                                                     \
+    do {                                                                                                                             \
+        if (prm.cs_small_int) launch_fast<RR, unsigned char>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s); \
+        else launch_fast<RR, float>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s);     \
+    } while (0)
+        if (R <= 6) FAST(6);
+        else if (R <= 9) FAST(9);
+        else if (R <= 12) FAST(12);
+        else FAST(16);
+#undef FAST
+        only = redo;
+    }
+#endif
 #define LAUNCH(RR)                                                                                                              \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR, KLV>),                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
         k_fgw_coupling_small<RR, KLV><<<grid, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, \
-                                                                info, Ypart, Cpart, zvec, yvec);                                \
+                                                                info, Ypart, Cpart, zvec, yvec, only);                          \
     } while (0)
     if (prm.loss_fun) {
         constexpr bool KLV = true;

@@ -64,11 +64,14 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
     lam = None
     if lambdas is not None:
         lam = torch.as_tensor(lambdas, dtype=torch.float32, device=Ys_t.device)
+    # adjacency-like inputs (integers in [0, 255]: what to_dense_adj produces) take the byte-wide LDS layout of the N <= 64 kernel
+    small_int = bool(((Cs_t == Cs_t.round()) & (Cs_t >= 0) & (Cs_t <= 255)).all())
     res = ops.fgw_barycenter_batched(
         Ys_t.view(1, K, N, d), Cs_t.view(1, K, N, N), ps=ps_t, p=p_t, lambdas=lam,
         init_C=init_C.to(torch.float32).view(1, N, N), init_Y=None if init_Y is None else init_Y.to(torch.float32).view(1, N, d),
         alpha=alpha, epsilon=epsilon, max_iter=max_iter, tol=tol, inner_tol=1e-4, num_iter_max=num_iter_max, stop_thr=stop_thr,
-        fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT, loss_fun=loss_fun, keep_iterates=bool(log))
+        fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT, loss_fun=loss_fun, keep_iterates=bool(log),
+        cs_small_int=small_int)
     Y, C, T, info, errs = res[:5]
     if not log:
         return Y[0], C[0]

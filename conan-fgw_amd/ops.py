@@ -692,7 +692,7 @@ class _FgwBarycenterFn(torch.autograd.Function):
         prm = FgwParams(float(params["alpha"]), float(params["epsilon"]), int(params["max_iter"]), float(params["tol"]),
                         float(params["inner_tol"]), int(params["num_iter_max"]), float(params["stop_thr"]),
                         int(bool(params["fixed_structure"])), int(bool(params["fixed_features"])), int(bool(params["warmstart"])),
-                        {"square_loss": 0, "kl_loss": 1}[params.get("loss_fun", "square_loss")])
+                        {"square_loss": 0, "kl_loss": 1}[params.get("loss_fun", "square_loss")], int(bool(params.get("cs_small_int", False))))
         Y = torch.empty(B, N, d, dtype=f32, device=dev)
         C = torch.empty(B, N, N, dtype=f32, device=dev)
         T = torch.empty(B, K, N, N, dtype=f32, device=dev)

@@ -415,6 +415,9 @@ typedef struct conan_fgw_params {
     int fixed_features;     /* keep Y = init_Y                         (:292) */
     int warmstart;          /* warmstartT: start each coupling solve from the previous outer iteration's T (:285) */
     int loss_fun;           /* 0 = "square_loss" (:295, every model), 1 = "kl_loss" (utils.py:20-32,76-87) */
+    int cs_small_int;       /* promise of the caller: every entry of Cs is an integer in [0, 255] (to_dense_adj output: 0/1, or the
+                             * multiplicity of a repeated edge) — lets the N <= 64 kernel keep Cs as bytes in LDS (5 instead of 4
+                             * workgroups per CU at N = 33).  0 = arbitrary floats (fgw_barycenters called with general matrices). */
 } conan_fgw_params;
 
 /* Workspace size in BYTES for conan_fgw_barycenter_fwd. */

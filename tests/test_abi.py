@@ -54,7 +54,7 @@ def test_ctypes_table_matches_header(built):
 
 
 def test_params_struct_layout(built):
-    assert ctypes.sizeof(built.FgwParams) == 44          # 11 x 4-byte fields, matches conan_fgw_params
+    assert ctypes.sizeof(built.FgwParams) == 48          # 12 x 4-byte fields, matches conan_fgw_params
 
 
 def test_workspace_queries_need_no_gpu(built):

@@ -24,17 +24,21 @@ g = torch.Generator().manual_seed(0)
 Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
 print(f"B={B} K={K} N={N} d={d}  ({'register-resident kernel, N <= 64' if N <= 64 else 'large-N kernel'})")
 A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
-for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs)
+SMALL_INT = os.environ.get("PROF_FLOAT_CS", "") == ""
+for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=SMALL_INT)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 32)()
 PROF = L.conan_debug_fgw_prof if N <= 64 else L.conan_debug_fgw_prof_large
 PROF(buf, 1)
 reps = 5
-for _ in range(reps): out = ops.fgw_barycenter_batched(Ys, Cs)
+for _ in range(reps): out = ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=SMALL_INT)
 torch.cuda.synchronize()
 PROF(buf, 0)
 names = ["staging", "T0 + dot(Y,Z)", "base registers", "A = C1 @ T", "G = A @ 2C2^T", "K = exp(Mr-max) + 1st column step", "Sinkhorn iterations",
          "T store + err", "T -> global", "Ypart = T @ Z", "Cpart = T C2 T^T"]
+if N <= 64 and not os.environ.get("PROF_OLD"):      # round-3 kernel (k_fgw_coupling_fast): its marks
+    names = ["staging", "dot(Y,Z) + base", "T0", "A = C1 @ T", "G = A @ 2C2^T -> K = exp(Mr - ref)", "K -> registers", "Sinkhorn iterations",
+             "T store + err", "T -> global", "Ypart = T @ Z", "Cpart = T C2 T^T"]
 launches = reps * 5
 wgs = B * K
 tot = sum(buf[:11])
