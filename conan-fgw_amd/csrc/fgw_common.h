@@ -28,6 +28,10 @@ static __device__ long long g_fgw_prof[32];            // one copy per translati
             atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_prof[21]), (unsigned long long)(wall_clock64() - prof_w0)); \
         }                                                                                \
     } while (0)
+#elif defined(CONAN_FGW_MARK)      /* (static instruction counts per phase: comment markers in the assembly, tools only) */
+#define FGW_PROF_DECL
+#define FGW_PROF(k) asm volatile("; FGWMARK " #k)
+#define FGW_PROF_FLUSH
 #else
 #define FGW_PROF_DECL
 #define FGW_PROF(k)
@@ -454,93 +458,183 @@ __device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restri
     }
 }
 
-// mm_lds with the results HELD in registers until `mid()` has run: every wavefront finishes reading its operands, then mid() (a
-// workgroup barrier), then the stores — so that the output may overwrite an operand (A -> K in place) or a staging area that shares
-// storage with the output (the prologue's Y / Z against base).  Same tiling, fragment layout, summation order and border rule as
-// mm_lds: bitwise-equal results.  MAXT = compile-time bound on the tiles per wavefront (ceil(Mq * Nq / NW)).
-template <int NW, int MAXT, bool WT, typename TX, typename TW, class FM, class FS>
-__device__ __forceinline__ void mm_lds_hold(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FM mid,
-                                            FS st, const int tid = threadIdx.x) {
+// ---- Second generation of the LDS-operand products (the round-3 coupling kernel) ------------------------------------------------
+// Same tiling, fragment layout and border rule as mm_lds.  What changes:
+//   KMAX > 0  : compile-time bound on the k-steps (Kd <= 4 KMAX): all operand reads of a tile (and of a border output) are issued
+//               before the first MFMA / FMA — ONE LDS round trip per tile instead of one per 16 k.  KMAX = 0: chunked loops (any Kd).
+//               Measured on the round-3 coupling kernel (same-job A/B, cfg2 shape): KMAX = 9 0.779 ms per solve, KMAX = 0 0.726 ms —
+//               with five workgroups per CU the kernel is bound by vector-issue and register pressure, not by the length of a
+//               tile's LDS chain, so the kernel uses KMAX = 0; the batched form is kept for low-occupancy callers.
+//   HOLD      : the results stay in registers until `mid()` has run (every wavefront finishes READING its operands, then mid() — a
+//               workgroup barrier —, then the stores), so that the output may overwrite an operand (A -> K in place) or a staging
+//               area that shares storage with the output.  MAXT = compile-time bound on the tiles per wavefront (HOLD only).
+//   tid       : callers inside a long loop pass a copy of threadIdx.x laundered through an empty asm (see mm_lds).
+// Partial sums alternate between two accumulators per tile; the summation order differs from mm_lds in the last bits.
+// Rows / columns of a tile that lie outside the matrix are read from a clamped (valid) row / column and produce accumulator rows /
+// columns that are never stored — an MFMA output (i, j) depends on A row i and B column j only — so no operand is masked for them;
+// only the ragged LAST k-step zeroes its out-of-range A elements (B is read from a clamped, finite location).
+template <int KMAX, bool WT, typename TX, typename TW>
+__device__ __forceinline__ f64x4 mm2_tile(const TX *__restrict__ xp, const TW *__restrict__ wp, int pW, int Kd, int lk) {
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    const int nfull = Kd >> 2, rem = Kd & 3;                     // workgroup-uniform
+    if constexpr (KMAX > 0) {
+        // full k-steps: immediate-offset reads behind uniform guards, all in flight before the first MFMA
+        double a[KMAX], b[KMAX];
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u)
+            if (u < nfull) { a[u] = (double)xp[4 * u]; b[u] = (double)(WT ? wp[4 * u] : wp[4 * u * pW]); }
+        double at = 0.0, bt = 0.0;
+        if (rem) {                                                // ragged last step: lanes lk >= rem read element 0 of the step and are zeroed
+            const int o = 4 * nfull - (lk < rem ? 0 : lk);
+            at = (double)xp[o]; bt = (double)(WT ? wp[o] : wp[o * pW]);
+            at = lk < rem ? at : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            if (u < nfull) {
+                if (u & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+            }
+        }
+        if (rem) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bt, acc2, 0, 0, 0);
+    } else {
+        const int wstep = WT ? 4 : 4 * pW;
+        int k0 = 0;
+        for (; k0 + 4 <= nfull; k0 += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = (double)xp[4 * u]; b[u] = (double)wp[u * wstep]; }
+            xp += 16; wp += 4 * wstep;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc2, 0, 0, 0);
+        }
+        for (; k0 < nfull; ++k0) {
+            const double a = (double)xp[0], b = (double)wp[0];
+            xp += 4; wp += wstep;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        if (rem) {
+            const int back = lk < rem ? 0 : lk;
+            double a = (double)xp[-back];
+            const double b = (double)(WT ? wp[-back] : wp[-back * pW]);
+            a = lk < rem ? a : 0.0;
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+        }
+    }
+    return acc + acc2;
+}
+
+// one lane's share of a border output: k = sub, sub + S, ... (S lanes per output; xp / wp already point at k = sub)
+template <int KMAX, int S, bool WT, typename TX, typename TW>
+__device__ __forceinline__ double mm2_border_part(const TX *__restrict__ xp, const TW *__restrict__ wp, int pW, int Kd, int sub) {
+    const int nfull = Kd / S, rem = Kd - nfull * S;              // workgroup-uniform: steps every lane of the group takes; lanes sub < rem take one more
+    double acc = 0.0;
+    if constexpr (KMAX > 0) {
+        constexpr int KB = (4 * KMAX) / S;
+        double xa[KB], wb[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+            if (u < nfull) { xa[u] = (double)xp[S * u]; wb[u] = (double)(WT ? wp[S * u] : wp[S * u * pW]); }
+        double xt = 0.0, wt = 0.0;
+        if (rem) {
+            const int o = S * nfull - (sub < rem ? 0 : sub);
+            xt = (double)xp[o]; wt = (double)(WT ? wp[o] : wp[o * pW]);
+            xt = sub < rem ? xt : 0.0;
+        }
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            if (u < nfull) {
+                if (u % 3 == 0) p0 = fma(xa[u], wb[u], p0);
+                else if (u % 3 == 1) p1 = fma(xa[u], wb[u], p1);
+                else p2 = fma(xa[u], wb[u], p2);
+            }
+        }
+        if (rem) p0 = fma(xt, wt, p0);
+        acc = (p0 + p1) + p2;
+    } else {
+        const int ws = WT ? S : S * pW;
+        int k0 = 0;
+        double p0 = 0.0, p1 = 0.0;
+        for (; k0 + 8 <= nfull; k0 += 8) {                        // 8 steps per trip: 16 reads in flight
+            double xa[8], wb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xa[u] = (double)xp[S * u]; wb[u] = (double)wp[u * ws]; }
+            xp += 8 * S; wp += 8 * ws;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { p0 = fma(xa[u], wb[u], p0); p1 = fma(xa[u + 1], wb[u + 1], p1); }
+        }
+        for (; k0 < nfull; ++k0) { p0 = fma((double)xp[0], (double)wp[0], p0); xp += S; wp += ws; }
+        if (rem) {
+            const int back = sub < rem ? 0 : sub;
+            double xt = (double)xp[-back];
+            const double wt = (double)(WT ? wp[-back] : wp[-back * pW]);
+            xt = sub < rem ? xt : 0.0;
+            p1 = fma(xt, wt, p1);
+        }
+        acc = p0 + p1;
+    }
+    return acc;
+}
+
+template <int NW, int MAXT, int KMAX, bool WT, bool HOLD, typename TX, typename TW, class FM, class FS>
+__device__ __forceinline__ void mm_lds2(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FM mid, FS st,
+                                        const int tid = threadIdx.x) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const bool border = border_path<NW>(M, Nn);
     const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;
-    const int kfull = Kd & ~3;
-    const int wstep = WT ? 4 : 4 * pW;
-    f64x4 res[MAXT];
+    auto tile = [&](int t) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool ra = ia < M, cb = jb < Nn;
+        const TX *xp = X + (ra ? ia : M - 1) * pX + lk;
+        const TW *wp = WT ? W + (cb ? jb : Nn - 1) * pW + lk : W + lk * pW + (cb ? jb : Nn - 1);
+        return mm2_tile<KMAX, WT>(xp, wp, pW, Kd, lk);
+    };
+    auto store_tile = [&](int t, const f64x4 &r) {
+        const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4, jb = j0 + li;
+        if (jb < Nn) {
 #pragma unroll
-    for (int tt = 0; tt < MAXT; ++tt) {
-        const int t = wave + tt * NW;
-        res[tt] = f64x4{0.0, 0.0, 0.0, 0.0};
-        if (t < Mq * Nq) {                                        // wave-uniform
-            const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4;
-            const int ia = i0 + li, jb = j0 + li;
-            const bool ra = ia < M, cb = jb < Nn;
-            const TX *xp = X + (ra ? ia : M - 1) * pX + lk;
-            const TW *wp = WT ? W + (cb ? jb : Nn - 1) * pW + lk : W + lk * pW + (cb ? jb : Nn - 1);
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-            int k0 = 0;
-            for (; k0 + 16 <= kfull; k0 += 16) {
-                double a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { a[u] = (double)xp[4 * u]; b[u] = (double)wp[u * wstep]; }
-                xp += 16; wp += 4 * wstep;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[0] : 0.0, cb ? b[0] : 0.0, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[1] : 0.0, cb ? b[1] : 0.0, acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[2] : 0.0, cb ? b[2] : 0.0, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a[3] : 0.0, cb ? b[3] : 0.0, acc2, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + lk + 4 * q;
+                if (i < M) st(i, jb, r[q]);
             }
-            for (; k0 < kfull; k0 += 4) {
-                const double a = (double)xp[0], b = (double)wp[0];
-                xp += 4; wp += wstep;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra ? a : 0.0, cb ? b : 0.0, acc, 0, 0, 0);
-            }
-            if (k0 < Kd) {
-                const bool kin = k0 + lk < Kd;
-                const int back = kin ? 0 : lk;
-                const double a = (double)xp[-back], b = (double)(WT ? wp[-back] : wp[-back * pW]);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((ra && kin) ? a : 0.0, (cb && kin) ? b : 0.0, acc2, 0, 0, 0);
-            }
-            res[tt] = acc + acc2;
         }
+    };
+    f64x4 res[HOLD ? MAXT : 1];
+    if constexpr (HOLD) {
+#pragma unroll
+        for (int tt = 0; tt < MAXT; ++tt) {
+            const int t = wave + tt * NW;
+            res[tt] = f64x4{0.0, 0.0, 0.0, 0.0};
+            if (t < Mq * Nq) res[tt] = tile(t);                   // wave-uniform
+        }
+    } else {
+        for (int t = wave; t < Mq * Nq; t += NW) store_tile(t, tile(t));
     }
-    // border outputs (see mm_lds): thin border = three lanes per output in one pass, else four lanes per output in up to two passes
+    // border outputs: thin border (<= 21 per wavefront) = three lanes per output in one pass, else four lanes per output in up to two
     const int Mc = (M >> 4) << 4, Nc = (Nn >> 4) << 4, nb1 = (M - Mc) * Nn;
     const int bcount = border ? nb1 + Mc * (Nn - Nc) : 0;
     const bool thin = bcount <= NW * 21;
     double bval[2] = {0.0, 0.0};
     int b_i[2] = {0, 0}, b_j[2] = {0, 0};
     bool b_on[2] = {false, false};
+    auto border_ij = [&](int o, int &bi, int &bj) {
+        if (o < nb1) { bi = Mc + o / Nn; bj = o % Nn; }
+        else { const int q = o - nb1; bi = q / (Nn - Nc); bj = Nc + q % (Nn - Nc); }
+    };
     if (border && thin) {
         const int o = wave * 21 + lane / 3, sub3 = lane % 3;
         const bool on = lane < 63 && o < bcount;
-        if (on) {
-            if (o < nb1) { b_i[0] = Mc + o / Nn; b_j[0] = o % Nn; }
-            else { const int q = o - nb1; b_i[0] = q / (Nn - Nc); b_j[0] = Nc + q % (Nn - Nc); }
-        }
+        if (on) border_ij(o, b_i[0], b_j[0]);
         double acc = 0.0;
         if (on) {
-            const int ws3 = WT ? 3 : 3 * pW;
             const TX *xp = X + b_i[0] * pX + sub3;
             const TW *wp = WT ? W + b_j[0] * pW + sub3 : W + sub3 * pW + b_j[0];
-            int k = sub3;
-            for (; k + 9 < Kd; k += 12) {
-                double xa[4], wb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { xa[u] = (double)xp[3 * u]; wb[u] = (double)wp[u * ws3]; }
-                xp += 12; wp += 4 * ws3;
-                acc += (xa[0] * wb[0] + xa[2] * wb[2]) + (xa[1] * wb[1] + xa[3] * wb[3]);
-            }
-            if (k < Kd) {
-                double xa[4], wb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int uu = k + 3 * u < Kd ? u : 0;
-                    xa[u] = (double)xp[3 * uu]; wb[u] = (double)wp[uu * ws3];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc += (k + 3 * u < Kd) ? xa[u] * wb[u] : 0.0;
-            }
+            acc = mm2_border_part<KMAX, 3, WT>(xp, wp, pW, Kd, sub3);
         }
         const double a1 = __shfl(acc, lane + 1, 64), a2 = __shfl(acc, lane + 2, 64);
         bval[0] = acc + a1 + a2;
@@ -550,35 +644,14 @@ __device__ __forceinline__ void mm_lds_hold(int M, int Nn, int Kd, const TX *__r
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (p * (NW * 16) >= bcount) break;
-            const int t = p * (NW * 16) + (tid >> 2);
-            const bool on = t < bcount;
-            if (on) {
-                if (t < nb1) { b_i[p] = Mc + t / Nn; b_j[p] = t % Nn; }
-                else { const int q = t - nb1; b_i[p] = q / (Nn - Nc); b_j[p] = Nc + q % (Nn - Nc); }
-            }
+            const int o = p * (NW * 16) + (tid >> 2);
+            const bool on = o < bcount;
+            if (on) border_ij(o, b_i[p], b_j[p]);
             double acc = 0.0;
             if (on) {
                 const TX *xp = X + b_i[p] * pX + sub;
                 const TW *wp = WT ? W + b_j[p] * pW + sub : W + sub * pW + b_j[p];
-                int k = sub;
-                for (; k + 28 < Kd; k += 32) {
-                    double xa[8], wb[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { xa[u] = (double)xp[4 * u]; wb[u] = (double)wp[u * wstep]; }
-                    xp += 32; wp += 8 * wstep;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += xa[u] * wb[u];
-                }
-                if (k < Kd) {
-                    double xa[8], wb[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int uu = k + 4 * u < Kd ? u : 0;
-                        xa[u] = (double)xp[4 * uu]; wb[u] = (double)wp[uu * wstep];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += (k + 4 * u < Kd) ? xa[u] * wb[u] : 0.0;
-                }
+                acc = mm2_border_part<KMAX, 4, WT>(xp, wp, pW, Kd, sub);
             }
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
@@ -587,18 +660,11 @@ __device__ __forceinline__ void mm_lds_hold(int M, int Nn, int Kd, const TX *__r
         }
     }
     mid();
+    if constexpr (HOLD) {
 #pragma unroll
-    for (int tt = 0; tt < MAXT; ++tt) {
-        const int t = wave + tt * NW;
-        if (t < Mq * Nq) {
-            const int i0 = (t / Nq) << 4, j0 = (t % Nq) << 4, jb = j0 + li;
-            if (jb < Nn) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = i0 + lk + 4 * q;
-                    if (i < M) st(i, jb, res[tt][q]);
-                }
-            }
+        for (int tt = 0; tt < MAXT; ++tt) {
+            const int t = wave + tt * NW;
+            if (t < Mq * Nq) store_tile(t, res[tt]);
         }
     }
 #pragma unroll

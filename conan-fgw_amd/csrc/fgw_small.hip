@@ -447,10 +447,15 @@ __host__ __device__ inline FastLds fast_lds(int N) {
     return L;
 }
 
+// Uniform fp64 constants, formed on the host: the scalar unit has no fp64 conversions, so the same values derived in the kernel from the
+// fp32 parameters live in VECTOR registers for the whole kernel (the register budget of five workgroups per CU has no room for them).
+struct FastConst {
+    double two_alpha, one_m_alpha, four_alpha_inv_eps, inv_eps, inner_tol, stop_thr, inv_n;
+};
 template <int R, int MAXT, typename C2T>
 __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_fast(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
-    FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
+    FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
     double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -485,7 +490,6 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     const double *C1 = Cw + (size_t)b * NN;
     const double *Y = Yw + (size_t)b * N * d;
     float *Tg = Tw + ((size_t)b * D.K + s) * NN;
-    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
 
     // ---- loads first: every global load of the prologue is in flight before the first LDS store.  (row, column) of a thread's
     // matrix entries: ONE division, then steps of 256 entries (the staging loops below walk them incrementally).
@@ -518,8 +522,8 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         }
     };
     if (!stage_yz) load_c1_t();
-    const double p_own = tid < N ? (pb ? (double)pb[(size_t)b * N + tid] : 1.0 / (double)N) : 1.0;
-    const double q_own = tid < N ? (ps ? (double)ps[((size_t)b * D.K + s) * N + tid] : 1.0 / (double)N) : 1.0;
+    const double p_own = tid < N ? (pb ? (double)pb[(size_t)b * N + tid] : fc.inv_n) : 1.0;
+    const double q_own = tid < N ? (ps ? (double)ps[((size_t)b * D.K + s) * N + tid] : fc.inv_n) : 1.0;
     double vec_own;
     {
         const int v = tid >> 6, i = tid & 63;
@@ -548,7 +552,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     auto base_of = [&](int i, int j, double dot) {                      // utils.py:39-43,154-171, bregman.py:124-125
         double m = -2.0 * dot; m += y2v[i]; m += z2v[j];
         m = m > 0.0 ? m : 0.0;
-        return 2.0 * alpha * (r1v[i] + r2v[j]) + (1.0 - alpha) * m;
+        return fc.two_alpha * (r1v[i] + r2v[j]) + fc.one_m_alpha * m;
     };
     // ---- base = 2 alpha constC + (1 - alpha) M, M from dot(Y_i, Z_j) on MFMA.  With Y / Z staged over AK | base and C1, the products are
     // held in registers until every wavefront has read its operands (base lands on Y's second half).
@@ -561,24 +565,25 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             if (j >= N) { j -= N; ++i; }
         }
     } else if (stage_yz) {
-        mm_lds_hold<FGW_WAVES, MAXT, true>(N, N, d, Yl, d, Zl, d, [&]() { load_c1_t(); __syncthreads(); },
-                                           [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
+        mm_lds2<FGW_WAVES, MAXT, 0, true, true>(N, N, d, Yl, d, Zl, d, [&]() { load_c1_t(); __syncthreads(); },
+                                                [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
         for_entries([&](int u, int o) { C1l[o] = c1v[u]; });            // Z is consumed (the barrier inside the product): C1 takes its place
     } else {
         mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
                [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
     }
     // ---- T0 = G0 (warm start) or p q^T (bregman.py:98-101), written over the vectors once nobody reads them any more
-    double pA[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { const int q = w + 4 * r; pA[r] = pq[q < N ? q : N - 1]; }
     __syncthreads();
     FGW_PROF(1);      // dot(Y, Z) + base
     if (warm) {
         for_entries([&](int u, int o) { Tl[o] = tv[u]; });
     } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) { const int i = w + 4 * r; if (i < N && lane_ok) Tl[i * P + lane] = (float)(pA[r] * qj); }
+        for (int r = 0; r < R; ++r) {                                   // (first outer iteration only: p comes straight from global memory)
+            const int i = w + 4 * r;
+            const double pi_r = pb ? (double)pb[(size_t)b * N + (i < N ? i : N - 1)] : fc.inv_n;
+            if (i < N && lane_ok) Tl[i * P + lane] = (float)(pi_r * qj);
+        }
     }
     __syncthreads();
     FGW_PROF(2);      // T0
@@ -586,22 +591,21 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     int cpt = 0, sk_total = 0;
     double err = 1.0;
     bool bail = false;                                                  // workgroup-uniform
-    while (err > (double)prm.inner_tol && cpt < prm.max_iter) {          // bregman.py:119
+    while (err > fc.inner_tol && cpt < prm.max_iter) {                  // bregman.py:119
         // Everything per-lane below (LDS offsets, tile indices, fragment pointers) is derived from THIS copy of the thread index, which the
         // optimiser cannot see through: left alone it hoists some sixty loop-invariant offsets out of the loop and spills them.
-        int tq = tid;
-        asm volatile("" : "+v"(tq));
+        int tq = tid, N = D.N, P = D.P;                                 // (shadow the kernel-wide N, P on purpose)
+        asm volatile("" : "+v"(tq), "+s"(N), "+s"(P));                  // uniform offsets (k * P, tile counts ...) are re-derived too: they spill SGPRs
         const int lq = tq & 63, wq = tq >> 6;
         const bool lq_ok = lq < N;
-        const BorderIdx bnn = border_prepare(N, N, tq);                 // (only the thick-border branch of mm_lds reads it)
         // ---- A = C1 @ T                                                        (utils.py:48-53)
-        mm_lds<FGW_WAVES, false>(N, N, N, C1l, P, Tl, P, [&](int i, int j, double v) { AKl[i * P + j] = v; }, bnn, tq);
+        mm_lds2<FGW_WAVES, 1, 0, false, false>(N, N, N, C1l, P, Tl, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; }, tq);
         __syncthreads();
         FGW_PROF(3);  // A = C1 @ T
         // ---- G = A @ (2 C2)^T, Mr = -(base - 2 alpha G) / eps (utils.py:62-64, sinkhorn.py:388), K = exp(Mr - ref_j) with the column
         // reference ref_j = -base_jj / eps: formed where the product leaves its result, written over A once every wavefront has read A.
-        mm_lds_hold<FGW_WAVES, MAXT, true>(N, N, N, AKl, P, C2l, P, [&]() { __syncthreads(); }, [&](int i, int j, double v) {
-            const double x = ((Bl[j * P + j] - Bl[i * P + j]) + 4.0 * alpha * v) * inv_eps;      // Mr_ij - ref_j, G = 2 v
+        mm_lds2<FGW_WAVES, MAXT, 0, true, true>(N, N, N, AKl, P, C2l, P, [&]() { __syncthreads(); }, [&](int i, int j, double v) {
+            const double x = fma(v, fc.four_alpha_inv_eps, (Bl[j * P + j] - Bl[i * P + j]) * fc.inv_eps);      // Mr_ij - ref_j, G = 2 v
             AKl[i * P + j] = exp_fast(x);
         }, tq);
         __syncthreads();
@@ -624,6 +628,17 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         const int permL = (lq & 3) * 16 + (lq >> 2);                    // slot of this lane's factor in fvP / gvP
         double *bufCw = bufC + wq * 64 + lq, *bufRw = bufR + wq * 64 + lq;
         const double *fw = fvP + wq * 16, *gw = gvP + wq * 16;
+        // this thread's share of a matrix-vector product: sum_r k[r] * v[r], three partial sums (the dependent-FMA chain is what a phase waits for)
+        auto dotR = [&](const double (&k)[R], const double *v) {
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r % 3 == 0) p0 = fma(k[r], v[r], p0);
+                else if (r % 3 == 1) p1 = fma(k[r], v[r], p1);
+                else p2 = fma(k[r], v[r], p2);
+            }
+            return (p0 + p1) + p2;
+        };
         int ii = 0;
         double f = 0.0, g = 0.0, colp = 0.0;
         bool have_colp = false;
@@ -631,11 +646,12 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             if (!have_colp) {                                           // v update (:415): column products against the current g (1 at ii = 0)
                 double pc = 0.0;
                 if (ii == 0) {
+                    double p1 = 0.0, p2 = 0.0;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) pc += kA[r];
+                    for (int r = 0; r < R; ++r) { if (r % 3 == 0) pc += kA[r]; else if (r % 3 == 1) p1 += kA[r]; else p2 += kA[r]; }
+                    pc = (pc + p1) + p2;
                 } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) pc = fma(kA[r], gw[r], pc);
+                    pc = dotR(kA, gw);
                 }
                 *bufCw = pc;
                 __syncthreads();
@@ -645,26 +661,20 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             if (__any(lq_ok && !(colp > 1e-150 && colp < 1e150))) { bail = true; break; }
             f = lq_ok ? qj * rcp_pos(colp) : 0.0;
             fvP[permL] = f;                                             // every wavefront writes the same 64 values and reads back its own
-            double pr = 0.0;                                            // u update (:416)
-#pragma unroll
-            for (int r = 0; r < R; ++r) pr = fma(kB[r], fw[r], pr);
-            *bufRw = pr;
+            *bufRw = dotR(kB, fw);                                      // u update (:416)
             __syncthreads();
             const double rs = ((bufR[lq] + bufR[64 + lq]) + bufR[128 + lq]) + bufR[192 + lq];
             if (__any(lq_ok && !(rs > 1e-150 && rs < 1e150))) { bail = true; break; }
             g = lq_ok ? pi_l * rcp_pos(rs) : 0.0;
             gvP[permL] = g;
             if (ii % 10 == 0) {                                         // marginal violation (:418-433): || f * (K^T g) - b ||_2
-                double pc = 0.0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) pc = fma(kA[r], gw[r], pc);
-                *bufCw = pc;
+                *bufCw = dotR(kA, gw);
                 __syncthreads();
                 colp = ((bufC[lq] + bufC[64 + lq]) + bufC[128 + lq]) + bufC[192 + lq];
                 have_colp = true;                                       // the next v update starts from these products
                 double df = lq_ok ? f * colp - qj : 0.0;
                 df = wave_sum_d(df * df);                              // identical in every wavefront: the break is workgroup-uniform
-                if (sqrt(df) < (double)prm.stop_thr) { ++ii; break; }
+                if (sqrt(df) < fc.stop_thr) { ++ii; break; }
             }
         }
         if (bail) break;
@@ -694,7 +704,17 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         return;
     }
     __syncthreads();
-    for (int t = tid; t < NN; t += FGW_THREADS) { const int i = t / N, j = t - i * N; Tg[t] = Tl[i * P + j]; }
+    {   // per-thread global addresses are re-derived here instead of being kept (spilled) from the prologue
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        int i = te / N, j = te - i * N;
+        const int dq = FGW_THREADS / N, dr = FGW_THREADS - dq * N;
+        for (int t = te; t < NN; t += FGW_THREADS) {
+            Tg[t] = Tl[i * P + j];
+            j += dr; i += dq;
+            if (j >= N) { j -= N; ++i; }
+        }
+    }
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[blockIdx.x] = 0; }
     FGW_PROF(8);      // T -> global
 
@@ -711,7 +731,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
                 for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) Zl[t] = zv[u]; }
             }
             __syncthreads();
-            mm_lds<FGW_WAVES, false>(N, d, N, Tl, P, Zl, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; }, border_prepare(N, d));
+            mm_lds2<FGW_WAVES, 1, 0, false, false>(N, d, N, Tl, P, Zl, d, [] {}, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
         } else {
             mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
                    [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
@@ -720,10 +740,9 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        const BorderIdx bnn = border_prepare(N, N);
-        mm_lds<FGW_WAVES, false>(N, N, N, Tl, P, C2l, P, [&](int i, int j, double v) { AKl[i * P + j] = v; }, bnn);
+        mm_lds2<FGW_WAVES, 1, 0, false, false>(N, N, N, Tl, P, C2l, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; });
         __syncthreads();
-        mm_lds<FGW_WAVES, true>(N, N, N, AKl, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = v; }, bnn);
+        mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, N, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
@@ -894,7 +913,9 @@ static void launch_fast_t(const float *Ys, const float *Cs, const float *ps, con
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_fast<R, MAXT, C2T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    k_fgw_coupling_fast<R, MAXT, C2T><<<D.B * D.K, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart,
+    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
+    const FastConst fc{2.0 * alpha, 1.0 - alpha, 4.0 * alpha * inv_eps, inv_eps, (double)prm.inner_tol, (double)prm.stop_thr, 1.0 / (double)D.N};
+    k_fgw_coupling_fast<R, MAXT, C2T><<<D.B * D.K, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, fc, outer, y_zero, Cw, Yw, active, Tw, info, Ypart,
                                                                           Cpart, zvec, yvec, redo);
 }
 template <int R, typename C2T>
