@@ -58,12 +58,13 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
-    double *__restrict__ Ypart, double *__restrict__ Cpart) {
+    double *__restrict__ Ypart, double *__restrict__ Cpart, const int *__restrict__ only) {
     constexpr bool LDS_MODE = MODE == 2, MR_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
+    if (only && !only[blockIdx.x]) return;      // second pass behind k_fgw_coupling_big: only the couplings it handed back
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,6 +362,243 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     FGW_PROF_FLUSH;
 }
 
+// ------------------------------------------------------------------------------------------------ round-3 coupling kernel, N > 64
+// Same algorithm as k_fgw_coupling (square loss), re-cut like the N <= 64 kernel of fgw_small.hip (k_fgw_coupling_fast):
+//   * Sinkhorn iterates on the scaling VECTORS against a FIXED kernel matrix K = exp(Mr - ref_j), formed once per projected-gradient
+//     iteration where the product G = A (2 C2)^T leaves its result; every half-iteration is a matrix-vector product streamed from
+//     LDS (one read + one FMA per entry, no write-back) instead of an in-place rescaling of the whole matrix.
+//   * K is kept in LDS as fp32 — its entries carry the ~1e-7 relative error of the hardware exp2 anyway, every sum over them is
+//     accumulated in fp64 — with ref_j = max_i(-base_ij / eps), so that the exponent of every entry is <= 2 G_ij (a few units: no
+//     overflow in fp32; entries below e^-87 of their column's best vanish, as they do in the fp32 coupling that is returned).
+//     Half the LDS (27.5 KB + vectors at N = 83) puts THREE 8-wavefront workgroups on a CU instead of two: the 640 couplings
+//     of a Lipophilicity-shaped shard of 128 molecules are resident at once (768 slots) instead of running 1.25 rounds.
+//   * The coupling itself lives in K's storage between iterations (fp32, the values that are returned).
+// A row / column sum outside [1e-150, 1e150] makes the workgroup give up without writing anything and raise redo[b, s]; the launcher then
+// runs k_fgw_coupling — which carries the exact log-domain path — on the flagged couplings only.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
+    const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
+    FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
+    double *__restrict__ Ypart, double *__restrict__ Cpart, int *__restrict__ redo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 64 * NW;
+    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    if (!active[b]) return;
+    const int N = D.N, P = D.P, d = D.d;
+    const int NN = N * N, NP = N * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FGW_PROF_DECL;
+
+    float *Kf = reinterpret_cast<float *>(smem);                          // [N,P]  T (between iterations) / K (inside one)
+    double *vec = reinterpret_cast<double *>(smem + (((size_t)NP * 4 + 15) & ~(size_t)15));
+    double *fv = vec, *gv = vec + N, *pa = vec + 2 * N, *qb = vec + 3 * N, *refb = vec + 4 * N;      // f_j, g_i, p_i, q_j, min_i base_ij
+    double *ra = vec + 5 * N, *rb = vec + 6 * N, *y2a = vec + 7 * N, *z2a = vec + 8 * N;             // prologue: r1_i, r2_j, |y_i|^2, |z_j|^2
+    double *red = vec + 9 * N;                                            // [16]; red[15] = range flag
+    double *part = red + 16;                                              // [NW][N] partial sums
+    double *bad_flag = red + 15;
+    static_assert(NW < 15, "red[15] is the range flag");
+    char *gs = scratch + (size_t)blockIdx.x * coupling_scratch_stride(NP);
+    double *Al = reinterpret_cast<double *>(gs) + NP;                     // [N,P] fp64, L2-resident scratch (same carve as k_fgw_coupling)
+    double *base = Al + NP;
+
+    const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
+    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
+    const double *C1 = Cw + (size_t)b * NN;
+    const double *Y = Yw + (size_t)b * N * d;
+    float *Tg = Tw + ((size_t)b * D.K + s) * NN;
+    const bool warm = outer > 0 && prm.warmstart;
+
+    for (int i = tid; i < N; i += NT) {
+        pa[i] = pb ? (double)pb[(size_t)b * N + i] : fc.inv_n;
+        qb[i] = ps ? (double)ps[((size_t)b * D.K + s) * N + i] : fc.inv_n;
+    }
+    if (tid == 0) *bad_flag = 0.0;
+    __syncthreads();
+    // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
+    for (int t = tid; t < NN; t += NT) {
+        const int i = t / N, j = t - i * N;
+        Kf[i * P + j] = warm ? Tg[t] : (float)(pa[i] * qb[j]);
+    }
+    {   // init_matrix vectors (utils.py:39-43) and squared feature norms: 8 lanes per index (see k_fgw_coupling)
+        constexpr int LPI = 8;
+        for (int i0 = 0; i0 < N; i0 += NT / LPI) {
+            const int i = i0 + tid / LPI, sub = tid % LPI;
+            double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
+            if (i < N) {
+                for (int k = sub; k < N; k += LPI) {
+                    const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
+                    r1 += c1 * c1 * pa[k];
+                    r2 += qb[k] * c2 * c2;
+                }
+                for (int c = sub; c < d; c += LPI) {
+                    const double yy = Y[i * d + c], zz = (double)Z[i * d + c];
+                    y2 += yy * yy; z2 += zz * zz;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < LPI; o <<= 1) {
+                r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); y2 += __shfl_xor(y2, o, 64); z2 += __shfl_xor(z2, o, 64);
+            }
+            if (i < N && sub == 0) { ra[i] = r1; rb[i] = r2; y2a[i] = y2; z2a[i] = z2; }
+        }
+    }
+    __syncthreads();
+    FGW_PROF(0);      // staging: T0, per-index vectors
+    if (!y_zero)
+        mm_f64_glb<NW, true>(N, N, d, Y, d, Z, d, [&](int i, int j, double v) { base[i * P + j] = v; });
+    __syncthreads();
+    FGW_PROF(1);      // dot(Y, Z)
+    // ---- base = 2 alpha constC + (1 - alpha) M (utils.py:154-171, bregman.py:124-125), lane <-> column, wavefronts split the rows;
+    // the column minimum of base rides along: ref_j = -min_i base_ij / eps is the stabiliser of K's column j
+    for (int j = lane; j < N; j += 64) {
+        double mn = 1.0e300;
+        for (int i = wave; i < N; i += NW) {
+            double m = -2.0 * (y_zero ? 0.0 : base[i * P + j]);
+            m += y2a[i]; m += z2a[j];
+            m = m > 0.0 ? m : 0.0;
+            const double bv = fc.two_alpha * (ra[i] + rb[j]) + fc.one_m_alpha * m;
+            base[i * P + j] = bv;
+            mn = bv < mn ? bv : mn;
+        }
+        part[wave * N + j] = mn;
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += NT) {
+        double mn = part[j];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const double o = part[w * N + j]; mn = o < mn ? o : mn; }
+        refb[j] = mn;
+    }
+    __syncthreads();
+    FGW_PROF(2);      // base
+
+    int cpt = 0, sk_total = 0;
+    double err = 1.0;
+    bool bail = false;
+    while (err > fc.inner_tol && cpt < prm.max_iter) {                  // bregman.py:119
+        // ---- A = C1 @ T                                                        (utils.py:48-53)
+        mm_f64_glb<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        __syncthreads();
+        FGW_PROF(3);  // A = C1 @ T
+        // ---- G = A @ (2 C2)^T ; K_ij = exp(Mr_ij - ref_j), Mr = -(base - 2 alpha G) / eps   (utils.py:62-64, sinkhorn.py:388)
+        mm_f64_glb<NW, true>(N, N, N, Al, P, C2, N, [&](int i, int j, double v) {
+            Kf[i * P + j] = (float)exp_fast(fma(v, fc.four_alpha_inv_eps, (refb[j] - base[i * P + j]) * fc.inv_eps));
+        });
+        for (int i = tid; i < N; i += NT) gv[i] = 1.0;                  // u = 0
+        __syncthreads();
+        FGW_PROF(4);  // G, K
+        // ---- Sinkhorn on the scaling vectors (sinkhorn.py:413-433): f_j = b_j / sum_i K_ij g_i ; g_i = a_i / sum_j K_ij f_j
+        auto bad = [](double x) { return !(x > 1e-150 && x < 1e150); };
+        auto col_products = [&]() {                                     // part[w][j] = sum over this wavefront's rows of K_ij g_i
+            for (int j = lane; j < N; j += 64) {
+                double c0 = 0.0, c1 = 0.0;
+                int i = wave;
+                for (; i + NW < N; i += 2 * NW) { c0 = fma((double)Kf[i * P + j], gv[i], c0); c1 = fma((double)Kf[(i + NW) * P + j], gv[i + NW], c1); }
+                if (i < N) c0 = fma((double)Kf[i * P + j], gv[i], c0);
+                part[wave * N + j] = c0 + c1;
+            }
+        };
+        int ii = 0;
+        bool have_f = false;                                            // fv already holds the next v update (from the marginal check)
+        for (; ii < prm.num_iter_max; ++ii) {
+            if (!have_f) {                                              // v update (:415)
+                col_products();
+                __syncthreads();
+                for (int j = tid; j < N; j += NT) {
+                    double c = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) c += part[w * N + j];
+                    if (bad(c)) *bad_flag = 1.0;
+                    fv[j] = qb[j] / c;
+                }
+                __syncthreads();
+            }
+            have_f = false;
+            if (*bad_flag != 0.0) { bail = true; break; }
+            for (int i = lane; i < N; i += 64) {                        // u update (:416): lane <-> row (odd pitch: conflict-free)
+                double r0 = 0.0, r1 = 0.0;
+                int j = wave;
+                for (; j + NW < N; j += 2 * NW) { r0 = fma((double)Kf[i * P + j], fv[j], r0); r1 = fma((double)Kf[i * P + j + NW], fv[j + NW], r1); }
+                if (j < N) r0 = fma((double)Kf[i * P + j], fv[j], r0);
+                part[wave * N + i] = r0 + r1;
+            }
+            __syncthreads();
+            for (int i = tid; i < N; i += NT) {
+                double r = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) r += part[w * N + i];
+                if (bad(r)) *bad_flag = 1.0;
+                gv[i] = pa[i] / r;
+            }
+            __syncthreads();
+            if (*bad_flag != 0.0) { bail = true; break; }
+            if (ii % 10 == 0) {                                         // marginal violation (:418-433): || f * (K^T g) - b ||_2
+                col_products();
+                __syncthreads();
+                double e2 = 0.0;
+                for (int j = tid; j < N; j += NT) {
+                    double c = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) c += part[w * N + j];
+                    if (bad(c)) *bad_flag = 1.0;
+                    const double df = fv[j] * c - qb[j];
+                    e2 += df * df;
+                    part[j] = qb[j] / c;                                // the next v update, parked in this thread's own slot of row 0 until the test below
+                }
+                const double tot = block_sum_d<NW>(e2, red);            // (its barriers publish the flag)
+                if (*bad_flag != 0.0) { bail = true; break; }
+                if (sqrt(tot) < fc.stop_thr) { ++ii; break; }           // stop: f stays the factor the marginals were measured with
+                for (int j = tid; j < N; j += NT) fv[j] = part[j];
+                have_f = true;
+                __syncthreads();
+            }
+        }
+        if (bail) break;
+        sk_total += ii;
+        FGW_PROF(6);  // Sinkhorn iterations
+        // ---- T = diag(g) K diag(f) (sinkhorn.py:450), in place; err = ||T - Tprev||_F when cpt % 10 == 0 (bregman.py:144-147).  Tprev at
+        // cpt = 0 is T0, re-read / re-formed here (K has taken its place).
+        double e2 = 0.0;
+        const bool want_err = cpt % 10 == 0;
+        for (int t = tid; t < NN; t += NT) {
+            const int i = t / N, j = t - i * N;
+            const float tn = (float)((gv[i] * (double)Kf[i * P + j]) * fv[j]);
+            if (want_err) {
+                const double tp = cpt == 0 ? (warm ? (double)Tg[t] : (double)(float)(pa[i] * qb[j])) : 0.0;
+                const double df = (double)tn - tp;
+                e2 += df * df;
+            }
+            Kf[i * P + j] = tn;
+        }
+        if (want_err) err = sqrt(block_sum_d<NW>(e2, red));
+        else __syncthreads();
+        ++cpt;
+        FGW_PROF(7);  // T store + err
+    }
+    if (bail) {
+        if (tid == 0) redo[blockIdx.x] = 1;
+        return;
+    }
+    __syncthreads();
+    for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Kf[i * P + j]; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[blockIdx.x] = 0; }
+    FGW_PROF(8);      // T -> global
+    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
+        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        mm_f64_glb<NW, false>(N, d, N, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+    }
+    FGW_PROF(9);      // Ypart = T @ Z
+    if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
+        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        mm_f64_glb<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        __syncthreads();
+        mm_f64_glb<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
+    }
+    FGW_PROF(10);     // Cpart = T @ C2 @ T^T
+    FGW_PROF_FLUSH;
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // dYs[b,s,j,c] = lam_s * sum_i T[b,s,i,j] * (1/p_i) * dY[b,i,c]
 template <bool LDS>
@@ -546,6 +784,7 @@ inline int pitch_of(int N) { return N | 1; }
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 constexpr int GEN_NW = 8;                   // wavefronts per workgroup of the large-N coupling kernel (16 measured no faster: 453 vs 443 us per workgroup and launch)
 inline size_t coupling_lds(int N) { return (size_t)((6 + 2 * GEN_NW) * N + 16) * 8 + (size_t)N * pitch_of(N) * 28; }
+inline size_t big_lds(int N) { return (((size_t)N * pitch_of(N) * 4 + 15) & ~(size_t)15) + (size_t)((9 + GEN_NW) * N + 16) * 8; }
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 }  // namespace
@@ -605,10 +844,27 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<M, KLV, GEN_NW>),                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                  \
         k_fgw_coupling<M, KLV, GEN_NW><<<B * K, 64 * GEN_NW, lds_bytes, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, \
-                                                                              info, sc_c, Ypart, Cpart);                            \
+                                                                              info, sc_c, Ypart, Cpart, only);                      \
     } while (0)
+    // N > 64, square loss: the round-3 kernel first (fp32 kernel matrix in LDS: three workgroups per CU), then k_fgw_coupling over the
+    // same grid for whatever it handed back (redo[b, s]; an early-exit launch otherwise)
+    const size_t lb = big_lds(N);
+#ifdef CONAN_FGW_NO_BIG       // (A/B switch of tools/ab.py: the round-2 kernel alone)
+    const bool big = false;
+#else
+    const bool big = !small && !kl && lb <= LDS_LIMIT;
+#endif
+    const FastConst fc = fast_const(*params, N);
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
+        const int *only = nullptr;
+        if (big) {
+            if (lb > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            k_fgw_coupling_big<GEN_NW><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, Ypart,
+                                                                     Cpart, redo);
+            only = redo;
+        }
         if (small)
             conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, redo, s);
         else if (mode == 2) { if (kl) CONAN_CPL(2, true); else CONAN_CPL(2, false); }

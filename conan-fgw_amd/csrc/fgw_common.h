@@ -45,6 +45,17 @@ struct FgwDims {
     int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
 };
 
+// Uniform fp64 constants of the round-3 coupling kernels, formed on the host: the scalar unit has no fp64 conversions, so the same
+// values derived in the kernel from the fp32 parameters live in VECTOR registers for the whole kernel (the register budgets of
+// those kernels have no room for them).
+struct FastConst {
+    double two_alpha, one_m_alpha, four_alpha_inv_eps, inv_eps, inner_tol, stop_thr, inv_n;
+};
+inline FastConst fast_const(const conan_fgw_params &prm, int N) {
+    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
+    return FastConst{2.0 * alpha, 1.0 - alpha, 4.0 * alpha * inv_eps, inv_eps, (double)prm.inner_tol, (double)prm.stop_thr, 1.0 / (double)N};
+}
+
 __device__ __forceinline__ double exp_acc(double x) {
     // exp(x) = 2^(x*log2e); integer part applied with ldexp, fractional part on the fp32 transcendental unit.
     if (x < -745.0) return 0.0;

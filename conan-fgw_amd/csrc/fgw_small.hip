@@ -447,11 +447,6 @@ __host__ __device__ inline FastLds fast_lds(int N) {
     return L;
 }
 
-// Uniform fp64 constants, formed on the host: the scalar unit has no fp64 conversions, so the same values derived in the kernel from the
-// fp32 parameters live in VECTOR registers for the whole kernel (the register budget of five workgroups per CU has no room for them).
-struct FastConst {
-    double two_alpha, one_m_alpha, four_alpha_inv_eps, inv_eps, inner_tol, stop_thr, inv_n;
-};
 template <int R, int MAXT, typename C2T>
 __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_fast(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
@@ -913,8 +908,7 @@ static void launch_fast_t(const float *Ys, const float *Cs, const float *ps, con
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_fast<R, MAXT, C2T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    const double alpha = (double)prm.alpha, inv_eps = 1.0 / (double)prm.epsilon;
-    const FastConst fc{2.0 * alpha, 1.0 - alpha, 4.0 * alpha * inv_eps, inv_eps, (double)prm.inner_tol, (double)prm.stop_thr, 1.0 / (double)D.N};
+    const FastConst fc = fast_const(prm, D.N);
     k_fgw_coupling_fast<R, MAXT, C2T><<<D.B * D.K, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, fc, outer, y_zero, Cw, Yw, active, Tw, info, Ypart,
                                                                           Cpart, zvec, yvec, redo);
 }
