@@ -375,6 +375,11 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 //   * The coupling itself lives in K's storage between iterations (fp32, the values that are returned).
 // A row / column sum outside [1e-150, 1e150] makes the workgroup give up without writing anything and raise redo[b, s]; the launcher then
 // runs k_fgw_coupling — which carries the exact log-domain path — on the flagged couplings only.
+#ifdef CONAN_FGW_NO_BLOCK22     // (A/B switch of tools/ab.py)
+#define FGW_MMG mm_f64_glb
+#else
+#define FGW_MMG mm_f64_glb22
+#endif
 template <int NW>
 __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
@@ -446,7 +451,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     __syncthreads();
     FGW_PROF(0);      // staging: T0, per-index vectors
     if (!y_zero)
-        mm_f64_glb<NW, true>(N, N, d, Y, d, Z, d, [&](int i, int j, double v) { base[i * P + j] = v; });
+        FGW_MMG<NW, true>(N, N, d, Y, d, Z, d, [&](int i, int j, double v) { base[i * P + j] = v; });
     __syncthreads();
     FGW_PROF(1);      // dot(Y, Z)
     // ---- base = 2 alpha constC + (1 - alpha) M (utils.py:154-171, bregman.py:124-125), lane <-> column, wavefronts split the rows;
@@ -477,14 +482,19 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     double err = 1.0;
     bool bail = false;
     while (err > fc.inner_tol && cpt < prm.max_iter) {                  // bregman.py:119
+        // per-lane and uniform offsets of this iteration are derived from laundered copies: hoisted out of the loop they spill
+        int tq = tid, N = D.N, P = D.P;
+        asm volatile("" : "+v"(tq), "+s"(N), "+s"(P));
+        const int lane = tq & 63, wave = tq >> 6;
+        const int tid = tq;
         // ---- A = C1 @ T                                                        (utils.py:48-53)
-        mm_f64_glb<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        FGW_MMG<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) { Al[i * P + j] = v; }, tq);
         __syncthreads();
         FGW_PROF(3);  // A = C1 @ T
         // ---- G = A @ (2 C2)^T ; K_ij = exp(Mr_ij - ref_j), Mr = -(base - 2 alpha G) / eps   (utils.py:62-64, sinkhorn.py:388)
-        mm_f64_glb<NW, true>(N, N, N, Al, P, C2, N, [&](int i, int j, double v) {
+        FGW_MMG<NW, true>(N, N, N, Al, P, C2, N, [&](int i, int j, double v) {
             Kf[i * P + j] = (float)exp_fast(fma(v, fc.four_alpha_inv_eps, (refb[j] - base[i * P + j]) * fc.inv_eps));
-        });
+        }, tq);
         for (int i = tid; i < N; i += NT) gv[i] = 1.0;                  // u = 0
         __syncthreads();
         FGW_PROF(4);  // G, K
@@ -586,14 +596,14 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     FGW_PROF(8);      // T -> global
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        mm_f64_glb<NW, false>(N, d, N, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        FGW_MMG<NW, false>(N, d, N, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        mm_f64_glb<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        FGW_MMG<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64_glb<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
+        FGW_MMG<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;

@@ -188,8 +188,9 @@ __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS
 // 8 wave-loads per trip that each touched 16 rows, and the products were bound by that.  Both operands use
 // the same permutation, so each k is still multiplied exactly once; the summation order inside a trip differs from mm_f64_pad.
 template <int NW, bool WT, typename TX, typename TW, class FS>
-__device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
+                                           const int tid = threadIdx.x) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
     for (int t = wave; t < Mq * Nq; t += NW) {
@@ -231,6 +232,98 @@ __device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__re
             const int i = i0 + lk + 4 * q;
             if (i < M && cb) st(i, jb, acc[q] + acc2[q]);
         }
+    }
+}
+
+// Register-blocked form of mm_f64_glb: a wavefront owns a 2 x 2 block of 16 x 16 tiles and feeds its four MFMAs per k-step from
+// TWO A fragments and TWO B fragments — one operand load per MFMA instead of two.  The large-N coupling kernel is bound by the
+// operand traffic of its products (every fragment comes from L2 or LDS; three workgroups per CU share the path), not by the matrix
+// pipe alone.  Work items: the 2 x 2 blocks that fill whole rounds of the NW wavefronts first, then the remaining tiles one by
+// one (so that no wavefront ends up with a whole block more than the others).  Same lane <-> k permutation as mm_f64_glb
+// (four consecutive k per lane and trip); one accumulator per tile (four independent chains per wavefront).
+template <int NW, bool WT, typename TX, typename TW, class FS, int KT = 2>      // KT consecutive k per lane and trip (a trip = 4 KT k)
+__device__ __forceinline__ void mm_f64_glb22(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
+                                             const int tid = threadIdx.x) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    const int Mb = Mq >> 1, Nb = Nq >> 1;                             // 2 x 2 blocks over the even part
+    const int nblk = Mb * Nb, nblk_used = (nblk / NW) * NW;          // blocks that fill whole rounds
+    auto load_a = [&](const TX *xr, int kb, int k0, double (&a)[KT]) {
+        if (k0 + 4 * KT <= Kd) {
+#pragma unroll
+            for (int u = 0; u < KT; ++u) a[u] = (double)xr[kb + u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < KT; ++u) { const int k = kb + u; const double v = (double)xr[k < Kd ? k : Kd - 1]; a[u] = k < Kd ? v : 0.0; }
+        }
+    };
+    auto load_b = [&](int jc, int kb, int k0, double (&b)[KT]) {
+        if (k0 + 4 * KT <= Kd) {
+#pragma unroll
+            for (int u = 0; u < KT; ++u) b[u] = (double)(WT ? W[(size_t)jc * pW + kb + u] : W[(size_t)(kb + u) * pW + jc]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                const int k = kb + u, kc = k < Kd ? k : Kd - 1;
+                const double v = (double)(WT ? W[(size_t)jc * pW + kc] : W[(size_t)kc * pW + jc]);
+                b[u] = k < Kd ? v : 0.0;
+            }
+        }
+    };
+    auto store_tile = [&](int i0, int j0, const f64x4 &r) {
+        const int jb = j0 + li;
+        if (jb < Nn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + lk + 4 * q; if (i < M) st(i, jb, r[q]); }
+        }
+    };
+    for (int t = wave; t < nblk_used; t += NW) {
+        const int i0 = (t / Nb) << 5, j0 = (t % Nb) << 5;
+        const TX *x0 = X + (size_t)min(i0 + li, M - 1) * pX, *x1 = X + (size_t)min(i0 + 16 + li, M - 1) * pX;     // clamped rows: outputs beyond M are not stored
+        const int jc0 = min(j0 + li, Nn - 1), jc1 = min(j0 + 16 + li, Nn - 1);
+        f64x4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+        for (int k0 = 0; k0 < Kd; k0 += 4 * KT) {
+            const int kb = k0 + KT * lk;
+            double a0[KT], a1[KT], b0[KT], b1[KT];
+            load_a(x0, kb, k0, a0); load_a(x1, kb, k0, a1); load_b(jc0, kb, k0, b0); load_b(jc1, kb, k0, b1);
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], c11, 0, 0, 0);
+            }
+        }
+        store_tile(i0, j0, c00); store_tile(i0, j0 + 16, c01); store_tile(i0 + 16, j0, c10); store_tile(i0 + 16, j0 + 16, c11);
+    }
+    // the remaining tiles, one per item: tiles of the unused blocks first, then the odd last row / column of tiles
+    const int rest_blk = nblk - nblk_used;
+    const int n_single = rest_blk * 4 + (Mq * Nq - 4 * nblk);
+    for (int t = wave; t < n_single; t += NW) {
+        int ti, tj;
+        if (t < rest_blk * 4) { const int bq = nblk_used + (t >> 2); ti = 2 * (bq / Nb) + ((t >> 1) & 1); tj = 2 * (bq % Nb) + (t & 1); }
+        else {
+            int q = t - rest_blk * 4;                                  // strips: odd last column of tiles (all rows), then odd last row (even columns part)
+            const int ncol = (Nq & 1) ? Mq : 0;
+            if (q < ncol) { ti = q; tj = Nq - 1; }
+            else { q -= ncol; ti = Mq - 1; tj = q; }
+        }
+        const int i0 = ti << 4, j0 = tj << 4;
+        const TX *xr = X + (size_t)min(i0 + li, M - 1) * pX;
+        const int jc = min(j0 + li, Nn - 1);
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kd; k0 += 4 * KT) {
+            const int kb = k0 + KT * lk;
+            double a[KT], bq[KT];
+            load_a(xr, kb, k0, a); load_b(jc, kb, k0, bq);
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                if (u & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+            }
+        }
+        store_tile(i0, j0, acc + acc2);
     }
 }
 
