@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
         FGW_PROF(7);  // T store + err
     }
     if (bail) {
-        if (tid == 0) redo[blockIdx.x] = 1;
+        if (tid == 0) { redo[blockIdx.x] = 1; atomicOr(&info[b * 4 + 3], 1); }      // info flag bit 0: a coupling of this molecule took the second pass
         return;
     }
     __syncthreads();

@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         FGW_PROF(7);  // T store + err
     }
     if (bail) {                                                         // nothing has been written: the launcher re-runs this coupling on the exact path
-        if (tid == 0) redo[blockIdx.x] = 1;
+        if (tid == 0) { redo[blockIdx.x] = 1; atomicOr(&info[b * 4 + 3], 1); }      // info flag bit 0: a coupling of this molecule took the second pass
         return;
     }
     __syncthreads();

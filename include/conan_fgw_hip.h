@@ -431,7 +431,9 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d);
  * Outputs: Y[B,N,d], C[B,N,N], T[B,K,N,N] (final couplings, saved for the backward),
  * T_iter[max_iter,B,K,N,N] or NULL: the couplings after every outer iteration (the reference's log["Ts_iter"], barycenter.py:196;
  * a molecule that stopped early keeps its last couplings in the later slots),
- * info[B,4] int32 = {outer iterations, total PGD iterations, total Sinkhorn iterations, flags},
+ * info[B,4] int32 = {outer iterations, total PGD iterations, total Sinkhorn iterations, flags}; flags bit 0: at least one coupling
+ * solve of the molecule left the range of the scaling-form Sinkhorn and was redone on the exact log-domain path (same result
+ * contract, slower),
  * errs[B,2,max_iter] fp32 = err_feature / err_structure per outer iteration (NaN where not executed).
  * Internal arithmetic is fp64 (DESIGN.md section "FGW numerics"); I/O is fp32. */
 int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,

@@ -29,10 +29,14 @@ def _run(Ys, Cs, **kw):
     return ops.fgw_barycenter_batched(Yt, Ct, **kw)
 
 
+@pytest.mark.parametrize("small_int", [False, True], ids=["cs_f32", "cs_u8"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
-def test_golden_vectors(path):
+def test_golden_vectors(path, small_int):
+    """small_int: the byte-wide adjacency layout the models request (conan_fgw_params.cs_small_int) and the fp32 one of general Cs."""
     g = np.load(path)
-    Y, C, T, info, errs = _run(g["Ys"], g["Cs"])
+    assert np.array_equal(g["Cs"], np.round(g["Cs"])) and g["Cs"].min() >= 0 and g["Cs"].max() <= 255
+    Y, C, T, info, errs = _run(g["Ys"], g["Cs"], cs_small_int=small_int)
+    assert int(info[0, 3]) == 0                                              # no coupling needed the exact second pass
     Y, C, T = Y[0].cpu().numpy(), C[0].cpu().numpy(), T[0].cpu().numpy()
     outer = int(info[0, 0])
     assert outer == len(g["r64_err_feature"])
@@ -65,6 +69,24 @@ def test_backward_matches_reference_autograd(path):
     yard = rel(g["r32_dYs"], g["r64_dYs"])
     e = rel(Yt.grad[0].cpu().numpy(), g["r64_dYs"])
     assert e <= max(1e-4, yard), (e, yard)
+
+
+@pytest.mark.parametrize("N,B", [(20, 3), (33, 2), (70, 2)], ids=["n20", "n33", "n70_large_kernel"])
+def test_second_pass_on_the_exact_path_when_the_scaling_form_leaves_its_range(N, B):
+    """A small epsilon spreads the Sinkhorn costs over thousands of units: whole rows of K = exp(Mr - ref) underflow, the round-3
+    kernels hand those couplings back (info flag bit 0) and the round-2 kernel redoes them on the log-domain path.  Same contract:
+    iteration counts of the fp64 oracle, Y / C within 1e-4."""
+    K, d = 4, 16
+    rng = np.random.default_rng(5)
+    Ys = (rng.random((B, K, N, d)) * 1.9 + 0.1).astype(np.float32)
+    A = (rng.random((B, K, N, N)) < 0.4).astype(np.float32); Cs = np.triu(A, 1); Cs = Cs + Cs.transpose(0, 1, 3, 2)
+    kw = dict(epsilon=2e-3, alpha=0.1)
+    Y, C, T, info, errs = ops.fgw_barycenter_batched(torch.from_numpy(Ys).to(dev), torch.from_numpy(Cs).to(dev), cs_small_int=True, **kw)
+    assert int(info[:, 3].max()) == 1, "the test shape no longer drives the scaling form out of range: pick a smaller epsilon"
+    for b in range(B):
+        ref = ofgw.fgw_barycenter(Ys[b], Cs[b], dtype=np.float64, **kw)
+        assert int(info[b, 0]) == ref["outer"] and int(info[b, 1]) == int(ref["pgd"].sum()) and int(info[b, 2]) == int(ref["sinkhorn"].sum())
+        assert rel(Y[b].cpu().numpy(), ref["Y"]) < 1e-4 and rel(C[b].cpu().numpy(), ref["C"]) < 1e-4
 
 
 def test_cfm_log_known_answer(golden_dir):

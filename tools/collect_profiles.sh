@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-2 measurement set (run on the GPU box through gpurun): bench lines, rocprofv3 kernel stats, PMC passes (each in its own
-# run: --pmc with --kernel-trace only).  Everything lands in gpurun_out/r2p/; the summaries are copied to profiles/ afterwards.
+# Round-3 measurement set (run on the GPU box through gpurun): bench lines, rocprofv3 kernel stats, PMC passes (each in its own
+# run: --pmc with --kernel-trace only).  Everything lands in gpurun_out/r3p/; the summaries are copied to profiles/ afterwards.
 set -u
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2p; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3p; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py"
 $B > $O/bench_train.json 2> $O/bench_train.err
 $B --mode fwd --no-cpu-baseline > $O/bench_fwd.json 2>/dev/null
@@ -19,8 +19,8 @@ done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > $O/pmc_sq.log 2>&1
-python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/r2_pmc_hbm.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_hbm.txt 2>&1
-python3 $R/tools/pmc_sq.py $O/pmc_sq $O/r2_pmc_mfma.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_sq.txt 2>&1
+python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/r3_pmc_hbm.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_hbm.txt 2>&1
+python3 $R/tools/pmc_sq.py $O/pmc_sq $O/r3_pmc_mfma.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_sq.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head; ls $O
 # keep the merge small: drop raw traces
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*.db" -delete
