@@ -53,7 +53,7 @@ __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict
 // MODE 2: the four matrices in LDS; 1: only the coupling (Mr / K) in LDS; 0: everything in the global scratch.  A template parameter,
 // not a runtime flag: a pointer chosen at run time between LDS and global memory compiles to flat_* accesses for every
 // element of the Sinkhorn passes.
-template <int MODE, bool KL, int NW>      // KL: loss_fun = "kl_loss", see fgw_small.hip
+template <int MODE, bool KL, int NW, bool SECOND = false>      // KL: loss_fun = "kl_loss"; SECOND: the pass behind k_fgw_coupling_big (see fgw_small.hip)
 __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
@@ -62,9 +62,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     constexpr bool LDS_MODE = MODE == 2, MR_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
-    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    auto solve = [&](const int cid) {
+    const int b = cid / D.K, s = cid % D.K;
     if (!active[b]) return;
-    if (only && !only[blockIdx.x]) return;      // second pass behind k_fgw_coupling_big: only the couplings it handed back
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     double *pm = red + 16, *psm = pm + NW * N;                // per-wavefront partial (max, sum) of the log-sum-exp loops
     // LDS_MODE: all four matrices in LDS.  Otherwise only the Sinkhorn cost Mr (read 2x per Sinkhorn iteration, once by
     // rows and once by columns) stays in LDS when it fits (mr_lds); A, base and T live in an L2-resident global scratch.
-    char *gs = scratch + (size_t)blockIdx.x * coupling_scratch_stride(NP);     // 16-byte aligned per workgroup
+    char *gs = scratch + (size_t)cid * coupling_scratch_stride(NP);     // 16-byte aligned per coupling
     char *ls = smem + (size_t)((6 + 2 * NW) * N + 16) * 8;
     double *Mr = MR_LDS ? reinterpret_cast<double *>(ls) : reinterpret_cast<double *>(gs);
     double *Al = LDS_MODE ? Mr + NP : reinterpret_cast<double *>(gs) + NP;
@@ -360,6 +360,18 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
+    };
+    if constexpr (!SECOND) solve(blockIdx.x);
+    else {      // one workgroup per 64 couplings: their flags are fetched by ONE load per lane (a ballot every wavefront forms for itself)
+        const int total = D.B * D.K, base = (int)blockIdx.x * 64, l = (int)threadIdx.x & 63;
+        unsigned long long m = __ballot(base + l < total && only[base + l < total ? base + l : 0] != 0);
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            solve(base + k);
+            __syncthreads();                                            // LDS is re-staged by the next trip
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ round-3 coupling kernel, N > 64
@@ -840,21 +852,26 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     const bool kl = params->loss_fun != 0;
     if (params->loss_fun != 0 && params->loss_fun != 1) return CONAN_E_BADARG;
 
-    k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
-    if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, s);
+    if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, init_C, init_Y, active, info, errs, Y, C, s);
+    else k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
     const size_t lc = coupling_lds(N);
     const bool c_lds = lc <= LDS_LIMIT;
     const size_t vec_c = (size_t)((6 + 2 * GEN_NW) * N + 16) * 8;
     const size_t mr_bytes = NP * 8;
     const int mode = c_lds ? 2 : (vec_c + mr_bytes <= LDS_LIMIT ? 1 : 0);
     const size_t lds_bytes = mode == 2 ? lc : vec_c + (mode == 1 ? mr_bytes : 0);
-#define CONAN_CPL(M, KLV)                                                                                                           \
+#define CONAN_CPL_(M, KLV, SEC, GRID)                                                                                               \
     do {                                                                                                                            \
         if (lds_bytes > 64 * 1024)                                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<M, KLV, GEN_NW>),                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<M, KLV, GEN_NW, SEC>),                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                  \
-        k_fgw_coupling<M, KLV, GEN_NW><<<B * K, 64 * GEN_NW, lds_bytes, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, \
+        k_fgw_coupling<M, KLV, GEN_NW, SEC><<<GRID, 64 * GEN_NW, lds_bytes, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, \
                                                                               info, sc_c, Ypart, Cpart, only);                      \
+    } while (0)
+#define CONAN_CPL(M, KLV)                                                                                                           \
+    do {                                                                                                                            \
+        if (!KLV && only) CONAN_CPL_(M, false, true, (B * K + 63) / 64);                                                            \
+        else CONAN_CPL_(M, KLV, false, B * K);                                                                                      \
     } while (0)
     // N > 64, square loss: the round-3 kernel first (fp32 kernel matrix in LDS: three workgroups per CU), then k_fgw_coupling over the
     // same grid for whatever it handed back (redo[b, s]; an early-exit launch otherwise)
@@ -885,6 +902,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
         conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, small ? yvec : nullptr, s);
     }
 #undef CONAN_CPL
+#undef CONAN_CPL_
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

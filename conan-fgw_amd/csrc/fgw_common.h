@@ -779,8 +779,10 @@ __device__ __forceinline__ void mm_lds2(int M, int Nn, int Kd, const TX *__restr
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
 bool conan_fgw_small_supported(int N, int d);
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
+// (also initialises the molecules: the N <= 64 path launches no k_fgw_init)
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
-                             const double *Cw, const double *Yw, double *zvec, double *yvec, hipStream_t s);
+                             double *Cw, double *Yw, double *zvec, double *yvec, const float *init_C, const float *init_Y, int *active, int *info,
+                             float *errs, float *Yout, float *Cout, hipStream_t s);
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
                               const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,

@@ -33,16 +33,19 @@ constexpr int SK_SCRATCH_DOUBLES = 3 * 256 + 2 * 64;      // Sinkhorn scratch: t
 // gradient, log(clamp(C_s, 1e-15)) in the structure update (exp applied by the update kernel).  The logarithms are evaluated in
 // fp64 where the operand is fetched (the kl path is a capability of the signature, not a tuned path); KL = false compiles to
 // exactly the square-loss kernel.
-template <int R, bool KL>
-__global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_small(
+template <int R, bool KL, bool SECOND = false>      // SECOND: the pass behind k_fgw_coupling_fast (walks the couplings, solves the flagged ones)
+__global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_coupling_small(      // (SECOND: full register budget — inside its loop the body's invariants are hoisted; a kernel with scratch costs every launch)
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
     double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, const int *__restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    // SECOND (the pass behind k_fgw_coupling_fast): a SMALL grid walks all couplings and solves the ones that were handed back (only[]) —
+    // an empty pass then costs a few dozen workgroups instead of B * K.  Otherwise: one workgroup per coupling, no loop (inside a loop
+    // the optimiser hoists the body's invariants and the kernel spills).
+    auto solve = [&](const int cid) {
+    const int b = cid / D.K, s = cid % D.K;
     if (!active[b]) return;
-    if (only && !only[blockIdx.x]) return;      // second pass behind k_fgw_coupling_fast: only the couplings it handed back
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -388,6 +391,18 @@ __global__ void __launch_bounds__(FGW_THREADS, R <= 9 ? 3 : 1) k_fgw_coupling_sm
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
+    };
+    if constexpr (!SECOND) solve(blockIdx.x);
+    else {      // one workgroup per 64 couplings: their flags are fetched by ONE load per lane (a ballot every wavefront forms for itself)
+        const int total = D.B * D.K, base = (int)blockIdx.x * 64, l = (int)threadIdx.x & 63;
+        unsigned long long m = __ballot(base + l < total && only[base + l < total ? base + l : 0] != 0);
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            solve(base + k);
+            __syncthreads();                                            // LDS is re-staged by the next trip
+        }
+    }
 }
 
 // ================================================================================================================================
@@ -766,11 +781,28 @@ __device__ __forceinline__ void molecule_vectors(const double *__restrict__ Y, c
 
 // One workgroup per (molecule, input graph): the static vectors |z_j|^2 and r2_j = sum_k q_k f2(C2[j,k]) (f2(b) = b^2, or b for kl),
 // and (s == 0) the molecule's initial |y_i|^2, r1_i.  Launched once per solve, after k_fgw_init.
+// The workgroup of input graph 0 also initialises its molecule (what k_fgw_init does on the N > 64 path: C <- init_C or Cs[b, 0], Y <- init_Y
+// or 0, barycenter.py:57-77; flags, counters, error log): one launch instead of two at the head of every solve.
 __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps,
-                                                           const float *__restrict__ pb, FgwDims D, int kl, const double *__restrict__ Cw,
-                                                           const double *__restrict__ Yw, double *__restrict__ zvec, double *__restrict__ yvec) {
+                                                           const float *__restrict__ pb, FgwDims D, int kl, double *__restrict__ Cw,
+                                                           double *__restrict__ Yw, double *__restrict__ zvec, double *__restrict__ yvec,
+                                                           const float *__restrict__ init_C, const float *__restrict__ init_Y, int max_iter,
+                                                           int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs,
+                                                           float *__restrict__ Yout, float *__restrict__ Cout) {
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     const int N = D.N, d = D.d;
+    if (s == 0) {                                                       // (workgroup-uniform)
+        const int NN = N * N, Nd = N * d;
+        const float *c0 = init_C ? init_C + (size_t)b * NN : Cs + (size_t)b * D.K * NN;      // init_C = Cs[0] (schnet_no_sum.py:303)
+        for (int t = threadIdx.x; t < NN; t += 256) { Cw[(size_t)b * NN + t] = (double)c0[t]; Cout[(size_t)b * NN + t] = c0[t]; }
+        for (int t = threadIdx.x; t < Nd; t += 256) {
+            const float y = init_Y ? init_Y[(size_t)b * Nd + t] : 0.f;                          // barycenter.py:76-77
+            Yw[(size_t)b * Nd + t] = (double)y; Yout[(size_t)b * Nd + t] = y;
+        }
+        if (threadIdx.x == 0) { active[b] = 1; info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
+        for (int t = threadIdx.x; t < 2 * max_iter; t += 256) errs[(size_t)b * 2 * max_iter + t] = __builtin_nanf("");
+        __syncthreads();                                                // Cw / Yw of this molecule are read back below (same workgroup)
+    }
     const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
     const float *C2 = Cs + ((size_t)b * D.K + s) * N * N;
     const float *q = ps ? ps + ((size_t)b * D.K + s) * N : nullptr;
@@ -896,8 +928,10 @@ size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
 }
 
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
-                             const double *Cw, const double *Yw, double *zvec, double *yvec, hipStream_t s) {
-    k_fgw_small_vectors<<<D.B * D.K, 256, 0, s>>>(Ys, Cs, ps, pb, D, prm.loss_fun, Cw, Yw, zvec, yvec);
+                             double *Cw, double *Yw, double *zvec, double *yvec, const float *init_C, const float *init_Y, int *active, int *info,
+                             float *errs, float *Yout, float *Cout, hipStream_t s) {
+    k_fgw_small_vectors<<<D.B * D.K, 256, 0, s>>>(Ys, Cs, ps, pb, D, prm.loss_fun, Cw, Yw, zvec, yvec, init_C, init_Y, prm.max_iter, active, info,
+                                                 errs, Yout, Cout);
 }
 
 template <int R, int MAXT, typename C2T>
@@ -955,13 +989,19 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
         only = redo;
     }
 #endif
-#define LAUNCH(RR)                                                                                                              \
+#define LAUNCH_(RR, SEC, GRID)                                                                                                  \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR, KLV>),                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR, KLV, SEC>),                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
-        k_fgw_coupling_small<RR, KLV><<<grid, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, \
+        k_fgw_coupling_small<RR, KLV, SEC><<<GRID, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, \
                                                                 info, Ypart, Cpart, zvec, yvec, only);                          \
+    } while (0)
+#define LAUNCH(RR)                                                                                                              \
+    do {                                                                                                                        \
+        if constexpr (KLV) LAUNCH_(RR, false, grid);                                                                            \
+        else if (only) LAUNCH_(RR, true, (grid + 63) / 64);                                                                     \
+        else LAUNCH_(RR, false, grid);                                                                                          \
     } while (0)
     if (prm.loss_fun) {
         constexpr bool KLV = true;
@@ -977,6 +1017,7 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
         else LAUNCH(16);
     }
 #undef LAUNCH
+#undef LAUNCH_
 }
 
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
