@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
-    double *__restrict__ Ypart, double *__restrict__ Cpart, const int *__restrict__ only) {
+    fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, const int *__restrict__ only) {
     constexpr bool LDS_MODE = MODE == 2, MR_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
@@ -343,12 +343,12 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     FGW_PROF(8);      // T -> global
     // ---- contributions to the barycenter update (summed over s by k_fgw_update_parts)
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
-        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        mm_f64_glb<NW, false>(N, d, N, Mr, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        mm_f64_glb<NW, false>(N, d, N, Mr, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
-        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
         if constexpr (KL)
             mm_f64<NW>(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
                    [&](int k, int j) { const double cv = (double)C2[k * N + j]; return log(cv > 1e-15 ? cv : 1e-15); },
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         else
             mm_f64_glb<NW, false>(N, N, N, Mr, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        mm_f64_glb<NW, true>(N, N, N, Al, P, Mr, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
+        mm_f64_glb<NW, true>(N, N, N, Al, P, Mr, P, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
-    double *__restrict__ Ypart, double *__restrict__ Cpart, int *__restrict__ redo) {
+    fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, int *__restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
@@ -607,15 +607,15 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[blockIdx.x] = 0; }
     FGW_PROF(8);      // T -> global
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
-        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        FGW_MMG<NW, false>(N, d, N, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+        fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        FGW_MMG<NW, false>(N, d, N, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
-        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
         FGW_MMG<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        FGW_MMG<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = v; });
+        FGW_MMG<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
@@ -843,9 +843,9 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     int *active = reinterpret_cast<int *>(w); w += al256((size_t)B * 4);
     char *sc_c = w; w += al256((size_t)B * K * coupling_scratch_stride(NP));
     w += al256((size_t)B * NP * 16);        // (reserved)
-    double *Ypart = reinterpret_cast<double *>(w);
-    double *Cpart = Ypart + (size_t)B * K * N * d;
-    double *zvec = Cpart + (size_t)B * K * NN;              // [B,K,2N]  |z_j|^2, r2_j      (register-resident path)
+    fgw_part_t *Ypart = reinterpret_cast<fgw_part_t *>(w);
+    fgw_part_t *Cpart = Ypart + (size_t)B * K * N * d;
+    double *zvec = reinterpret_cast<double *>(w + conan_fgw_part_offset(B, K, N, d));      // [B,K,2N]  |z_j|^2, r2_j      (register-resident path)
     double *yvec = zvec + (size_t)B * K * 2 * N;            // [B,2N]    |y_i|^2, r1_i
     int *redo = reinterpret_cast<int *>(yvec + (size_t)B * 2 * N);      // [B,K]  couplings the round-3 kernel hands back to the exact path
     const bool small = conan_fgw_small_supported(N, d);

@@ -41,6 +41,13 @@ static __device__ long long g_fgw_prof[32];            // one copy per translati
 constexpr int FGW_THREADS = 256;
 constexpr int FGW_WAVES = FGW_THREADS / 64;
 
+// Per-graph contributions to the barycenter update (T_s Z_s and T_s C_s T_s^T, summed over s by k_fgw_update_parts).  fp64: they are the
+// largest HBM streams of a solve (41 MB written + 41 MB read per outer iteration at cfg2), but as fp32 (measured: coupling launch
+// 132.3 -> 130.8 us, update 16.3 -> 15.3 us) their rounding — 6e-8 relative per outer iteration — is amplified by the scheme like every
+// other perturbation: tests/test_gpu_fgw.py::test_large_graphs_vs_oracle[64-2-16] moved from < 1e-4 to 1.6e-4 of the fp64 reference on
+// T.  Not worth 1.5 % of a solve.
+typedef double fgw_part_t;
+
 struct FgwDims {
     int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
 };
@@ -779,15 +786,16 @@ __device__ __forceinline__ void mm_lds2(int M, int Nn, int Kd, const TX *__restr
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
 bool conan_fgw_small_supported(int N, int d);
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
+size_t conan_fgw_part_offset(int B, int K, int N, int d);      // bytes of Ypart + Cpart (16-byte aligned): where the fp64 vectors start
 // (also initialises the molecules: the N <= 64 path launches no k_fgw_init)
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
                              double *Cw, double *Yw, double *zvec, double *yvec, const float *init_C, const float *init_Y, int *active, int *info,
                              float *errs, float *Yout, float *Cout, hipStream_t s);
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
-                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
+                              const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart, const double *zvec,
                               const double *yvec, int *redo, hipStream_t s);
 // yvec (nullable): the register-resident path's per-molecule vectors, refreshed after every update
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
-                            const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
+                            const fgw_part_t *Ypart, const fgw_part_t *Cpart, double *Cw, double *Yw, int *active, int *info,
                             float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s);

@@ -37,8 +37,8 @@ template <int R, bool KL, bool SECOND = false>      // SECOND: the pass behind k
 __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_coupling_small(      // (SECOND: full register budget — inside its loop the body's invariants are hoisted; a kernel with scratch costs every launch)
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
-    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
-    double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, const int *__restrict__ only) {
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, fgw_part_t *__restrict__ Ypart,
+    fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, const int *__restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // SECOND (the pass behind k_fgw_coupling_fast): a SMALL grid walks all couplings and solves the ones that were handed back (only[]) —
     // an empty pass then costs a few dozen workgroups instead of B * K.  Otherwise: one workgroup per coupling, no loop (inside a loop
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
 
     // ---- contributions to the barycenter update while T is resident
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
-        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
         if (z_lds) {                                                    // G's storage is idle again: Z through LDS, one coalesced pass
             const int Nd = N * d;
             for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
@@ -371,15 +371,15 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
                 for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) Zl2[t] = zv[u]; }
             }
             __syncthreads();
-            mm_lds<FGW_WAVES, false>(N, d, N, Tl, P, Zl2, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; }, border_prepare(N, d));
+            mm_lds<FGW_WAVES, false>(N, d, N, Tl, P, Zl2, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; }, border_prepare(N, d));
         } else {
             mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
-                   [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+                   [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
         }
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
-        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
         if constexpr (KL)
             mm_f64(N, N, N, [&](int i, int k) { return (double)Tl[i * P + k]; },
                    [&](int k, int j) { const double cv = (double)C2l[k * P + j]; return log(cv > 1e-15 ? cv : 1e-15); },
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
         else
             mm_lds<FGW_WAVES, false>(N, N, N, Tl, P, C2l, P, [&](int i, int j, double v) { Al[i * P + j] = v; }, bnn);
         __syncthreads();
-        mm_lds<FGW_WAVES, true>(N, N, N, Al, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = v; }, bnn);
+        mm_lds<FGW_WAVES, true>(N, N, N, Al, P, Tl, P, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; }, bnn);
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
@@ -466,8 +466,8 @@ template <int R, int MAXT, typename C2T>
 __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_fast(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
-    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, double *__restrict__ Ypart,
-    double *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo) {
+    const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, fgw_part_t *__restrict__ Ypart,
+    fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
 
     // ---- contributions to the barycenter update while T is resident
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
-        double *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
+        fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
         if (yz_lds) {                                                   // C1 is dead: Z through its storage, one coalesced pass
             const int Nd = N * d;
             for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
@@ -741,18 +741,18 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
                 for (int u = 0; u < 4; ++u) { const int t = t0 + u * FGW_THREADS; if (t < Nd) Zl[t] = zv[u]; }
             }
             __syncthreads();
-            mm_lds2<FGW_WAVES, 1, 0, false, false>(N, d, N, Tl, P, Zl, d, [] {}, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+            mm_lds2<FGW_WAVES, 1, 0, false, false>(N, d, N, Tl, P, Zl, d, [] {}, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
         } else {
             mm_f64(N, d, N, [&](int i, int k) { return (double)Tl[i * P + k]; }, [&](int k, int c) { return (double)Z[(size_t)k * d + c]; },
-                   [&](int i, int c, double v) { Yp[(size_t)i * d + c] = v; });
+                   [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
         }
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
-        double *Cp = Cpart + ((size_t)b * D.K + s) * NN;
+        fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
         mm_lds2<FGW_WAVES, 1, 0, false, false>(N, N, N, Tl, P, C2l, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; });
         __syncthreads();
-        mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, N, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) { Cp[i * N + j] = v; });
+        mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, N, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
 constexpr int UPD_THREADS = 1024;       // the kernel is a few dependent L2 round trips per molecule: more threads, fewer trips each
 __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
     const float *__restrict__ pb, const float *__restrict__ lambdas, FgwDims D, conan_fgw_params prm, int outer,
-    const double *__restrict__ Ypart, const double *__restrict__ Cpart, double *__restrict__ Cw, double *__restrict__ Yw,
+    const fgw_part_t *__restrict__ Ypart, const fgw_part_t *__restrict__ Cpart, double *__restrict__ Cw, double *__restrict__ Yw,
     int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout,
     double *__restrict__ yvec) {
     __shared__ double red[UPD_THREADS / 64 + 1];
@@ -922,9 +922,12 @@ inline size_t small_lds(int N, int d) {
 
 bool conan_fgw_small_supported(int N, int d) { return N <= 64 && small_lds(N, d) <= 160 * 1024; }
 
+size_t conan_fgw_part_offset(int B, int K, int N, int d) {
+    return (((size_t)B * K * N * d + (size_t)B * K * N * N) * sizeof(fgw_part_t) + 15) & ~(size_t)15;
+}
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
-    // Ypart [B,K,N,d] + Cpart [B,K,N,N] + zvec [B,K,2N] + yvec [B,2N], fp64; redo [B,K] int32
-    return ((size_t)B * K * N * d + (size_t)B * K * N * N + (size_t)B * K * 2 * N + (size_t)B * 2 * N) * 8 + (size_t)B * K * 4 + 512;
+    // Ypart [B,K,N,d] + Cpart [B,K,N,N] (fgw_part_t); zvec [B,K,2N] + yvec [B,2N], fp64; redo [B,K] int32
+    return conan_fgw_part_offset(B, K, N, d) + ((size_t)B * K * 2 * N + (size_t)B * 2 * N) * 8 + (size_t)B * K * 4 + 512;
 }
 
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
@@ -936,7 +939,7 @@ void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, 
 
 template <int R, int MAXT, typename C2T>
 static void launch_fast_t(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm, int outer, int y_zero,
-                        const double *Cw, const double *Yw, const int *active, float *Tw, int *info, double *Ypart, double *Cpart,
+                        const double *Cw, const double *Yw, const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart,
                         const double *zvec, const double *yvec, int *redo, hipStream_t s) {
     const size_t lds = fast_lds<C2T>(D.N).bytes;
     if (lds > 64 * 1024)
@@ -948,7 +951,7 @@ static void launch_fast_t(const float *Ys, const float *Cs, const float *ps, con
 }
 template <int R, typename C2T>
 static void launch_fast(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm, int outer, int y_zero,
-                        const double *Cw, const double *Yw, const int *active, float *Tw, int *info, double *Ypart, double *Cpart,
+                        const double *Cw, const double *Yw, const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart,
                         const double *zvec, const double *yvec, int *redo, hipStream_t s) {
     const int tpw = fast_tiles_per_wave(D.N);                          // <= ceil(ceil(4R / 16)^2 / 4)
 #define ARGS Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s
@@ -966,7 +969,7 @@ bool conan_fgw_fast_supported(int N, int d, int small_int) {
 
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
-                              const int *active, float *Tw, int *info, double *Ypart, double *Cpart, const double *zvec,
+                              const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart, const double *zvec,
                               const double *yvec, int *redo, hipStream_t s) {
     const size_t lds = small_lds(D.N, D.d);
     const int R = (D.N + 3) / 4;
@@ -1021,7 +1024,7 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
 }
 
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
-                            const double *Ypart, const double *Cpart, double *Cw, double *Yw, int *active, int *info,
+                            const fgw_part_t *Ypart, const fgw_part_t *Cpart, double *Cw, double *Yw, int *active, int *info,
                             float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s) {
     k_fgw_update_parts<<<D.B, UPD_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout, yvec);
 }
