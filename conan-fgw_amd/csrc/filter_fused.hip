@@ -39,9 +39,31 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
     }
 }
 
+// Two-plane fp16 split of 8 fp32 values: v = h1 + h2 up to 2^-22 |v| while the remainder v - h1 is a normal fp16 number (|v| >~ 0.06),
+// and to 3e-8 absolute below that (fp16 subnormal spacing).  With the three products p1q1, p1q2, p2q1 (the dropped p2q2 is 2^-22
+// relative) an fp16 MFMA chain reproduces the fp32 product to ~2.4e-7 at HALF the matrix-pipe time and ~2/3 of the splitting work
+// of the three-plane bf16 form (6 products).  Range: the operands here are O(1e-2..1e2) — Gaussians in [0, 1], shifted-softplus
+// outputs, weights pre-scaled by 2^6 (exact, undone in the epilogue's FMA) — far inside fp16's 6e-5..65504.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(const float *v, f16x8 &p1, f16x8 &p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h1 = (_Float16)v[j];
+        p1[j] = h1; p2[j] = (_Float16)(v[j] - (float)h1);
+    }
+}
+constexpr float WSCALE = 64.0f, WUNSCALE = 1.0f / 64.0f;      // weight pre-scale of the fp16 planes
+
 constexpr int GP = 64;        // gaussians padded to four MFMA k-steps of 16 (zero weights beyond num_gaussians)
 constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (bf16 elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
 constexpr int FF_THREADS = 512;
+
+#ifdef CONAN_FILTER_BF16X3      // (A/B switch of tools/ab.py: the round-2 three-plane bf16 form)
+constexpr bool FF_H16 = false;
+#else
+constexpr bool FF_H16 = true;
+#endif
+constexpr int FF_NPL = FF_H16 ? 2 : 3;                       // operand planes
 
 template <int F>
 __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
@@ -50,9 +72,9 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out) {
     constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
     constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (bf16 elements; 16-B slots stay distinct)
-    constexpr int W2WORDS = (3 * F * W2S) / 2;      // floats occupied by the three bf16 W2 images
+    constexpr int W2WORDS = (FF_NPL * F * W2S) / 2;      // floats occupied by the 16-bit W2 images
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int W1WORDS = (3 * F * W1S) / 2;      // floats occupied by the three bf16 W1 images
+    constexpr int W1WORDS = (FF_NPL * F * W1S) / 2;      // floats occupied by the 16-bit W1 images
     float *W1L = lds;                     // 3 x bf16 [F][W1S]
     float *W2L = W1L + W1WORDS;           // 3 x bf16 [F][W2S], columns permuted per 16-group
     float *B1L = W2L + W2WORDS;           // [F]
@@ -76,12 +98,20 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
         for (int u = 0; u < PER1; ++u) {
             const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
             if (t >= F * GP) continue;
+            if constexpr (FF_H16) {
+                _Float16 *W1H = reinterpret_cast<_Float16 *>(W1L);
+                const float v = wv[u] * WSCALE;
+                const _Float16 h1 = (_Float16)v;
+                W1H[(0 * F + f) * W1S + k] = h1;
+                W1H[(1 * F + f) * W1S + k] = (_Float16)(v - (float)h1);
+            } else {
             const float v = wv[u];
             const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
             const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
             W1B[(0 * F + f) * W1S + k] = h1;
             W1B[(1 * F + f) * W1S + k] = h2;
             W1B[(2 * F + f) * W1S + k] = (__bf16)r2;
+            }
         }
     }
     {
@@ -102,12 +132,20 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             const int f2 = t / F, f = t - f2 * F;
             const int kk = f & 15, hh = (kk >> 2) & 1, jj = (kk & 3) + 4 * (kk >> 3);
             const int colp = (f & ~15) + 8 * hh + jj;
+            if constexpr (FF_H16) {
+                _Float16 *W2H = reinterpret_cast<_Float16 *>(W2L);
+                const float v = wv[u] * WSCALE;
+                const _Float16 h1 = (_Float16)v;
+                W2H[(0 * F + f2) * W2S + colp] = h1;
+                W2H[(1 * F + f2) * W2S + colp] = (_Float16)(v - (float)h1);
+            } else {
             const float v = wv[u];
             const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
             const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
             W2B[(0 * F + f2) * W2S + colp] = h1;
             W2B[(1 * F + f2) * W2S + colp] = h2;
             W2B[(2 * F + f2) * W2S + colp] = (__bf16)r2;
+            }
         }
     }
     for (int t = tid; t < F; t += FF_THREADS) { B1L[t] = b1[t]; B2L[t] = b2[t]; }
@@ -140,6 +178,22 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 float rb[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float t0 = d - of[j]; rb[j] = exp_neg_f(coeff * (t0 * t0)); }
+                if constexpr (FF_H16) {
+                    const _Float16 *W1H = reinterpret_cast<const _Float16 *>(W1L);
+                    f16x8 q1, q2;
+                    split2h(rb, q1, q2);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int row = 32 * mb + l31;
+                        const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&W1H[(0 * F + row) * W1S + kb]);
+                        const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&W1H[(1 * F + row) * W1S + kb]);
+                        acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc1[mb], 0, 0, 0);      // smallest terms first
+                        acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc1[mb], 0, 0, 0);
+                        acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc1[mb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 bf16x8 q1, q2, q3;
                 split3(rb, q1, q2, q3);
 #pragma unroll
@@ -164,10 +218,11 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&B1L[32 * mb + 8 * q + 4 * h]);
-                acc1[mb][4 * q + 0] = ssp_f(acc1[mb][4 * q + 0] + bb.x);
-                acc1[mb][4 * q + 1] = ssp_f(acc1[mb][4 * q + 1] + bb.y);
-                acc1[mb][4 * q + 2] = ssp_f(acc1[mb][4 * q + 2] + bb.z);
-                acc1[mb][4 * q + 3] = ssp_f(acc1[mb][4 * q + 3] + bb.w);
+                constexpr float us = FF_H16 ? WUNSCALE : 1.0f;      // the fp16 planes of the weights carry 2^6
+                acc1[mb][4 * q + 0] = ssp_f(fmaf(acc1[mb][4 * q + 0], us, bb.x));
+                acc1[mb][4 * q + 1] = ssp_f(fmaf(acc1[mb][4 * q + 1], us, bb.y));
+                acc1[mb][4 * q + 2] = ssp_f(fmaf(acc1[mb][4 * q + 2], us, bb.z));
+                acc1[mb][4 * q + 3] = ssp_f(fmaf(acc1[mb][4 * q + 3], us, bb.w));
             }
         if (h1_out && valid) {
 #pragma unroll
@@ -201,9 +256,25 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     float hv[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
+                    const int colp = 32 * mb + 16 * sgrp + 8 * h;
+                    if constexpr (FF_H16) {
+                        const _Float16 *W2H = reinterpret_cast<const _Float16 *>(W2L);
+                        f16x8 q1, q2;
+                        split2h(hv, q1, q2);
+#pragma unroll
+                        for (int nb = 0; nb < NG; ++nb) {
+                            const int row = 32 * (n0 + nb) + l31;
+                            const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&W2H[(0 * F + row) * W2S + colp]);
+                            const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&W2H[(1 * F + row) * W2S + colp]);
+                            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc2[nb], 0, 0, 0);
+                            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc2[nb], 0, 0, 0);
+                            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc2[nb], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
                     bf16x8 q1, q2, q3;
                     split3(hv, q1, q2, q3);
-                    const int colp = 32 * mb + 16 * sgrp + 8 * h;
 #pragma unroll
                     for (int nb = 0; nb < NG; ++nb) {
                         const int row = 32 * (n0 + nb) + l31;
@@ -229,10 +300,11 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     for (int q = 0; q < 4; ++q) {
                         const float4 bb = *reinterpret_cast<const float4 *>(&B2L[32 * (n0 + nb) + 8 * q + 4 * h]);
                         float4 o;
-                        o.x = (acc2[nb][4 * q + 0] + bb.x) * C;
-                        o.y = (acc2[nb][4 * q + 1] + bb.y) * C;
-                        o.z = (acc2[nb][4 * q + 2] + bb.z) * C;
-                        o.w = (acc2[nb][4 * q + 3] + bb.w) * C;
+                        constexpr float us = FF_H16 ? WUNSCALE : 1.0f;
+                        o.x = fmaf(acc2[nb][4 * q + 0], us, bb.x) * C;
+                        o.y = fmaf(acc2[nb][4 * q + 1], us, bb.y) * C;
+                        o.z = fmaf(acc2[nb][4 * q + 2], us, bb.z) * C;
+                        o.w = fmaf(acc2[nb][4 * q + 3], us, bb.w) * C;
                         *reinterpret_cast<float4 *>(Wout + (size_t)e * F + 32 * (n0 + nb) + 8 * q + 4 * h) = o;
                     }
             }
@@ -244,7 +316,7 @@ template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    const size_t lds = ((size_t)(3 * F * W1S) / 2 + (size_t)(3 * F * (F + 8)) / 2 + 2 * F + GP) * 4;
+    const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;
