@@ -70,6 +70,7 @@ SIGNATURES = {
     "conan_zero_tail": (c_int, [_P, _P, c_int, c_int, _P]),
     "conan_rbf_wgrad": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
     "conan_wgrad_batchable": (c_int, [c_int, c_int]),
+    "conan_linear_wgrad_scaled": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "conan_linear_wgrad_slabs": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_rbf_wgrad_slabs": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P]),
     "conan_wgrad_reduce_batch": (c_int, [ctypes.POINTER(WgradJob), c_int, _P]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     "conan_filter_bwd_supported": (c_int, [c_int, c_int]),
     "conan_filter_bwd_slices": (c_int, [c_int]),
     "conan_filter_bwd_ws": (c_ll, [c_int, c_int, c_int]),
-    "conan_filter_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P]),
+    "conan_filter_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_stage2_head_supported": (c_int, [c_int]),
@@ -93,7 +94,7 @@ SIGNATURES = {
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
-    "conan_cfconv_bwd_w_pairs": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_float, _P, _P]),
+    "conan_cfconv_bwd_w_pairs": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, _P]),
     "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_float, _P, _P]),
     "conan_segment_sum_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_segment_sum_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),

@@ -209,10 +209,12 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_wp(const float *__restrict__
 __global__ void __launch_bounds__(256) k_cfconv_bwd_wp128(const float *__restrict__ x, const float *__restrict__ dout,
                                                           const int *__restrict__ num_pairs_dev, int max_pairs, const int *__restrict__ pe0,
                                                           const int *__restrict__ pe1, const int *__restrict__ col, const int *__restrict__ tgt,
-                                                          const float *__restrict__ pdist, float cutoff, float *__restrict__ dWp) {
+                                                          const float *__restrict__ pdist, float cutoff, float *__restrict__ dWp,
+                                                          unsigned *__restrict__ gmax_bits) {
     constexpr int F = 128;
     const int P = min(*num_pairs_dev, max_pairs);
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    float amax = 0.f;                                             // max |dWp| seen by this thread (gmax_bits: see conan_cfconv_bwd_w_pairs)
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (P + (int)gridDim.x - 1) / (int)gridDim.x;                  // contiguous pairs per workgroup
     const int p_lo = lb * per, p_hi = min(P, (lb + 1) * per);
@@ -249,8 +251,16 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_wp128(const float *__restric
                 r.z = (xa[u].z * ga[u].z + mm[u] * xb[u].z * gb[u].z) * c2[u];
                 r.w = (xa[u].w * ga[u].w + mm[u] * xb[u].w * gb[u].w) * c2[u];
                 reinterpret_cast<float4 *>(dWp + (size_t)(base + kk[u]) * F)[l32] = r;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
             }
         }
+    }
+    if (gmax_bits) {
+        // non-negative floats order like their bit patterns: one atomicMax per wavefront, and only when it can raise the value (a plain
+        // read first: after the first few workgroups almost nobody has to touch the word)
+        amax = wave_max(amax);
+        const unsigned bits = __float_as_uint(amax);
+        if (lane == 0 && bits > *reinterpret_cast<volatile unsigned *>(gmax_bits) && bits < 0x7f800000u) atomicMax(gmax_bits, bits);
     }
 }
 
@@ -297,13 +307,15 @@ int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_d
 
 int conan_cfconv_bwd_w_pairs(const float *x, const float *dout, const int *num_pairs_dev, int max_pairs, const int *pair_e0,
                              const int *pair_e1, const int *col, const int *tgt, int num_filters, const float *pair_dist,
-                             float cutoff, float *dWp, void *stream) {
+                             float cutoff, float *dWp, float *gmax, void *stream) {
     if (!x || !dout || !num_pairs_dev || !pair_e0 || !pair_e1 || !col || !tgt || !pair_dist || !dWp || max_pairs < 0 || num_filters <= 0 ||
         (num_filters & 3))
         return CONAN_E_BADARG;
     if (max_pairs == 0) return CONAN_OK;
+    if (gmax && num_filters != 128) return CONAN_E_UNSUPPORTED;
     if (num_filters == 128)
-        k_cfconv_bwd_wp128<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, pair_dist, cutoff, dWp);
+        k_cfconv_bwd_wp128<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, pair_dist, cutoff, dWp,
+                                                                reinterpret_cast<unsigned *>(gmax));
     else
         k_cfconv_bwd_wp<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, num_filters, pair_dist,
                                                               cutoff, dWp);

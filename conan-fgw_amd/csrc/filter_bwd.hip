@@ -47,19 +47,44 @@ __device__ __forceinline__ void fb_split3(const float *v, bf16x8 &p1, bf16x8 &p2
     }
 }
 
-template <int F>
+// H16 (round 3): both products on TWO fp16 planes per operand (p1q1 + p1q2 + p2q1: 3 MFMAs instead of the 6 of the three-plane bf16
+// form, ~2^-22 relative) — see filter_fused.hip.  fp16's range needs the gradient operand scaled: `gmax` is max |g| over the whole
+// tensor (the kernel that produced g tracked it, conan_cfconv_bwd_w_pairs), s = 2^k with s * gmax in [16, 32); A = s * g, the w2
+// planes carry 2^6, dh1 is formed as s * dh1 (<= 32 * column abs-sum of w2: far inside 65504) and the accumulated s * dW1 is
+// unscaled once, when the slab is written.  Entries below 2e-6 * gmax fall into fp16's subnormal spacing (3e-8 / s absolute): they
+// cannot matter to a sum dominated by entries 1e6 times larger.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fb_split2h(const float *v, float sc, f16x8 &p1, f16x8 &p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * sc;
+        const _Float16 h1 = (_Float16)x;
+        p1[j] = h1; p2[j] = (_Float16)(x - (float)h1);
+    }
+}
+constexpr float FB_WSCALE = 64.0f;
+
+template <int F, bool H16>
 __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restrict__ g, const float *__restrict__ h1,
                                                            const float *__restrict__ dist, const float *__restrict__ offset, int Gs,
                                                            float coeff, const float *__restrict__ w2, int M,
                                                            const int *__restrict__ m_dev, float *__restrict__ slabs,
-                                                           float *__restrict__ bias_slabs) {
+                                                           float *__restrict__ bias_slabs, const float *__restrict__ gmax) {
     constexpr int NB = F / 32;            // 32-wide blocks of the channel dimension
     constexpr int S = F / 16;             // MFMA k-steps of the dx GEMM
     constexpr int WS = F + 8;             // LDS pitch of a w2 image row (bf16 elements)
     constexpr int JP = 64;                // Gaussians padded to two 32-wide blocks; column 63 = bias
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [3][k][WS]: image row k holds w2[n][k] for n = 0..F-1
-    float *DL = lds + (3 * F * WS) / 2;                         // [FB_WAVES][32] distances of the wave's tile
+    constexpr int NPL = H16 ? 2 : 3;                            // operand planes
+    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [NPL][k][WS]: image row k holds w2[n][k] for n = 0..F-1
+    _Float16 *WH = reinterpret_cast<_Float16 *>(lds);
+    float *DL = lds + (NPL * F * WS) / 2;                       // [FB_WAVES][32] distances of the wave's tile
+    float gsc = 1.0f, gun = 1.0f;                               // H16: scale of the gradient operand and its inverse
+    if constexpr (H16) {
+        const float gm = *gmax;
+        if (gm > 0.f && gm < 3.0e38f) { int e; (void)frexpf(gm, &e); gsc = ldexpf(1.0f, 5 - e); gun = ldexpf(1.0f, e - 5); }      // s * gm in [16, 32)
+    }
     if (m_dev) M = min(M, *m_dev);
     const int tiles = (M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,6 +114,14 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                                      e == 0 ? wv[u][1].x : e == 1 ? wv[u][1].y : e == 2 ? wv[u][1].z : wv[u][1].w,
                                      e == 0 ? wv[u][2].x : e == 1 ? wv[u][2].y : e == 2 ? wv[u][2].z : wv[u][2].w,
                                      e == 0 ? wv[u][3].x : e == 1 ? wv[u][3].y : e == 2 ? wv[u][3].z : wv[u][3].w};
+                if constexpr (H16) {
+                    f16x4 q1, q2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float x = v4[j] * FB_WSCALE; q1[j] = (_Float16)x; q2[j] = (_Float16)(x - (float)q1[j]); }
+                    *reinterpret_cast<f16x4 *>(&WH[(0 * F + c0 + e) * WS + r0]) = q1;
+                    *reinterpret_cast<f16x4 *>(&WH[(1 * F + c0 + e) * WS + r0]) = q2;
+                    continue;
+                }
                 bf16x4 q1, q2, q3;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -158,11 +191,83 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+        const bool has_next = tile + wave_stride < tiles;
+        const float *xn = g + (size_t)min((FB_PHYS(tile + wave_stride) << 5) + l31, M - 1) * F + 8 * h;
+        if constexpr (H16) {
+            // ---- both products on two fp16 planes (three MFMAs per product, issued over the four channel blocks: independent chains)
+            f16x8 qa[2][2];                                        // [double buffer][plane] of the A fragment (s * g)
+            auto split_xh = [&](f16x8 (&dst)[2], int s) {
+                const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+                fb_split2h(xv, gsc, dst[0], dst[1]);
+                if (has_next) {                                    // this k-step's slice of g is consumed: reload it for the next tile
+                    xa[s] = *reinterpret_cast<const float4 *>(xn + 16 * s);
+                    xb[s] = *reinterpret_cast<const float4 *>(xn + 16 * s + 4);
+                }
+            };
+            split_xh(qa[0], 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f16x8 p[NB][2];
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        p[kb][pl] = *reinterpret_cast<const f16x8 *>(&WH[(pl * F + 32 * kb + l31) * WS + 16 * s + 8 * h]);
+                if (s + 1 < S) split_xh(qa[(s + 1) & 1], s + 1);
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s & 1][1], p[kb][0], acc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s & 1][0], p[kb][1], acc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s & 1][0], p[kb][0], acc[kb], 0, 0, 0);
+            }
+            // rbf B fragments: [e-step s2][column block jb][plane]
+            f16x8 rbh[2][2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float4 da = *reinterpret_cast<const float4 *>(dl + 16 * s2 + 4 * h);
+                const float4 db = *reinterpret_cast<const float4 *>(dl + 16 * s2 + 4 * h + 8);
+                const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    float rv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = dv[j] - mu[jb];
+                        const float ex = exp_neg_f(coeff * (t * t));
+                        rv[j] = jkind[jb] == 0 ? ex : (jkind[jb] == 2 ? 1.0f : 0.0f);
+                    }
+                    fb_split2h(rv, 1.0f, rbh[s2][jb][0], rbh[s2][jb][1]);
+                }
+            }
+            // epilogue per channel block: s * dh1 = acc / 2^6 * ssp'(h1), then s * dw1[32kb.., :] += (s * dh1)^T rbf
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * s2 + j;
+                        const bool ok = e0 + (r & 3) + 8 * (r >> 2) + 4 * h < M;
+                        const float d = acc[kb][r] * (1.0f / FB_WSCALE) * (1.0f - 0.5f * __expf(-hv[kb][r]));      // ssp'(pre) from the saved output
+                        v[j] = ok ? d : 0.f;
+                    }
+                    f16x8 a1, a2;
+                    fb_split2h(v, 1.0f, a1, a2);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) dwacc[kb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, rbh[s2][jb][0], dwacc[kb][jb], 0, 0, 0);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) dwacc[kb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, rbh[s2][jb][1], dwacc[kb][jb], 0, 0, 0);
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) dwacc[kb][jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, rbh[s2][jb][0], dwacc[kb][jb], 0, 0, 0);
+                }
+            }
+            continue;
+        }
         // MFMAs on ONE accumulator wait for each other (16 passes each): with a single wave per SIMD nothing else fills the
         // gaps, so the six partial products are issued round-robin over two channel blocks (two independent chains).
         constexpr int PQ[6] = {0, 1, 2, 0, 1, 0}, PP[6] = {2, 1, 0, 1, 0, 0};
-        const bool has_next = tile + wave_stride < tiles;
-        const float *xn = g + (size_t)min((FB_PHYS(tile + wave_stride) << 5) + l31, M - 1) * F + 8 * h;
         // Software pipeline over the 2 * S groups (k-step s, channel-block pair): the w2 fragments of group i + 1 are read from
         // LDS and (at the first group of a k-step) the next k-step's slice of g is split while the 12 MFMAs of group i run —
         // there is one wave per SIMD, nobody else covers an LDS round trip or a VALU burst.
@@ -261,7 +366,8 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                     for (int r = 0; r < 16; ++r) {
                         const int k = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
                         float *p = &RED[k * JP + 32 * jb + l31];
-                        *p = w == 0 ? dwacc[kb][jb][r] : *p + dwacc[kb][jb][r];
+                        const float val = dwacc[kb][jb][r] * gun;          // (H16: the accumulators carry the gradient's scale; 1 otherwise)
+                        *p = w == 0 ? val : *p + val;
                     }
         }
         __syncthreads();
@@ -295,15 +401,21 @@ long long conan_filter_bwd_ws(int M, int num_gaussians, int num_filters) {
 }
 
 int conan_filter_bwd(const float *g, const float *h1, const float *dist, int M, const float *offset, int num_gaussians, float coeff,
-                     const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, void *stream) {
+                     const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, const float *gmax, void *stream) {
     if (!g || !h1 || !dist || !offset || !w2 || !ws || M < 1) return CONAN_E_BADARG;
     if (!conan_filter_bwd_supported(num_gaussians, num_filters)) return CONAN_E_UNSUPPORTED;
     const int F = num_filters, Gs = num_gaussians, slices = conan_filter_bwd_slices(M);
     hipStream_t s = as_stream(stream);
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * F * Gs;
-    const size_t lds = ((size_t)(3 * F * (F + 8)) / 2 + FB_WAVES * 32) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_bwd<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_filter_bwd<128><<<slices, FB_THREADS, lds, s>>>(g, h1, dist, offset, Gs, coeff, w2, M, m_dev, slabs, bias_slabs);
+    if (gmax) {       // two fp16 planes, gradient scaled from its maximum
+        const size_t lds = ((size_t)(2 * F * (F + 8)) / 2 + FB_WAVES * 32) * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_bwd<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_filter_bwd<128, true><<<slices, FB_THREADS, lds, s>>>(g, h1, dist, offset, Gs, coeff, w2, M, m_dev, slabs, bias_slabs, gmax);
+    } else {
+        const size_t lds = ((size_t)(3 * F * (F + 8)) / 2 + FB_WAVES * 32) * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_bwd<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_filter_bwd<128, false><<<slices, FB_THREADS, lds, s>>>(g, h1, dist, offset, Gs, coeff, w2, M, m_dev, slabs, bias_slabs, nullptr);
+    }
     CONAN_LAUNCH_CHECK();
     if (!dW1) return CONAN_OK;                        // slabs only: reduced later by conan_wgrad_reduce_batch (job.slices = conan_filter_bwd_slices(M))
     return conan_wgrad_reduce_now(slabs, bias_slabs, slices, F * Gs, F, dW1, db1, s);

@@ -283,16 +283,27 @@ __device__ __forceinline__ f32x16 wg_mma6(const bf16x8 &a1, const bf16x8 &a2, co
 // loaded — the backward of the first filter layer then reads no [P, 50] buffer at all.
 // `slice` of `num_slices` row slices, 128-row tile `tile_n` of N, KT-wide tile `tile_k` of K: blockIdx / gridDim of the plain launch,
 // decoded from a job table by the batched one.
-template <int KT, bool RBF>
+// H16 (round 3, the edge-level dw2 = g^T h1 of the filter network): two fp16 planes per operand and three MFMAs per product instead of
+// three bf16 planes and six (filter_fused.hip); g is scaled by s = 2^k with s * gmax in [16, 32) (gmax = max |g|, tracked by the kernel
+// that produced g), x (shifted-softplus outputs, O(1)) goes in unscaled, the slab is unscaled as it is written.
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+template <int KT, bool RBF, bool H16 = false>
 __device__ __forceinline__ void wgrad_lds_body(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
                                                float *__restrict__ slabs, float *__restrict__ bias_slabs,
                                                const int *__restrict__ m_dev, const float *__restrict__ dist,
-                                               const float *__restrict__ offset, float coeff, int slice, int num_slices, int tile_n, int tile_k) {
+                                               const float *__restrict__ offset, float coeff, int slice, int num_slices, int tile_n, int tile_k,
+                                               const float *__restrict__ gmax = nullptr) {
     constexpr int ROWS = 16, RG = ROWS / 8, W = 128 + KT, FRAGS = RG * W, NF = (FRAGS + 255) / 256;
     constexpr int TNB = KT == 128 ? 2 : 1;
+    constexpr int NPL = H16 ? 2 : 3;
     static_assert(W % 64 == 0, "a wave's 64 fragments share one row group and one operand");
-    __shared__ uint4 frag[2][3][RG][W];
+    __shared__ uint4 frag[2][NPL][RG][W];
     if (m_dev) M = min(M, *m_dev);
+    float gsc = 1.0f, gun = 1.0f;
+    if constexpr (H16) {
+        const float gm = *gmax;
+        if (gm > 0.f && gm < 3.0e38f) { int e; (void)frexpf(gm, &e); gsc = ldexpf(1.0f, 5 - e); gun = ldexpf(1.0f, e - 5); }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n0 = KT == 128 ? (wave >> 1) * 64 : wave * 32, k0 = KT == 128 ? (wave & 1) * 64 : 0;     // inside the tile
@@ -366,6 +377,15 @@ __device__ __forceinline__ void wgrad_lds_body(const float *__restrict__ g, cons
                 for (int j = 0; j < 8; ++j) st[i][j] = (f_on[i] && (m0 + 8 * f_rg[i] + j < r_end)) ? st[i][j] : 0.f;
             }
             if (f_isg[i]) bsum[i] += ((st[i][0] + st[i][1]) + (st[i][2] + st[i][3])) + ((st[i][4] + st[i][5]) + (st[i][6] + st[i][7]));
+            if constexpr (H16) {
+                const float sc = f_isg[i] ? gsc : 1.0f;
+                wg_f16x8 p1, p2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float v = st[i][j] * sc; p1[j] = (_Float16)v; p2[j] = (_Float16)(v - (float)p1[j]); }
+                frag[buf][0][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p1);
+                frag[buf][1][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p2);
+                continue;
+            }
             bf16x8 p1, p2, p3;
             wg_split3(st[i], p1, p2, p3);
             frag[buf][0][f_rg[i]][f_col[i]] = __builtin_bit_cast(uint4, p1);
@@ -374,6 +394,24 @@ __device__ __forceinline__ void wgrad_lds_body(const float *__restrict__ g, cons
         }
     };
     auto compute = [&](int buf) {
+        if constexpr (H16) {
+            wg_f16x8 p[TNB][2], q[2][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int a = 0; a < TNB; ++a) p[a][pl] = __builtin_bit_cast(wg_f16x8, frag[buf][pl][h][n0 + 32 * a + l31]);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) q[b][pl] = __builtin_bit_cast(wg_f16x8, frag[buf][pl][h][128 + k0 + 32 * b + l31]);
+            }
+            constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};          // (a2,b1) (a1,b2) (a1,b1): smallest terms first
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int a = 0; a < TNB; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[a][HA[t]], q[b][HB[t]], acc[a][b], 0, 0, 0);
+            return;
+        }
         bf16x8 p[TNB][3], q[2][3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -424,7 +462,7 @@ __device__ __forceinline__ void wgrad_lds_body(const float *__restrict__ g, cons
             for (int r = 0; r < 16; ++r) {
                 const int n = nb + n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int k = kb + k0 + b * 32 + l31;
-                if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r];
+                if (n < N && k < K) slab[(size_t)n * K + k] = acc[a][b][r] * gun;      // (H16: undo the gradient's scale; 1 otherwise)
             }
     if (tile_k == 0) {                           // bias gradient = column sums of g, combined over the row groups in LDS
         float *bp = reinterpret_cast<float *>(&frag[0][0][0][0]);            // [RG][128]; the stages are idle by now
@@ -447,6 +485,11 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const floa
                                                    const int *__restrict__ m_dev, const float *__restrict__ dist,
                                                    const float *__restrict__ offset, float coeff) {
     wgrad_lds_body<KT, RBF>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+__global__ void __launch_bounds__(256, 2) k_wgrad_lds_h16(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
+                                                          float *__restrict__ slabs, float *__restrict__ bias_slabs, const int *__restrict__ m_dev,
+                                                          const float *__restrict__ gmax) {
+    wgrad_lds_body<128, false, true>(g, x, M, K, N, slabs, bias_slabs, m_dev, nullptr, nullptr, 0.f, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gmax);
 }
 
 // Many weight gradients in ONE launch.  A node-level layer (25 k rows) is a latency chain of 8 stages in 198 workgroups — 16-21 us
@@ -665,14 +708,17 @@ long long conan_linear_wgrad_ws(int M, int K, int N) {
 }
 
 static int wgrad_launch(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias, float *ws,
-                        hipStream_t s, const float *dist, const float *offset, float coeff) {
+                        hipStream_t s, const float *dist, const float *offset, float coeff, const float *gmax = nullptr) {
     const bool rbf = dist != nullptr;
     const int slices = wgrad_slices(M, K);
     float *slabs = ws, *bias_slabs = ws + (size_t)slices * N * K;
     {
         const int KT = K > 64 ? 128 : 64;
         dim3 grid(slices, (N + 127) / 128, (K + KT - 1) / KT);
-        if (KT == 128) {
+        if (gmax) {
+            if (rbf || KT != 128) return CONAN_E_UNSUPPORTED;
+            k_wgrad_lds_h16<<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, gmax);
+        } else if (KT == 128) {
             if (rbf) k_wgrad_lds<128, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
             else k_wgrad_lds<128, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
         } else {
@@ -705,6 +751,12 @@ int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, cons
                        float *ws, void *stream) {
     if (!g || !x || !dW || !ws || M < 0 || K <= 0 || N <= 0) return CONAN_E_BADARG;
     return wgrad_launch(g, x, M, K, N, m_dev, dW, dbias, ws, as_stream(stream), nullptr, nullptr, 0.f);
+}
+
+int conan_linear_wgrad_scaled(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias, float *ws,
+                              const float *gmax, void *stream) {
+    if (!g || !x || !ws || !gmax || M < 0 || K <= 64 || N <= 0 || (!dW && !conan_wgrad_batchable(K, N))) return CONAN_E_BADARG;
+    return wgrad_launch(g, x, M, K, N, m_dev, dW, dbias, ws, as_stream(stream), nullptr, nullptr, 0.f, gmax);
 }
 
 int conan_rbf_wgrad(const float *g, const float *dist, int M, const float *offset, int num_gaussians, float coeff, int N,

@@ -176,7 +176,13 @@ _LATE_STAGE1_ROWS = 65536   # below this row count a weight gradient's slab kern
 _flushed = {}              # weight data_ptr -> (dW data_ptr, db data_ptr | None) of the last flushes (cleared by whoever verifies them)
 
 
-def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
+# max |g| of pair-level filter gradients, keyed by the gradient's data pointer: produced by conan_cfconv_bwd_w_pairs (one device float per
+# backward of a CFConv), consumed by the filter network's backward, whose two MFMA kernels then run on two fp16 planes (half the
+# matrix-pipe work).  A gradient that was copied or accumulated on the way has another pointer and simply takes the bf16 path.
+_GMAX = {}
+
+
+def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None, gmax=None):
     """dW [N,K] (+ db [N]) = g^T x, or g^T rbf(dist) with rbf = (dist, offset, coeff).  Immediate, or slabs now + batched sum later.
 
     Deferred mode hands autograd tensors whose values arrive at the flush.  That is only sound if autograd ADOPTS them (it does when it
@@ -194,10 +200,13 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
     # Node-level layers (a few ten thousand rows) are latency chains that leave most of the chip idle: in deferred mode their slab
     # kernels are postponed too and all of them run as ONE launch at the flush (conan_linear_wgrad_slabs_batch).  g and x stay alive
     # until then (a node-level pair is 26 MB); edge-level layers already fill the chip and keep their immediate stage 1.
-    late = defer and rbf is None and M <= _LATE_STAGE1_ROWS
+    late = defer and rbf is None and M <= _LATE_STAGE1_ROWS and not (gmax is not None and K > 64)      # (the fp16-plane form has no batched launch)
     if rbf is None:
         if late:
             pass
+        elif gmax is not None and K > 64:
+            call("conan_linear_wgrad_scaled", ptr(g), ptr(x), M, K, N, ptr(md), None if defer else ptr(dw), None if defer else ptr(db), ptr(ws),
+                 ptr(gmax), stream_ptr())
         elif defer:
             call("conan_linear_wgrad_slabs", ptr(g), ptr(x), M, K, N, ptr(md), ptr(ws), stream_ptr())
         else:
@@ -217,7 +226,7 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None):
     return dw, db
 
 
-def _filter_bwd(g, h1, dist, offset, coeff, w1, w2, M, md):
+def _filter_bwd(g, h1, dist, offset, coeff, w1, w2, M, md, gmax=None):
     """dW1 [F,Gs], db1 [F] of the filter network's first Linear from the gradient g of its output, fused (conan_filter_bwd): the
     input gradient of the second Linear times ssp'(h1) is formed tile by tile in registers and contracted with the regenerated
     rbf(dist) on the spot.  Immediate, or slabs now + batched sum later (see _wgrad)."""
@@ -232,7 +241,7 @@ def _filter_bwd(g, h1, dist, offset, coeff, w1, w2, M, md):
         flush_weight_gradients()
         defer = False
     call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M, ptr(offset, f32), Gs, coeff, ptr(w2), F, ptr(md),
-         None if defer else ptr(dw), None if defer else ptr(db), ptr(ws), stream_ptr())
+         None if defer else ptr(dw), None if defer else ptr(db), ptr(ws), ptr(gmax), stream_ptr())
     if defer:
         _pending.append(dict(ws=ws, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr(), keep=(dw.untyped_storage(), db.untyped_storage()),
                              M=M, K=Gs, N=F, slices=int(lib().conan_filter_bwd_slices(M)), weight_ptr=wptr, stream=torch.cuda.current_stream()))
@@ -558,9 +567,10 @@ class _FilterFn(torch.autograd.Function):
         ME = g_.max_edges
         dev = dW.device
         g = _c(dW)                                   # already multiplied by C(d): cfconv(..., pre_cutoff_grad=True)
-        dw2, db2 = _wgrad(g, h1, ME, F, F, md, w2, True)
+        gmax = _GMAX.pop(g.data_ptr(), None) if F == 128 else None      # max |g|, when the producer tracked it: the two kernels below run on fp16 planes
+        dw2, db2 = _wgrad(g, h1, ME, F, F, md, w2, True, gmax=gmax)
         if lib().conan_filter_bwd_supported(Gs, F):              # (g @ w2) * ssp'(h1) and its contraction with rbf(dist) in one pass
-            dw1, db1 = _filter_bwd(g, h1, dist, _c(offset), ctx.coeff, w1, _c(w2), ME, md)
+            dw1, db1 = _filter_bwd(g, h1, dist, _c(offset), ctx.coeff, w1, _c(w2), ME, md, gmax=gmax)
         else:
             dh1 = torch.empty_like(g)
             call("conan_linear_fwd", ptr(g), ptr(_c(w2)), None, ptr(h1), ME, F, F, 1, 2, ptr(md), ptr(dh1), stream_ptr())   # (g @ w2) * ssp'(h1)
@@ -608,8 +618,13 @@ class _CFConvFn(torch.autograd.Function):
             if ctx.pairs:
                 if not ctx.pre:
                     raise RuntimeError("use_pairs requires pre_cutoff_grad=True (the pair gradient includes the cosine cutoff)")
+                gmax = torch.zeros(1, dtype=f32, device=x.device) if F == 128 else None      # raised to max |dW| by the kernel
                 call("conan_cfconv_bwd_w_pairs", ptr(x), ptr(dout), ptr(g.num_pairs_dev), g.max_edges, ptr(g.pair_e0), ptr(g.pair_e1), ptr(g.col),
-                     ptr(g.tgt), F, ptr(g.pair_dist), float(g.cutoff), ptr(dW), stream_ptr())
+                     ptr(g.tgt), F, ptr(g.pair_dist), float(g.cutoff), ptr(dW), ptr(gmax), stream_ptr())
+                if gmax is not None:
+                    if len(_GMAX) > 64:
+                        _GMAX.clear()                      # (entries whose consumer never ran)
+                    _GMAX[dW.data_ptr()] = gmax
             else:
                 call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F,
                      ptr(g.dist) if ctx.pre else None, float(g.cutoff or 0.0), ptr(dW), stream_ptr())

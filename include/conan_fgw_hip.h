@@ -159,6 +159,12 @@ int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const in
 long long conan_linear_wgrad_ws(int M, int K, int N);
 int conan_linear_wgrad(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias,
                        float *ws, void *stream);
+/* conan_linear_wgrad (dW != NULL) / conan_linear_wgrad_slabs (dW == NULL: slabs only, reduced later by conan_wgrad_reduce_batch) for a
+ * gradient g whose maximum magnitude is known on the device (`gmax`: one float, e.g. from conan_cfconv_bwd_w_pairs): the product runs
+ * on two fp16 planes per operand with g scaled into fp16's range — 3 MFMAs per product instead of 6.  x must be O(1..1e3)
+ * (activations); K > 64. */
+int conan_linear_wgrad_scaled(const float *g, const float *x, int M, int K, int N, const int *m_dev, float *dW, float *dbias, float *ws,
+                              const float *gmax, void *stream);
 /* Same with x = GaussianSmearing(dist) generated on the fly: dW[N,Gs] = g^T rbf(dist), rbf[m,k] = exp(coeff (dist[m]-offset[k])^2)
  * (weight gradient of the first filter-network layer, schnet_no_sum.py InteractionBlock.mlp[0]; no [M,Gs] buffer is read).
  * ws as conan_linear_wgrad_ws(M, Gs, N). */
@@ -209,7 +215,7 @@ int conan_filter_bwd_supported(int num_gaussians, int num_filters);
 int conan_filter_bwd_slices(int M);
 long long conan_filter_bwd_ws(int M, int num_gaussians, int num_filters);
 int conan_filter_bwd(const float *g, const float *h1, const float *dist, int M, const float *offset, int num_gaussians, float coeff,
-                     const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, void *stream);
+                     const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, const float *gmax, void *stream);
 
 /* rbf[e,k] = exp(coeff * (dist[e] - offset[k])^2): GaussianSmearing (PyG; schnet_no_sum.py:161,209).  `offset` is the
  * module's buffer (distance_expansion.offset), coeff = -0.5/(offset[1]-offset[0])^2.  num_edges_dev (nullable) = device
@@ -281,10 +287,12 @@ int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const in
 int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt,
                        const int *pid, int num_atoms, int num_filters, float *dx, void *stream);
 /* Pair-level filter gradient (before the cosine cutoff): dWp[p,:] = C(d_p) * sum over the (1 or 2) edges of pair p of
- * x[src(e),:] * dout[tgt(e),:]. */
+ * x[src(e),:] * dout[tgt(e),:].  gmax (nullable, num_filters = 128 only): one device float, ZEROED by the caller before the call; the
+ * kernel raises it to max |dWp| as it writes.  conan_filter_bwd / conan_linear_wgrad take that word to run their products on two
+ * fp16 planes of the gradient scaled into fp16's range (half the matrix-pipe work of the three-plane bf16 form). */
 int conan_cfconv_bwd_w_pairs(const float *x, const float *dout, const int *num_pairs_dev, int max_pairs, const int *pair_e0,
                              const int *pair_e1, const int *col, const int *tgt, int num_filters, const float *pair_dist,
-                             float cutoff, float *dWp, void *stream);
+                             float cutoff, float *dWp, float *gmax, void *stream);
 /* dist (nullable) + cutoff: additionally multiply row e by 0.5*(cos(dist[e]*pi/cutoff)+1), i.e. return the gradient with
  * respect to the filter BEFORE the cosine cutoff. */
 int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_dev, int max_edges, const int *col,

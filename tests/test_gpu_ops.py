@@ -150,6 +150,47 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
     assert rel(W[:E].detach().cpu(), W2[:E].cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("gscale", [1.0, 2e-6, 3e3])
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (40000, 128, 128), (33, 128, 128), (5000, 256, 128)])
+def test_wgrad_scaled_two_plane_fp16_matches_fp64(M, N, K, gscale):
+    """conan_linear_wgrad_scaled: dW = g^T x on two fp16 planes with g scaled from its device-side maximum (the edge-level dw2 of the
+    filter network); 1e-5 of an fp64 matmul whatever the gradient's magnitude, bias sums exact to fp32, bitwise reproducible."""
+    from conan_fgw_amd._lib import call, lib, ptr, stream_ptr
+    gen = torch.Generator().manual_seed(M + N + K)
+    g = (torch.randn(M + 40, N, generator=gen) * gscale).to(dev)
+    x = (torch.rand(M + 40, K, generator=gen) * 4 - 0.69).to(dev)            # shifted-softplus outputs
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    gmax = g[:M].abs().max().reshape(1).contiguous()
+    dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    ws = torch.empty(int(lib().conan_linear_wgrad_ws(M + 40, K, N)), device=dev)
+    call("conan_linear_wgrad_scaled", ptr(g), ptr(x), M + 40, K, N, ptr(md), ptr(dW), ptr(db), ptr(ws), ptr(gmax), stream_ptr())
+    ref = g[:M].double().T @ x[:M].double()
+    assert rel(dW.double().cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert rel(db.double().cpu().numpy(), g[:M].double().sum(0).cpu().numpy()) < 1e-5
+    dW2 = torch.empty_like(dW)
+    call("conan_linear_wgrad_scaled", ptr(g), ptr(x), M + 40, K, N, ptr(md), ptr(dW2), ptr(db), ptr(ws), ptr(gmax), stream_ptr())
+    assert torch.equal(dW, dW2)
+    assert lib().conan_linear_wgrad_scaled(ptr(g), ptr(x), M, 64, N, None, ptr(dW), None, ptr(ws), ptr(gmax), stream_ptr()) < 0      # K <= 64: not offered
+
+
+def test_pair_gradient_kernel_reports_its_maximum():
+    """conan_cfconv_bwd_w_pairs(gmax): the device float ends up as max |dWp| over the pair rows it wrote (zeroed by the caller)."""
+    from conan_fgw_amd._lib import call, ptr, stream_ptr
+    from conan_fgw_amd.synthetic import make_batch
+    b = make_batch("esol", 6, 3, seed=11)
+    pos = torch.from_numpy(b.pos).to(dev); batch = torch.from_numpy(b.batch).to(dev)
+    gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
+    g = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0, 32).pairs()
+    n, F = len(b.z), 128
+    x = torch.randn(n, F, device=dev); dout = torch.randn(n, F, device=dev) * 1e-3
+    dWp = torch.zeros(g.max_edges, F, device=dev)
+    gmax = torch.zeros(1, device=dev)
+    call("conan_cfconv_bwd_w_pairs", ptr(x), ptr(dout), ptr(g.num_pairs_dev), g.max_edges, ptr(g.pair_e0), ptr(g.pair_e1), ptr(g.col), ptr(g.tgt), F,
+         ptr(g.pair_dist), 10.0, ptr(dWp), ptr(gmax), stream_ptr())
+    P = int(g.num_pairs_dev.item())
+    assert P > 0 and float(gmax) == float(dWp[:P].abs().max()) and float(gmax) > 0
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (4133, 128, 64), (777, 64, 128), (2500, 32, 32), (300, 128, 52), (33, 64, 64), (5000, 256, 128)])
 def test_wgrad_lds_staged_matches_fp64(M, N, K):
     """conan_linear_wgrad (LDS-staged bf16-split path: N % 4 == 0, K % 4 == 0) against an fp64 matmul; a device-side row
@@ -303,8 +344,9 @@ def test_wgrad_slabs_batch_equals_the_per_job_launches():
         assert rel(long_slices[q][1].double().cpu().numpy(), gs[q][:rows[q]].double().sum(0).cpu().numpy()) < 1e-5, shapes[q]
 
 
+@pytest.mark.parametrize("gscale", [None, 1.0, 3e-7, 4e4], ids=["bf16x3", "f16x2", "f16x2_tiny_grad", "f16x2_huge_grad"])
 @pytest.mark.parametrize("M,Gs", [(1, 50), (31, 50), (4133, 50), (40000, 50), (3000, 20), (2500, 63)])
-def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs):
+def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs, gscale):
     """conan_filter_bwd (dh1 = (g w2) * ssp'(h1) kept in registers, dW1 = dh1^T rbf, db1 = colsum dh1) against the fp64 formula and
     against the two kernels it replaces (conan_linear_fwd act=2 + conan_rbf_wgrad); rows beyond the device-side count are
     masked; the slab form reduced through conan_wgrad_reduce_batch gives the same bits; repeat runs are bitwise equal."""
@@ -313,7 +355,11 @@ def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs):
     Fh, pad = 128, 37
     assert lib().conan_filter_bwd_supported(Gs, Fh) == 1 and lib().conan_filter_bwd_supported(64, Fh) == 0 and lib().conan_filter_bwd_supported(50, 64) == 0
     gen = torch.Generator().manual_seed(M + Gs)
-    g = torch.randn(M + pad, Fh, generator=gen).to(dev)
+    g = (torch.randn(M + pad, Fh, generator=gen) * (gscale or 1.0)).to(dev)
+    # gscale given: the two-plane fp16 path, which takes max |g| from the device (here: over the VALID rows, as the producer kernel
+    # would have tracked it) and scales the gradient into fp16's range — tiny (3e-7) and huge (4e4) gradients must come out as exact
+    gmax = g[:M].abs().max().reshape(1).contiguous() if gscale is not None else None
+    gm = ptr(gmax) if gmax is not None else None
     h1 = (torch.rand(M + pad, Fh, generator=gen) * 3 - 0.6).to(dev)                    # ssp output range (> -ln 2)
     dist = (torch.rand(M + pad, generator=gen) * 10).to(dev)
     w2 = (torch.randn(Fh, Fh, generator=gen) / 11).to(dev)
@@ -322,7 +368,7 @@ def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs):
     md = torch.tensor([M], dtype=torch.int32, device=dev)
     ws = torch.empty(int(lib().conan_filter_bwd_ws(M + pad, Gs, Fh)), device=dev)
     dW, db = torch.empty(Fh, Gs, device=dev), torch.empty(Fh, device=dev)
-    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), ptr(dW), ptr(db), ptr(ws), stream_ptr())
+    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), ptr(dW), ptr(db), ptr(ws), gm, stream_ptr())
     dh = (g[:M].double() @ w2.double()) * (1 - 0.5 * torch.exp(-h1[:M].double()))
     rbf = torch.exp(coeff * (dist[:M, None].double() - off[None].double()) ** 2)
     assert rel(dW.double().cpu().numpy(), (dh.T @ rbf).cpu().numpy()) < 1e-5
@@ -336,7 +382,7 @@ def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs):
     assert rel(dW.cpu().numpy(), dWc.cpu().numpy()) < 1e-5 and rel(db.cpu().numpy(), dbc.cpu().numpy()) < 1e-5
     # slab form + batched reduction; bitwise reproducibility
     dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
-    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), None, None, ptr(ws), stream_ptr())
+    call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), None, None, ptr(ws), gm, stream_ptr())
     job = (WgradJob * 1)()
     job[0].ws, job[0].dW, job[0].dbias = ws.data_ptr(), dW2.data_ptr(), db2.data_ptr()
     job[0].M, job[0].K, job[0].N, job[0].slices = M + pad, Gs, Fh, int(lib().conan_filter_bwd_slices(M + pad))

@@ -53,9 +53,17 @@ print(f"{tag} node-level (M={Mn}): linear {tn1:6.1f} us (abs err {en:.1e})  line
 extra = ""
 if hasattr(_lib.lib(), "conan_filter_bwd"):
     ws2 = torch.empty(_lib.lib().conan_filter_bwd_ws(P, Gs, F), device=dev); dwf = torch.empty(F, Gs, device=dev); dbf = torch.empty(F, device=dev)
-    def kf(): call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), P, ptr(offset, f32), Gs, coeff, ptr(w2), F, ptr(md), ptr(dwf), ptr(dbf), ptr(ws2), stream_ptr())
+    def kf(): call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), P, ptr(offset, f32), Gs, coeff, ptr(w2), F, ptr(md), ptr(dwf), ptr(dbf), ptr(ws2), None, stream_ptr())
     tf = timed(kf)
     dh = (g.double() @ w2.double()) * (1 - 0.5 * torch.exp(-h1.double()))
     rw, rbias = dh.t() @ rb, dh.sum(0)
     extra = f"   fused dx+dw1 {tf:7.1f} us (err {float((dwf.double() - rw).abs().max() / rw.abs().max()):.1e}, bias {float((dbf.double() - rbias).abs().max() / rbias.abs().max()):.1e})"
+# the two-plane fp16 forms (round 3): gradient scaled from its device-side maximum
+gmax = g.abs().max().reshape(1).contiguous()
+if hasattr(_lib.lib(), "conan_linear_wgrad_scaled"):
+    def k2h(): call("conan_linear_wgrad_scaled", ptr(g), ptr(h1), P, F, F, ptr(md), ptr(dw), ptr(db), ptr(ws), ptr(gmax), stream_ptr())
+    t2h = timed(k2h); k2h(); ref = g.double().t() @ h1.double(); e2h = float((dw.double() - ref).abs().max() / ref.abs().max())
+    def kfh(): call("conan_filter_bwd", ptr(g), ptr(h1), ptr(dist), P, ptr(offset, f32), Gs, coeff, ptr(w2), F, ptr(md), ptr(dwf), ptr(dbf), ptr(ws2), ptr(gmax), stream_ptr())
+    tfh = timed(kfh); kfh()
+    extra += f"\n{tag} f16x2: wgrad[128x128] {t2h:7.1f} us (err {e2h:.1e})   fused dx+dw1 {tfh:7.1f} us (err {float((dwf.double() - rw).abs().max() / rw.abs().max()):.1e}, bias {float((dbf.double() - rbias).abs().max() / rbias.abs().max()):.1e})"
 print(f"{tag} wgrad[128x128] {t2:7.1f} us (err {e2:.1e})   rbf wgrad[128x50] {t4:7.1f} us (err {e4:.1e}, bias {eb:.1e})   dx+ssp' {t3:7.1f} us{extra}")
