@@ -464,7 +464,7 @@ def run_rank(args):
     # committed under profiles/) -- only valid for the default workload
     traffic, traffic_src = None, None
     if args.shape == "esol" and args.batch == 256 and K == 5 and args.model == "schnet":
-        for name in ("r2_pmc_hbm.json", "r1_pmc_hbm.json"):
+        for name in ("r3_pmc_hbm.json", "r2_pmc_hbm.json", "r1_pmc_hbm.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["k_cfconv_fwd<1>"]
                 traffic, traffic_src = int(pm["traffic_bytes_corrected"]), f"profiles/{name} (separate rocprofv3 --pmc passes)"
@@ -510,7 +510,20 @@ def run_rank(args):
         N_, d_ = b.max_nodes, 64
         fgw_bytes = 4 * (2 * K * N_ ** 2 + K * N_ * d_ + N_ * d_ + N_ ** 2)
         fgw_flop = 5 * K * 5 * (4 * N_ ** 3 + 5 * 12 * N_ ** 2)    # outer 5 x K x PGD 5 x (4N^3 + Sinkhorn 5 x ~12N^2), worst case
-        other.append({"kernel": "FGW barycenter, whole batched solve (init + 5 x (coupling + update))", "bound": "fp64 issue / latency",
+        fgw_pmc = None                                                  # counters of the coupling kernel from the committed PMC passes (profiles/)
+        if args.shape == "esol" and args.batch == 256 and K == 5 and args.model == "schnet":
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", "r3_fgw_pmc_sq.json")))["kernels"]
+                hb = json.load(open(os.path.join(ROOT, "profiles", "r3_fgw_pmc_hbm.json")))["kernels"]
+                kk = [k for k in sq if k.startswith("k_fgw_coupling_fast")][0]
+                fgw_pmc = {"kernel": kk, "valu_issue_frac": sq[kk].get("valu_issue_frac"), "mfma_busy_frac": sq[kk].get("mfma_busy_frac"),
+                           "avg_launch_us_under_pmc": sq[kk].get("avg_duration_us_under_pmc"),
+                           "hbm_traffic_bytes_per_launch": hb.get(kk, {}).get("traffic_bytes_corrected"),
+                           "source": "profiles/r3_fgw_pmc_sq.json, profiles/r3_fgw_pmc_hbm.json (separate rocprofv3 --pmc passes over tools/fgw_pmc.py)"}
+            except Exception:
+                fgw_pmc = None
+        other.append({"kernel": "FGW barycenter, whole batched solve (init + 5 x (coupling + second pass + update))", "bound": "fp64 vector issue / latency",
+                      "coupling_kernel_counters": fgw_pmc,
                       "avg_ms": round(t_ms, 4), "us_per_molecule": round(1e3 * t_ms / args.batch, 3),
                       "algorithmic_bytes_per_molecule": fgw_bytes, "worst_case_flop_per_molecule": fgw_flop,
                       "achieved_fp64_tflops_upper": round(args.batch * fgw_flop / (t_ms * 1e-3) / 1e12, 3), "fp64_peak_tflops": 78.6,

@@ -21,6 +21,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > $O/pmc_sq.log 2>&1
 python3 $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/r3_pmc_hbm.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_hbm.txt 2>&1
 python3 $R/tools/pmc_sq.py $O/pmc_sq $O/r3_pmc_mfma.json "bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager" > $O/pmc_sq.txt 2>&1
+# the batched FGW solve by itself (cfg2 shape, the models' byte-wide adjacency): per-kernel durations and PMC passes of the coupling kernel
+bash $R/tools/fgw_pmc.sh r3p/fgw_pmc > $O/fgw_pmc.txt 2>&1
+python3 $R/tools/ab.py CONAN_FGW_NO_FAST=1 $R/tools/probe_fgw_small.py 2 2>/dev/null | grep -v amdgpu > $O/ab_fgw_small.txt
+python3 $R/tools/ab.py CONAN_FGW_NO_BIG=1,CONAN_FGW_NO_BLOCK22=1 $R/tools/probe_fgw_large.py 2 2>/dev/null | grep -v amdgpu > $O/ab_fgw_large.txt
+python3 $R/tools/ab.py CONAN_FILTER_BF16X3=1 $R/tools/probe_filter_fwd.py 2 2>/dev/null | grep -v amdgpu > $O/ab_filter_fwd.txt
+python3 $R/tools/probe_edge_bwd.py "" in-tree 2>/dev/null | grep -v amdgpu > $O/edge_bwd.txt
 find $O -name "*_kernel_stats.csv" | head; ls $O
 # keep the merge small: drop raw traces
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*.db" -delete

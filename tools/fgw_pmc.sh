@@ -6,4 +6,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p3 -o c -- python3 $R/tools/fgw_pmc.py > $O/p3.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p4 -o d -- python3 $R/tools/fgw_pmc.py > $O/p4.log 2>&1
 python3 $R/tools/pmc_dump.py "fgw" $O/p1 $O/p2 $O/p3 $O/p4 | tee $O/summary.txt
+python3 $R/tools/pmc_sq.py $O/p1 $O/fgw_pmc_sq.json "tools/fgw_pmc.py (3 batched FGW solves at cfg2 shape)" > /dev/null 2>&1
+python3 $R/tools/pmc_summary.py $O/p3 $O/p4 $O/fgw_pmc_hbm.json "tools/fgw_pmc.py (3 batched FGW solves at cfg2 shape)" > /dev/null 2>&1
 find $O -name "*.db" -delete
