@@ -489,22 +489,25 @@ def run_rank(args):
     if ev_other["conan_filter_fwd"]:
         t_ms = mean_ms(ev_other["conan_filter_fwd"])
         fl = P * 2.0 * (50 * 128 + 128 * 128)                       # (2*Gs*F + 2*F*F) per filter row; P rows (pairs)
-        issued = P * 6 * 2.0 * (64 * 128 + 128 * 128)              # what the matrix pipe executes: 6 bf16 partial products per fp32 product, Gs padded to 64
+        issued = P * 3 * 2.0 * (64 * 128 + 128 * 128)              # what the matrix pipe executes: 3 fp16 partial products per fp32 product (two planes per operand), Gs padded to 64
         other.append({"kernel": "k_filter_fused (rbf -> filter MLP -> cosine cutoff)", "bound": "mfma", "achieved": round(issued / (t_ms * 1e-3) / 1e12, 1),
                       "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(issued / (t_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4), "avg_launch_ms": round(t_ms, 5),
                       "algorithmic_fp32_tflops": round(fl / (t_ms * 1e-3) / 1e12, 2),
-                      "note": "both GEMMs run as exact 3-way bf16 splits (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block): `achieved` counts the issued bf16 "
-                              "FLOP against the dense bf16 peak; algorithmic_fp32_tflops is the fp32-equivalent rate (2*(50*F + F*F) per row) for reference "
-                              "(fp32 MFMA peak 157.3 TF/s)"})
+                      "note": "both GEMMs run on two fp16 planes per operand (3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32-class result; round 2: three "
+                              "bf16 planes, 6 MFMAs): `achieved` counts the issued fp16 FLOP against the dense 16-bit peak; algorithmic_fp32_tflops is the "
+                              "fp32-equivalent rate (2*(50*F + F*F) per row) against the fp32 MFMA peak 157.3 TF/s.  With half the matrix work the kernel now "
+                              "sits on its two 132 MB output streams (W and, in training, h1): hbm_gbs_of_output below"})
+        other[-1]["hbm_gbs_of_output"] = round(P * 128 * 4 * (2 if train else 1) / (t_ms * 1e-3) / 1e9, 1)
     if ev_other["conan_filter_bwd"]:
         t_ms = mean_ms(ev_other["conan_filter_bwd"])
         byts = P * (2 * 4 * 128 + 4)                                # compulsory: g and h1 rows in, distances in; the [128 x 50] slabs are noise
-        issued = P * 6 * 2.0 * (128 * 128 + 64 * 128)               # dx GEMM + the dh1^T rbf contraction (Gs padded to 64), 6 bf16 partial products each
+        issued = P * 3 * 2.0 * (128 * 128 + 64 * 128)               # dx GEMM + the dh1^T rbf contraction (Gs padded to 64), 3 fp16 partial products each
         other.append({"kernel": "k_filter_bwd (filter-network backward: (g w2) * ssp'(h1) in registers, contracted with the regenerated rbf)", "bound": "hbm",
                       "achieved": round(byts / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      "avg_launch_ms": round(t_ms, 5), "issued_bf16_tflops": round(issued / (t_ms * 1e-3) / 1e12, 1),
-                      "note": "event bracket around kernel + slab write (the slab reduction is batched elsewhere); counters: MFMA 35 % + VALU 34 % of the SIMD "
-                              "cycles, 14 % of the MFMA cycles overlapped - bound by the sum of the two pipes (bf16 splitting), not by HBM"})
+                      "avg_launch_ms": round(t_ms, 5), "issued_fp16_tflops": round(issued / (t_ms * 1e-3) / 1e12, 1),
+                      "note": "event bracket around kernel + slab write (the slab reduction is batched elsewhere); two fp16 planes per operand with the "
+                              "gradient scaled from its device-side maximum (round 2: three bf16 planes); one wavefront per SIMD: vector work, matrix work and "
+                              "the memory stream add up instead of overlapping (profiles/r3_pmc_mfma.json)"})
     if ev_other["conan_fgw_barycenter_fwd"]:
         t_ms = mean_ms(ev_other["conan_fgw_barycenter_fwd"])
         N_, d_ = b.max_nodes, 64
