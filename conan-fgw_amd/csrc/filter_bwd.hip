@@ -50,7 +50,7 @@ __device__ __forceinline__ void fb_split3(const float *v, bf16x8 &p1, bf16x8 &p2
 // H16 (round 3): both products on TWO fp16 planes per operand (p1q1 + p1q2 + p2q1: 3 MFMAs instead of the 6 of the three-plane bf16
 // form, ~2^-22 relative) — see filter_fused.hip.  fp16's range needs the gradient operand scaled: `gmax` is max |g| over the whole
 // tensor (the kernel that produced g tracked it, conan_cfconv_bwd_w_pairs), s = 2^k with s * gmax in [16, 32); A = s * g, the w2
-// planes carry 2^6, dh1 is formed as s * dh1 (<= 32 * column abs-sum of w2: far inside 65504) and the accumulated s * dW1 is
+// planes carry their own power-of-two scale (from max |w2|), dh1 is formed as s * dh1 (<= 32 * column abs-sum of w2: far inside 65504) and the accumulated s * dW1 is
 // unscaled once, when the slab is written.  Entries below 2e-6 * gmax fall into fp16's subnormal spacing (3e-8 / s absolute): they
 // cannot matter to a sum dominated by entries 1e6 times larger.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -63,7 +63,11 @@ __device__ __forceinline__ void fb_split2h(const float *v, float sc, f16x8 &p1, 
         p1[j] = h1; p2[j] = (_Float16)(x - (float)h1);
     }
 }
-constexpr float FB_WSCALE = 64.0f;
+// plane scale of w2 (see filter_fused.hip: 2^k with max |w| * 2^k in [256, 512)); its inverse is applied where dh1 is formed
+__device__ __forceinline__ void fb_plane_scale(float amax, float &sc, float &un) {
+    sc = 1.0f; un = 1.0f;
+    if (amax > 0.f && amax < 3.0e38f) { int e; (void)frexpf(amax, &e); sc = ldexpf(1.0f, 9 - e); un = ldexpf(1.0f, e - 9); }
+}
 
 template <int F, bool H16>
 __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restrict__ g, const float *__restrict__ h1,
@@ -80,11 +84,8 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
     __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [NPL][k][WS]: image row k holds w2[n][k] for n = 0..F-1
     _Float16 *WH = reinterpret_cast<_Float16 *>(lds);
     float *DL = lds + (NPL * F * WS) / 2;                       // [FB_WAVES][32] distances of the wave's tile
-    float gsc = 1.0f, gun = 1.0f;                               // H16: scale of the gradient operand and its inverse
-    if constexpr (H16) {
-        const float gm = *gmax;
-        if (gm > 0.f && gm < 3.0e38f) { int e; (void)frexpf(gm, &e); gsc = ldexpf(1.0f, 5 - e); gun = ldexpf(1.0f, e - 5); }      // s * gm in [16, 32)
-    }
+    __shared__ float wred[FB_WAVES];
+    float gsc = 1.0f, gun = 1.0f, wsc = 1.0f, wun = 1.0f;       // H16: scales of the gradient operand and of the w2 planes, and their inverses
     if (m_dev) M = min(M, *m_dev);
     const int tiles = (M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,6 +104,28 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
             for (int j = 0; j < 4; ++j)
                 wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w2 + (size_t)(r0 + j) * F + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if constexpr (H16) {
+            float am = 0.f;
+#pragma unroll
+            for (int u = 0; u < PERW; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    am = fmaxf(fmaxf(am, fmaxf(fabsf(wv[u][j].x), fabsf(wv[u][j].y))), fmaxf(fabsf(wv[u][j].z), fabsf(wv[u][j].w)));
+            am = wave_max(am);
+            if (lane == 0) wred[wave] = am;
+            __syncthreads();
+            const float wmax = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+            fb_plane_scale(wmax, wsc, wun);
+            // gradient scale: s * gmax in [16, 32), lowered when the weights are so large that s * dh1 (<= 32 * F * max |w2|) could leave fp16
+            const float gm = *gmax;
+            if (gm > 0.f && gm < 3.0e38f) {
+                int e; (void)frexpf(gm, &e);
+                int sh = 5 - e;
+                const float bound = 32.0f * F * wmax;                   // upper bound of |s * dh1| at the nominal scale
+                if (bound > 16384.0f && bound < 3.0e38f) { int eb; (void)frexpf(bound * (1.0f / 16384.0f), &eb); sh -= eb; }
+                gsc = ldexpf(1.0f, sh); gun = ldexpf(1.0f, -sh);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < PERW; ++u) {
             const int pt = wave + u * FB_WAVES;
@@ -117,7 +140,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                 if constexpr (H16) {
                     f16x4 q1, q2;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float x = v4[j] * FB_WSCALE; q1[j] = (_Float16)x; q2[j] = (_Float16)(x - (float)q1[j]); }
+                    for (int j = 0; j < 4; ++j) { const float x = v4[j] * wsc; q1[j] = (_Float16)x; q2[j] = (_Float16)(x - (float)q1[j]); }
                     *reinterpret_cast<f16x4 *>(&WH[(0 * F + c0 + e) * WS + r0]) = q1;
                     *reinterpret_cast<f16x4 *>(&WH[(1 * F + c0 + e) * WS + r0]) = q2;
                     continue;
@@ -250,7 +273,7 @@ __global__ void __launch_bounds__(FB_THREADS) k_filter_bwd(const float *__restri
                     for (int j = 0; j < 8; ++j) {
                         const int r = 8 * s2 + j;
                         const bool ok = e0 + (r & 3) + 8 * (r >> 2) + 4 * h < M;
-                        const float d = acc[kb][r] * (1.0f / FB_WSCALE) * (1.0f - 0.5f * __expf(-hv[kb][r]));      // ssp'(pre) from the saved output
+                        const float d = acc[kb][r] * wun * (1.0f - 0.5f * __expf(-hv[kb][r]));      // ssp'(pre) from the saved output
                         v[j] = ok ? d : 0.f;
                     }
                     f16x8 a1, a2;

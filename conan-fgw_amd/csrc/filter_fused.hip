@@ -43,7 +43,7 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
 // and to 3e-8 absolute below that (fp16 subnormal spacing).  With the three products p1q1, p1q2, p2q1 (the dropped p2q2 is 2^-22
 // relative) an fp16 MFMA chain reproduces the fp32 product to ~2.4e-7 at HALF the matrix-pipe time and ~2/3 of the splitting work
 // of the three-plane bf16 form (6 products).  Range: the operands here are O(1e-2..1e2) — Gaussians in [0, 1], shifted-softplus
-// outputs, weights pre-scaled by 2^6 (exact, undone in the epilogue's FMA) — far inside fp16's 6e-5..65504.
+// outputs, weights pre-scaled by a power of two chosen from their maximum (exact, undone in the epilogue's FMA) — far inside fp16's 6e-5..65504.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2h(const float *v, f16x8 &p1, f16x8 &p2) {
 #pragma unroll
@@ -52,7 +52,24 @@ __device__ __forceinline__ void split2h(const float *v, f16x8 &p1, f16x8 &p2) {
         p1[j] = h1; p2[j] = (_Float16)(v[j] - (float)h1);
     }
 }
-constexpr float WSCALE = 64.0f, WUNSCALE = 1.0f / 64.0f;      // weight pre-scale of the fp16 planes
+// Weight pre-scale of the fp16 planes: 2^k with max |w| * 2^k in [256, 512) — whatever the magnitude of the weights, their planes sit in the
+// middle of fp16's range (remainders normal, nothing near 65504); the exact inverse goes into the epilogue's FMA.  One block-wide
+// maximum per matrix at staging time.
+__device__ __forceinline__ void plane_scale(float amax, float &sc, float &un) {
+    sc = 1.0f; un = 1.0f;
+    if (amax > 0.f && amax < 3.0e38f) { int e; (void)frexpf(amax, &e); sc = ldexpf(1.0f, 9 - e); un = ldexpf(1.0f, e - 9); }
+}
+template <int NT>
+__device__ __forceinline__ float block_absmax(float v, float *red) {      // red: NT / 64 floats of LDS; every thread gets the maximum
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
+    return m;
+}
 
 constexpr int GP = 64;        // gaussians padded to four MFMA k-steps of 16 (zero weights beyond num_gaussians)
 constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (bf16 elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
@@ -80,6 +97,8 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     float *B1L = W2L + W2WORDS;           // [F]
     float *B2L = B1L + F;                 // [F]
     float *OFL = B2L + F;                 // [GP]
+    __shared__ float wred[FF_THREADS / 64];
+    float us1 = 1.0f, us2 = 1.0f;                                 // inverse plane scales of W1 / W2 (fp16 form)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int E = num_edges_dev ? min(*num_edges_dev, max_edges) : max_edges;
     const int tiles = (E + 31) >> 5;
@@ -94,13 +113,20 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
             wv[u] = (t < F * GP && k < Gs) ? w1[(size_t)f * Gs + k] : 0.f;
         }
+        float sc1 = 1.0f;
+        if constexpr (FF_H16) {
+            float am = 0.f;
+#pragma unroll
+            for (int u = 0; u < PER1; ++u) am = fmaxf(am, fabsf(wv[u]));
+            plane_scale(block_absmax<FF_THREADS>(am, wred), sc1, us1);
+        }
 #pragma unroll
         for (int u = 0; u < PER1; ++u) {
             const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
             if (t >= F * GP) continue;
             if constexpr (FF_H16) {
                 _Float16 *W1H = reinterpret_cast<_Float16 *>(W1L);
-                const float v = wv[u] * WSCALE;
+                const float v = wv[u] * sc1;
                 const _Float16 h1 = (_Float16)v;
                 W1H[(0 * F + f) * W1S + k] = h1;
                 W1H[(1 * F + f) * W1S + k] = (_Float16)(v - (float)h1);
@@ -125,6 +151,13 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
         float wv[PER2];
 #pragma unroll
         for (int u = 0; u < PER2; ++u) { const int t = tid + u * FF_THREADS; wv[u] = t < F * F ? w2[t] : 0.f; }
+        float sc2 = 1.0f;
+        if constexpr (FF_H16) {
+            float am = 0.f;
+#pragma unroll
+            for (int u = 0; u < PER2; ++u) am = fmaxf(am, fabsf(wv[u]));
+            plane_scale(block_absmax<FF_THREADS>(am, wred), sc2, us2);
+        }
 #pragma unroll
         for (int u = 0; u < PER2; ++u) {
             const int t = tid + u * FF_THREADS;
@@ -134,7 +167,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             const int colp = (f & ~15) + 8 * hh + jj;
             if constexpr (FF_H16) {
                 _Float16 *W2H = reinterpret_cast<_Float16 *>(W2L);
-                const float v = wv[u] * WSCALE;
+                const float v = wv[u] * sc2;
                 const _Float16 h1 = (_Float16)v;
                 W2H[(0 * F + f2) * W2S + colp] = h1;
                 W2H[(1 * F + f2) * W2S + colp] = (_Float16)(v - (float)h1);
@@ -218,7 +251,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&B1L[32 * mb + 8 * q + 4 * h]);
-                constexpr float us = FF_H16 ? WUNSCALE : 1.0f;      // the fp16 planes of the weights carry 2^6
+                const float us = us1;                                // the fp16 planes of W1 carry its plane scale (1 in the bf16 form)
                 acc1[mb][4 * q + 0] = ssp_f(fmaf(acc1[mb][4 * q + 0], us, bb.x));
                 acc1[mb][4 * q + 1] = ssp_f(fmaf(acc1[mb][4 * q + 1], us, bb.y));
                 acc1[mb][4 * q + 2] = ssp_f(fmaf(acc1[mb][4 * q + 2], us, bb.z));
@@ -300,7 +333,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     for (int q = 0; q < 4; ++q) {
                         const float4 bb = *reinterpret_cast<const float4 *>(&B2L[32 * (n0 + nb) + 8 * q + 4 * h]);
                         float4 o;
-                        constexpr float us = FF_H16 ? WUNSCALE : 1.0f;
+                        const float us = us2;
                         o.x = fmaf(acc2[nb][4 * q + 0], us, bb.x) * C;
                         o.y = fmaf(acc2[nb][4 * q + 1], us, bb.y) * C;
                         o.z = fmaf(acc2[nb][4 * q + 2], us, bb.z) * C;

@@ -117,9 +117,12 @@ def test_rbf_cutoff_embedding_segment_sum():
     assert torch.equal(xd.grad.cpu(), gg[torch.from_numpy(b.batch)])
 
 
+@pytest.mark.parametrize("wmag", [1.0, 1e-4, 300.0], ids=["w1", "w1e-4", "w300"])
 @pytest.mark.parametrize("F_,Gs", [(128, 50), (64, 50), (32, 50), (128, 10)])
-def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
-    """conan_filter_fwd (rbf -> mlp -> cosine cutoff in registers) vs the oracle's GaussianSmearing + mlp + C(d)."""
+def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs, wmag):
+    """conan_filter_fwd (rbf -> mlp -> cosine cutoff in registers) vs the oracle's GaussianSmearing + mlp + C(d).  wmag: the second
+    layer's weights scaled by 1e-4 / 300 — the fp16 planes of the weights take their scale from the matrix's maximum, so tiny and huge
+    weights must come out as exact as ordinary ones."""
     assert ops.filter_fused_supported(Gs, F_)
     b = make_batch("esol", 5, 5, seed=13, box=14.0)
     g = _edges(b)
@@ -130,6 +133,7 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs):
     with torch.no_grad():
         for p in mlp.parameters():
             p.add_(0.1 * torch.randn_like(p))
+        mlp[2].weight.mul_(wmag); mlp[0].weight.mul_(min(wmag, 3.0))
     prm = [p.detach().to(dev).requires_grad_(True) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
     W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm, use_pairs=False)  # NB: backward expects a pre-cutoff gradient
     d = g.edge_weight().cpu().double()
