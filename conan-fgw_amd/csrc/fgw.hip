@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 #else
 #define FGW_MMG mm_f64_glb22
 #endif
-template <int NW>
+// C2U8: the adjacency of the input graph is staged ONCE into LDS as bytes (caller's promise cs_small_int: integers in [0, 255]) and both
+// products that contract with it read it there instead of fetching fp32 from L2 in every projected-gradient iteration.
+template <int NW, bool C2U8>
 __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
@@ -413,6 +415,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     double *ra = vec + 5 * N, *rb = vec + 6 * N, *y2a = vec + 7 * N, *z2a = vec + 8 * N;             // prologue: r1_i, r2_j, |y_i|^2, |z_j|^2
     double *red = vec + 9 * N;                                            // [16]; red[15] = range flag
     double *part = red + 16;                                              // [NW][N] partial sums
+    unsigned char *C2b = reinterpret_cast<unsigned char *>(part + NW * N);      // C2U8: [N,P] adjacency bytes
     double *bad_flag = red + 15;
     static_assert(NW < 15, "red[15] is the range flag");
     char *gs = scratch + (size_t)blockIdx.x * coupling_scratch_stride(NP);
@@ -436,6 +439,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
         Kf[i * P + j] = warm ? Tg[t] : (float)(pa[i] * qb[j]);
+        if constexpr (C2U8) C2b[i * P + j] = (unsigned char)C2[t];
     }
     {   // init_matrix vectors (utils.py:39-43) and squared feature norms: 8 lanes per index (see k_fgw_coupling)
         constexpr int LPI = 8;
@@ -504,9 +508,11 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
         __syncthreads();
         FGW_PROF(3);  // A = C1 @ T
         // ---- G = A @ (2 C2)^T ; K_ij = exp(Mr_ij - ref_j), Mr = -(base - 2 alpha G) / eps   (utils.py:62-64, sinkhorn.py:388)
-        FGW_MMG<NW, true>(N, N, N, Al, P, C2, N, [&](int i, int j, double v) {
+        auto k_entry = [&](int i, int j, double v) {
             Kf[i * P + j] = (float)exp_fast(fma(v, fc.four_alpha_inv_eps, (refb[j] - base[i * P + j]) * fc.inv_eps));
-        }, tq);
+        };
+        if constexpr (C2U8) FGW_MMG<NW, true>(N, N, N, Al, P, C2b, P, k_entry, tq);
+        else FGW_MMG<NW, true>(N, N, N, Al, P, C2, N, k_entry, tq);
         for (int i = tid; i < N; i += NT) gv[i] = 1.0;                  // u = 0
         __syncthreads();
         FGW_PROF(4);  // G, K
@@ -613,7 +619,8 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        FGW_MMG<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        if constexpr (C2U8) FGW_MMG<NW, false>(N, N, N, Kf, P, C2b, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        else FGW_MMG<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
         FGW_MMG<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
     }
@@ -806,7 +813,9 @@ inline int pitch_of(int N) { return N | 1; }
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 constexpr int GEN_NW = 8;                   // wavefronts per workgroup of the large-N coupling kernel (16 measured no faster: 453 vs 443 us per workgroup and launch)
 inline size_t coupling_lds(int N) { return (size_t)((6 + 2 * GEN_NW) * N + 16) * 8 + (size_t)N * pitch_of(N) * 28; }
-inline size_t big_lds(int N) { return (((size_t)N * pitch_of(N) * 4 + 15) & ~(size_t)15) + (size_t)((9 + GEN_NW) * N + 16) * 8; }
+inline size_t big_lds(int N, bool c2_bytes) {
+    return (((size_t)N * pitch_of(N) * 4 + 15) & ~(size_t)15) + (size_t)((9 + GEN_NW) * N + 16) * 8 + (c2_bytes ? (size_t)N * pitch_of(N) : 0);
+}
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 }  // namespace
@@ -875,7 +884,8 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     } while (0)
     // N > 64, square loss: the round-3 kernel first (fp32 kernel matrix in LDS: three workgroups per CU), then k_fgw_coupling over the
     // same grid for whatever it handed back (redo[b, s]; an early-exit launch otherwise)
-    const size_t lb = big_lds(N);
+    const bool c2b = params->cs_small_int != 0;
+    const size_t lb = big_lds(N, c2b);
 #ifdef CONAN_FGW_NO_BIG       // (A/B switch of tools/ab.py: the round-2 kernel alone)
     const bool big = false;
 #else
@@ -886,10 +896,16 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         const int *only = nullptr;
         if (big) {
-            if (lb > 64 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-            k_fgw_coupling_big<GEN_NW><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, Ypart,
-                                                                     Cpart, redo);
+#define CONAN_BIG(U8)                                                                                                               \
+    do {                                                                                                                            \
+        if (lb > 64 * 1024)                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW, U8>),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);                                         \
+        k_fgw_coupling_big<GEN_NW, U8><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
+                                                                       Ypart, Cpart, redo);                                          \
+    } while (0)
+            if (c2b) CONAN_BIG(true); else CONAN_BIG(false);
+#undef CONAN_BIG
             only = redo;
         }
         if (small)

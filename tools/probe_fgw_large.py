@@ -13,8 +13,11 @@ for name, B, K, N, d in (("bace B=64", 64, 5, 97, 64), ("lipo B=128", 128, 5, 85
     g = torch.Generator().manual_seed(0)
     Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
     A = (torch.rand(B, K, N, N, generator=g) < 0.1).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
-    for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): ops.fgw_barycenter_batched(Ys, Cs)
-    torch.cuda.synchronize(); out.append("%s N=%d: %.3f ms" % (name, N, (time.perf_counter() - t0) / 5 * 1e3))
+    ts = []
+    for small_int in (True, False):          # the models' promise (adjacency bytes in LDS) / general fp32 structure matrices
+        for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=small_int)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=small_int)
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 5 * 1e3)
+    out.append("%s N=%d: %.3f ms (Cs as bytes) %.3f ms (Cs fp32)" % (name, N, ts[0], ts[1]))
 print(tag, "  ".join(out))
