@@ -27,6 +27,69 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
     }
 }
 
+// Two-plane fp16 form (default; see filter_fused.hip): v = h1 + h2 with the three products p1q1, p1q2, p2q1 on v_mfma_f32_32x32x16_f16 —
+// half the matrix-pipe time and 2/3 of the splitting work of the three-plane bf16 form.  fp16's narrow exponent range is met by exact
+// power-of-two scales: the weight by one factor per matrix (block maximum at staging time -> max |w| in [256, 512)), every x ROW by its
+// own factor (the row lives on one lane pair, so its maximum costs one cross-half exchange) — both undone by one multiply per output in
+// the epilogue (the D column is the x row, so the row factor is a per-lane scalar).  Inside a row, elements down to 2^-12 of the row
+// maximum keep 22 bits; below that the absolute error is 3e-8 / 256 of the row maximum.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifdef CONAN_LINEAR_BF16X3      // (A/B switch of tools/ab.py: the round-2 three-plane bf16 form)
+constexpr bool LT_H16 = false;
+#else
+constexpr bool LT_H16 = true;
+#endif
+constexpr int LT_NPL = LT_H16 ? 2 : 3;
+__device__ __forceinline__ void split2h(const float *v, float sc, f16x8 &p1, f16x8 &p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t = v[j] * sc;
+        const _Float16 h1 = (_Float16)t;
+        p1[j] = h1; p2[j] = (_Float16)(t - (float)h1);
+    }
+}
+// 2^k with amax * 2^k in [256, 512) and its inverse, from the exponent field (zero / subnormal / non-finite maxima: 1)
+__device__ __forceinline__ void pow2_scale(float amax, float &sc, float &un) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    const bool ok = e >= 9 && e <= 254;
+    sc = ok ? __uint_as_float((unsigned)(262 - e) << 23) : 1.0f;
+    un = ok ? __uint_as_float((unsigned)(e - 8) << 23) : 1.0f;
+}
+template <int NT>
+__device__ __forceinline__ float lt_block_absmax(float v, float *red) {      // red: NT / 64 floats of LDS; every thread gets the maximum
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w]);
+    return m;
+}
+// four consecutive k of image row n: 8-byte stores, one per plane
+__device__ __forceinline__ void lt_store4(void *WBv, int N, int WS, int n, int k, const float *v4, float sc) {
+    if constexpr (LT_H16) {
+        _Float16 *WB = reinterpret_cast<_Float16 *>(WBv);
+        f16x4 h1, h2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v4[e] * sc; h1[e] = (_Float16)t; h2[e] = (_Float16)(t - (float)h1[e]); }
+        *reinterpret_cast<f16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
+        *reinterpret_cast<f16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
+    } else {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        __bf16 *WB = reinterpret_cast<__bf16 *>(WBv);
+        bf16x4 h1, h2, h3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h1[e] = (__bf16)v4[e]; const float r1 = v4[e] - (float)h1[e];
+            h2[e] = (__bf16)r1; h3[e] = (__bf16)(r1 - (float)h2[e]);
+        }
+        *reinterpret_cast<bf16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
+        *reinterpret_cast<bf16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
+        *reinterpret_cast<bf16x4 *>(&WB[(2 * N + n) * WS + k]) = h3;
+    }
+}
+
 // SPLIT variant: both operands are split into three bf16 parts and the product is formed from the six significant
 // partial products on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, 2.7x the fp32 MFMA rate).  W's three images are
 // staged once per workgroup; x is split in registers after the global load.
@@ -48,8 +111,10 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     constexpr int S = K / 16;             // MFMA k-steps
     constexpr int WS = K + 8;             // LDS pitch (bf16 elements)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [3][N][WS]
-    float *BL = lds + (3 * N * WS) / 2;                         // [N]
+    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [planes][N][WS] (bf16 or fp16)
+    float *BL = lds + (LT_NPL * N * WS) / 2;                    // [N]
+    __shared__ float wred[NT / 64];
+    float wun = 1.0f;                                           // inverse scale of the weight planes (fp16 form)
     if (m_dev) M = min(M, *m_dev);
     const int tiles = (M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,7 +136,6 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     };
     if ((int)blockIdx.x * (NT / 64) + wave < tiles) load_x(blockIdx.x * (NT / 64) + wave);
     // Staging of the three bf16 images of W as [n][k]; all of a thread's loads are in flight before the first use.
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     if (!w_kn) {                                              // w is [N][K]: float4 = 4 consecutive k -> one 8-byte store per image
         constexpr int V4 = N * K / 4, PER = (V4 + NT - 1) / NT;
         float4 wv[PER];
@@ -81,21 +145,20 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
             const int n = (4 * q) / K, k = 4 * q - n * K;
             wv[u] = q < V4 ? *reinterpret_cast<const float4 *>(w + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float wsc = 1.0f;
+        if constexpr (LT_H16) {
+            float am = 0.f;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u].x), fabsf(wv[u].y)), fmaxf(fabsf(wv[u].z), fabsf(wv[u].w))));
+            pow2_scale(lt_block_absmax<NT>(am, wred), wsc, wun);
+        }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int q = tid + u * NT;
             if (q >= V4) continue;
             const float v4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
-            bf16x4 h1, h2, h3;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h1[e] = (__bf16)v4[e]; const float r1 = v4[e] - (float)h1[e];
-                h2[e] = (__bf16)r1; h3[e] = (__bf16)(r1 - (float)h2[e]);
-            }
             const int n = (4 * q) / K, k = 4 * q - n * K;
-            *reinterpret_cast<bf16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
-            *reinterpret_cast<bf16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
-            *reinterpret_cast<bf16x4 *>(&WB[(2 * N + n) * WS + k]) = h3;
+            lt_store4(WB, N, WS, n, k, v4, wsc);
         }
     } else {
         // w is [K][N] (the dx GEMM of the backward reads the forward weight transposed).  A thread owns a 4(k) x 4(n) block:
@@ -113,6 +176,16 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
             for (int j = 0; j < 4; ++j)
                 wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * ldw + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float wsc = 1.0f;
+        if constexpr (LT_H16) {
+            float am = 0.f;
+#pragma unroll
+            for (int u = 0; u < PERW; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u][j].x), fabsf(wv[u][j].y)), fmaxf(fabsf(wv[u][j].z), fabsf(wv[u][j].w))));
+            pow2_scale(lt_block_absmax<NT>(am, wred), wsc, wun);
+        }
 #pragma unroll
         for (int u = 0; u < PERW; ++u) {
             const int pt = wave + u * (NT / 64);
@@ -124,15 +197,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
                                      e == 0 ? wv[u][1].x : e == 1 ? wv[u][1].y : e == 2 ? wv[u][1].z : wv[u][1].w,
                                      e == 0 ? wv[u][2].x : e == 1 ? wv[u][2].y : e == 2 ? wv[u][2].z : wv[u][2].w,
                                      e == 0 ? wv[u][3].x : e == 1 ? wv[u][3].y : e == 2 ? wv[u][3].z : wv[u][3].w};
-                bf16x4 h1, h2, h3;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h1[j] = (__bf16)v4[j]; const float r1 = v4[j] - (float)h1[j];
-                    h2[j] = (__bf16)r1; h3[j] = (__bf16)(r1 - (float)h2[j]);
-                }
-                *reinterpret_cast<bf16x4 *>(&WB[(0 * N + n0 + e) * WS + k0]) = h1;
-                *reinterpret_cast<bf16x4 *>(&WB[(1 * N + n0 + e) * WS + k0]) = h2;
-                *reinterpret_cast<bf16x4 *>(&WB[(2 * N + n0 + e) * WS + k0]) = h3;
+                lt_store4(WB, N, WS, n0 + e, k0, v4, wsc);
             }
         }
     }
@@ -147,6 +212,43 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        float xun = 1.0f;                                      // inverse of this lane's row scale x inverse weight scale
+        if constexpr (LT_H16) {
+            float am = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(xa[s].x), fabsf(xa[s].y)), fmaxf(fabsf(xa[s].z), fabsf(xa[s].w))));
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(xb[s].x), fabsf(xb[s].y)), fmaxf(fabsf(xb[s].z), fabsf(xb[s].w))));
+            }
+            am = fmaxf(am, __shfl_xor(am, 32));                // the other half of the row sits on lane ^ 32
+            float xsc, xu;
+            pow2_scale(am, xsc, xu);
+            xun = xu * wun;
+            const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB);
+            // the whole tile becomes fp16 planes first (same register count as the fp32 rows): the fp32 registers are then free for the
+            // NEXT tile's rows, whose loads fly during this tile's MFMA loop and epilogue instead of during the epilogue alone
+            f16x8 q1[S], q2[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+                split2h(xv, xsc, q1[s], q2[s]);
+            }
+            if (tile + wave_stride < tiles) load_x(tile + wave_stride);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int colp = 16 * s + 8 * h;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = 32 * nb + l31;
+                    const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * N + row) * WS + colp]);
+                    const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * N + row) * WS + colp]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1[s], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2[s], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1[s], acc[nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
@@ -168,7 +270,8 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (tile + wave_stride < tiles) load_x(tile + wave_stride);
+        }
+        if (!LT_H16 && tile + wave_stride < tiles) load_x(tile + wave_stride);
         if (!valid) continue;
         float *yr = y + (size_t)m * ldy + 4 * h;
         const float *rr = residual ? residual + (size_t)m * ldy + 4 * h : nullptr;
@@ -185,7 +288,8 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
-                float v[4] = {acc[nb][4 * q] + bb.x, acc[nb][4 * q + 1] + bb.y, acc[nb][4 * q + 2] + bb.z, acc[nb][4 * q + 3] + bb.w};
+                float v[4] = {fmaf(acc[nb][4 * q], xun, bb.x), fmaf(acc[nb][4 * q + 1], xun, bb.y), fmaf(acc[nb][4 * q + 2], xun, bb.z),
+                              fmaf(acc[nb][4 * q + 3], xun, bb.w)};
                 if (ar) {
                     const float4 av = *reinterpret_cast<const float4 *>(ar + 32 * nb + 8 * q);
                     v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w;
@@ -208,7 +312,7 @@ template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
              const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr) {
     if (ldw == 0) ldw = w_kn ? N : K;
-    const size_t lds16 = ((size_t)(3 * N * (K + 8)) / 2 + N) * 4;
+    const size_t lds16 = ((size_t)(LT_NPL * N * (K + 8)) / 2 + N) * 4;
     const int tiles16 = (M + 31) / 32;
     // 8 waves per workgroup (2 per SIMD cover each other's latencies) once every CU gets a full workgroup; below that 4-wave
     // workgroups spread the tiles over twice as many CUs (node-level layers: 790 tiles -> 198 instead of 99 CUs).

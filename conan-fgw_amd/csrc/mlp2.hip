@@ -14,9 +14,11 @@
 // 32-row tile: GEMM1's B operand are its x rows straight from global memory (requested before the weights are staged), GEMM2's B
 // operand IS GEMM1's accumulator after the element-wise step (register r of lane-half h = channel 32nb + (r&3) + 8(r>>2) + 4h, so
 // the second weight is staged with the matching column permutation) — nothing crosses lanes or LDS between the two GEMMs.  Both
-// products are exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-class).  The LDS weight buffer is reused: stage W1,
-// barrier, GEMM1, barrier, stage W2, barrier, GEMM2.  `mid` (h forward, dh backward) is also written out: the weight gradients
-// of the two layers need it.
+// products are two-plane fp16 splits on v_mfma_f32_32x32x16_f16 (fp32-class; gemm_t.hip describes the form and its exact power-of-two
+// scales: one per weight matrix, one per x row — and here one per row of the intermediate, taken from the accumulators).  Both weights
+// (2 x 70 KB of planes) sit in LDS from the start: one staging phase, one barrier.  (The three-plane bf16 form of round 2, kept behind
+// -DCONAN_LINEAR_BF16X3 for A/B runs, needed 104 KB per weight and staged them one after the other with two more barriers.)  `mid`
+// (h forward, dh backward) is also written out: the weight gradients of the two layers need it.
 #include "common.h"
 
 namespace {
@@ -24,6 +26,32 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int M2_THREADS = 256, M2_WAVES = 4;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifdef CONAN_LINEAR_BF16X3
+constexpr bool M2_H16 = false;
+#else
+constexpr bool M2_H16 = true;
+#endif
+constexpr int M2_NPL = M2_H16 ? 2 : 3;
+__device__ __forceinline__ void m2_split2h(const float *v, float sc, f16x8 &p1, f16x8 &p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t = v[j] * sc;
+        const _Float16 h1 = (_Float16)t;
+        p1[j] = h1; p2[j] = (_Float16)(t - (float)h1);
+    }
+}
+// 2^k with amax * 2^k in [256, 512) and its inverse (gemm_t.hip)
+__device__ __forceinline__ void m2_pow2_scale(float amax, float &sc, float &un) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    const bool ok = e >= 9 && e <= 254;
+    sc = ok ? __uint_as_float((unsigned)(262 - e) << 23) : 1.0f;
+    un = ok ? __uint_as_float((unsigned)(e - 8) << 23) : 1.0f;
+}
+__device__ __forceinline__ float m2_absmax4(float m, const float4 &v) {
+    return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
 
 __device__ __forceinline__ void m2_split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
 #pragma unroll
@@ -49,7 +77,16 @@ __device__ __forceinline__ int m2_perm4(int k, bool perm) {
     const int a = (k & 15) >> 2;
     return (k & ~15) + 8 * (a & 1) + 4 * (a >> 1);
 }
-__device__ __forceinline__ void m2_store4(__bf16 *WB, int NO, int WS, int n, int kp, const float *v4) {
+__device__ __forceinline__ void m2_store4(__bf16 *WB, int NO, int WS, int n, int kp, const float *v4, float sc) {
+    if constexpr (M2_H16) {
+        _Float16 *WH = reinterpret_cast<_Float16 *>(WB);
+        f16x4 h1, h2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v4[e] * sc; h1[e] = (_Float16)t; h2[e] = (_Float16)(t - (float)h1[e]); }
+        *reinterpret_cast<f16x4 *>(&WH[(0 * NO + n) * WS + kp]) = h1;
+        *reinterpret_cast<f16x4 *>(&WH[(1 * NO + n) * WS + kp]) = h2;
+        return;
+    }
     bf16x4 h1, h2, h3;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -85,7 +122,13 @@ struct M2Weight {
             }
         }
     }
-    __device__ __forceinline__ void park(__bf16 *__restrict__ WB, int tid, bool perm) const {
+    __device__ __forceinline__ float absmax() const {
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < (TRANS ? PERW * 4 : PER); ++u) m = m2_absmax4(m, v[u]);
+        return m;
+    }
+    __device__ __forceinline__ void park(__bf16 *__restrict__ WB, int tid, bool perm, float sc = 1.0f) const {
         constexpr int WS = KD + 8;
         const int lane = tid & 63, wave = tid >> 6;
         if (!TRANS) {
@@ -95,7 +138,7 @@ struct M2Weight {
                 if (q >= V4) continue;
                 const int n = (4 * q) / KD, k = 4 * q - n * KD;
                 const float v4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                m2_store4(WB, NO, WS, n, m2_perm4(k, perm), v4);
+                m2_store4(WB, NO, WS, n, m2_perm4(k, perm), v4, sc);
             }
         } else {
             const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
@@ -110,7 +153,7 @@ struct M2Weight {
                                          e == 0 ? v[4 * u + 1].x : e == 1 ? v[4 * u + 1].y : e == 2 ? v[4 * u + 1].z : v[4 * u + 1].w,
                                          e == 0 ? v[4 * u + 2].x : e == 1 ? v[4 * u + 2].y : e == 2 ? v[4 * u + 2].z : v[4 * u + 2].w,
                                          e == 0 ? v[4 * u + 3].x : e == 1 ? v[4 * u + 3].y : e == 2 ? v[4 * u + 3].z : v[4 * u + 3].w};
-                    m2_store4(WB, NO, WS, n0 + e, m2_perm4(k0, perm), v4);
+                    m2_store4(WB, NO, WS, n0 + e, m2_perm4(k0, perm), v4, sc);
                 }
             }
         }
@@ -128,10 +171,14 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     constexpr bool BWD = (MODE & 1) != 0;
     constexpr int SA = KA / 16, SB = NA / 16, MBA = NA / 32, MBB = NB / 32;
     constexpr int WSA = KA + 8, WSB = NA + 8;
-    constexpr int WORDS_A = (3 * NA * WSA) / 2, WORDS_B = (3 * NB * WSB) / 2, WORDS = WORDS_A > WORDS_B ? WORDS_A : WORDS_B;
+    constexpr int WORDS_A = (M2_NPL * NA * WSA) / 2, WORDS_B = (M2_NPL * NB * WSB) / 2;
+    constexpr int WORDS = M2_H16 ? WORDS_A + WORDS_B : (WORDS_A > WORDS_B ? WORDS_A : WORDS_B);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16 *WB = reinterpret_cast<__bf16 *>(lds);
+    __bf16 *WB2 = M2_H16 ? reinterpret_cast<__bf16 *>(lds + WORDS_A) : WB;      // the second weight: its own buffer (fp16 form) or the first one's, reused
     float *BL = lds + WORDS;                                   // [NA + NB] biases
+    __shared__ float wred[2 * M2_WAVES];
+    float unA = 1.0f, unB = 1.0f;                              // inverse plane scales of the two weights (fp16 form)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x * M2_WAVES + wave;
@@ -169,8 +216,22 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     M2Weight<NA, KA, BWD> stA;
     M2Weight<NB, NA, BWD> stB;
     stA.fetch(wA, tid);
-    stB.fetch(wB, tid);                                        // in flight during the first GEMM
-    stA.park(WB, tid, false);
+    stB.fetch(wB, tid);                                        // bf16 form: in flight during the first GEMM
+    if constexpr (M2_H16) {
+        const float ma = wave_max(stA.absmax()), mb = wave_max(stB.absmax());
+        if (lane == 0) { wred[wave] = ma; wred[M2_WAVES + wave] = mb; }
+        __syncthreads();
+        float a = wred[0], b = wred[M2_WAVES];
+#pragma unroll
+        for (int w = 1; w < M2_WAVES; ++w) { a = fmaxf(a, wred[w]); b = fmaxf(b, wred[M2_WAVES + w]); }
+        float scA, scB;
+        m2_pow2_scale(a, scA, unA);
+        m2_pow2_scale(b, scB, unB);
+        stA.park(WB, tid, false, scA);
+        stB.park(WB2, tid, true, scB);
+    } else {
+        stA.park(WB, tid, false);
+    }
     for (int t = tid; t < NA + NB; t += M2_THREADS) BL[t] = BWD ? 0.f : (t < NA ? bA[t] : bB[t - NA]);
     if (MODE == 3) {                                           // g = dy * ssp'(pre) from the saved output, in place and out for the weight gradient
 #pragma unroll
@@ -194,6 +255,38 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     for (int nb = 0; nb < MBA; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
+    float un1 = 1.0f;                                          // fp16 form: inverse of (row scale of x) x (scale of the first weight)
+    if constexpr (M2_H16) {
+        float am = 0.f;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) { am = m2_absmax4(am, xa[s]); am = m2_absmax4(am, xb[s]); }
+        am = fmaxf(am, __shfl_xor(am, 32));                    // the other half of the row sits on lane ^ 32
+        float xsc, xu;
+        m2_pow2_scale(am, xsc, xu);
+        un1 = xu * unA;
+        const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB);
+#pragma unroll
+        for (int s = 0; s < SA; ++s) {
+            const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+            f16x8 q1, q2;
+            m2_split2h(xv, xsc, q1, q2);
+            const int colp = 16 * s + 8 * h;
+#pragma unroll
+            for (int nb = 0; nb < MBA; ++nb) {
+                const int row = 32 * nb + l31;
+                const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * NA + row) * WSA + colp]);
+                const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * NA + row) * WSA + colp]);
+                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc1[nb], 0, 0, 0);
+                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc1[nb], 0, 0, 0);
+                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc1[nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < MBA; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[nb][r] *= un1;
+    } else {
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
         const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
@@ -214,6 +307,7 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
             acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc1[nb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // element-wise step on the accumulators (register r of half h is channel 32nb + (r&3) + 8(r>>2) + 4h) and the `mid` output
 #pragma unroll
@@ -239,8 +333,10 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
             if (mid_out && valid)
                 *reinterpret_cast<float4 *>(mid_out + (size_t)m * NA + 32 * nb + 8 * q + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
         }
-    __syncthreads();                                           // every wave is done with the first weight
-    stB.park(WB, tid, true);
+    if constexpr (!M2_H16) {
+        __syncthreads();                                       // every wave is done with the first weight
+        stB.park(WB, tid, true);
+    }
     float4 rv[MODE == 0 ? MBB : 1][4];
     if (MODE == 0 && residual) {
         const float *rr = residual + (size_t)mr * NB + 4 * h;
@@ -249,7 +345,7 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
 #pragma unroll
             for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
     }
-    __syncthreads();
+    if constexpr (!M2_H16) __syncthreads();
 
     // ---------------- GEMM2^T: acc2[nb] = WB[32nb.., :] . mid^T, B operand = acc1 (k order of the A fragments permuted to match)
     f32x16 acc2[MBB];
@@ -257,6 +353,39 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     for (int nb = 0; nb < MBB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+    float un2 = 1.0f;
+    if constexpr (M2_H16) {
+        float am = 0.f;                                        // the row of `mid`: 64 channels here, 64 on lane ^ 32
+#pragma unroll
+        for (int nb = 0; nb < MBA; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc1[nb][r]));
+        am = fmaxf(am, __shfl_xor(am, 32));
+        float msc, mu;
+        m2_pow2_scale(am, msc, mu);
+        un2 = mu * unB;
+        const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB2);
+#pragma unroll
+        for (int ms = 0; ms < SB; ++ms) {
+            const int mb = ms >> 1, sgrp = ms & 1;
+            float hv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
+            f16x8 q1, q2;
+            m2_split2h(hv, msc, q1, q2);
+            const int colp = 32 * mb + 16 * sgrp + 8 * h;
+#pragma unroll
+            for (int nb = 0; nb < MBB; ++nb) {
+                const int row = 32 * nb + l31;
+                const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * NB + row) * WSB + colp]);
+                const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * NB + row) * WSB + colp]);
+                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc2[nb], 0, 0, 0);
+                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc2[nb], 0, 0, 0);
+                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc2[nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
 #pragma unroll
     for (int ms = 0; ms < SB; ++ms) {
         const int mb = ms >> 1, sgrp = ms & 1;
@@ -281,13 +410,15 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }
     if (!valid) return;
 #pragma unroll
     for (int nb = 0; nb < MBB; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bb = *reinterpret_cast<const float4 *>(&BL[NA + 32 * nb + 8 * q + 4 * h]);
-            float4 o = make_float4(acc2[nb][4 * q] + bb.x, acc2[nb][4 * q + 1] + bb.y, acc2[nb][4 * q + 2] + bb.z, acc2[nb][4 * q + 3] + bb.w);
+            float4 o = make_float4(fmaf(acc2[nb][4 * q], un2, bb.x), fmaf(acc2[nb][4 * q + 1], un2, bb.y), fmaf(acc2[nb][4 * q + 2], un2, bb.z),
+                                   fmaf(acc2[nb][4 * q + 3], un2, bb.w));
             if (MODE == 0 && residual) { o.x += rv[nb][q].x; o.y += rv[nb][q].y; o.z += rv[nb][q].z; o.w += rv[nb][q].w; }
             if (MODE == 2) { o.x = ssp_f(o.x); o.y = ssp_f(o.y); o.z = ssp_f(o.z); o.w = ssp_f(o.w); }
             *reinterpret_cast<float4 *>(y + (size_t)m * NB + 32 * nb + 8 * q + 4 * h) = o;
@@ -297,8 +428,8 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
 template <int KA, int NA, int NB, int MODE>
 int m2_launch(const float *x, const float *wA, const float *bA, const float *wB, const float *bB, const float *aux, const float *residual, int M,
               float *mid_out, float *y, float *in_out, hipStream_t s) {
-    constexpr int WA = (3 * NA * (KA + 8)) / 2, WBw = (3 * NB * (NA + 8)) / 2;
-    const size_t lds = ((size_t)(WA > WBw ? WA : WBw) + NA + NB) * 4;
+    constexpr int WA = (M2_NPL * NA * (KA + 8)) / 2, WBw = (M2_NPL * NB * (NA + 8)) / 2;
+    const size_t lds = ((size_t)(M2_H16 ? WA + WBw : (WA > WBw ? WA : WBw)) + NA + NB) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp2<KA, NA, NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (M + 31) / 32;
     k_mlp2<KA, NA, NB, MODE><<<(tiles + M2_WAVES - 1) / M2_WAVES, M2_THREADS, lds, s>>>(x, wA, bA, wB, bB, aux, residual, M, mid_out, y, in_out);

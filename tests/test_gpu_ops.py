@@ -39,6 +39,41 @@ def test_linear_fwd_bwd(M, K, N, act):
     assert rel(bd.grad.cpu(), b64.grad) < 5e-6
 
 
+@pytest.mark.parametrize("wmag", [1e-4, 0.2, 300.0])
+def test_linear_rows_of_very_different_magnitude_keep_their_own_precision(wmag):
+    """The two-plane fp16 GEMM (gemm_t.hip, mlp2.hip) scales every x row by its own power of two: a batch whose rows span ten decades
+    (and a zero row, and a row with one non-zero element) must come out with fp32-class error in EVERY row, forward and input gradient."""
+    g = torch.Generator().manual_seed(7)
+    M, K, N = 2000, 128, 128
+    x = torch.randn(M, K, generator=g) * (10.0 ** (torch.rand(M, 1, generator=g) * 10.0 - 6.0))
+    x[5] = 0.0; x[6] = 0.0; x[6, 17] = 3.0e-3
+    gy = torch.randn(M, N, generator=g) * (10.0 ** (torch.rand(M, 1, generator=g) * 10.0 - 6.0))
+    w = torch.randn(N, K, generator=g) * wmag
+    xd = x.to(dev).requires_grad_(True); wd = w.to(dev)
+    y = ops.linear(xd, wd, None)
+    y.backward(gy.to(dev))
+    r = x.double() @ w.double().T
+    rx = gy.double() @ w.double()
+
+    def rows(a, b):
+        err = (a.double().cpu() - b).norm(dim=1); nrm = b.norm(dim=1)
+        return float((err / nrm.clamp_min(1e-300))[nrm > 0].max()), float(err[nrm == 0].max()) if bool((nrm == 0).any()) else 0.0
+    e, z = rows(y.detach(), r)
+    assert e < 2e-6 and z == 0.0
+    e, z = rows(xd.grad, rx)
+    assert e < 2e-6 and z == 0.0
+    # the fused pair of layers: the intermediate is scaled per row as well (taken from the accumulators).  Rows from 1 to 1e3 here:
+    # below that the fp32 shifted softplus itself (softplus(r) - ln 2 for r -> 0) is the larger error, in any GEMM form
+    x2 = torch.randn(M, K, generator=g) * (10.0 ** (torch.rand(M, 1, generator=g) * 3.0))
+    w1 = torch.randn(N, K, generator=g) * 0.2
+    w2 = torch.randn(N, N, generator=g) * wmag
+    zb = torch.zeros(N, device=dev)
+    y2 = ops.mlp2(x2.to(dev), w1.to(dev), zb, w2.to(dev), zb)
+    r2 = _ssp(x2.double() @ w1.double().T) @ w2.double().T
+    e, _ = rows(y2, r2)
+    assert e < 3e-6
+
+
 def test_linear_residual_nobias_and_device_row_count():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(500, 128, generator=g); w = torch.randn(128, 128, generator=g) * 0.1; res = torch.randn(500, 128, generator=g)
