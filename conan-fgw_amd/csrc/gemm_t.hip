@@ -41,6 +41,7 @@ constexpr bool LT_H16 = false;
 constexpr bool LT_H16 = true;
 #endif
 constexpr int LT_NPL = LT_H16 ? 2 : 3;
+constexpr int LT_OP = 68;                                      // pitch of the per-wave output slab (floats): 64 channels + 4
 __device__ __forceinline__ void split2h(const float *v, float sc, f16x8 &p1, f16x8 &p2) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [planes][N][WS] (bf16 or fp16)
     float *BL = lds + (LT_NPL * N * WS) / 2;                    // [N]
+    float *OT = BL + N + (threadIdx.x >> 6) * (32 * LT_OP);    // fp16 form: this wave's [32][LT_OP] output slab
     __shared__ float wred[NT / 64];
     float wun = 1.0f;                                           // inverse scale of the weight planes (fp16 form)
     if (m_dev) M = min(M, *m_dev);
@@ -272,10 +274,10 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
         }
         }
         if (!LT_H16 && tile + wave_stride < tiles) load_x(tile + wave_stride);
-        if (!valid) continue;
-        float *yr = y + (size_t)m * ldy + 4 * h;
-        const float *rr = residual ? residual + (size_t)m * ldy + 4 * h : nullptr;
-        const float *ar = accum ? accum + (size_t)m * ldy + 4 * h : nullptr;
+        const int mc = valid ? m : M - 1;                      // rows beyond M compute on a clamped row and are not stored
+        float *yr = y + (size_t)mc * ldy + 4 * h;
+        const float *rr = residual ? residual + (size_t)mc * ldy + 4 * h : nullptr;
+        const float *ar = accum ? accum + (size_t)mc * ldy + 4 * h : nullptr;
         float4 rv[NB][4];
         if (rr) {
 #pragma unroll
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
                 for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
@@ -294,17 +296,35 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
                     const float4 av = *reinterpret_cast<const float4 *>(ar + 32 * nb + 8 * q);
                     v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w;
                 }
-                if (pre_out) *reinterpret_cast<float4 *>(pre_out + (size_t)m * ldy + 4 * h + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                if (pre_out && valid) *reinterpret_cast<float4 *>(pre_out + (size_t)m * ldy + 4 * h + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
                 const float r4[4] = {rr ? rv[nb][q].x : 0.f, rr ? rv[nb][q].y : 0.f, rr ? rv[nb][q].z : 0.f, rr ? rv[nb][q].w : 0.f};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (act == 1) v[u] = ssp_f(v[u]);
-                    else if (act == 3) v[u] = v[u] / (1.0f + __expf(-v[u]));
+                    else if (act == 3) v[u] = v[u] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[u]));      // hardware reciprocal (1 ulp), as visnet.hip's silu_f
                     if (act == 2) v[u] *= 1.0f - 0.5f * __expf(-r4[u]);
                     else if (rr) v[u] += r4[u];
                 }
-                *reinterpret_cast<float4 *>(yr + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (LT_H16)
+                    *reinterpret_cast<float4 *>(&OT[l31 * LT_OP + 32 * (nb & 1) + 8 * q + 4 * h]) = make_float4(v[0], v[1], v[2], v[3]);
+                else if (valid)
+                    *reinterpret_cast<float4 *>(yr + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
             }
+            // fp16 form: the planes leave room in LDS for a [32][64] slab per wave — the outputs cross it so that a store instruction
+            // writes 4 rows x 256 contiguous bytes instead of 32 rows x 32 bytes (partial lines that L2 has to merge; with the loads
+            // switched off the kernel took 86 us of its 128 for the stores alone: 128 -> 116 us).  The slab is private to the wave: no barrier.
+            if constexpr (LT_H16) {
+                if (nb & 1) {
+                    const int rbase = tile << 5;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = 4 * i + (lane >> 4), c = 4 * (lane & 15);
+                        const float4 o = *reinterpret_cast<const float4 *>(&OT[r * LT_OP + c]);
+                        if (rbase + r < M) *reinterpret_cast<float4 *>(y + (size_t)(rbase + r) * ldy + 32 * (nb - 1) + c) = o;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -312,11 +332,12 @@ template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
              const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr) {
     if (ldw == 0) ldw = w_kn ? N : K;
-    const size_t lds16 = ((size_t)(LT_NPL * N * (K + 8)) / 2 + N) * 4;
+    const size_t lds_w = ((size_t)(LT_NPL * N * (K + 8)) / 2 + N) * 4;
     const int tiles16 = (M + 31) / 32;
     // 8 waves per workgroup (2 per SIMD cover each other's latencies) once every CU gets a full workgroup; below that 4-wave
     // workgroups spread the tiles over twice as many CUs (node-level layers: 790 tiles -> 198 instead of 99 CUs).
     const bool narrow = tiles16 < 8 * 256;
+    const size_t lds16 = lds_w + (LT_H16 ? (size_t)(narrow ? 4 : 8) * 32 * LT_OP * 4 : 0);
     const int per = narrow ? 4 : 8;
     int grid16 = (tiles16 + per - 1) / per;
     if (grid16 > 256) grid16 = 256;
