@@ -284,13 +284,220 @@ __global__ void __launch_bounds__(256) k_gat_bwd_source(const float *__restrict_
     }
 }
 
+// ---- round 3: the same two passes on 16-lane groups -----------------------------------------------------------------------
+// The kernels above give a node a whole wavefront and walk its row as a chain of dependent loads and 6-step reductions: by itself
+// the pair takes 36 + 14.5 us at 25 k atoms (3 nodes per wavefront, one L2 / Infinity-Cache round trip per link of the chain).  Here a
+// node is owned by a group of 16 lanes (lane <-> CH = C/16 consecutive channels, float4 loads, 4-step reductions, 4 nodes per
+// wavefront, one node per group at cfg2 size) and every level of indirection is ONE trip for the whole row: indices of all edges,
+// then all rows (rows up to GAT_MD edges; longer ones walk serially).  Scalars of the row live in every lane of the group — no
+// wave-wide reductions for the means and the parameter sums.  Parameter gradients: registers -> LDS (16 groups, fixed order) -> one
+// partial row per workgroup -> k_gat_param_reduce.  No float atomics.  (A one-kernel form that recomputes the target sums two hops
+// away was measured and rejected: 70 us — five levels of indirection in one chain, 190 VGPRs.  The forward aggregation in this
+// form measured 24.8 us against 21.2 us for k_gat_aggregate_fwd, which already stages its row one edge per lane: not kept.)
+// grid: one node per group (16 groups per workgroup), rounded up to a multiple of 64 rows for k_gat_param_reduce, at most GAT_BW_WGS
+static inline int gat_g_wgs(int n) { const int w = ((n + 15) / 16 + 63) / 64 * 64; return w > GAT_BW_WGS ? GAT_BW_WGS : w; }
+#ifndef CONAN_GAT_MD
+#define CONAN_GAT_MD 6
+#endif
+constexpr int GAT_MD = CONAN_GAT_MD;
+template <int CH>
+__device__ __forceinline__ void gat_row(const float *__restrict__ base, int node, int sub, float (&r)[CH]) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + (size_t)node * (16 * CH) + sub * CH);
+#pragma unroll
+    for (int u = 0; u < CH / 4; ++u) { const float4 t = p[u]; r[4 * u] = t.x; r[4 * u + 1] = t.y; r[4 * u + 2] = t.z; r[4 * u + 3] = t.w; }
+}
+template <int CH>
+__device__ __forceinline__ float gat_dot16(const float (&a)[CH], const float (&b)[CH]) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) t += a[u] * b[u];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 16);
+    return t;
+}
+// the 16 groups of a workgroup -> columns [c0, c0 + cols) of its partial row, fixed order; sm: [16][cols]
+__device__ __forceinline__ void gat_part_row(const float *sm, int cols, float *__restrict__ dst, int cols_out) {
+    for (int t = threadIdx.x; t < cols_out; t += 256) {
+        float r = sm[t];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) r += sm[g * cols + t];
+        dst[t] = r;
+    }
+}
+
+// target side: dpre per edge / self loop, da_dst, partial dv
+template <int CH, int DT>
+__global__ void __launch_bounds__(256) k_gat_bwd_target16(const float *__restrict__ h, const float *__restrict__ dout, const float *__restrict__ alpha,
+                                                          const float *__restrict__ alpha_self, const float *__restrict__ a_src,
+                                                          const float *__restrict__ a_dst, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                          const int *__restrict__ eid, const float *__restrict__ edge_attr, int D,
+                                                          const float *__restrict__ v, float slope, int n, float *__restrict__ dpre,
+                                                          float *__restrict__ dpre_self, float *__restrict__ da_dst, float *__restrict__ part, int PW) {
+    constexpr int C = 16 * CH, M = GAT_MD;
+    const int sub = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int ngroups = gridDim.x * 16;
+    float vd[DT], dvacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { vd[d] = d < D ? v[d] : 0.f; dvacc[d] = 0.f; }
+    for (int j = blockIdx.x * 16 + gl; j < n; j += ngroups) {
+        const int e0 = rowptr[j], e1 = rowptr[j + 1], deg = e1 - e0;
+        const float ad_j = a_dst[j], as_j = alpha_self[j], asrc_j = a_src[j];
+        float dj[CH], hj[CH];
+        gat_row<CH>(dout, j, sub, dj);
+        gat_row<CH>(h, j, sub, hj);
+        const float dal_self = gat_dot16<CH>(dj, hj);
+        float S = as_j * dal_self, sum_dot = 0.f, dad = 0.f, mean_ea[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) mean_ea[d] = 0.f;
+        const float inv_deg = deg > 0 ? 1.0f / (float)deg : 0.f;
+        if (deg <= M) {
+            int kk[M], ee[M];
+            float al[M];
+#pragma unroll
+            for (int t = 0; t < M; ++t) { kk[t] = t < deg ? col[e0 + t] : j; ee[t] = t < deg ? eid[e0 + t] : 0; al[t] = t < deg ? alpha[e0 + t] : 0.f; }
+            float hk[M][CH], ask[M], eav[M][DT], dal[M];
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                gat_row<CH>(h, kk[t], sub, hk[t]);
+                ask[t] = a_src[kk[t]];
+#pragma unroll
+                for (int d = 0; d < DT; ++d) eav[t][d] = (d < D && t < deg) ? edge_attr[(size_t)ee[t] * D + d] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                dal[t] = gat_dot16<CH>(dj, hk[t]);
+                if (t < deg) {
+                    S += al[t] * dal[t];
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) if (d < D) { mean_ea[d] += eav[t][d]; sum_dot += eav[t][d] * vd[d]; }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+                if (t < deg) {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) if (d < D) dot += eav[t][d] * vd[d];
+                    const float pre = ask[t] + ad_j + dot;
+                    const float g = al[t] * (dal[t] - S) * (pre > 0.f ? 1.f : slope);
+                    if (sub == 0) dpre[e0 + t] = g;
+                    dad += g;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) if (d < D) dvacc[d] += g * eav[t][d];
+                }
+        } else {
+            for (int p = e0; p < e1; ++p) {
+                float hk[CH];
+                gat_row<CH>(h, col[p], sub, hk);
+                S += alpha[p] * gat_dot16<CH>(dj, hk);
+                const float *ea = edge_attr + (size_t)eid[p] * D;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) if (d < D) { mean_ea[d] += ea[d]; sum_dot += ea[d] * vd[d]; }
+            }
+            for (int p = e0; p < e1; ++p) {
+                const int k = col[p];
+                float hk[CH];
+                gat_row<CH>(h, k, sub, hk);
+                const float dal = gat_dot16<CH>(dj, hk);
+                const float *ea = edge_attr + (size_t)eid[p] * D;
+                const float pre = a_src[k] + ad_j + gat_dot<DT>(ea, vd, D);
+                const float g = alpha[p] * (dal - S) * (pre > 0.f ? 1.f : slope);
+                if (sub == 0) dpre[p] = g;
+                dad += g;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) if (d < D) dvacc[d] += g * ea[d];
+            }
+        }
+        const float pre_self = asrc_j + ad_j + sum_dot * inv_deg;
+        const float g_self = as_j * (dal_self - S) * (pre_self > 0.f ? 1.f : slope);
+        dad += g_self;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dvacc[d] += g_self * (mean_ea[d] * inv_deg);
+        if (sub == 0) { dpre_self[j] = g_self; da_dst[j] = dad; }
+    }
+    __shared__ float sm_dv[16 * DT];
+    if (sub == 0)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) sm_dv[gl * DT + d] = dvacc[d];
+    __syncthreads();
+    gat_part_row(sm_dv, DT, part + (size_t)blockIdx.x * PW + 3 * C, D);
+}
+
+// source side: da_src, dh (messages sent by node j, its self loop, the two attention projections) and the partial sums of d att_src, d att_dst, d bias
+template <int CH>
+__global__ void __launch_bounds__(256) k_gat_bwd_source16(const float *__restrict__ h, const float *__restrict__ dout, const float *__restrict__ alpha,
+                                                          const float *__restrict__ alpha_self, const float *__restrict__ dpre,
+                                                          const float *__restrict__ dpre_self, const float *__restrict__ da_dst,
+                                                          const float *__restrict__ att_src, const float *__restrict__ att_dst,
+                                                          const int *__restrict__ t_rowptr, const int *__restrict__ t_pos, const int *__restrict__ t_tgt,
+                                                          int n, float *__restrict__ dh, float *__restrict__ part, int PW) {
+    constexpr int C = 16 * CH, M = GAT_MD;
+    const int sub = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int ngroups = gridDim.x * 16;
+    float ats[CH], atd[CH], p_as[CH], p_ad[CH], p_b[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) { ats[u] = att_src[sub * CH + u]; atd[u] = att_dst[sub * CH + u]; p_as[u] = 0.f; p_ad[u] = 0.f; p_b[u] = 0.f; }
+    for (int j = blockIdx.x * 16 + gl; j < n; j += ngroups) {
+        const int q0 = t_rowptr[j], q1 = t_rowptr[j + 1], deg = q1 - q0;
+        const float dad = da_dst[j], as_j = alpha_self[j];
+        float das = dpre_self[j];
+        float dj[CH], hj[CH], acc[CH];
+        gat_row<CH>(dout, j, sub, dj);
+        gat_row<CH>(h, j, sub, hj);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) acc[u] = as_j * dj[u];
+        if (deg <= M) {
+            int op[M], oi[M];
+#pragma unroll
+            for (int t = 0; t < M; ++t) { op[t] = t < deg ? t_pos[q0 + t] : 0; oi[t] = t < deg ? t_tgt[q0 + t] : j; }
+            float di[M][CH], oa[M], og[M];
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                gat_row<CH>(dout, oi[t], sub, di[t]);
+                oa[t] = t < deg ? alpha[op[t]] : 0.f; og[t] = t < deg ? dpre[op[t]] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+                if (t < deg) {
+                    das += og[t];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) acc[u] += oa[t] * di[t][u];
+                }
+        } else {
+            for (int q = q0; q < q1; ++q) {
+                const int pos = t_pos[q];
+                float di[CH];
+                gat_row<CH>(dout, t_tgt[q], sub, di);
+                const float a = alpha[pos];
+                das += dpre[pos];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) acc[u] += a * di[u];
+            }
+        }
+        float4 *o = reinterpret_cast<float4 *>(dh + (size_t)j * C + sub * CH);
+#pragma unroll
+        for (int u = 0; u < CH / 4; ++u)
+            o[u] = make_float4(acc[4 * u] + das * ats[4 * u] + dad * atd[4 * u], acc[4 * u + 1] + das * ats[4 * u + 1] + dad * atd[4 * u + 1],
+                               acc[4 * u + 2] + das * ats[4 * u + 2] + dad * atd[4 * u + 2], acc[4 * u + 3] + das * ats[4 * u + 3] + dad * atd[4 * u + 3]);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { p_as[u] += das * hj[u]; p_ad[u] += dad * hj[u]; p_b[u] += dj[u]; }
+    }
+    extern __shared__ float sm_f[];                                                   // [16][3 C]
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        sm_f[gl * 3 * C + sub * CH + u] = p_as[u]; sm_f[gl * 3 * C + C + sub * CH + u] = p_ad[u]; sm_f[gl * 3 * C + 2 * C + sub * CH + u] = p_b[u];
+    }
+    __syncthreads();
+    gat_part_row(sm_f, 3 * C, part + (size_t)blockIdx.x * PW, 3 * C);
+}
+
 // out[w] = sum over the GAT_BW_WGS partial rows, fixed order: a workgroup owns 32 columns and splits the rows 8 ways
-__global__ void __launch_bounds__(256) k_gat_param_reduce(const float *__restrict__ part, int PW, float *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_gat_param_reduce(const float *__restrict__ part, int PW, float *__restrict__ out, int rows) {
     __shared__ float sm[8][32];
     const int g = threadIdx.x >> 5, c = threadIdx.x & 31, w = blockIdx.x * 32 + c;
     float a0 = 0.f, a1 = 0.f;
     if (w < PW) {
-        for (int r = g; r < GAT_BW_WGS; r += 64) {              // 8 loads in flight
+        for (int r = g; r < rows; r += 64) {                    // 8 loads in flight (rows: a multiple of 64)
             float t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(r + 8 * u) * PW + w];
@@ -364,6 +571,27 @@ int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alph
     hipStream_t s = as_stream(stream);
     const int PW = 3 * channels + edge_dim;
     float *dpre_self = ws, *da_dst = ws + n, *dpre = ws + 2 * (size_t)n, *part = dpre + (num_edges > 0 ? num_edges : 1);
+#ifndef CONAN_GAT_NO_GROUP16     // (A/B switch of tools/ab.py: the round-2 wavefront-per-node kernels)
+    if (edge_dim <= 4 && (channels == 64 || channels == 128 || channels == 256)) {
+        const int wgs16 = gat_g_wgs(n);
+#define GAT_G16(CHN)                                                                                                                          \
+        do {                                                                                                                                  \
+            const size_t lds = (size_t)16 * 3 * 16 * CHN * sizeof(float);                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gat_bwd_source16<CHN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            k_gat_bwd_target16<CHN, 4><<<wgs16, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v,  \
+                                                                negative_slope, n, dpre, dpre_self, da_dst, part, PW);                        \
+            k_gat_bwd_source16<CHN><<<wgs16, 256, lds, s>>>(h, dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr,    \
+                                                               t_pos, t_tgt, n, dh, part, PW);                                                \
+        } while (0)
+        if (channels == 64) GAT_G16(4);
+        else if (channels == 128) GAT_G16(8);
+        else GAT_G16(16);
+#undef GAT_G16
+        k_gat_param_reduce<<<(PW + 31) / 32, 256, 0, s>>>(part, PW, dparams, wgs16);
+        CONAN_LAUNCH_CHECK();
+        return CONAN_OK;
+    }
+#endif
     if (edge_dim <= 4)
         k_gat_bwd_target<4><<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
                                                           channels, dpre, dpre_self, da_dst, part, PW);
@@ -372,7 +600,7 @@ int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alph
                                                                  negative_slope, n, channels, dpre, dpre_self, da_dst, part, PW);
     k_gat_bwd_source<<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, dpre, dpre_self, da_dst, att_src, att_dst, t_rowptr, t_pos, t_tgt, n,
                                                        channels, dh, part, PW);
-    k_gat_param_reduce<<<(PW + 31) / 32, 256, 0, s>>>(part, PW, dparams);
+    k_gat_param_reduce<<<(PW + 31) / 32, 256, 0, s>>>(part, PW, dparams, GAT_BW_WGS);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

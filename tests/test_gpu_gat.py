@@ -135,3 +135,41 @@ def test_gat_high_degree_rows_and_empty_graph():
     o0 = m(x.to(dev), e0.to(dev), torch.zeros(0, 3).to(dev), bt.to(dev), num_graphs=2)
     r0 = ref(x, e0, torch.zeros(0, 3), bt)
     assert rel(o0.detach().cpu().double().numpy(), r0.detach().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_gat_directed_graph_with_rows_around_the_staging_width(C):
+    """A random DIRECTED graph (in-degree != out-degree, 0..12 edges per row): rows up to 6 edges take the staged path of the 16-lane-group
+    backward kernels, longer ones the serial walk, in both roles of a node; C = 64 / 128 / 256 are the three channel splits (4 / 8 / 16
+    channels per lane)."""
+    from conan_fgw_amd.gat import GATBased
+    from oracle.gat import GATBasedOracle
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(C)
+    n = 300
+    src, dst = [], []
+    for i in range(n):
+        for j in torch.randperm(n, generator=gen)[: int(torch.randint(0, 13, (1,), generator=gen))].tolist():
+            if j != i:
+                src.append(j); dst.append(i)
+    ei = torch.tensor([src, dst], dtype=torch.int64)
+    ea = torch.randint(0, 4, (ei.shape[1], 3), generator=gen).float()
+    x = torch.randint(0, 6, (n, 9), generator=gen).float()
+    bt = (torch.arange(n) // 100).to(torch.int64)
+    torch.manual_seed(C + 1)
+    m = GATBased(out_channels=C).to(dev)
+    with torch.no_grad():
+        m.gat_conv1.bias.normal_(0, 0.1); m.gat_conv2.bias.normal_(0, 0.1)
+    ref = GATBasedOracle(out_channels=C).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    out = m(x.to(dev), ei.to(dev), ea.to(dev), bt.to(dev), num_graphs=3)
+    r = ref(x, ei, ea, bt)
+    assert rel(out.detach().cpu().double().numpy(), r.detach().numpy()) < 2e-6
+    wgt = torch.randn(3, C, generator=gen)
+    (out * wgt.to(dev)).sum().backward()
+    (r * wgt.double()).sum().backward()
+    gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
+    gmax = max(float(rp[k].grad.norm()) for k in rp)
+    for k in gp:
+        err = float((gp[k].grad.cpu().double() - rp[k].grad).norm())
+        assert err <= 1e-5 * float(rp[k].grad.norm()) + 1e-6 * gmax, (k, err)
