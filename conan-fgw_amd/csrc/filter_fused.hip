@@ -81,6 +81,7 @@ constexpr bool FF_H16 = false;
 constexpr bool FF_H16 = true;
 #endif
 constexpr int FF_NPL = FF_H16 ? 2 : 3;                       // operand planes
+constexpr int FF_OP = 36;                                    // pitch of the per-wave output slab (floats): 32 channels + 4
 
 template <int F>
 __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
@@ -97,6 +98,9 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     float *B1L = W2L + W2WORDS;           // [F]
     float *B2L = B1L + F;                 // [F]
     float *OFL = B2L + F;                 // [GP]
+    // fp16 form: a [32][FF_OP] output slab per wave — the outputs of a 32-channel block cross it so that a store instruction writes 8 rows
+    // x 128 contiguous bytes (whole lines) instead of 32 rows x 32 bytes that L2 has to merge (gemm_t.hip measured the effect)
+    float *OT = OFL + GP + (threadIdx.x >> 6) * (32 * FF_OP);
     __shared__ float wred[FF_THREADS / 64];
     float us1 = 1.0f, us2 = 1.0f;                                 // inverse plane scales of W1 / W2 (fp16 form)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -257,18 +261,32 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 acc1[mb][4 * q + 2] = ssp_f(fmaf(acc1[mb][4 * q + 2], us, bb.z));
                 acc1[mb][4 * q + 3] = ssp_f(fmaf(acc1[mb][4 * q + 3], us, bb.w));
             }
-        if (h1_out && valid) {
+        if (h1_out) {
+            // streaming stores: h1 is not read again before the backward pass, W is read by the very next kernel — without the hint
+            // the two 132 MB streams together overflow the 256 MiB Infinity Cache and the gather finds none of W there
+            typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb) {
+                if constexpr (FF_H16) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                {
-                    // streaming stores: h1 is not read again before the backward pass, W is read by the very next kernel — without the hint
-                    // the two 132 MB streams together overflow the 256 MiB Infinity Cache and the gather finds none of W there
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-                    const f4 hv4 = {acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]};
-                    __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)e * F + 32 * mb + 8 * q + 4 * h));
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) =
+                            make_float4(acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
+                        const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
+                        const f4 hv4 = {o.x, o.y, o.z, o.w};
+                        if ((tile << 5) + r < E) __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)((tile << 5) + r) * F + 32 * mb + c));
+                    }
+                } else if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f4 hv4 = {acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]};
+                        __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)e * F + 32 * mb + 8 * q + 4 * h));
+                    }
                 }
+            }
         }
 
         // ---------------- GEMM2^T in groups of NG output row-blocks (bounds the live accumulators: 16*(MB + NG) registers)
@@ -325,21 +343,29 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // epilogue: + b2, * C(d), store W[e, 32nb + 8q + 4h .. +3]
-            if (valid) {
+            // epilogue: + b2, * C(d), store W[e, 32nb + 8q + 4h .. +3] (fp16 form: through the slab, whole lines)
 #pragma unroll
-                for (int nb = 0; nb < NG; ++nb)
+            for (int nb = 0; nb < NG; ++nb) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 bb = *reinterpret_cast<const float4 *>(&B2L[32 * (n0 + nb) + 8 * q + 4 * h]);
-                        float4 o;
-                        const float us = us2;
-                        o.x = fmaf(acc2[nb][4 * q + 0], us, bb.x) * C;
-                        o.y = fmaf(acc2[nb][4 * q + 1], us, bb.y) * C;
-                        o.z = fmaf(acc2[nb][4 * q + 2], us, bb.z) * C;
-                        o.w = fmaf(acc2[nb][4 * q + 3], us, bb.w) * C;
-                        *reinterpret_cast<float4 *>(Wout + (size_t)e * F + 32 * (n0 + nb) + 8 * q + 4 * h) = o;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(&B2L[32 * (n0 + nb) + 8 * q + 4 * h]);
+                    float4 o;
+                    const float us = us2;
+                    o.x = fmaf(acc2[nb][4 * q + 0], us, bb.x) * C;
+                    o.y = fmaf(acc2[nb][4 * q + 1], us, bb.y) * C;
+                    o.z = fmaf(acc2[nb][4 * q + 2], us, bb.z) * C;
+                    o.w = fmaf(acc2[nb][4 * q + 3], us, bb.w) * C;
+                    if constexpr (FF_H16) *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) = o;
+                    else if (valid) *reinterpret_cast<float4 *>(Wout + (size_t)e * F + 32 * (n0 + nb) + 8 * q + 4 * h) = o;
+                }
+                if constexpr (FF_H16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
+                        const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
+                        if ((tile << 5) + r < E) *reinterpret_cast<float4 *>(Wout + (size_t)((tile << 5) + r) * F + 32 * (n0 + nb) + c) = o;
                     }
+                }
             }
         }
     }
@@ -349,7 +375,7 @@ template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP) * 4;
+    const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP + (FF_H16 ? (FF_THREADS / 64) * 32 * FF_OP : 0)) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;
