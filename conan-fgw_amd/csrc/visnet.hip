@@ -106,6 +106,11 @@ __global__ void k_vecdot(const float *__restrict__ vp, int n, int H, float *__re
 // Attention message + scalar aggregation (ViS_MP.message first half + aggregate, :632-645, :671):
 // attn_h = SiLU(sum_{c in head h} q_i k_j dk_e) * C(r_e);  vmsg_e = v_j * dv_e * attn_h;  xagg_i = sum_e vmsg_e.
 // One wavefront per target; lane l owns CPL consecutive channels; a head spans LPH lanes (xor-shuffle reduction).
+// Round 3: a row's col[] / dist[] entries are fetched once, one edge per lane, and handed out with cross-lane reads (a wave-uniform
+// index becomes a scalar register: row base in SGPRs, lane offset in a VGPR), and the rows of EB edges are requested before the first
+// of them is used — the loop was a chain of two dependent round trips per edge (index, then the k_j / v_j rows) and ran at 2.3 TB/s.
+// The sums run in edge order as before (bitwise-equal results).
+constexpr int VN_EB = 4;      // edges in flight per wavefront
 template <int CPL>
 __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                   const float *__restrict__ dk, const float *__restrict__ dv, const int *__restrict__ rowptr,
@@ -115,29 +120,48 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = lane * CPL;
     const bool on = c0 < H;
+    const int cl = on ? c0 : 0;                                       // idle lanes (H < 64 CPL) read column 0 and store nothing
     for (int i = wave; i < n; i += nw) {
         float qi[CPL], acc[CPL];
 #pragma unroll
-        for (int u = 0; u < CPL; ++u) { qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f; acc[u] = 0.f; }
-        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-            const int j = col[e];
-            float part = 0.f, dvv[CPL], vj[CPL];
+        for (int u = 0; u < CPL; ++u) { qi[u] = q[(size_t)i * H + cl + u]; acc[u] = 0.f; }
+        const int e0 = rowptr[i], e1 = rowptr[i + 1];
+        for (int base = e0; base < e1; base += 64) {
+            const int cnt = min(64, e1 - base);
+            const int my_j = lane < cnt ? col[base + lane] : 0;
+            const float my_c = lane < cnt ? cos_cutoff(dist[base + lane], cutoff) : 0.f;
+            for (int t = 0; t < cnt; t += VN_EB) {
+                float kj[VN_EB][CPL], vj[VN_EB][CPL], dke[VN_EB][CPL], dve[VN_EB][CPL];
 #pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                const float kj = on ? k[(size_t)j * H + c0 + u] : 0.f;
-                float dke = on ? dk[(size_t)e * H + c0 + u] : 0.f;
-                dvv[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
-                if (pre) { dke = silu_f(dke); dvv[u] = silu_f(dvv[u]); }      // dk / dv arrive as the projections' pre-activations
-                vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f;
-                part += qi[u] * kj * dke;
-            }
-            for (int o = 1; o < lph; o <<= 1) part += __shfl_xor(part, o, 64);
-            const float attn = silu_f(part) * cos_cutoff(dist[e], cutoff);
+                for (int b = 0; b < VN_EB; ++b) {
+                    const int tt = min(t + b, cnt - 1);                  // slots past the row repeat its last edge (not used)
+                    const int j = __shfl(my_j, tt, 64);
+                    const size_t e = (size_t)(base + tt);
 #pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                const float m = vj[u] * dvv[u] * attn;
-                if (on) vmsg[(size_t)e * H + c0 + u] = m;
-                acc[u] += m;
+                    for (int u = 0; u < CPL; ++u) {
+                        kj[b][u] = k[(size_t)j * H + cl + u]; vj[b][u] = v[(size_t)j * H + cl + u];
+                        dke[b][u] = dk[e * H + cl + u]; dve[b][u] = dv[e * H + cl + u];
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    if (t + b >= cnt) break;
+                    float part = 0.f;
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        if (pre) { dke[b][u] = silu_f(dke[b][u]); dve[b][u] = silu_f(dve[b][u]); }      // dk / dv arrive as the projections' pre-activations
+                        part += qi[u] * kj[b][u] * dke[b][u];
+                    }
+                    if (!on) part = 0.f;
+                    for (int o = 1; o < lph; o <<= 1) part += __shfl_xor(part, o, 64);
+                    const float attn = silu_f(part) * __shfl(my_c, t + b, 64);
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        const float m = vj[b][u] * dve[b][u] * attn;
+                        if (on) vmsg[(size_t)(base + t + b) * H + c0 + u] = m;
+                        acc[u] += m;
+                    }
+                }
             }
         }
         if (on)
@@ -147,9 +171,63 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
 }
 
 // Vector message + aggregation (:646-653, :672): vagg_i[sp] = sum_e vec_j[sp]*s1_e + s2_e*d_e[sp],  s = [s1|s2] in [E,2H]
+template <int CPL>
 __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__ vec, const float *__restrict__ s, const float *__restrict__ dvec,
                                                        const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int pre,
                                                        float *__restrict__ vagg) {
+    // lane <-> CPL consecutive channels (H = 64 CPL: one pass over the row); indices and unit vectors handed out per lane, VN_EB edges in flight
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int c0 = lane * CPL;
+    for (int i = wave; i < n; i += nw) {
+        float a0[CPL], a1[CPL], a2[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) { a0[u] = 0.f; a1[u] = 0.f; a2[u] = 0.f; }
+        const int e0 = rowptr[i], e1 = rowptr[i + 1];
+        for (int base = e0; base < e1; base += 64) {
+            const int cnt = min(64, e1 - base);
+            const int my_j = lane < cnt ? col[base + lane] : 0;
+            float my_d[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec[(size_t)(base + lane) * 3 + sp] : 0.f;
+            for (int t = 0; t < cnt; t += VN_EB) {
+                float s1[VN_EB][CPL], s2[VN_EB][CPL], vj[VN_EB][3][CPL];
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    const int tt = min(t + b, cnt - 1);
+                    const int j = __shfl(my_j, tt, 64);
+                    const size_t e = (size_t)(base + tt);
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        s1[b][u] = s[e * 2 * H + c0 + u]; s2[b][u] = s[e * 2 * H + H + c0 + u];
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) vj[b][sp][u] = vec[((size_t)j * 3 + sp) * H + c0 + u];
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    if (t + b >= cnt) break;
+                    const float d0 = __shfl(my_d[0], t + b, 64), d1 = __shfl(my_d[1], t + b, 64), d2 = __shfl(my_d[2], t + b, 64);
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        float x1 = s1[b][u], x2 = s2[b][u];
+                        if (pre) { x1 = silu_f(x1); x2 = silu_f(x2); }             // s arrives as s_proj's pre-activation
+                        a0[u] += vj[b][0][u] * x1 + x2 * d0;
+                        a1[u] += vj[b][1][u] * x1 + x2 * d1;
+                        a2[u] += vj[b][2][u] * x1 + x2 * d2;
+                    }
+                }
+            }
+        }
+        float *o = vagg + (size_t)i * 3 * H;
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) { o[c0 + u] = a0[u]; o[H + c0 + u] = a1[u]; o[2 * H + c0 + u] = a2[u]; }
+    }
+}
+// any H: lane <-> channel, strided passes (the round-1 form)
+__global__ void __launch_bounds__(256) k_vec_aggregate_any(const float *__restrict__ vec, const float *__restrict__ s, const float *__restrict__ dvec,
+                                                           const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int pre,
+                                                           float *__restrict__ vagg) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw) {
@@ -158,7 +236,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
             for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
                 const int j = col[e];
                 float s1 = s[(size_t)e * 2 * H + c], s2 = s[(size_t)e * 2 * H + H + c];
-                if (pre) { s1 = silu_f(s1); s2 = silu_f(s2); }                 // s arrives as s_proj's pre-activation
+                if (pre) { s1 = silu_f(s1); s2 = silu_f(s2); }
                 const float *vj = vec + (size_t)j * 3 * H;
                 a0 += vj[c] * s1 + s2 * dvec[e * 3];
                 a1 += vj[H + c] * s1 + s2 * dvec[e * 3 + 1];
@@ -305,7 +383,9 @@ int conan_visnet_vec_aggregate(const float *vec, const float *s, const float *dv
                                int pre_act, float *vagg, void *stream) {
     VN_CHECK(vec && s && dvec && rowptr && col && vagg && n >= 0 && H > 0);
     if (n == 0) return CONAN_OK;
-    k_vec_aggregate<<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
+    if (H == 128) k_vec_aggregate<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
+    else if (H == 64) k_vec_aggregate<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
+    else k_vec_aggregate_any<<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_node_update(const float *x, const float *vec, const float *vdot, const float *o, const float *vp, const float *vagg, int n,
