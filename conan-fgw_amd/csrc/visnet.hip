@@ -110,7 +110,30 @@ __global__ void k_vecdot(const float *__restrict__ vp, int n, int H, float *__re
 // index becomes a scalar register: row base in SGPRs, lane offset in a VGPR), and the rows of EB edges are requested before the first
 // of them is used — the loop was a chain of two dependent round trips per edge (index, then the k_j / v_j rows) and ran at 2.3 TB/s.
 // The sums run in edge order as before (bitwise-equal results).
+// CPL consecutive channels of one row as ONE load / store (float2 for CPL = 2: c0 is even and every row starts at a multiple of H floats from a
+// 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
+template <int CPL>
+__device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
+    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) r[u] = p[u];
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
+    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) p[u] = r[u];
+    }
+}
+
 constexpr int VN_EB = 4;      // edges in flight per wavefront
+#ifndef CONAN_VB_RUN
+#define CONAN_VB_RUN 16
+#endif
+constexpr int VN_RUN = CONAN_VB_RUN;    // edges per wavefront in the kernels that walk runs of consecutive edges (64 left too few wavefronts in flight)
 template <int CPL>
 __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                   const float *__restrict__ dk, const float *__restrict__ dv, const int *__restrict__ rowptr,
@@ -137,11 +160,8 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
                     const int tt = min(t + b, cnt - 1);                  // slots past the row repeat its last edge (not used)
                     const int j = __shfl(my_j, tt, 64);
                     const size_t e = (size_t)(base + tt);
-#pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        kj[b][u] = k[(size_t)j * H + cl + u]; vj[b][u] = v[(size_t)j * H + cl + u];
-                        dke[b][u] = dk[e * H + cl + u]; dve[b][u] = dv[e * H + cl + u];
-                    }
+                    vld<CPL>(k + (size_t)j * H + cl, kj[b]); vld<CPL>(v + (size_t)j * H + cl, vj[b]);
+                    vld<CPL>(dk + e * H + cl, dke[b]); vld<CPL>(dv + e * H + cl, dve[b]);
                 }
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
@@ -155,12 +175,10 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
                     if (!on) part = 0.f;
                     for (int o = 1; o < lph; o <<= 1) part += __shfl_xor(part, o, 64);
                     const float attn = silu_f(part) * __shfl(my_c, t + b, 64);
+                    float m[CPL];
 #pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        const float m = vj[b][u] * dve[b][u] * attn;
-                        if (on) vmsg[(size_t)(base + t + b) * H + c0 + u] = m;
-                        acc[u] += m;
-                    }
+                    for (int u = 0; u < CPL; ++u) { m[u] = vj[b][u] * dve[b][u] * attn; acc[u] += m[u]; }
+                    if (on) vst<CPL>(vmsg + (size_t)(base + t + b) * H + c0, m);
                 }
             }
         }
@@ -197,12 +215,9 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
                     const int tt = min(t + b, cnt - 1);
                     const int j = __shfl(my_j, tt, 64);
                     const size_t e = (size_t)(base + tt);
+                    vld<CPL>(s + e * 2 * H + c0, s1[b]); vld<CPL>(s + e * 2 * H + H + c0, s2[b]);
 #pragma unroll
-                    for (int u = 0; u < CPL; ++u) {
-                        s1[b][u] = s[e * 2 * H + c0 + u]; s2[b][u] = s[e * 2 * H + H + c0 + u];
-#pragma unroll
-                        for (int sp = 0; sp < 3; ++sp) vj[b][sp][u] = vec[((size_t)j * 3 + sp) * H + c0 + u];
-                    }
+                    for (int sp = 0; sp < 3; ++sp) vld<CPL>(vec + ((size_t)j * 3 + sp) * H + c0, vj[b][sp]);
                 }
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
@@ -266,22 +281,55 @@ __global__ void k_node_update(const float *__restrict__ x, const float *__restri
 
 // Edge update (:655-661): w1 = rej(wt[tgt], d), w2 = rej(ws[src], -d), f' = f + SiLU(f_proj(f)) * sum_sp w1*w2
 // wt = w_trg_proj(vec), ws = w_src_proj(vec) are node-level [n,3,H]; t = SiLU(f_proj(f_ij)) [E,H]
-__global__ void k_edge_update(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t, const float *__restrict__ dvec,
-                              const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H,
-                              int pre, const float *__restrict__ f, float *__restrict__ fo) {
+// One wavefront per run of VN_RUN consecutive edges (round 3; was one thread per element: a 64-bit division, two index loads and six gathered
+// rows per ELEMENT, each waiting for its index): sources, targets and unit vectors of the run are fetched once, one edge per lane, and
+// handed out; lane <-> CPL channels; VN_EB edges in flight (consecutive edges share their target: its rows are L1 hits).
+template <int CPL>
+__global__ void __launch_bounds__(256) k_edge_update(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t,
+                                                     const float *__restrict__ dvec, const int *__restrict__ col, const int *__restrict__ tgt,
+                                                     const int *__restrict__ ne_dev, int max_edges, int H, int pre, const float *__restrict__ f,
+                                                     float *__restrict__ fo) {
     const int E = min(*ne_dev, max_edges);
-    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
-        const int e = (int)(q / H), c = (int)(q - (long long)e * H);
-        const float d0 = dvec[e * 3], d1 = dvec[e * 3 + 1], d2 = dvec[e * 3 + 2];
-        const float *a = wt + (size_t)tgt[e] * 3 * H, *b = ws + (size_t)col[e] * 3 * H;
-        const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c], b0 = b[c], b1 = b[H + c], b2 = b[2 * H + c];
-        const float pa = a0 * d0 + a1 * d1 + a2 * d2;                 // vec . d
-        const float pb = b0 * (-d0) + b1 * (-d1) + b2 * (-d2);        // vec . (-d)
-        const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
-        const float w20 = b0 - pb * (-d0), w21 = b1 - pb * (-d1), w22 = b2 - pb * (-d2);
-        const float tv = pre ? silu_f(t[q]) : t[q];                  // t arrives as f_proj's pre-activation
-        fo[q] = f[q] + tv * (w10 * w20 + w11 * w21 + w12 * w22);
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
+        const int cnt = min(VN_RUN, E - base);
+        const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
+        float my_d[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec[(size_t)(base + lane) * 3 + sp] : 0.f;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += VN_EB) {
+                float aa[VN_EB][3][CPL], bb[VN_EB][3][CPL], tv[VN_EB][CPL], fv[VN_EB][CPL];
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    const int tt = min(tq + b, cnt - 1);
+                    const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64), e = (size_t)(base + tt);
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) { vld<CPL>(wt + (i * 3 + sp) * H + cl, aa[b][sp]); vld<CPL>(ws + (j * 3 + sp) * H + cl, bb[b][sp]); }
+                    vld<CPL>(t + e * H + cl, tv[b]); vld<CPL>(f + e * H + cl, fv[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    if (tq + b >= cnt) break;
+                    const size_t e = (size_t)(base + tq + b);
+                    const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                    float ov[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        const float a0 = aa[b][0][u], a1 = aa[b][1][u], a2 = aa[b][2][u], b0 = bb[b][0][u], b1 = bb[b][1][u], b2 = bb[b][2][u];
+                        const float pa = a0 * d0 + a1 * d1 + a2 * d2;                 // vec . d
+                        const float pb = b0 * (-d0) + b1 * (-d1) + b2 * (-d2);        // vec . (-d)
+                        const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
+                        const float w20 = b0 - pb * (-d0), w21 = b1 - pb * (-d1), w22 = b2 - pb * (-d2);
+                        const float tvv = pre ? silu_f(tv[b][u]) : tv[b][u];          // t arrives as f_proj's pre-activation
+                        ov[u] = fv[b][u] + tvv * (w10 * w20 + w11 * w21 + w12 * w22);
+                    }
+                    if (on) vst<CPL>(fo + e * H + c0, ov);
+                }
+            }
+        }
     }
 }
 
@@ -397,7 +445,8 @@ int conan_visnet_node_update(const float *x, const float *vec, const float *vdot
 int conan_visnet_edge_update(const float *wt, const float *ws, const float *t, const float *dvec, const int *col, const int *tgt,
                              const int *num_edges_dev, int max_edges, int H, int pre_act, const float *f, float *f_out, void *stream) {
     VN_CHECK(wt && ws && t && dvec && col && tgt && num_edges_dev && f && f_out && H > 0);
-    k_edge_update<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
+    if (H % 128 == 0) k_edge_update<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
+    else k_edge_update<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_spatial_norm(const float *v, int n, int H, float *out, void *stream) {

@@ -146,6 +146,34 @@ __device__ __forceinline__ void attn_edge(const float *qi, const float *kj, cons
     da = t1 * cut * (sg * (1.0f + part * (1.0f - sg)));        // d attn * C * SiLU'(a)
 }
 
+// Round 3 (all row-walking kernels below): a row's indices (and what hangs off them per edge: target, cutoff, unit vector) are fetched once,
+// one edge per lane, and handed out with cross-lane reads; the rows of VB_EB edges are requested before the first is used.  The loops were
+// chains of two or three dependent round trips per edge (2.3-3 TB/s); the sums still run in list order (bitwise-equal results).
+// CPL consecutive channels of one row as ONE load / store (float2 for CPL = 2: c0 is even and every row starts at a multiple of H floats from a
+// 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
+template <int CPL>
+__device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
+    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) r[u] = p[u];
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
+    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) p[u] = r[u];
+    }
+}
+
+constexpr int VB_EB = 4;
+#ifndef CONAN_VB_RUN
+#define CONAN_VB_RUN 16
+#endif
+constexpr int VB_RUN = CONAN_VB_RUN;     // edges per wavefront in the kernels that walk runs of consecutive edges
+
 // target side: dq[i] (sum over row i), and the edge gradients d dk[e], d dv[e]
 template <int CPL>
 __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
@@ -157,27 +185,48 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = lane * CPL;
     const bool on = c0 < H;
+    const int cl = on ? c0 : 0;                                       // idle lanes read column 0 and store nothing
     for (int i = wave; i < n; i += nw) {
         float qi[CPL], gx[CPL], acc[CPL];
 #pragma unroll
-        for (int u = 0; u < CPL; ++u) { qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f; gx[u] = on ? dxagg[(size_t)i * H + c0 + u] : 0.f; acc[u] = 0.f; }
-        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-            const int j = col[e];
-            float kj[CPL], vj[CPL], dke[CPL], dve[CPL], dm[CPL], sk[CPL], sv[CPL];
+        for (int u = 0; u < CPL; ++u) { qi[u] = on ? q[(size_t)i * H + cl + u] : 0.f; gx[u] = dxagg[(size_t)i * H + cl + u]; acc[u] = 0.f; }
+        const int e0 = rowptr[i], e1 = rowptr[i + 1];
+        for (int base = e0; base < e1; base += 64) {
+            const int cnt = min(64, e1 - base);
+            const int my_j = lane < cnt ? col[base + lane] : 0;
+            const float my_c = lane < cnt ? cos_cutoff(dist[base + lane], cutoff) : 0.f;
+            for (int t = 0; t < cnt; t += VB_EB) {
+                float kj[VB_EB][CPL], vj[VB_EB][CPL], dke[VB_EB][CPL], dve[VB_EB][CPL], dm[VB_EB][CPL];
 #pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                kj[u] = on ? k[(size_t)j * H + c0 + u] : 0.f; vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f;
-                dke[u] = on ? dk[(size_t)e * H + c0 + u] : 0.f; dve[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
-                sk[u] = 1.f; sv[u] = 1.f;
-                if (pre) { sk[u] = dsilu_f(dke[u]); sv[u] = dsilu_f(dve[u]); dke[u] = silu_f(dke[u]); dve[u] = silu_f(dve[u]); }   // pre-activations in, gradients w.r.t. them out
-                dm[u] = on ? dvmsg[(size_t)e * H + c0 + u] + gx[u] : 0.f;
-            }
-            float attn, da;
-            attn_edge<CPL>(qi, kj, vj, dke, dve, dm, cos_cutoff(dist[e], cutoff), lph, attn, da);
+                for (int b = 0; b < VB_EB; ++b) {
+                    const int tt = min(t + b, cnt - 1);
+                    const int j = __shfl(my_j, tt, 64);
+                    const size_t e = (size_t)(base + tt);
+                    vld<CPL>(k + (size_t)j * H + cl, kj[b]); vld<CPL>(v + (size_t)j * H + cl, vj[b]);
+                    vld<CPL>(dk + e * H + cl, dke[b]); vld<CPL>(dv + e * H + cl, dve[b]); vld<CPL>(dvmsg + e * H + cl, dm[b]);
+                }
 #pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                if (on) { ddv[(size_t)e * H + c0 + u] = dm[u] * vj[u] * attn * sv[u]; ddk[(size_t)e * H + c0 + u] = da * qi[u] * kj[u] * sk[u]; }
-                acc[u] += da * kj[u] * dke[u];
+                for (int b = 0; b < VB_EB; ++b) {
+                    if (t + b >= cnt) break;
+                    const size_t e = (size_t)(base + t + b);
+                    float sk[CPL], sv[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        sk[u] = 1.f; sv[u] = 1.f;
+                        if (pre) { sk[u] = dsilu_f(dke[b][u]); sv[u] = dsilu_f(dve[b][u]); dke[b][u] = silu_f(dke[b][u]); dve[b][u] = silu_f(dve[b][u]); }   // pre-activations in, gradients w.r.t. them out
+                        dm[b][u] = on ? dm[b][u] + gx[u] : 0.f;
+                        if (!on) { kj[b][u] = 0.f; vj[b][u] = 0.f; dke[b][u] = 0.f; dve[b][u] = 0.f; }
+                    }
+                    float attn, da;
+                    attn_edge<CPL>(qi, kj[b], vj[b], dke[b], dve[b], dm[b], __shfl(my_c, t + b, 64), lph, attn, da);
+                    float o1[CPL], o2[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        o1[u] = dm[b][u] * vj[b][u] * attn * sv[u]; o2[u] = da * qi[u] * kj[b][u] * sk[u];
+                        acc[u] += da * kj[b][u] * dke[b][u];
+                    }
+                    if (on) { vst<CPL>(ddv + e * H + c0, o1); vst<CPL>(ddk + e * H + c0, o2); }
+                }
             }
         }
         if (on)
@@ -196,24 +245,41 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = lane * CPL;
     const bool on = c0 < H;
+    const int cl = on ? c0 : 0;
     for (int j = wave; j < n; j += nw) {
         float kj[CPL], vj[CPL], ak[CPL], av[CPL];
 #pragma unroll
-        for (int u = 0; u < CPL; ++u) { kj[u] = on ? k[(size_t)j * H + c0 + u] : 0.f; vj[u] = on ? v[(size_t)j * H + c0 + u] : 0.f; ak[u] = 0.f; av[u] = 0.f; }
-        for (int s = t_rowptr[j]; s < t_rowptr[j + 1]; ++s) {
-            const int e = t_eid[s], i = tgt[e];
-            float qi[CPL], dke[CPL], dve[CPL], dm[CPL];
+        for (int u = 0; u < CPL; ++u) { kj[u] = on ? k[(size_t)j * H + cl + u] : 0.f; vj[u] = on ? v[(size_t)j * H + cl + u] : 0.f; ak[u] = 0.f; av[u] = 0.f; }
+        const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
+        for (int base = s0; base < s1; base += 64) {
+            const int cnt = min(64, s1 - base);
+            const int my_e = lane < cnt ? t_eid[base + lane] : 0;
+            const int my_i = lane < cnt ? tgt[my_e] : 0;
+            const float my_c = lane < cnt ? cos_cutoff(dist[my_e], cutoff) : 0.f;
+            for (int t = 0; t < cnt; t += VB_EB) {
+                float qi[VB_EB][CPL], dke[VB_EB][CPL], dve[VB_EB][CPL], dm[VB_EB][CPL], gx[VB_EB][CPL];
 #pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                qi[u] = on ? q[(size_t)i * H + c0 + u] : 0.f;
-                dke[u] = on ? dk[(size_t)e * H + c0 + u] : 0.f; dve[u] = on ? dv[(size_t)e * H + c0 + u] : 0.f;
-                if (pre) { dke[u] = silu_f(dke[u]); dve[u] = silu_f(dve[u]); }
-                dm[u] = on ? dvmsg[(size_t)e * H + c0 + u] + dxagg[(size_t)i * H + c0 + u] : 0.f;
+                for (int b = 0; b < VB_EB; ++b) {
+                    const int tt = min(t + b, cnt - 1);
+                    const size_t e = (size_t)__shfl(my_e, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
+                    vld<CPL>(q + i * H + cl, qi[b]); vld<CPL>(dxagg + i * H + cl, gx[b]);
+                    vld<CPL>(dk + e * H + cl, dke[b]); vld<CPL>(dv + e * H + cl, dve[b]); vld<CPL>(dvmsg + e * H + cl, dm[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) {
+                    if (t + b >= cnt) break;
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        if (pre) { dke[b][u] = silu_f(dke[b][u]); dve[b][u] = silu_f(dve[b][u]); }
+                        dm[b][u] = on ? dm[b][u] + gx[b][u] : 0.f;
+                        if (!on) { qi[b][u] = 0.f; dke[b][u] = 0.f; dve[b][u] = 0.f; }
+                    }
+                    float attn, da;
+                    attn_edge<CPL>(qi[b], kj, vj, dke[b], dve[b], dm[b], __shfl(my_c, t + b, 64), lph, attn, da);
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) { ak[u] += da * qi[b][u] * dke[b][u]; av[u] += dm[b][u] * dve[b][u] * attn; }
+                }
             }
-            float attn, da;
-            attn_edge<CPL>(qi, kj, vj, dke, dve, dm, cos_cutoff(dist[e], cutoff), lph, attn, da);
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) { ak[u] += da * qi[u] * dke[u]; av[u] += dm[u] * dve[u] * attn; }
         }
         if (on)
 #pragma unroll
@@ -223,39 +289,98 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
 
 // ---------------------------------------------------------------------------------------------- vector aggregate backward
 // ds[e] = [ sum_sp dvagg[tgt,sp]*vec[src,sp] | sum_sp dvagg[tgt,sp]*d_e[sp] ]
-__global__ void k_vec_aggregate_bwd_s(const float *__restrict__ vec, const float *__restrict__ dvagg, const float *__restrict__ dvec3,
-                                      const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges,
-                                      int H, const float *__restrict__ s_pre, float *__restrict__ ds) {
+template <int CPL>
+__global__ void __launch_bounds__(256) k_vec_aggregate_bwd_s(const float *__restrict__ vec, const float *__restrict__ dvagg, const float *__restrict__ dvec3,
+                                                             const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev,
+                                                             int max_edges, int H, const float *__restrict__ s_pre, float *__restrict__ ds) {
+    // one wavefront per run of VB_RUN consecutive edges, indices and unit vectors handed out per lane, VB_EB edges in flight (see k_edge_update)
     const int E = min(*ne_dev, max_edges);
-    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int e = (int)(t / H), c = (int)(t - (long long)e * H);
-        const float *g = dvagg + (size_t)tgt[e] * 3 * H, *vj = vec + (size_t)col[e] * 3 * H;
-        const float g0 = g[c], g1 = g[H + c], g2 = g[2 * H + c];
-        float r1 = g0 * vj[c] + g1 * vj[H + c] + g2 * vj[2 * H + c];
-        float r2 = g0 * dvec3[e * 3] + g1 * dvec3[e * 3 + 1] + g2 * dvec3[e * 3 + 2];
-        if (s_pre) { r1 *= dsilu_f(s_pre[(size_t)e * 2 * H + c]); r2 *= dsilu_f(s_pre[(size_t)e * 2 * H + H + c]); }   // gradient w.r.t. the pre-activation
-        ds[(size_t)e * 2 * H + c] = r1;
-        ds[(size_t)e * 2 * H + H + c] = r2;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int base = wave * VB_RUN; base < E; base += nw * VB_RUN) {
+        const int cnt = min(VB_RUN, E - base);
+        const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
+        float my_d[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec3[(size_t)(base + lane) * 3 + sp] : 0.f;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += VB_EB) {
+                float g[VB_EB][3][CPL], vj[VB_EB][3][CPL], p1[VB_EB][CPL], p2[VB_EB][CPL];
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) {
+                    const int tt = min(tq + b, cnt - 1);
+                    const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64), e = (size_t)(base + tt);
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) { vld<CPL>(dvagg + (i * 3 + sp) * H + cl, g[b][sp]); vld<CPL>(vec + (j * 3 + sp) * H + cl, vj[b][sp]); }
+                    if (s_pre) { vld<CPL>(s_pre + e * 2 * H + cl, p1[b]); vld<CPL>(s_pre + e * 2 * H + H + cl, p2[b]); }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) { p1[b][u] = 0.f; p2[b][u] = 0.f; }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) {
+                    if (tq + b >= cnt) break;
+                    const size_t e = (size_t)(base + tq + b);
+                    const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                    float r1[CPL], r2[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) {
+                        const float g0 = g[b][0][u], g1 = g[b][1][u], g2 = g[b][2][u];
+                        r1[u] = g0 * vj[b][0][u] + g1 * vj[b][1][u] + g2 * vj[b][2][u];
+                        r2[u] = g0 * d0 + g1 * d1 + g2 * d2;
+                        if (s_pre) { r1[u] *= dsilu_f(p1[b][u]); r2[u] *= dsilu_f(p2[b][u]); }   // gradient w.r.t. the pre-activation
+                    }
+                    if (on) { vst<CPL>(ds + e * 2 * H + c0, r1); vst<CPL>(ds + e * 2 * H + H + c0, r2); }
+                }
+            }
+        }
     }
 }
 // dvec[j,sp] = sum_{e in srclist(j)} dvagg[tgt_e,sp] * s1_e
+template <int CPL>
 __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__restrict__ s, const float *__restrict__ dvagg, const int *__restrict__ t_rowptr,
                                                              const int *__restrict__ t_eid, const int *__restrict__ tgt, int n, int H, int pre,
                                                              float *__restrict__ dvec) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
-        for (int c = lane; c < H; c += 64) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            for (int q = t_rowptr[j]; q < t_rowptr[j + 1]; ++q) {
-                const int e = t_eid[q];
-                const float s1 = pre ? silu_f(s[(size_t)e * 2 * H + c]) : s[(size_t)e * 2 * H + c];
-                const float *g = dvagg + (size_t)tgt[e] * 3 * H;
-                a0 += g[c] * s1; a1 += g[H + c] * s1; a2 += g[2 * H + c] * s1;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;                        // H = 64 CPL: one pass; every lane walks the row (idle ones: column 0, no stores)
+            float a0[CPL], a1[CPL], a2[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { a0[u] = 0.f; a1[u] = 0.f; a2[u] = 0.f; }
+            const int q0 = t_rowptr[j], q1 = t_rowptr[j + 1];
+            for (int base = q0; base < q1; base += 64) {
+                const int cnt = min(64, q1 - base);
+                const int my_e = lane < cnt ? t_eid[base + lane] : 0;
+                const int my_i = lane < cnt ? tgt[my_e] : 0;
+                for (int t = 0; t < cnt; t += VB_EB) {
+                    float s1[VB_EB][CPL], g[VB_EB][3][CPL];
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        const int tt = min(t + b, cnt - 1);
+                        const size_t e = (size_t)__shfl(my_e, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
+                        vld<CPL>(s + e * 2 * H + cl, s1[b]);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) vld<CPL>(dvagg + (i * 3 + sp) * H + cl, g[b][sp]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        if (t + b >= cnt) break;
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const float x1 = pre ? silu_f(s1[b][u]) : s1[b][u];
+                            a0[u] += g[b][0][u] * x1; a1[u] += g[b][1][u] * x1; a2[u] += g[b][2][u] * x1;
+                        }
+                    }
+                }
             }
             float *o = dvec + (size_t)j * 3 * H;
-            o[c] = a0; o[H + c] = a1; o[2 * H + c] = a2;
+            if (on)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { o[c0 + u] = a0[u]; o[H + c0 + u] = a1[u]; o[2 * H + c0 + u] = a2[u]; }
         }
 }
 
@@ -286,58 +411,116 @@ __global__ void k_node_update_bwd(const float *__restrict__ dxo, const float *__
 // ---------------------------------------------------------------------------------------------- edge update backward
 // forward: fo = f + t * sum_sp w1*w2, w1 = a - (a.d)d, w2 = b - (b.d)d  (a = wt[tgt], b = ws[src]; the sign of d cancels)
 // target pass: dwt[i] = sum_{e in row(i)} P_d (g * w2), and dt[e] = dfo * (w1.w2)   with g = dfo * t, P_d u = u - (u.d)d
+template <int CPL>
 __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t,
                                                            const float *__restrict__ dvec3, const float *__restrict__ dfo, const int *__restrict__ rowptr,
                                                            const int *__restrict__ col, int n, int H, int pre, float *__restrict__ dwt, float *__restrict__ dt) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
-        for (int c = lane; c < H; c += 64) {
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
             const float *a = wt + (size_t)i * 3 * H;
-            const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c];
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-                const float d0 = dvec3[e * 3], d1 = dvec3[e * 3 + 1], d2 = dvec3[e * 3 + 2];
-                const float *b = ws + (size_t)col[e] * 3 * H;
-                const float b0 = b[c], b1 = b[H + c], b2 = b[2 * H + c];
-                const float pa = a0 * d0 + a1 * d1 + a2 * d2, pb = b0 * d0 + b1 * d1 + b2 * d2;
-                const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
-                const float w20 = b0 - pb * d0, w21 = b1 - pb * d1, w22 = b2 - pb * d2;
-                const float gf = dfo[(size_t)e * H + c];
-                const float tr = t[(size_t)e * H + c];
-                dt[(size_t)e * H + c] = gf * (w10 * w20 + w11 * w21 + w12 * w22) * (pre ? dsilu_f(tr) : 1.0f);
-                const float g = gf * (pre ? silu_f(tr) : tr);
-                const float u0 = g * w20, u1 = g * w21, u2 = g * w22;
-                const float pu = u0 * d0 + u1 * d1 + u2 * d2;
-                s0 += u0 - pu * d0; s1 += u1 - pu * d1; s2 += u2 - pu * d2;
+            float a0[CPL], a1[CPL], a2[CPL], s0[CPL], s1[CPL], s2[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { a0[u] = a[cl + u]; a1[u] = a[H + cl + u]; a2[u] = a[2 * H + cl + u]; s0[u] = 0.f; s1[u] = 0.f; s2[u] = 0.f; }
+            const int e0 = rowptr[i], e1 = rowptr[i + 1];
+            for (int base = e0; base < e1; base += 64) {
+                const int cnt = min(64, e1 - base);
+                const int my_j = lane < cnt ? col[base + lane] : 0;
+                float my_d[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec3[(size_t)(base + lane) * 3 + sp] : 0.f;
+                for (int tq = 0; tq < cnt; tq += VB_EB) {
+                    float bb[VB_EB][3][CPL], gf[VB_EB][CPL], tr[VB_EB][CPL];
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        const int tt = min(tq + b, cnt - 1);
+                        const size_t j = (size_t)__shfl(my_j, tt, 64), e = (size_t)(base + tt);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) vld<CPL>(ws + (j * 3 + sp) * H + cl, bb[b][sp]);
+                        vld<CPL>(dfo + e * H + cl, gf[b]); vld<CPL>(t + e * H + cl, tr[b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        if (tq + b >= cnt) break;
+                        const size_t e = (size_t)(base + tq + b);
+                        const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                        float dtv[CPL];
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const float b0 = bb[b][0][u], b1 = bb[b][1][u], b2 = bb[b][2][u];
+                            const float pa = a0[u] * d0 + a1[u] * d1 + a2[u] * d2, pb = b0 * d0 + b1 * d1 + b2 * d2;
+                            const float w10 = a0[u] - pa * d0, w11 = a1[u] - pa * d1, w12 = a2[u] - pa * d2;
+                            const float w20 = b0 - pb * d0, w21 = b1 - pb * d1, w22 = b2 - pb * d2;
+                            dtv[u] = gf[b][u] * (w10 * w20 + w11 * w21 + w12 * w22) * (pre ? dsilu_f(tr[b][u]) : 1.0f);
+                            const float g = gf[b][u] * (pre ? silu_f(tr[b][u]) : tr[b][u]);
+                            const float u0 = g * w20, u1 = g * w21, u2 = g * w22;
+                            const float pu = u0 * d0 + u1 * d1 + u2 * d2;
+                            s0[u] += u0 - pu * d0; s1[u] += u1 - pu * d1; s2[u] += u2 - pu * d2;
+                        }
+                        if (on) vst<CPL>(dt + e * H + c0, dtv);
+                    }
+                }
             }
             float *o = dwt + (size_t)i * 3 * H;
-            o[c] = s0; o[H + c] = s1; o[2 * H + c] = s2;
+            if (on)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { o[c0 + u] = s0[u]; o[H + c0 + u] = s1[u]; o[2 * H + c0 + u] = s2[u]; }
         }
 }
 // source pass: dws[j] = sum_{e in srclist(j)} P_d (g * w1)
+template <int CPL>
 __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restrict__ wt, const float *__restrict__ t, const float *__restrict__ dvec3,
                                                            const float *__restrict__ dfo, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                            const int *__restrict__ tgt, int n, int H, int pre, float *__restrict__ dws) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
-        for (int c = lane; c < H; c += 64) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            for (int q = t_rowptr[j]; q < t_rowptr[j + 1]; ++q) {
-                const int e = t_eid[q];
-                const float d0 = dvec3[e * 3], d1 = dvec3[e * 3 + 1], d2 = dvec3[e * 3 + 2];
-                const float *a = wt + (size_t)tgt[e] * 3 * H;
-                const float a0 = a[c], a1 = a[H + c], a2 = a[2 * H + c];
-                const float pa = a0 * d0 + a1 * d1 + a2 * d2;
-                const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
-                const float g = dfo[(size_t)e * H + c] * (pre ? silu_f(t[(size_t)e * H + c]) : t[(size_t)e * H + c]);
-                const float u0 = g * w10, u1 = g * w11, u2 = g * w12;
-                const float pu = u0 * d0 + u1 * d1 + u2 * d2;
-                s0 += u0 - pu * d0; s1 += u1 - pu * d1; s2 += u2 - pu * d2;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            float s0[CPL], s1[CPL], s2[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { s0[u] = 0.f; s1[u] = 0.f; s2[u] = 0.f; }
+            const int q0 = t_rowptr[j], q1 = t_rowptr[j + 1];
+            for (int base = q0; base < q1; base += 64) {
+                const int cnt = min(64, q1 - base);
+                const int my_e = lane < cnt ? t_eid[base + lane] : 0;
+                const int my_i = lane < cnt ? tgt[my_e] : 0;
+                float my_d[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec3[(size_t)my_e * 3 + sp] : 0.f;
+                for (int tq = 0; tq < cnt; tq += VB_EB) {
+                    float aa[VB_EB][3][CPL], gf[VB_EB][CPL], tr[VB_EB][CPL];
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        const int tt = min(tq + b, cnt - 1);
+                        const size_t e = (size_t)__shfl(my_e, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) vld<CPL>(wt + (i * 3 + sp) * H + cl, aa[b][sp]);
+                        vld<CPL>(dfo + e * H + cl, gf[b]); vld<CPL>(t + e * H + cl, tr[b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        if (tq + b >= cnt) break;
+                        const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) {
+                            const float a0 = aa[b][0][u], a1 = aa[b][1][u], a2 = aa[b][2][u];
+                            const float pa = a0 * d0 + a1 * d1 + a2 * d2;
+                            const float w10 = a0 - pa * d0, w11 = a1 - pa * d1, w12 = a2 - pa * d2;
+                            const float g = gf[b][u] * (pre ? silu_f(tr[b][u]) : tr[b][u]);
+                            const float u0 = g * w10, u1 = g * w11, u2 = g * w12;
+                            const float pu = u0 * d0 + u1 * d1 + u2 * d2;
+                            s0[u] += u0 - pu * d0; s1[u] += u1 - pu * d1; s2[u] += u2 - pu * d2;
+                        }
+                    }
+                }
             }
             float *o = dws + (size_t)j * 3 * H;
-            o[c] = s0; o[H + c] = s1; o[2 * H + c] = s2;
+            if (on)
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) { o[c0 + u] = s0[u]; o[H + c0 + u] = s1[u]; o[2 * H + c0 + u] = s2[u]; }
         }
 }
 
@@ -461,8 +644,12 @@ int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float
                                    float *ds, float *dvec, void *stream) {
     VB_CHECK(vec && s && dvec3 && dvagg && col && tgt && t_rowptr && t_eid && num_edges_dev && ds && dvec && H > 0);
     hipStream_t st = as_stream(stream);
-    k_vec_aggregate_bwd_s<<<nblk((long long)max_edges * H), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
-    if (n > 0) k_vec_aggregate_bwd_v<<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
+    if (H % 128 == 0) k_vec_aggregate_bwd_s<2><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
+    else k_vec_aggregate_bwd_s<1><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
+    if (n > 0) {
+        if (H % 128 == 0) k_vec_aggregate_bwd_v<2><<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
+        else k_vec_aggregate_bwd_v<1><<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
+    }
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp, int n, int H,
@@ -477,8 +664,13 @@ int conan_visnet_edge_update_bwd(const float *wt, const float *ws, const float *
     VB_CHECK(wt && ws && t && dvec3 && dfo && rowptr && col && tgt && t_rowptr && t_eid && dwt && dws && dt && n >= 0 && H > 0);
     if (n == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
-    k_edge_update_bwd_t<<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
-    k_edge_update_bwd_s<<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
+    if (H % 128 == 0) {
+        k_edge_update_bwd_t<2><<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
+        k_edge_update_bwd_s<2><<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
+    } else {
+        k_edge_update_bwd_t<1><<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
+        k_edge_update_bwd_s<1><<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
+    }
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_visnet_spatial_norm_bwd(const float *v, const float *dout, int n, int H, float *dv, void *stream) {
