@@ -40,14 +40,60 @@ __global__ void k_expnormal(const float *__restrict__ dist, const int *__restric
     }
 }
 
+// CPL consecutive channels of one row as ONE load / store (float2 for CPL = 2: c0 is even and every row starts at a multiple of H floats from a
+// 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
+template <int CPL>
+__device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
+    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) r[u] = p[u];
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
+    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) p[u] = r[u];
+    }
+}
+
+constexpr int VN_EB = 4;      // edges in flight per wavefront
+#ifndef CONAN_VB_RUN
+#define CONAN_VB_RUN 16
+#endif
+constexpr int VN_RUN = CONAN_VB_RUN;    // edges per wavefront in the kernels that walk runs of consecutive edges (64 left too few wavefronts in flight)
+
+// The three element-wise edge kernels below walk runs of VN_RUN consecutive edges per wavefront (round 3; were one thread per element with a
+// 64-bit division, the index loads and — in k_ne_scale — a full-precision cosine per ELEMENT): per-edge quantities are formed once, one edge
+// per lane, and handed out; lane <-> CPL channels; VN_EB edges in flight.
 // W[e,:] *= C(r_e) * [src != tgt]      (NeighborEmbedding, :408-415: loops removed, cosine cutoff)
-__global__ void k_ne_scale(float *__restrict__ W, const float *__restrict__ dist, const int *__restrict__ col, const int *__restrict__ tgt,
-                           const int *__restrict__ ne_dev, int max_edges, int H, float cutoff) {
+template <int CPL>
+__global__ void __launch_bounds__(256) k_ne_scale(float *__restrict__ W, const float *__restrict__ dist, const int *__restrict__ col,
+                                                  const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H, float cutoff) {
     const int E = min(*ne_dev, max_edges);
-    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int e = (int)(t / H);
-        W[t] *= (col[e] != tgt[e]) ? cos_cutoff(dist[e], cutoff) : 0.0f;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
+        const int cnt = min(VN_RUN, E - base);
+        const float my_s = (lane < cnt && col[base + lane] != tgt[base + lane]) ? cos_cutoff(dist[base + lane], cutoff) : 0.0f;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += VN_EB) {
+                float w[VN_EB][CPL];
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) vld<CPL>(W + (size_t)(base + min(tq + b, cnt - 1)) * H + cl, w[b]);
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    if (tq + b >= cnt) break;
+                    const float sc = __shfl(my_s, tq + b, 64);
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) w[b][u] *= sc;
+                    if (on) vst<CPL>(W + (size_t)(base + tq + b) * H + c0, w[b]);
+                }
+            }
+        }
     }
 }
 
@@ -61,13 +107,35 @@ __global__ void k_concat2(const float *__restrict__ a, int Ha, const float *__re
 }
 
 // f_ij = (x_i + x_j) * p_e    (EdgeEmbedding, :463-465)
-__global__ void k_edge_embed(const float *__restrict__ x, const float *__restrict__ p, const int *__restrict__ col, const int *__restrict__ tgt,
-                             const int *__restrict__ ne_dev, int max_edges, int H, float *__restrict__ f) {
+template <int CPL>
+__global__ void __launch_bounds__(256) k_edge_embed(const float *__restrict__ x, const float *__restrict__ p, const int *__restrict__ col,
+                                                    const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H, float *__restrict__ f) {
     const int E = min(*ne_dev, max_edges);
-    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int e = (int)(t / H), c = (int)(t - (long long)e * H);
-        f[t] = (x[(size_t)tgt[e] * H + c] + x[(size_t)col[e] * H + c]) * p[t];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
+        const int cnt = min(VN_RUN, E - base);
+        const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += VN_EB) {
+                float xi[VN_EB][CPL], xj[VN_EB][CPL], pv[VN_EB][CPL];
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    const int tt = min(tq + b, cnt - 1);
+                    const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
+                    vld<CPL>(x + i * H + cl, xi[b]); vld<CPL>(x + j * H + cl, xj[b]); vld<CPL>(p + (size_t)(base + tt) * H + cl, pv[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < VN_EB; ++b) {
+                    if (tq + b >= cnt) break;
+                    float o[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) o[u] = (xi[b][u] + xj[b][u]) * pv[b][u];
+                    if (on) vst<CPL>(f + (size_t)(base + tq + b) * H + c0, o);
+                }
+            }
+        }
     }
 }
 
@@ -110,30 +178,6 @@ __global__ void k_vecdot(const float *__restrict__ vp, int n, int H, float *__re
 // index becomes a scalar register: row base in SGPRs, lane offset in a VGPR), and the rows of EB edges are requested before the first
 // of them is used — the loop was a chain of two dependent round trips per edge (index, then the k_j / v_j rows) and ran at 2.3 TB/s.
 // The sums run in edge order as before (bitwise-equal results).
-// CPL consecutive channels of one row as ONE load / store (float2 for CPL = 2: c0 is even and every row starts at a multiple of H floats from a
-// 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
-template <int CPL>
-__device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
-    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
-    else {
-#pragma unroll
-        for (int u = 0; u < CPL; ++u) r[u] = p[u];
-    }
-}
-template <int CPL>
-__device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
-    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
-    else {
-#pragma unroll
-        for (int u = 0; u < CPL; ++u) p[u] = r[u];
-    }
-}
-
-constexpr int VN_EB = 4;      // edges in flight per wavefront
-#ifndef CONAN_VB_RUN
-#define CONAN_VB_RUN 16
-#endif
-constexpr int VN_RUN = CONAN_VB_RUN;    // edges per wavefront in the kernels that walk runs of consecutive edges (64 left too few wavefronts in flight)
 template <int CPL>
 __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                   const float *__restrict__ dk, const float *__restrict__ dv, const int *__restrict__ rowptr,
@@ -383,7 +427,8 @@ int conan_visnet_expnormal(const float *dist, const int *num_edges_dev, int max_
 int conan_visnet_neighbor_scale(float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
                                 float cutoff, void *stream) {
     VN_CHECK(W && dist && col && tgt && num_edges_dev && H > 0);
-    k_ne_scale<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    if (H % 128 == 0) k_ne_scale<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    else k_ne_scale<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows, float *out, void *stream) {
@@ -394,7 +439,8 @@ int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows
 int conan_visnet_edge_embed(const float *x, const float *p, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
                             float *f, void *stream) {
     VN_CHECK(x && p && col && tgt && num_edges_dev && f && H > 0);
-    k_edge_embed<<<nblk((long long)max_edges * H), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
+    if (H % 128 == 0) k_edge_embed<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
+    else k_edge_embed<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 int conan_layernorm_fwd(const float *x, const float *gamma, const float *beta, int rows, int H, float eps, float *out, void *stream) {

@@ -45,28 +45,108 @@ __global__ void k_rowsum(const float *__restrict__ x, int rows, int width, float
 }
 
 // ---------------------------------------------------------------------------------------------- EdgeEmbedding backward
-// dp[e] = (x_i + x_j) * df[e]
-__global__ void k_edge_embed_bwd_p(const float *__restrict__ x, const float *__restrict__ df, const int *__restrict__ col, const int *__restrict__ tgt,
-                                   const int *__restrict__ ne_dev, int max_edges, int H, float *__restrict__ dp) {
+// CPL consecutive channels of one row as ONE load / store (float2 for CPL = 2: c0 is even and every row starts at a multiple of H floats from a
+// 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
+template <int CPL>
+__device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
+    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) r[u] = p[u];
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
+    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
+    else {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) p[u] = r[u];
+    }
+}
+
+constexpr int VB_EB = 4;
+#ifndef CONAN_VB_RUN
+#define CONAN_VB_RUN 16
+#endif
+constexpr int VB_RUN = CONAN_VB_RUN;     // edges per wavefront in the kernels that walk runs of consecutive edges
+// dp[e] = (x_i + x_j) * df[e]      (runs of VB_RUN consecutive edges per wavefront, as k_edge_embed)
+template <int CPL>
+__global__ void __launch_bounds__(256) k_edge_embed_bwd_p(const float *__restrict__ x, const float *__restrict__ df, const int *__restrict__ col,
+                                                          const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H,
+                                                          float *__restrict__ dp) {
     const int E = min(*ne_dev, max_edges);
-    const long long n = (long long)E * H, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int e = (int)(t / H), c = (int)(t - (long long)e * H);
-        dp[t] = (x[(size_t)tgt[e] * H + c] + x[(size_t)col[e] * H + c]) * df[t];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int base = wave * VB_RUN; base < E; base += nw * VB_RUN) {
+        const int cnt = min(VB_RUN, E - base);
+        const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += VB_EB) {
+                float xi[VB_EB][CPL], xj[VB_EB][CPL], gv[VB_EB][CPL];
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) {
+                    const int tt = min(tq + b, cnt - 1);
+                    const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
+                    vld<CPL>(x + i * H + cl, xi[b]); vld<CPL>(x + j * H + cl, xj[b]); vld<CPL>(df + (size_t)(base + tt) * H + cl, gv[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) {
+                    if (tq + b >= cnt) break;
+                    float o[CPL];
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) o[u] = (xi[b][u] + xj[b][u]) * gv[b][u];
+                    if (on) vst<CPL>(dp + (size_t)(base + tq + b) * H + c0, o);
+                }
+            }
+        }
     }
 }
 // dx[i] = sum_{e in row(i)} df[e]*p[e] + sum_{e in srclist(i)} df[e]*p[e]
+template <int CPL>
 __global__ void __launch_bounds__(256) k_edge_embed_bwd_x(const float *__restrict__ p, const float *__restrict__ df, const int *__restrict__ rowptr,
                                                           const int *__restrict__ t_rowptr, const int *__restrict__ t_eid, int n, int H,
                                                           float *__restrict__ dx) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
-        for (int c = lane; c < H; c += 64) {
-            float a = 0.f;
-            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) a += df[(size_t)e * H + c] * p[(size_t)e * H + c];
-            for (int s = t_rowptr[i]; s < t_rowptr[i + 1]; ++s) { const int e = t_eid[s]; a += df[(size_t)e * H + c] * p[(size_t)e * H + c]; }
-            dx[(size_t)i * H + c] = a;
+        for (int cp = 0; cp < H; cp += 64 * CPL) {
+            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            float a[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) a[u] = 0.f;
+            const int e0 = rowptr[i], e1 = rowptr[i + 1];
+            for (int e = e0; e < e1; e += VB_EB) {                                  // the row itself: consecutive edges, no indices
+                float g[VB_EB][CPL], q[VB_EB][CPL];
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) { const size_t ee = (size_t)min(e + b, e1 - 1); vld<CPL>(df + ee * H + cl, g[b]); vld<CPL>(p + ee * H + cl, q[b]); }
+#pragma unroll
+                for (int b = 0; b < VB_EB; ++b) {
+                    if (e + b >= e1) break;
+#pragma unroll
+                    for (int u = 0; u < CPL; ++u) a[u] += g[b][u] * q[b][u];
+                }
+            }
+            const int s0 = t_rowptr[i], s1 = t_rowptr[i + 1];
+            for (int base = s0; base < s1; base += 64) {                            // the by-source list: edge ids handed out per lane
+                const int cnt = min(64, s1 - base);
+                const int my_e = lane < cnt ? t_eid[base + lane] : 0;
+                for (int tq = 0; tq < cnt; tq += VB_EB) {
+                    float g[VB_EB][CPL], q[VB_EB][CPL];
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        const size_t ee = (size_t)__shfl(my_e, min(tq + b, cnt - 1), 64);
+                        vld<CPL>(df + ee * H + cl, g[b]); vld<CPL>(p + ee * H + cl, q[b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < VB_EB; ++b) {
+                        if (tq + b >= cnt) break;
+#pragma unroll
+                        for (int u = 0; u < CPL; ++u) a[u] += g[b][u] * q[b][u];
+                    }
+                }
+            }
+            if (on) vst<CPL>(dx + (size_t)i * H + c0, a);
         }
 }
 
@@ -149,30 +229,6 @@ __device__ __forceinline__ void attn_edge(const float *qi, const float *kj, cons
 // Round 3 (all row-walking kernels below): a row's indices (and what hangs off them per edge: target, cutoff, unit vector) are fetched once,
 // one edge per lane, and handed out with cross-lane reads; the rows of VB_EB edges are requested before the first is used.  The loops were
 // chains of two or three dependent round trips per edge (2.3-3 TB/s); the sums still run in list order (bitwise-equal results).
-// CPL consecutive channels of one row as ONE load / store (float2 for CPL = 2: c0 is even and every row starts at a multiple of H floats from a
-// 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
-template <int CPL>
-__device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
-    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
-    else {
-#pragma unroll
-        for (int u = 0; u < CPL; ++u) r[u] = p[u];
-    }
-}
-template <int CPL>
-__device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
-    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
-    else {
-#pragma unroll
-        for (int u = 0; u < CPL; ++u) p[u] = r[u];
-    }
-}
-
-constexpr int VB_EB = 4;
-#ifndef CONAN_VB_RUN
-#define CONAN_VB_RUN 16
-#endif
-constexpr int VB_RUN = CONAN_VB_RUN;     // edges per wavefront in the kernels that walk runs of consecutive edges
 
 // target side: dq[i] (sum over row i), and the edge gradients d dk[e], d dv[e]
 template <int CPL>
@@ -594,8 +650,13 @@ int conan_visnet_edge_embed_bwd(const float *x, const float *p, const float *df,
                                 float *dx, void *stream) {
     VB_CHECK(x && p && df && rowptr && col && tgt && t_rowptr && t_eid && num_edges_dev && dp && dx && H > 0);
     hipStream_t s = as_stream(stream);
-    k_edge_embed_bwd_p<<<nblk((long long)max_edges * H), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
-    k_edge_embed_bwd_x<<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
+    if (H % 128 == 0) {
+        k_edge_embed_bwd_p<2><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
+        k_edge_embed_bwd_x<2><<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
+    } else {
+        k_edge_embed_bwd_p<1><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
+        k_edge_embed_bwd_x<1><<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
+    }
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 long long conan_layernorm_bwd_ws(int rows, int H) { return 2LL * rows + 2LL * ((rows + LN_CHUNK - 1) / LN_CHUNK) * H; }
