@@ -59,7 +59,10 @@ __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]
     }
 }
 
-constexpr int VN_EB = 4;      // edges in flight per wavefront
+#ifndef CONAN_V_EB
+#define CONAN_V_EB 4
+#endif
+constexpr int VN_EB = CONAN_V_EB;      // edges in flight per wavefront
 #ifndef CONAN_VB_RUN
 #define CONAN_VB_RUN 16
 #endif

@@ -64,7 +64,10 @@ __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]
     }
 }
 
-constexpr int VB_EB = 4;
+#ifndef CONAN_V_EB
+#define CONAN_V_EB 4
+#endif
+constexpr int VB_EB = CONAN_V_EB;
 #ifndef CONAN_VB_RUN
 #define CONAN_VB_RUN 16
 #endif
