@@ -101,6 +101,7 @@ SIGNATURES = {
     "conan_visnet_edge_unit": (c_int, [_P, _P, _P, _P, c_int, _P, _P]),
     "conan_visnet_expnormal": (c_int, [_P, _P, c_int, _P, _P, c_int, c_float, c_float, _P, _P]),
     "conan_visnet_neighbor_scale": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "conan_visnet_neighbor_scale_to": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "conan_concat2": (c_int, [_P, c_int, _P, c_int, c_ll, _P, _P]),
     "conan_visnet_edge_embed": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_layernorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),

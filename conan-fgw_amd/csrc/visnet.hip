@@ -73,7 +73,7 @@ constexpr int VN_RUN = CONAN_VB_RUN;    // edges per wavefront in the kernels th
 // per lane, and handed out; lane <-> CPL channels; VN_EB edges in flight.
 // W[e,:] *= C(r_e) * [src != tgt]      (NeighborEmbedding, :408-415: loops removed, cosine cutoff)
 template <int CPL>
-__global__ void __launch_bounds__(256) k_ne_scale(float *__restrict__ W, const float *__restrict__ dist, const int *__restrict__ col,
+__global__ void __launch_bounds__(256) k_ne_scale(const float *Win, float *W, const float *__restrict__ dist, const int *__restrict__ col,
                                                   const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H, float cutoff) {
     const int E = min(*ne_dev, max_edges);
     const int lane = threadIdx.x & 63;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_ne_scale(float *__restrict__ W, const f
             for (int tq = 0; tq < cnt; tq += VN_EB) {
                 float w[VN_EB][CPL];
 #pragma unroll
-                for (int b = 0; b < VN_EB; ++b) vld<CPL>(W + (size_t)(base + min(tq + b, cnt - 1)) * H + cl, w[b]);
+                for (int b = 0; b < VN_EB; ++b) vld<CPL>(Win + (size_t)(base + min(tq + b, cnt - 1)) * H + cl, w[b]);
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
                     if (tq + b >= cnt) break;
@@ -427,12 +427,17 @@ int conan_visnet_expnormal(const float *dist, const int *num_edges_dev, int max_
     k_expnormal<<<nblk((long long)max_edges * num_rbf), 256, 0, as_stream(stream)>>>(dist, num_edges_dev, max_edges, means, betas, num_rbf, alpha, cutoff, out);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
+int conan_visnet_neighbor_scale_to(const float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
+                                   float cutoff, float *out, void *stream) {
+    VN_CHECK(W && out && dist && col && tgt && num_edges_dev && H > 0);
+    if (max_edges <= 0) return CONAN_OK;
+    if (H % 128 == 0) k_ne_scale<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, out, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    else k_ne_scale<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, out, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
 int conan_visnet_neighbor_scale(float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
                                 float cutoff, void *stream) {
-    VN_CHECK(W && dist && col && tgt && num_edges_dev && H > 0);
-    if (H % 128 == 0) k_ne_scale<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
-    else k_ne_scale<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
-    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+    return conan_visnet_neighbor_scale_to(W, dist, col, tgt, num_edges_dev, max_edges, H, cutoff, W, stream);
 }
 int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows, float *out, void *stream) {
     VN_CHECK(a && b && out && Ha > 0 && Hb > 0 && rows >= 0);

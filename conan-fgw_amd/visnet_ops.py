@@ -170,18 +170,20 @@ def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Te
 class _NeighborScale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, graph, cutoff):
-        out = W.clone()
-        call("conan_visnet_neighbor_scale", ptr(out), ptr(graph.dist), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev),
-             graph.max_edges, W.shape[1], float(cutoff), stream_ptr())
+        W = _c(W)
+        out = torch.empty_like(W)                                   # rows beyond the device-side edge count are never read (see _tail0_shape)
+        call("conan_visnet_neighbor_scale_to", ptr(W), ptr(graph.dist), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev),
+             graph.max_edges, W.shape[1], float(cutoff), ptr(out), stream_ptr())
         ctx.graph, ctx.cutoff = graph, float(cutoff)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         g = ctx.graph
-        d = _c(dout).clone()
-        call("conan_visnet_neighbor_scale", ptr(d), ptr(g.dist), ptr(g.col), ptr(g.tgt), ptr(g.num_edges_dev), g.max_edges, d.shape[1],
-             ctx.cutoff, stream_ptr())
+        dout = _c(dout)
+        d = torch.empty_like(dout)
+        call("conan_visnet_neighbor_scale_to", ptr(dout), ptr(g.dist), ptr(g.col), ptr(g.tgt), ptr(g.num_edges_dev), g.max_edges, dout.shape[1],
+             ctx.cutoff, ptr(d), stream_ptr())
         return d, None, None
 
 

@@ -317,6 +317,9 @@ int conan_visnet_expnormal(const float *dist, const int *num_edges_dev, int max_
 /* NeighborEmbedding (:408-415): W[e,:] *= C(d_e) for src != tgt, 0 for self loops (in place). */
 int conan_visnet_neighbor_scale(float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev,
                                 int max_edges, int H, float cutoff, void *stream);
+/* Same, out of place: out[e,:] = W[e,:] * C(d_e) (out may be W).  The autograd wrapper uses this form: no clone of the worst-case-sized buffer. */
+int conan_visnet_neighbor_scale_to(const float *W, const float *dist, const int *col, const int *tgt, const int *num_edges_dev,
+                                   int max_edges, int H, float cutoff, float *out, void *stream);
 /* out[r,:] = [a[r,:Ha] | b[r,:Hb]]   (torch.cat(dim=1), :419, :945). */
 int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows, float *out, void *stream);
 /* EdgeEmbedding (:463-465): f[e,:] = (x[tgt] + x[src]) * p[e,:]. */

@@ -27,6 +27,11 @@ python3 $R/tools/ab.py CONAN_FGW_NO_FAST=1 $R/tools/probe_fgw_small.py 2 2>/dev/
 python3 $R/tools/ab.py CONAN_FGW_NO_BIG=1,CONAN_FGW_NO_BLOCK22=1 $R/tools/probe_fgw_large.py 2 2>/dev/null | grep -v amdgpu > $O/ab_fgw_large.txt
 python3 $R/tools/ab.py CONAN_FILTER_BF16X3=1 $R/tools/probe_filter_fwd.py 2 2>/dev/null | grep -v amdgpu > $O/ab_filter_fwd.txt
 python3 $R/tools/probe_edge_bwd.py "" in-tree 2>/dev/null | grep -v amdgpu > $O/edge_bwd.txt
+python3 $R/tools/ab.py CONAN_LINEAR_BF16X3=1 $R/tools/probe_linear.py 2 2>/dev/null | grep -v amdgpu > $O/ab_linear.txt
+python3 $R/tools/ab.py CONAN_GAT_NO_GROUP16=1 $R/tools/probe_gat.py 2 2>/dev/null | grep -v amdgpu > $O/ab_gat.txt
+bash $R/tools/linear_pmc.sh r3p/linear_pmc > $O/linear_pmc.txt 2>&1
+bash $R/tools/linear_pmc.sh r3p/wgrad_pmc wgrad_pmc.py > $O/wgrad_pmc.txt 2>&1
+bash $R/tools/gat_kstats.sh r3p/gat_kstats > $O/gat_kstats.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head; ls $O
 # keep the merge small: drop raw traces
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*.db" -delete
