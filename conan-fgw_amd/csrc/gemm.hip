@@ -483,7 +483,15 @@ template <int KT, bool RBF>
 __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
                                                    float *__restrict__ slabs, float *__restrict__ bias_slabs,
                                                    const int *__restrict__ m_dev, const float *__restrict__ dist,
-                                                   const float *__restrict__ offset, float coeff) {
+                                                   const float *__restrict__ offset, float coeff, int tn_remap, int slices) {
+    // tn_remap > 1 (1-D grid, N > 128, slices % 8 == 0): the n tiles of one row slice sit on consecutive block ids of the SAME XCD
+    // (id = lo + 8 (tile_n + tn * hi), slice = lo + 8 hi), so that they stream the slice's x rows together and all but the first find
+    // them in that XCD's L2 — with the 3-D grid (slice fastest) every n tile re-read x from HBM a whole sweep later
+    if (tn_remap > 1) {
+        const int b = blockIdx.x, lo = b & 7, q = b >> 3;
+        wgrad_lds_body<KT, RBF>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, lo + 8 * (q / tn_remap), slices, q % tn_remap, 0);
+        return;
+    }
     wgrad_lds_body<KT, RBF>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
 }
 __global__ void __launch_bounds__(256, 2) k_wgrad_lds_h16(const float *__restrict__ g, const float *__restrict__ x, int M, int K, int N,
@@ -502,6 +510,7 @@ struct WgradSlabJobs {
     const int *m_dev[WGS_BATCH];
     float *slabs[WGS_BATCH], *bias_slabs[WGS_BATCH];
     int M[WGS_BATCH], K[WGS_BATCH], N[WGS_BATCH], slices[WGS_BATCH], tiles_n[WGS_BATCH], first[WGS_BATCH + 1];
+    int gsz[WGS_BATCH];      // > 1 at the LAST job of a run of jobs that read the same x (same M, K, N <= 128, slices % 8 == 0): interleaved, see the kernel
     int count;
 };
 template <int KT>
@@ -510,6 +519,15 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds_batch(cons
     int j = 0;
     while (j + 1 < J.count && b >= J.first[j + 1]) ++j;            // uniform scan over <= 24 entries held in scalar registers
     const int local = b - J.first[j];
+    if (J.gsz[j] > 1) {
+        // a run of jobs over the SAME x (q / k / v, dk / dv / f_proj of one input): their workgroups for one row slice sit on consecutive
+        // block ids of one XCD (id = lo + 8 (member + gsz * hi), slice = lo + 8 hi) and stream the slice's x rows together — x comes
+        // from HBM once per run instead of once per job.  The members' ranges are zero-width except the last one's, which the scan finds.
+        const int gs = J.gsz[j], lo = local & 7, q = local >> 3, jm = j - (gs - 1) + q % gs;
+        wgrad_lds_body<KT, false>(J.g[jm], J.x[jm], J.M[jm], J.K[jm], J.N[jm], J.slabs[jm], J.bias_slabs[jm], J.m_dev[jm], nullptr, nullptr, 0.f,
+                                  lo + 8 * (q / gs), J.slices[jm], 0, 0);
+        return;
+    }
     const int slice = local % J.slices[j], rest = local / J.slices[j];
     const int tile_n = rest % J.tiles_n[j], tile_k = rest / J.tiles_n[j];
     wgrad_lds_body<KT, false>(J.g[j], J.x[j], J.M[j], J.K[j], J.N[j], J.slabs[j], J.bias_slabs[j], J.m_dev[j], nullptr, nullptr, 0.f, slice,
@@ -715,15 +733,17 @@ static int wgrad_launch(const float *g, const float *x, int M, int K, int N, con
     {
         const int KT = K > 64 ? 128 : 64;
         dim3 grid(slices, (N + 127) / 128, (K + KT - 1) / KT);
+        int tn_remap = 0;
+        if (grid.y > 1 && grid.z == 1 && (slices & 7) == 0 && !gmax) { tn_remap = (int)grid.y; grid = dim3(slices * tn_remap, 1, 1); }
         if (gmax) {
             if (rbf || KT != 128) return CONAN_E_UNSUPPORTED;
             k_wgrad_lds_h16<<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, gmax);
         } else if (KT == 128) {
-            if (rbf) k_wgrad_lds<128, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
-            else k_wgrad_lds<128, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            if (rbf) k_wgrad_lds<128, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, tn_remap, slices);
+            else k_wgrad_lds<128, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, tn_remap, slices);
         } else {
-            if (rbf) k_wgrad_lds<64, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
-            else k_wgrad_lds<64, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff);
+            if (rbf) k_wgrad_lds<64, true><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, tn_remap, slices);
+            else k_wgrad_lds<64, false><<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, dist, offset, coeff, tn_remap, slices);
         }
     }
     const int NK = N * K;
@@ -811,14 +831,28 @@ int conan_linear_wgrad_slabs_batch(const conan_wgrad_slab_job *jobs, int num_job
         for (int j = 0; j < num_jobs; ++j) {
             const conan_wgrad_slab_job &b = jobs[j];
             if ((b.K > 64) != (wide != 0)) continue;              // (a job with M = 0 still runs: its one slice writes zero slabs for the reducer)
-            const int KT = wide ? 128 : 64, q = J.count;
+            const int KT = wide ? 128 : 64;
             const int dflt = wgrad_slices(b.M, b.K), slices = (b.slices > 0 && b.slices <= dflt) ? b.slices : dflt;
             const int tn = (b.N + 127) / 128, tk = (b.K + KT - 1) / KT;
-            J.g[q] = b.g; J.x[q] = b.x; J.m_dev[q] = b.m_dev;
-            J.slabs[q] = b.ws; J.bias_slabs[q] = b.ws + (size_t)slices * b.N * b.K;
-            J.M[q] = b.M; J.K[q] = b.K; J.N[q] = b.N; J.slices[q] = slices; J.tiles_n[q] = tn;
-            J.first[q + 1] = J.first[q] + slices * tn * tk;
-            if (++J.count == WGS_BATCH) flush();
+            // how many of the following jobs read the same x with the same shape (a run is kept inside one launch)
+            int run = 1;
+            if (tn == 1 && tk == 1 && (slices & 7) == 0 && b.M > 0)
+                while (j + run < num_jobs && run < 4 && jobs[j + run].x == b.x && jobs[j + run].M == b.M && jobs[j + run].K == b.K && jobs[j + run].N == b.N &&
+                       jobs[j + run].m_dev == b.m_dev && jobs[j + run].slices == b.slices)
+                    ++run;
+            if (J.count + run > WGS_BATCH) flush();
+            for (int r = 0; r < run; ++r) {
+                const conan_wgrad_slab_job &c = jobs[j + r];
+                const int q = J.count;
+                J.g[q] = c.g; J.x[q] = c.x; J.m_dev[q] = c.m_dev;
+                J.slabs[q] = c.ws; J.bias_slabs[q] = c.ws + (size_t)slices * c.N * c.K;
+                J.M[q] = c.M; J.K[q] = c.K; J.N[q] = c.N; J.slices[q] = slices; J.tiles_n[q] = tn;
+                J.gsz[q] = (run > 1 && r == run - 1) ? run : 1;
+                J.first[q + 1] = J.first[q] + ((run > 1 && r < run - 1) ? 0 : run * slices * tn * tk);
+                ++J.count;
+            }
+            j += run - 1;
+            if (J.count == WGS_BATCH) flush();
         }
         flush();
     }

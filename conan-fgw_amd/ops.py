@@ -226,6 +226,43 @@ def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None, gmax=None):
     return dw, db
 
 
+def _wgrad_shared_x(gs, x, M, K, N, md, weights, has_bias):
+    """[_wgrad(g_i, x, ...) for g_i in gs] for several Linear layers of the SAME input and the same width (dk / dv / f_proj of f; q / k / v): the
+    slab kernels of the run are ONE launch whose workgroups for one row slice sit next to each other, so x is streamed from HBM once per run
+    instead of once per layer (conan_linear_wgrad_slabs_batch; the slabs, and with them the results, are bit for bit those of the separate
+    launches).  Falls back to the separate launches where the batched kernel does not apply."""
+    n = len(gs)
+    usable = n > 1 and bool(lib().conan_wgrad_batchable(K, N)) and K > 64 and N <= 128 and M > _LATE_STAGE1_ROWS      # (node level: the late batch groups such runs itself)
+    wptrs = [w.data_ptr() for w in weights]
+    if usable and _pending is not None and (len(set(wptrs)) < n or any(j["weight_ptr"] in wptrs for j in _pending)):
+        usable = False                                            # a weight used twice in one backward: the immediate path of _wgrad handles it
+    if not usable:
+        return [_wgrad(g, x, M, K, N, md, w, hb) for g, w, hb in zip(gs, weights, has_bias)]
+    from ._lib import WgradJob, WgradSlabJob
+    dev = x.device
+    wsz = int(lib().conan_linear_wgrad_ws(M, K, N))
+    wss = [torch.empty(wsz, dtype=f32, device=dev) for _ in range(n)]
+    dws = [torch.empty(N, K, dtype=f32, device=dev) for _ in range(n)]
+    dbs = [torch.empty(N, dtype=f32, device=dev) if hb else None for hb in has_bias]
+    sj = (WgradSlabJob * n)()
+    for q in range(n):
+        sj[q].g, sj[q].x, sj[q].m_dev, sj[q].ws = ptr(gs[q]), ptr(x), ptr(md), ptr(wss[q])
+        sj[q].M, sj[q].K, sj[q].N, sj[q].slices = M, K, N, 0
+    call("conan_linear_wgrad_slabs_batch", sj, n, stream_ptr())
+    if _pending is not None:
+        for q in range(n):
+            _pending.append(dict(ws=wss[q], dw_ptr=dws[q].data_ptr(), db_ptr=dbs[q].data_ptr() if dbs[q] is not None else None,
+                                 keep=(dws[q].untyped_storage(), dbs[q].untyped_storage() if dbs[q] is not None else None),
+                                 M=M, K=K, N=N, weight_ptr=wptrs[q], stream=torch.cuda.current_stream()))
+    else:
+        jobs = (WgradJob * n)()
+        for q in range(n):
+            jobs[q].ws, jobs[q].dW, jobs[q].dbias = ptr(wss[q]), dws[q].data_ptr(), dbs[q].data_ptr() if dbs[q] is not None else None
+            jobs[q].M, jobs[q].K, jobs[q].N, jobs[q].slices = M, K, N, 0
+        call("conan_wgrad_reduce_batch", jobs, n, stream_ptr())
+    return list(zip(dws, dbs))
+
+
 def _filter_bwd(g, h1, dist, offset, coeff, w1, w2, M, md, gmax=None):
     """dW1 [F,Gs], db1 [F] of the filter network's first Linear from the gradient g of its output, fused (conan_filter_bwd): the
     input gradient of the second Linear times ssp'(h1) is formed tile by tile in registers and contracted with the regenerated

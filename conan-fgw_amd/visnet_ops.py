@@ -124,7 +124,7 @@ class _MultiLinear(torch.autograd.Function):
         M, K = x.shape
         seed = _c(dys[n]) if (ctx.tap and dys[n] is not None) else None      # gradient of the handed-through x: seeds the running sum
         dx = None
-        dws, dbs = [None] * n, [None] * n
+        dws, dbs, gs = [None] * n, [None] * n, [None] * n
         for i in range(n):
             if dys[i] is None:
                 continue
@@ -146,7 +146,15 @@ class _MultiLinear(torch.autograd.Function):
                     tmp = _tail0_shape(M, K, x.device, md)
                     call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(tmp), stream_ptr())
                     dx = res + tmp
-            dws[i], dbs[i] = ops._wgrad(g, x, M, K, N, md, w, ctx.has_b[i])
+            gs[i] = g
+        live = [i for i in range(n) if gs[i] is not None]
+        if len(live) > 1 and len({ws[i].shape[0] for i in live}) == 1:      # same input, same width: one batched slab launch (x streamed once)
+            for i, (dw, db) in zip(live, ops._wgrad_shared_x([gs[i] for i in live], x, M, K, ws[live[0]].shape[0], md, [ws[i] for i in live],
+                                                               [ctx.has_b[i] for i in live])):
+                dws[i], dbs[i] = dw, db
+        else:
+            for i in live:
+                dws[i], dbs[i] = ops._wgrad(gs[i], x, M, K, ws[i].shape[0], md, ws[i], ctx.has_b[i])
         if dx is None and seed is not None:
             dx = seed
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
