@@ -132,10 +132,12 @@ long long conan_embedding_bwd_ws(int num_atoms, int hidden, int num_embeddings);
 int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int hidden, int num_embeddings,
                         int padding_idx, float *dweight, float *ws, void *stream);
 
-/* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]).  Arithmetic: K, N multiples of 64 run as an exact 3-way bf16 split
- * of both operands (v = p1 + p2 + p3, six partial products per block on v_mfma_f32_32x32x16_bf16, fp32 accumulation):
- * fp32-CLASS accuracy (measured 2e-6 relative to an fp64 reference, the same as a plain fp32 GEMM), not bit-identical to
- * an fp32 FMA chain; other shapes run on the fp32 MFMA (v_mfma_f32_32x32x2_f32).  No reduced-precision mode exists.
+/* y[M,N] = act(x[M,K] @ W^T + bias) (+ residual[M,N]).  Arithmetic: K, N multiples of 64 run as a two-plane fp16 split of both operands
+ * (v = h1 + h2, three partial products per block on v_mfma_f32_32x32x16_f16, fp32 accumulation) with exact power-of-two scales taken from
+ * the data — one per weight matrix, one per x row, undone by one multiply per output — so that operands of any magnitude sit in the middle
+ * of fp16's range: fp32-CLASS accuracy (measured 1.4e-7 relative to an fp64 reference, rows spanning ten decades each to 2e-6 of their own
+ * norm; a plain fp32 GEMM measures the same), not bit-identical to an fp32 FMA chain; other shapes run on the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  No reduced-precision mode exists.
  * W is torch.nn.Linear's [N,K] when w_kn == 0, or a [K,N] matrix when w_kn == 1 (used by the backward: dx = g @ W).
  * act: 0 = identity, 1 = shifted softplus (softplus(v) - ln 2), 3 = SiLU, 2 = multiply by ssp'(.) evaluated from `residual`, which
  * then holds the saved OUTPUT o of an ssp layer (ssp' = 1 - 0.5*exp(-o)) instead of being added: the fused backward
@@ -246,8 +248,9 @@ int conan_stage2_head_bwd(const float *dout, const float *W3, const float *Wb, c
  *             = InteractionBlock's  conv.lin2 -> act -> lin (+ x)  (schnet_no_sum.py:164 with PyG's InteractionBlock.forward)
  *   backward: dmid = (dy w2) * ssp'(mid) [M,N1];  dx = dmid w1 [M,K]   (mid = the forward's saved output; the weight gradients are
  *             conan_linear_wgrad(dy, mid) and conan_linear_wgrad(dmid, x))
- * Same arithmetic as two conan_linear_fwd calls (exact 3-way bf16 split, fp32-class).  mid_out / dmid_out nullable.
- * Supported: conan_mlp2_supported(M, K, N1, N2) (K = N1 = N2 = 128, M <= 65536: one 32-row tile per wavefront, weights staged twice per
+ * Same arithmetic as two conan_linear_fwd calls (two fp16 planes with per-matrix / per-row scales, fp32-class; the intermediate's row scale
+ * is taken from the accumulators).  mid_out / dmid_out nullable.
+ * Supported: conan_mlp2_supported(M, K, N1, N2) (K = N1 = N2 = 128, M <= 65536: one 32-row tile per wavefront, weights staged once per
  * workgroup — a node-level kernel); otherwise CONAN_E_UNSUPPORTED (compose the two calls). */
 int conan_mlp2_supported(int M, int K, int N1, int N2);
 int conan_mlp2_fwd(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *residual, int M, int K, int N1,
@@ -267,8 +270,8 @@ int conan_mlp2_outact_bwd(const float *dy, const float *y, const float *w2, cons
 
 /* Fused continuous-filter generator: for every edge e
  *   W[e,:] = ( mlp2( ssp( mlp0( rbf(dist[e]) ) ) ) ) * 0.5*(cos(dist[e]*pi/cutoff)+1)
- * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel, both GEMMs as exact 3-way bf16 splits
- * on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, see conan_linear_fwd), every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
+ * = GaussianSmearing + InteractionBlock.mlp + CFConv's cosine cutoff in ONE kernel, both GEMMs on two fp16 planes per operand
+ * (v_mfma_f32_32x32x16_f16; weights scaled by a power of two from their block maximum; fp32-class accuracy, see conan_linear_fwd), every intermediate in registers (PyG; reached from schnet_no_sum.py:161-164,209-212).  w1[F,Gs], b1[F], w2[F,F], b2[F]
  * are the torch Linear parameters of interactions.{i}.mlp.{0,2}.  h1_out (nullable) receives ssp(mlp0(rbf)) [E,F] for the
  * backward.  Supported shapes: conan_filter_fused_supported(Gs, F) (Gs <= 64, F in {32,64,128}); otherwise
  * CONAN_E_UNSUPPORTED and the caller composes conan_rbf_fwd / conan_linear_fwd / conan_cutoff_scale. */
