@@ -809,7 +809,7 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
     }
 }
 
-inline int pitch_of(int N) { return N | 1; }
+inline int pitch_of(int N) { return fgw_pitch(N); }
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 constexpr int GEN_NW = 8;                   // wavefronts per workgroup of the large-N coupling kernel (16 measured no faster: 453 vs 443 us per workgroup and launch)
 inline size_t coupling_lds(int N) { return (size_t)((6 + 2 * GEN_NW) * N + 16) * 8 + (size_t)N * pitch_of(N) * 28; }

@@ -448,7 +448,7 @@ struct FastLds {
 template <typename C2T>
 __host__ __device__ inline FastLds fast_lds(int N) {
     FastLds L;
-    const int NP = N * (N | 1);
+    const int NP = N * fgw_pitch(N);
     L.npa = (NP + 1) & ~1;
     size_t o = (size_t)3 * L.npa * 8;                                // C1 | AK | base
     L.off_t = o; o += ((size_t)NP * 4 + 15) & ~(size_t)15;           // T (fp32)
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
 }
 
 inline size_t small_lds(int N, int d) {
-    const size_t NP = (size_t)N * (N | 1);
+    const size_t NP = (size_t)N * fgw_pitch(N);
     (void)d; return NP * 8 * 4 + (256 + 128 + 8 + (NP >= (size_t)SK_SCRATCH_DOUBLES ? 0 : SK_SCRATCH_DOUBLES)) * 8 + NP * 4 * 2;
 }
 

@@ -1,11 +1,13 @@
 """Idle time inside graph-replayed steps: from a rocprofv3 --kernel-trace CSV of `bench.py` (graph replay), take the steps between consecutive
-k_fgw_init launches in the timed region and report step length, union-of-kernels busy time and the largest gaps."""
+k_fgw_init (N > 64) / k_fgw_small_vectors (N <= 64) launches in the timed region and report step length, union-of-kernels busy time and the largest gaps."""
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); return re.sub(r"\(.*", "", n)[:44]
 idx = [i for i, r in enumerate(rows) if "k_fgw_init" in r["Kernel_Name"]]
+if not idx:                                  # N <= 64: the per-solve vector kernel initialises the molecules (one launch per step)
+    idx = [i for i, r in enumerate(rows) if "k_fgw_small_vectors" in r["Kernel_Name"]]
 steps = []
 for a, b in zip(idx[:-1], idx[1:]):
     steps.append((int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]), a, b))
