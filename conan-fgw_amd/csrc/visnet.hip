@@ -44,15 +44,24 @@ __global__ void k_expnormal(const float *__restrict__ dist, const int *__restric
 // 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
 template <int CPL>
 __device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
-    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
+    if constexpr (CPL == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+    else if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
     else {
 #pragma unroll
         for (int u = 0; u < CPL; ++u) r[u] = p[u];
     }
 }
+template <int CPL, bool HALF>
+__device__ __forceinline__ void vfold(float (&a)[CPL]) {      // HALF: even entries (lanes 0-31) + odd entries (lanes 32-63), fixed order
+    if constexpr (HALF) {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) a[u] += __shfl_xor(a[u], 32, 64);
+    }
+}
 template <int CPL>
 __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
-    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
+    if constexpr (CPL == 4) *reinterpret_cast<float4 *>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    else if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
     else {
 #pragma unroll
         for (int u = 0; u < CPL; ++u) p[u] = r[u];
@@ -61,6 +70,11 @@ __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]
 
 #ifndef CONAN_V_EB
 #define CONAN_V_EB 4
+#endif
+#ifdef CONAN_V_NO_HALF      // (A/B switch: a whole wavefront per edge at H = 128, float2 per lane)
+constexpr bool V_HALF = false;
+#else
+constexpr bool V_HALF = true;     // H = 128: a half-wavefront per edge (32 lanes x float4 = one 512-byte row), two edges per instruction
 #endif
 constexpr int VN_EB = CONAN_V_EB;      // edges in flight per wavefront
 #ifndef CONAN_VB_RUN
@@ -72,28 +86,30 @@ constexpr int VN_RUN = CONAN_VB_RUN;    // edges per wavefront in the kernels th
 // 64-bit division, the index loads and — in k_ne_scale — a full-precision cosine per ELEMENT): per-edge quantities are formed once, one edge
 // per lane, and handed out; lane <-> CPL channels; VN_EB edges in flight.
 // W[e,:] *= C(r_e) * [src != tgt]      (NeighborEmbedding, :408-415: loops removed, cosine cutoff)
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_ne_scale(const float *Win, float *W, const float *__restrict__ dist, const int *__restrict__ col,
                                                   const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H, float cutoff) {
     const int E = min(*ne_dev, max_edges);
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
         const int cnt = min(VN_RUN, E - base);
         const float my_s = (lane < cnt && col[base + lane] != tgt[base + lane]) ? cos_cutoff(dist[base + lane], cutoff) : 0.0f;
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
-            for (int tq = 0; tq < cnt; tq += VN_EB) {
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += ES * VN_EB) {
                 float w[VN_EB][CPL];
 #pragma unroll
-                for (int b = 0; b < VN_EB; ++b) vld<CPL>(Win + (size_t)(base + min(tq + b, cnt - 1)) * H + cl, w[b]);
+                for (int b = 0; b < VN_EB; ++b) vld<CPL>(Win + (size_t)(base + min(tq + ES * b + hf, cnt - 1)) * H + cl, w[b]);
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    if (tq + b >= cnt) break;
-                    const float sc = __shfl(my_s, tq + b, 64);
+                    const float sc = __shfl(my_s, min(tq + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (tq + ES * b + hf >= cnt) continue;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) w[b][u] *= sc;
-                    if (on) vst<CPL>(W + (size_t)(base + tq + b) * H + c0, w[b]);
+                    if (on) vst<CPL>(W + (size_t)(base + tq + ES * b + hf) * H + c0, w[b]);
                 }
             }
         }
@@ -110,32 +126,34 @@ __global__ void k_concat2(const float *__restrict__ a, int Ha, const float *__re
 }
 
 // f_ij = (x_i + x_j) * p_e    (EdgeEmbedding, :463-465)
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_edge_embed(const float *__restrict__ x, const float *__restrict__ p, const int *__restrict__ col,
                                                     const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H, float *__restrict__ f) {
     const int E = min(*ne_dev, max_edges);
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
         const int cnt = min(VN_RUN, E - base);
         const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
-            for (int tq = 0; tq < cnt; tq += VN_EB) {
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += ES * VN_EB) {
                 float xi[VN_EB][CPL], xj[VN_EB][CPL], pv[VN_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    const int tt = min(tq + b, cnt - 1);
+                    const int tt = min(tq + ES * b + hf, cnt - 1);
                     const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
                     vld<CPL>(x + i * H + cl, xi[b]); vld<CPL>(x + j * H + cl, xj[b]); vld<CPL>(p + (size_t)(base + tt) * H + cl, pv[b]);
                 }
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    if (tq + b >= cnt) break;
+                    if (tq + ES * b + hf >= cnt) continue;
                     float o[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) o[u] = (xi[b][u] + xj[b][u]) * pv[b][u];
-                    if (on) vst<CPL>(f + (size_t)(base + tq + b) * H + c0, o);
+                    if (on) vst<CPL>(f + (size_t)(base + tq + ES * b + hf) * H + c0, o);
                 }
             }
         }
@@ -181,14 +199,16 @@ __global__ void k_vecdot(const float *__restrict__ vp, int n, int H, float *__re
 // index becomes a scalar register: row base in SGPRs, lane offset in a VGPR), and the rows of EB edges are requested before the first
 // of them is used — the loop was a chain of two dependent round trips per edge (index, then the k_j / v_j rows) and ran at 2.3 TB/s.
 // The sums run in edge order as before (bitwise-equal results).
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                   const float *__restrict__ dk, const float *__restrict__ dv, const int *__restrict__ rowptr,
                                                   const int *__restrict__ col, const float *__restrict__ dist, float cutoff, int n, int H,
                                                   int lph, int pre, float *__restrict__ vmsg, float *__restrict__ xagg) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = lane * CPL;
+    const int c0 = ll * CPL;
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;                                       // idle lanes (H < 64 CPL) read column 0 and store nothing
     for (int i = wave; i < n; i += nw) {
@@ -200,11 +220,11 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
             const int cnt = min(64, e1 - base);
             const int my_j = lane < cnt ? col[base + lane] : 0;
             const float my_c = lane < cnt ? cos_cutoff(dist[base + lane], cutoff) : 0.f;
-            for (int t = 0; t < cnt; t += VN_EB) {
+            for (int t = 0; t < cnt; t += ES * VN_EB) {
                 float kj[VN_EB][CPL], vj[VN_EB][CPL], dke[VN_EB][CPL], dve[VN_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    const int tt = min(t + b, cnt - 1);                  // slots past the row repeat its last edge (not used)
+                    const int tt = min(t + ES * b + hf, cnt - 1);                  // slots past the row repeat its last edge (not used)
                     const int j = __shfl(my_j, tt, 64);
                     const size_t e = (size_t)(base + tt);
                     vld<CPL>(k + (size_t)j * H + cl, kj[b]); vld<CPL>(v + (size_t)j * H + cl, vj[b]);
@@ -212,7 +232,8 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
                 }
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    if (t + b >= cnt) break;
+                    const float cutb = __shfl(my_c, min(t + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (t + ES * b + hf >= cnt) continue;
                     float part = 0.f;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
@@ -221,29 +242,30 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
                     }
                     if (!on) part = 0.f;
                     for (int o = 1; o < lph; o <<= 1) part += __shfl_xor(part, o, 64);
-                    const float attn = silu_f(part) * __shfl(my_c, t + b, 64);
+                    const float attn = silu_f(part) * cutb;
                     float m[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) { m[u] = vj[b][u] * dve[b][u] * attn; acc[u] += m[u]; }
-                    if (on) vst<CPL>(vmsg + (size_t)(base + t + b) * H + c0, m);
+                    if (on) vst<CPL>(vmsg + (size_t)(base + t + ES * b + hf) * H + c0, m);
                 }
             }
         }
-        if (on)
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) xagg[(size_t)i * H + c0 + u] = acc[u];
+        vfold<CPL, HALF>(acc);
+        if (on && hf == 0) vst<CPL>(xagg + (size_t)i * H + c0, acc);
     }
 }
 
 // Vector message + aggregation (:646-653, :672): vagg_i[sp] = sum_e vec_j[sp]*s1_e + s2_e*d_e[sp],  s = [s1|s2] in [E,2H]
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__ vec, const float *__restrict__ s, const float *__restrict__ dvec,
                                                        const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int pre,
                                                        float *__restrict__ vagg) {
     // lane <-> CPL consecutive channels (H = 64 CPL: one pass over the row); indices and unit vectors handed out per lane, VN_EB edges in flight
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = lane * CPL;
+    const int c0 = ll * CPL;
     for (int i = wave; i < n; i += nw) {
         float a0[CPL], a1[CPL], a2[CPL];
 #pragma unroll
@@ -255,11 +277,11 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
             float my_d[3];
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec[(size_t)(base + lane) * 3 + sp] : 0.f;
-            for (int t = 0; t < cnt; t += VN_EB) {
+            for (int t = 0; t < cnt; t += ES * VN_EB) {
                 float s1[VN_EB][CPL], s2[VN_EB][CPL], vj[VN_EB][3][CPL];
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    const int tt = min(t + b, cnt - 1);
+                    const int tt = min(t + ES * b + hf, cnt - 1);
                     const int j = __shfl(my_j, tt, 64);
                     const size_t e = (size_t)(base + tt);
                     vld<CPL>(s + e * 2 * H + c0, s1[b]); vld<CPL>(s + e * 2 * H + H + c0, s2[b]);
@@ -268,8 +290,8 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
                 }
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    if (t + b >= cnt) break;
-                    const float d0 = __shfl(my_d[0], t + b, 64), d1 = __shfl(my_d[1], t + b, 64), d2 = __shfl(my_d[2], t + b, 64);
+                    const float d0 = __shfl(my_d[0], min(t + ES * b + hf, cnt - 1), 64), d1 = __shfl(my_d[1], min(t + ES * b + hf, cnt - 1), 64), d2 = __shfl(my_d[2], min(t + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (t + ES * b + hf >= cnt) continue;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
                         float x1 = s1[b][u], x2 = s2[b][u];
@@ -282,8 +304,8 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
             }
         }
         float *o = vagg + (size_t)i * 3 * H;
-#pragma unroll
-        for (int u = 0; u < CPL; ++u) { o[c0 + u] = a0[u]; o[H + c0 + u] = a1[u]; o[2 * H + c0 + u] = a2[u]; }
+        vfold<CPL, HALF>(a0); vfold<CPL, HALF>(a1); vfold<CPL, HALF>(a2);
+        if (hf == 0) { vst<CPL>(o + c0, a0); vst<CPL>(o + H + c0, a1); vst<CPL>(o + 2 * H + c0, a2); }
     }
 }
 // any H: lane <-> channel, strided passes (the round-1 form)
@@ -331,13 +353,15 @@ __global__ void k_node_update(const float *__restrict__ x, const float *__restri
 // One wavefront per run of VN_RUN consecutive edges (round 3; was one thread per element: a 64-bit division, two index loads and six gathered
 // rows per ELEMENT, each waiting for its index): sources, targets and unit vectors of the run are fetched once, one edge per lane, and
 // handed out; lane <-> CPL channels; VN_EB edges in flight (consecutive edges share their target: its rows are L1 hits).
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_edge_update(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t,
                                                      const float *__restrict__ dvec, const int *__restrict__ col, const int *__restrict__ tgt,
                                                      const int *__restrict__ ne_dev, int max_edges, int H, int pre, const float *__restrict__ f,
                                                      float *__restrict__ fo) {
     const int E = min(*ne_dev, max_edges);
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
         const int cnt = min(VN_RUN, E - base);
@@ -345,13 +369,13 @@ __global__ void __launch_bounds__(256) k_edge_update(const float *__restrict__ w
         float my_d[3];
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec[(size_t)(base + lane) * 3 + sp] : 0.f;
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
-            for (int tq = 0; tq < cnt; tq += VN_EB) {
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += ES * VN_EB) {
                 float aa[VN_EB][3][CPL], bb[VN_EB][3][CPL], tv[VN_EB][CPL], fv[VN_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    const int tt = min(tq + b, cnt - 1);
+                    const int tt = min(tq + ES * b + hf, cnt - 1);
                     const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64), e = (size_t)(base + tt);
 #pragma unroll
                     for (int sp = 0; sp < 3; ++sp) { vld<CPL>(wt + (i * 3 + sp) * H + cl, aa[b][sp]); vld<CPL>(ws + (j * 3 + sp) * H + cl, bb[b][sp]); }
@@ -359,9 +383,9 @@ __global__ void __launch_bounds__(256) k_edge_update(const float *__restrict__ w
                 }
 #pragma unroll
                 for (int b = 0; b < VN_EB; ++b) {
-                    if (tq + b >= cnt) break;
-                    const size_t e = (size_t)(base + tq + b);
-                    const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                    const float d0 = __shfl(my_d[0], min(tq + ES * b + hf, cnt - 1), 64), d1 = __shfl(my_d[1], min(tq + ES * b + hf, cnt - 1), 64), d2 = __shfl(my_d[2], min(tq + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (tq + ES * b + hf >= cnt) continue;
+                    const size_t e = (size_t)(base + tq + ES * b + hf);
                     float ov[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
@@ -431,7 +455,8 @@ int conan_visnet_neighbor_scale_to(const float *W, const float *dist, const int 
                                    float cutoff, float *out, void *stream) {
     VN_CHECK(W && out && dist && col && tgt && num_edges_dev && H > 0);
     if (max_edges <= 0) return CONAN_OK;
-    if (H % 128 == 0) k_ne_scale<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, out, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    if (H == 128 && V_HALF) k_ne_scale<4, true><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, out, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
+    else if (H % 128 == 0) k_ne_scale<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, out, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
     else k_ne_scale<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(W, out, dist, col, tgt, num_edges_dev, max_edges, H, cutoff);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
@@ -447,7 +472,8 @@ int conan_concat2(const float *a, int Ha, const float *b, int Hb, long long rows
 int conan_visnet_edge_embed(const float *x, const float *p, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, int H,
                             float *f, void *stream) {
     VN_CHECK(x && p && col && tgt && num_edges_dev && f && H > 0);
-    if (H % 128 == 0) k_edge_embed<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
+    if (H == 128 && V_HALF) k_edge_embed<4, true><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
+    else if (H % 128 == 0) k_edge_embed<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
     else k_edge_embed<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(x, p, col, tgt, num_edges_dev, max_edges, H, f);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
@@ -477,7 +503,9 @@ int conan_visnet_attn_message(const float *q, const float *k, const float *v, co
     const int lph = hd / cpl;
     if (lph & (lph - 1)) return CONAN_E_UNSUPPORTED;
     if (n == 0) return CONAN_OK;
-    if (cpl == 2) k_attn_msg<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
+    if (H == 128 && V_HALF && hd % 4 == 0 && (((hd / 4) & (hd / 4 - 1)) == 0))
+        k_attn_msg<4, true><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, hd / 4, pre_act, vmsg, xagg);
+    else if (cpl == 2) k_attn_msg<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
     else k_attn_msg<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
@@ -485,7 +513,8 @@ int conan_visnet_vec_aggregate(const float *vec, const float *s, const float *dv
                                int pre_act, float *vagg, void *stream) {
     VN_CHECK(vec && s && dvec && rowptr && col && vagg && n >= 0 && H > 0);
     if (n == 0) return CONAN_OK;
-    if (H == 128) k_vec_aggregate<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
+    if (H == 128 && V_HALF) k_vec_aggregate<4, true><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
+    else if (H == 128) k_vec_aggregate<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
     else if (H == 64) k_vec_aggregate<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
     else k_vec_aggregate_any<<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(vec, s, dvec, rowptr, col, n, H, pre_act, vagg);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
@@ -499,7 +528,8 @@ int conan_visnet_node_update(const float *x, const float *vec, const float *vdot
 int conan_visnet_edge_update(const float *wt, const float *ws, const float *t, const float *dvec, const int *col, const int *tgt,
                              const int *num_edges_dev, int max_edges, int H, int pre_act, const float *f, float *f_out, void *stream) {
     VN_CHECK(wt && ws && t && dvec && col && tgt && num_edges_dev && f && f_out && H > 0);
-    if (H % 128 == 0) k_edge_update<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
+    if (H == 128 && V_HALF) k_edge_update<4, true><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
+    else if (H % 128 == 0) k_edge_update<2><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
     else k_edge_update<1><<<nblk((long long)max_edges * (64 / VN_RUN)), 256, 0, as_stream(stream)>>>(wt, ws, t, dvec, col, tgt, num_edges_dev, max_edges, H, pre_act, f, f_out);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }

@@ -49,15 +49,24 @@ __global__ void k_rowsum(const float *__restrict__ x, int rows, int width, float
 // 256-byte aligned allocation; the compiler cannot prove that and would issue two dword instructions)
 template <int CPL>
 __device__ __forceinline__ void vld(const float *__restrict__ p, float (&r)[CPL]) {
-    if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
+    if constexpr (CPL == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+    else if constexpr (CPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r[0] = t.x; r[1] = t.y; }
     else {
 #pragma unroll
         for (int u = 0; u < CPL; ++u) r[u] = p[u];
     }
 }
+template <int CPL, bool HALF>
+__device__ __forceinline__ void vfold(float (&a)[CPL]) {      // HALF: even entries (lanes 0-31) + odd entries (lanes 32-63), fixed order
+    if constexpr (HALF) {
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) a[u] += __shfl_xor(a[u], 32, 64);
+    }
+}
 template <int CPL>
 __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]) {
-    if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
+    if constexpr (CPL == 4) *reinterpret_cast<float4 *>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    else if constexpr (CPL == 2) *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
     else {
 #pragma unroll
         for (int u = 0; u < CPL; ++u) p[u] = r[u];
@@ -67,65 +76,74 @@ __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]
 #ifndef CONAN_V_EB
 #define CONAN_V_EB 4
 #endif
+#ifdef CONAN_V_NO_HALF
+constexpr bool V_HALF = false;
+#else
+constexpr bool V_HALF = true;     // H = 128: a half-wavefront per edge (visnet.hip)
+#endif
 constexpr int VB_EB = CONAN_V_EB;
 #ifndef CONAN_VB_RUN
 #define CONAN_VB_RUN 16
 #endif
 constexpr int VB_RUN = CONAN_VB_RUN;     // edges per wavefront in the kernels that walk runs of consecutive edges
 // dp[e] = (x_i + x_j) * df[e]      (runs of VB_RUN consecutive edges per wavefront, as k_edge_embed)
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_edge_embed_bwd_p(const float *__restrict__ x, const float *__restrict__ df, const int *__restrict__ col,
                                                           const int *__restrict__ tgt, const int *__restrict__ ne_dev, int max_edges, int H,
                                                           float *__restrict__ dp) {
     const int E = min(*ne_dev, max_edges);
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VB_RUN; base < E; base += nw * VB_RUN) {
         const int cnt = min(VB_RUN, E - base);
         const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
-            for (int tq = 0; tq < cnt; tq += VB_EB) {
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += ES * VB_EB) {
                 float xi[VB_EB][CPL], xj[VB_EB][CPL], gv[VB_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    const int tt = min(tq + b, cnt - 1);
+                    const int tt = min(tq + ES * b + hf, cnt - 1);
                     const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
                     vld<CPL>(x + i * H + cl, xi[b]); vld<CPL>(x + j * H + cl, xj[b]); vld<CPL>(df + (size_t)(base + tt) * H + cl, gv[b]);
                 }
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    if (tq + b >= cnt) break;
+                    if (tq + ES * b + hf >= cnt) continue;
                     float o[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) o[u] = (xi[b][u] + xj[b][u]) * gv[b][u];
-                    if (on) vst<CPL>(dp + (size_t)(base + tq + b) * H + c0, o);
+                    if (on) vst<CPL>(dp + (size_t)(base + tq + ES * b + hf) * H + c0, o);
                 }
             }
         }
     }
 }
 // dx[i] = sum_{e in row(i)} df[e]*p[e] + sum_{e in srclist(i)} df[e]*p[e]
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_edge_embed_bwd_x(const float *__restrict__ p, const float *__restrict__ df, const int *__restrict__ rowptr,
                                                           const int *__restrict__ t_rowptr, const int *__restrict__ t_eid, int n, int H,
                                                           float *__restrict__ dx) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
             float a[CPL];
 #pragma unroll
             for (int u = 0; u < CPL; ++u) a[u] = 0.f;
             const int e0 = rowptr[i], e1 = rowptr[i + 1];
-            for (int e = e0; e < e1; e += VB_EB) {                                  // the row itself: consecutive edges, no indices
+            for (int e = e0; e < e1; e += ES * VB_EB) {                             // the row itself: consecutive edges, no indices
                 float g[VB_EB][CPL], q[VB_EB][CPL];
 #pragma unroll
-                for (int b = 0; b < VB_EB; ++b) { const size_t ee = (size_t)min(e + b, e1 - 1); vld<CPL>(df + ee * H + cl, g[b]); vld<CPL>(p + ee * H + cl, q[b]); }
+                for (int b = 0; b < VB_EB; ++b) { const size_t ee = (size_t)min(e + ES * b + hf, e1 - 1); vld<CPL>(df + ee * H + cl, g[b]); vld<CPL>(p + ee * H + cl, q[b]); }
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    if (e + b >= e1) break;
+                    if (e + ES * b + hf >= e1) continue;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) a[u] += g[b][u] * q[b][u];
                 }
@@ -134,22 +152,23 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd_x(const float *__restric
             for (int base = s0; base < s1; base += 64) {                            // the by-source list: edge ids handed out per lane
                 const int cnt = min(64, s1 - base);
                 const int my_e = lane < cnt ? t_eid[base + lane] : 0;
-                for (int tq = 0; tq < cnt; tq += VB_EB) {
+                for (int tq = 0; tq < cnt; tq += ES * VB_EB) {
                     float g[VB_EB][CPL], q[VB_EB][CPL];
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        const size_t ee = (size_t)__shfl(my_e, min(tq + b, cnt - 1), 64);
+                        const size_t ee = (size_t)__shfl(my_e, min(tq + ES * b + hf, cnt - 1), 64);
                         vld<CPL>(df + ee * H + cl, g[b]); vld<CPL>(p + ee * H + cl, q[b]);
                     }
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        if (tq + b >= cnt) break;
+                        if (tq + ES * b + hf >= cnt) continue;
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) a[u] += g[b][u] * q[b][u];
                     }
                 }
             }
-            if (on) vst<CPL>(dx + (size_t)i * H + c0, a);
+            vfold<CPL, HALF>(a);
+            if (on && hf == 0) vst<CPL>(dx + (size_t)i * H + c0, a);
         }
 }
 
@@ -234,15 +253,17 @@ __device__ __forceinline__ void attn_edge(const float *qi, const float *kj, cons
 // chains of two or three dependent round trips per edge (2.3-3 TB/s); the sums still run in list order (bitwise-equal results).
 
 // target side: dq[i] (sum over row i), and the edge gradients d dk[e], d dv[e]
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                          const float *__restrict__ dk, const float *__restrict__ dv, const float *__restrict__ dvmsg,
                                                          const float *__restrict__ dxagg, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                          const float *__restrict__ dist, float cutoff, int n, int H, int lph, int pre,
                                                          float *__restrict__ dq, float *__restrict__ ddk, float *__restrict__ ddv) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = lane * CPL;
+    const int c0 = ll * CPL;
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;                                       // idle lanes read column 0 and store nothing
     for (int i = wave; i < n; i += nw) {
@@ -254,11 +275,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
             const int cnt = min(64, e1 - base);
             const int my_j = lane < cnt ? col[base + lane] : 0;
             const float my_c = lane < cnt ? cos_cutoff(dist[base + lane], cutoff) : 0.f;
-            for (int t = 0; t < cnt; t += VB_EB) {
+            for (int t = 0; t < cnt; t += ES * VB_EB) {
                 float kj[VB_EB][CPL], vj[VB_EB][CPL], dke[VB_EB][CPL], dve[VB_EB][CPL], dm[VB_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    const int tt = min(t + b, cnt - 1);
+                    const int tt = min(t + ES * b + hf, cnt - 1);
                     const int j = __shfl(my_j, tt, 64);
                     const size_t e = (size_t)(base + tt);
                     vld<CPL>(k + (size_t)j * H + cl, kj[b]); vld<CPL>(v + (size_t)j * H + cl, vj[b]);
@@ -266,8 +287,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
                 }
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    if (t + b >= cnt) break;
-                    const size_t e = (size_t)(base + t + b);
+                    const float cutb = __shfl(my_c, min(t + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (t + ES * b + hf >= cnt) continue;
+                    const size_t e = (size_t)(base + t + ES * b + hf);
                     float sk[CPL], sv[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
@@ -277,7 +299,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
                         if (!on) { kj[b][u] = 0.f; vj[b][u] = 0.f; dke[b][u] = 0.f; dve[b][u] = 0.f; }
                     }
                     float attn, da;
-                    attn_edge<CPL>(qi, kj[b], vj[b], dke[b], dve[b], dm[b], __shfl(my_c, t + b, 64), lph, attn, da);
+                    attn_edge<CPL>(qi, kj[b], vj[b], dke[b], dve[b], dm[b], cutb, lph, attn, da);
                     float o1[CPL], o2[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
@@ -288,21 +310,22 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
                 }
             }
         }
-        if (on)
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) dq[(size_t)i * H + c0 + u] = acc[u];
+        vfold<CPL, HALF>(acc);
+        if (on && hf == 0) vst<CPL>(dq + (size_t)i * H + c0, acc);
     }
 }
 // source side: dk[j], dv[j] (sum over the by-source list of j)
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                          const float *__restrict__ dk, const float *__restrict__ dv, const float *__restrict__ dvmsg,
                                                          const float *__restrict__ dxagg, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                          const int *__restrict__ tgt, const float *__restrict__ dist, float cutoff, int n, int H, int lph,
                                                          int pre, float *__restrict__ dkn, float *__restrict__ dvn) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = lane * CPL;
+    const int c0 = ll * CPL;
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;
     for (int j = wave; j < n; j += nw) {
@@ -315,18 +338,19 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
             const int my_e = lane < cnt ? t_eid[base + lane] : 0;
             const int my_i = lane < cnt ? tgt[my_e] : 0;
             const float my_c = lane < cnt ? cos_cutoff(dist[my_e], cutoff) : 0.f;
-            for (int t = 0; t < cnt; t += VB_EB) {
+            for (int t = 0; t < cnt; t += ES * VB_EB) {
                 float qi[VB_EB][CPL], dke[VB_EB][CPL], dve[VB_EB][CPL], dm[VB_EB][CPL], gx[VB_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    const int tt = min(t + b, cnt - 1);
+                    const int tt = min(t + ES * b + hf, cnt - 1);
                     const size_t e = (size_t)__shfl(my_e, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
                     vld<CPL>(q + i * H + cl, qi[b]); vld<CPL>(dxagg + i * H + cl, gx[b]);
                     vld<CPL>(dk + e * H + cl, dke[b]); vld<CPL>(dv + e * H + cl, dve[b]); vld<CPL>(dvmsg + e * H + cl, dm[b]);
                 }
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    if (t + b >= cnt) break;
+                    const float cutb = __shfl(my_c, min(t + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (t + ES * b + hf >= cnt) continue;
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
                         if (pre) { dke[b][u] = silu_f(dke[b][u]); dve[b][u] = silu_f(dve[b][u]); }
@@ -334,27 +358,28 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
                         if (!on) { qi[b][u] = 0.f; dke[b][u] = 0.f; dve[b][u] = 0.f; }
                     }
                     float attn, da;
-                    attn_edge<CPL>(qi[b], kj, vj, dke[b], dve[b], dm[b], __shfl(my_c, t + b, 64), lph, attn, da);
+                    attn_edge<CPL>(qi[b], kj, vj, dke[b], dve[b], dm[b], cutb, lph, attn, da);
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) { ak[u] += da * qi[b][u] * dke[b][u]; av[u] += dm[b][u] * dve[b][u] * attn; }
                 }
             }
         }
-        if (on)
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) { dkn[(size_t)j * H + c0 + u] = ak[u]; dvn[(size_t)j * H + c0 + u] = av[u]; }
+        vfold<CPL, HALF>(ak); vfold<CPL, HALF>(av);
+        if (on && hf == 0) { vst<CPL>(dkn + (size_t)j * H + c0, ak); vst<CPL>(dvn + (size_t)j * H + c0, av); }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- vector aggregate backward
 // ds[e] = [ sum_sp dvagg[tgt,sp]*vec[src,sp] | sum_sp dvagg[tgt,sp]*d_e[sp] ]
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_s(const float *__restrict__ vec, const float *__restrict__ dvagg, const float *__restrict__ dvec3,
                                                              const int *__restrict__ col, const int *__restrict__ tgt, const int *__restrict__ ne_dev,
                                                              int max_edges, int H, const float *__restrict__ s_pre, float *__restrict__ ds) {
     // one wavefront per run of VB_RUN consecutive edges, indices and unit vectors handed out per lane, VB_EB edges in flight (see k_edge_update)
     const int E = min(*ne_dev, max_edges);
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VB_RUN; base < E; base += nw * VB_RUN) {
         const int cnt = min(VB_RUN, E - base);
@@ -362,13 +387,13 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_s(const float *__rest
         float my_d[3];
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec3[(size_t)(base + lane) * 3 + sp] : 0.f;
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
-            for (int tq = 0; tq < cnt; tq += VB_EB) {
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+            for (int tq = 0; tq < cnt; tq += ES * VB_EB) {
                 float g[VB_EB][3][CPL], vj[VB_EB][3][CPL], p1[VB_EB][CPL], p2[VB_EB][CPL];
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    const int tt = min(tq + b, cnt - 1);
+                    const int tt = min(tq + ES * b + hf, cnt - 1);
                     const size_t j = (size_t)__shfl(my_j, tt, 64), i = (size_t)__shfl(my_i, tt, 64), e = (size_t)(base + tt);
 #pragma unroll
                     for (int sp = 0; sp < 3; ++sp) { vld<CPL>(dvagg + (i * 3 + sp) * H + cl, g[b][sp]); vld<CPL>(vec + (j * 3 + sp) * H + cl, vj[b][sp]); }
@@ -380,9 +405,9 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_s(const float *__rest
                 }
 #pragma unroll
                 for (int b = 0; b < VB_EB; ++b) {
-                    if (tq + b >= cnt) break;
-                    const size_t e = (size_t)(base + tq + b);
-                    const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                    const float d0 = __shfl(my_d[0], min(tq + ES * b + hf, cnt - 1), 64), d1 = __shfl(my_d[1], min(tq + ES * b + hf, cnt - 1), 64), d2 = __shfl(my_d[2], min(tq + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                    if (tq + ES * b + hf >= cnt) continue;
+                    const size_t e = (size_t)(base + tq + ES * b + hf);
                     float r1[CPL], r2[CPL];
 #pragma unroll
                     for (int u = 0; u < CPL; ++u) {
@@ -398,15 +423,17 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_s(const float *__rest
     }
 }
 // dvec[j,sp] = sum_{e in srclist(j)} dvagg[tgt_e,sp] * s1_e
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__restrict__ s, const float *__restrict__ dvagg, const int *__restrict__ t_rowptr,
                                                              const int *__restrict__ t_eid, const int *__restrict__ tgt, int n, int H, int pre,
                                                              float *__restrict__ dvec) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;                        // H = 64 CPL: one pass; every lane walks the row (idle ones: column 0, no stores)
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;                        // H = 64 CPL: one pass; every lane walks the row (idle ones: column 0, no stores)
             float a0[CPL], a1[CPL], a2[CPL];
 #pragma unroll
             for (int u = 0; u < CPL; ++u) { a0[u] = 0.f; a1[u] = 0.f; a2[u] = 0.f; }
@@ -415,11 +442,11 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__rest
                 const int cnt = min(64, q1 - base);
                 const int my_e = lane < cnt ? t_eid[base + lane] : 0;
                 const int my_i = lane < cnt ? tgt[my_e] : 0;
-                for (int t = 0; t < cnt; t += VB_EB) {
+                for (int t = 0; t < cnt; t += ES * VB_EB) {
                     float s1[VB_EB][CPL], g[VB_EB][3][CPL];
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        const int tt = min(t + b, cnt - 1);
+                        const int tt = min(t + ES * b + hf, cnt - 1);
                         const size_t e = (size_t)__shfl(my_e, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
                         vld<CPL>(s + e * 2 * H + cl, s1[b]);
 #pragma unroll
@@ -427,7 +454,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__rest
                     }
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        if (t + b >= cnt) break;
+                        if (t + ES * b + hf >= cnt) continue;
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) {
                             const float x1 = pre ? silu_f(s1[b][u]) : s1[b][u];
@@ -437,9 +464,8 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__rest
                 }
             }
             float *o = dvec + (size_t)j * 3 * H;
-            if (on)
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) { o[c0 + u] = a0[u]; o[H + c0 + u] = a1[u]; o[2 * H + c0 + u] = a2[u]; }
+            vfold<CPL, HALF>(a0); vfold<CPL, HALF>(a1); vfold<CPL, HALF>(a2);
+            if (on && hf == 0) { vst<CPL>(o + c0, a0); vst<CPL>(o + H + c0, a1); vst<CPL>(o + 2 * H + c0, a2); }
         }
 }
 
@@ -470,15 +496,17 @@ __global__ void k_node_update_bwd(const float *__restrict__ dxo, const float *__
 // ---------------------------------------------------------------------------------------------- edge update backward
 // forward: fo = f + t * sum_sp w1*w2, w1 = a - (a.d)d, w2 = b - (b.d)d  (a = wt[tgt], b = ws[src]; the sign of d cancels)
 // target pass: dwt[i] = sum_{e in row(i)} P_d (g * w2), and dt[e] = dfo * (w1.w2)   with g = dfo * t, P_d u = u - (u.d)d
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restrict__ wt, const float *__restrict__ ws, const float *__restrict__ t,
                                                            const float *__restrict__ dvec3, const float *__restrict__ dfo, const int *__restrict__ rowptr,
                                                            const int *__restrict__ col, int n, int H, int pre, float *__restrict__ dwt, float *__restrict__ dt) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
             const float *a = wt + (size_t)i * 3 * H;
             float a0[CPL], a1[CPL], a2[CPL], s0[CPL], s1[CPL], s2[CPL];
 #pragma unroll
@@ -490,11 +518,11 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restri
                 float my_d[3];
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec3[(size_t)(base + lane) * 3 + sp] : 0.f;
-                for (int tq = 0; tq < cnt; tq += VB_EB) {
+                for (int tq = 0; tq < cnt; tq += ES * VB_EB) {
                     float bb[VB_EB][3][CPL], gf[VB_EB][CPL], tr[VB_EB][CPL];
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        const int tt = min(tq + b, cnt - 1);
+                        const int tt = min(tq + ES * b + hf, cnt - 1);
                         const size_t j = (size_t)__shfl(my_j, tt, 64), e = (size_t)(base + tt);
 #pragma unroll
                         for (int sp = 0; sp < 3; ++sp) vld<CPL>(ws + (j * 3 + sp) * H + cl, bb[b][sp]);
@@ -502,9 +530,9 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restri
                     }
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        if (tq + b >= cnt) break;
-                        const size_t e = (size_t)(base + tq + b);
-                        const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                        const float d0 = __shfl(my_d[0], min(tq + ES * b + hf, cnt - 1), 64), d1 = __shfl(my_d[1], min(tq + ES * b + hf, cnt - 1), 64), d2 = __shfl(my_d[2], min(tq + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                        if (tq + ES * b + hf >= cnt) continue;
+                        const size_t e = (size_t)(base + tq + ES * b + hf);
                         float dtv[CPL];
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) {
@@ -523,21 +551,22 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restri
                 }
             }
             float *o = dwt + (size_t)i * 3 * H;
-            if (on)
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) { o[c0 + u] = s0[u]; o[H + c0 + u] = s1[u]; o[2 * H + c0 + u] = s2[u]; }
+            vfold<CPL, HALF>(s0); vfold<CPL, HALF>(s1); vfold<CPL, HALF>(s2);
+            if (on && hf == 0) { vst<CPL>(o + c0, s0); vst<CPL>(o + H + c0, s1); vst<CPL>(o + 2 * H + c0, s2); }
         }
 }
 // source pass: dws[j] = sum_{e in srclist(j)} P_d (g * w1)
-template <int CPL>
+template <int CPL, bool HALF = false>
 __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restrict__ wt, const float *__restrict__ t, const float *__restrict__ dvec3,
                                                            const float *__restrict__ dfo, const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                            const int *__restrict__ tgt, int n, int H, int pre, float *__restrict__ dws) {
     const int lane = threadIdx.x & 63;
+    const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
+    constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
-        for (int cp = 0; cp < H; cp += 64 * CPL) {
-            const int c0 = cp + lane * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
+        for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
+            const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
             float s0[CPL], s1[CPL], s2[CPL];
 #pragma unroll
             for (int u = 0; u < CPL; ++u) { s0[u] = 0.f; s1[u] = 0.f; s2[u] = 0.f; }
@@ -549,11 +578,11 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restri
                 float my_d[3];
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) my_d[sp] = lane < cnt ? dvec3[(size_t)my_e * 3 + sp] : 0.f;
-                for (int tq = 0; tq < cnt; tq += VB_EB) {
+                for (int tq = 0; tq < cnt; tq += ES * VB_EB) {
                     float aa[VB_EB][3][CPL], gf[VB_EB][CPL], tr[VB_EB][CPL];
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        const int tt = min(tq + b, cnt - 1);
+                        const int tt = min(tq + ES * b + hf, cnt - 1);
                         const size_t e = (size_t)__shfl(my_e, tt, 64), i = (size_t)__shfl(my_i, tt, 64);
 #pragma unroll
                         for (int sp = 0; sp < 3; ++sp) vld<CPL>(wt + (i * 3 + sp) * H + cl, aa[b][sp]);
@@ -561,8 +590,8 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restri
                     }
 #pragma unroll
                     for (int b = 0; b < VB_EB; ++b) {
-                        if (tq + b >= cnt) break;
-                        const float d0 = __shfl(my_d[0], tq + b, 64), d1 = __shfl(my_d[1], tq + b, 64), d2 = __shfl(my_d[2], tq + b, 64);
+                        const float d0 = __shfl(my_d[0], min(tq + ES * b + hf, cnt - 1), 64), d1 = __shfl(my_d[1], min(tq + ES * b + hf, cnt - 1), 64), d2 = __shfl(my_d[2], min(tq + ES * b + hf, cnt - 1), 64);      // before the halves diverge
+                        if (tq + ES * b + hf >= cnt) continue;
 #pragma unroll
                         for (int u = 0; u < CPL; ++u) {
                             const float a0 = aa[b][0][u], a1 = aa[b][1][u], a2 = aa[b][2][u];
@@ -577,9 +606,8 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restri
                 }
             }
             float *o = dws + (size_t)j * 3 * H;
-            if (on)
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) { o[c0 + u] = s0[u]; o[H + c0 + u] = s1[u]; o[2 * H + c0 + u] = s2[u]; }
+            vfold<CPL, HALF>(s0); vfold<CPL, HALF>(s1); vfold<CPL, HALF>(s2);
+            if (on && hf == 0) { vst<CPL>(o + c0, s0); vst<CPL>(o + H + c0, s1); vst<CPL>(o + 2 * H + c0, s2); }
         }
 }
 
@@ -654,8 +682,10 @@ int conan_visnet_edge_embed_bwd(const float *x, const float *p, const float *df,
     VB_CHECK(x && p && df && rowptr && col && tgt && t_rowptr && t_eid && num_edges_dev && dp && dx && H > 0);
     hipStream_t s = as_stream(stream);
     if (H % 128 == 0) {
-        k_edge_embed_bwd_p<2><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
-        k_edge_embed_bwd_x<2><<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
+        if (H == 128 && V_HALF) k_edge_embed_bwd_p<4, true><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
+        else k_edge_embed_bwd_p<2><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
+        if (H == 128 && V_HALF) k_edge_embed_bwd_x<4, true><<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
+        else k_edge_embed_bwd_x<2><<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
     } else {
         k_edge_embed_bwd_p<1><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, s>>>(x, df, col, tgt, num_edges_dev, max_edges, H, dp);
         k_edge_embed_bwd_x<1><<<nblk((long long)n * 64), 256, 0, s>>>(p, df, rowptr, t_rowptr, t_eid, n, H, dx);
@@ -694,7 +724,10 @@ int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v
     if (n == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
     const int g = nblk((long long)n * 64);
-    if (cpl == 2) {
+    if (H == 128 && V_HALF && hd % 4 == 0 && (((hd / 4) & (hd / 4 - 1)) == 0)) {
+        k_attn_bwd_target<4, true><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, hd / 4, pre_act, dq, ddk, ddv);
+        k_attn_bwd_source<4, true><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, hd / 4, pre_act, dkn, dvn);
+    } else if (cpl == 2) {
         k_attn_bwd_target<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, pre_act, dq, ddk, ddv);
         k_attn_bwd_source<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, pre_act, dkn, dvn);
     } else {
@@ -708,10 +741,12 @@ int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float
                                    float *ds, float *dvec, void *stream) {
     VB_CHECK(vec && s && dvec3 && dvagg && col && tgt && t_rowptr && t_eid && num_edges_dev && ds && dvec && H > 0);
     hipStream_t st = as_stream(stream);
-    if (H % 128 == 0) k_vec_aggregate_bwd_s<2><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
+    if (H == 128 && V_HALF) k_vec_aggregate_bwd_s<4, true><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
+    else if (H % 128 == 0) k_vec_aggregate_bwd_s<2><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
     else k_vec_aggregate_bwd_s<1><<<nblk((long long)max_edges * (64 / VB_RUN)), 256, 0, st>>>(vec, dvagg, dvec3, col, tgt, num_edges_dev, max_edges, H, pre_act ? s : nullptr, ds);
     if (n > 0) {
-        if (H % 128 == 0) k_vec_aggregate_bwd_v<2><<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
+        if (H == 128 && V_HALF) k_vec_aggregate_bwd_v<4, true><<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
+        else if (H % 128 == 0) k_vec_aggregate_bwd_v<2><<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
         else k_vec_aggregate_bwd_v<1><<<nblk((long long)n * 64), 256, 0, st>>>(s, dvagg, t_rowptr, t_eid, tgt, n, H, pre_act, dvec);
     }
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
@@ -729,8 +764,10 @@ int conan_visnet_edge_update_bwd(const float *wt, const float *ws, const float *
     if (n == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
     if (H % 128 == 0) {
-        k_edge_update_bwd_t<2><<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
-        k_edge_update_bwd_s<2><<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
+        if (H == 128 && V_HALF) k_edge_update_bwd_t<4, true><<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
+        else k_edge_update_bwd_t<2><<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
+        if (H == 128 && V_HALF) k_edge_update_bwd_s<4, true><<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
+        else k_edge_update_bwd_s<2><<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
     } else {
         k_edge_update_bwd_t<1><<<nblk((long long)n * 64), 256, 0, s>>>(wt, ws, t, dvec3, dfo, rowptr, col, n, H, pre_act, dwt, dt);
         k_edge_update_bwd_s<1><<<nblk((long long)n * 64), 256, 0, s>>>(wt, t, dvec3, dfo, t_rowptr, t_eid, tgt, n, H, pre_act, dws);
