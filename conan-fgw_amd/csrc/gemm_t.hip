@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
                                                            int M, int w_kn, float *y,
                                                            const int *__restrict__ m_dev, int ldx, int ldw, int ldy,
-                                                           const float *accum, float *pre_out) {
+                                                           const float *accum, float *pre_out, int nc) {
     // ldx / ldw / ldy: row pitches of x, w and of y / residual / accum — the launcher tiles wider layers into 64/128-wide
     // (K, N) chunks of one strided problem; `accum` (may alias y) carries the partial sum of the previous K chunks and is
     // added BEFORE the activation.  pre_out (nullable): also store the pre-activation (bias and accum included), which the
@@ -120,12 +120,26 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     if (m_dev) M = min(M, *m_dev);
     const int tiles = (M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x * (NT / 64) >= tiles) return;
+    // nc > 1: the nc N-wide output chunks of ONE wider layer in one launch.  Block b serves chunk b % nc for tile slot b / nc, so the
+    // workgroups that read the same x tiles are dispatched side by side and all but the first find the rows in L2 / the Infinity Cache
+    // (as separate launches every chunk streamed x from HBM again, and a node-level layer paid launch + staging per chunk).
+    const int chunk = nc > 1 ? (int)blockIdx.x % nc : 0, slot = nc > 1 ? (int)blockIdx.x / nc : (int)blockIdx.x;
+    const int nslots = nc > 1 ? (int)gridDim.x / nc : (int)gridDim.x;
+    if (nc > 1) {
+        const int n0 = chunk * N;
+        w += w_kn ? (size_t)n0 : (size_t)n0 * ldw;
+        if (bias) bias += n0;
+        if (residual) residual += n0;
+        if (accum) accum += n0;
+        if (pre_out) pre_out += n0;
+        y += n0;
+    }
+    if (slot * (NT / 64) >= tiles) return;
     // The wave's first tile of x is requested BEFORE the weights are staged (the two are independent): at node-level sizes a
     // wave owns exactly one tile and the kernel is two serial memory round trips otherwise.  Later tiles are requested as soon
     // as the MFMA loop has consumed the current one, i.e. they fly during the epilogue.
     const int l31 = lane & 31, h = lane >> 5;
-    const int wave_stride = gridDim.x * (NT / 64);
+    const int wave_stride = nslots * (NT / 64);
     float4 xa[S], xb[S];
     auto load_x = [&](int t) {
         const int mr = min((t << 5) + l31, M - 1);
@@ -136,7 +150,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
             xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
         }
     };
-    if ((int)blockIdx.x * (NT / 64) + wave < tiles) load_x(blockIdx.x * (NT / 64) + wave);
+    if (slot * (NT / 64) + wave < tiles) load_x(slot * (NT / 64) + wave);
     // Staging of the three bf16 images of W as [n][k]; all of a thread's loads are in flight before the first use.
     if (!w_kn) {                                              // w is [N][K]: float4 = 4 consecutive k -> one 8-byte store per image
         constexpr int V4 = N * K / 4, PER = (V4 + NT - 1) / NT;
@@ -206,7 +220,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     for (int t = tid; t < N; t += NT) BL[t] = bias ? bias[t] : 0.f;
     __syncthreads();
 
-    for (int tile = blockIdx.x * (NT / 64) + wave; tile < tiles; tile += wave_stride) {
+    for (int tile = slot * (NT / 64) + wave; tile < tiles; tile += wave_stride) {
         const int m = (tile << 5) + l31;
         const bool valid = m < M;
         f32x16 acc[NB];
@@ -330,7 +344,8 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
 
 template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
-             const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr) {
+             const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr,
+             int nc = 1) {
     if (ldw == 0) ldw = w_kn ? N : K;
     const size_t lds_w = ((size_t)(LT_NPL * N * (K + 8)) / 2 + N) * 4;
     const int tiles16 = (M + 31) / 32;
@@ -340,18 +355,19 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     const size_t lds16 = lds_w + (LT_H16 ? (size_t)(narrow ? 4 : 8) * 32 * LT_OP * 4 : 0);
     const int per = narrow ? 4 : 8;
     int grid16 = (tiles16 + per - 1) / per;
-    if (grid16 > 256) grid16 = 256;
+    if (grid16 > 256 / nc) grid16 = 256 / nc;          // (nc chunks: 256 / nc tile slots x nc)
+    grid16 *= nc;
 #define LAUNCH16(A)                                                                                                              \
     do {                                                                                                                         \
         if (narrow) {                                                                                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A, 256>),                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);                                   \
-            k_linear_t16<K, N, A, 256><<<grid16, 256, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out); \
+            k_linear_t16<K, N, A, 256><<<grid16, 256, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out, nc); \
         } else {                                                                                                                 \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A, LT_THREADS>),                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);                                   \
             k_linear_t16<K, N, A, LT_THREADS><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, \
-                                                                                pre_out);                                        \
+                                                                                pre_out, nc);                                    \
         }                                                                                                                        \
     } while (0)
     switch (act) {
@@ -373,6 +389,10 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
 template <int KC, int NC>
 static int chunk_launch(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn, int act,
                         float *y, const int *m_dev, hipStream_t s, float *pre_out) {
+#ifndef CONAN_LINEAR_NO_NCHUNK      // (A/B switch: one launch per chunk, as in round 2)
+    if (K == KC && N / NC > 1 && N / NC <= 4)              // one contraction chunk: the N / NC output chunks share their x tiles in ONE launch
+        return launch_t<KC, NC>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, K, w_kn ? N : K, N, nullptr, pre_out, N / NC);
+#endif
     for (int n0 = 0; n0 < N; n0 += NC)
         for (int k0 = 0; k0 < K; k0 += KC) {
             const bool first = k0 == 0, last = k0 + KC >= K;
