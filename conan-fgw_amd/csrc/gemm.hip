@@ -662,6 +662,8 @@ static int wgrad_slices(int M, int K) {
 
 int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
                        int act, float *y, const int *m_dev, hipStream_t s, int *rc, float *pre_out);      // gemm_t.hip
+int conan_linear_t_multi(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int njobs, int act, float *const *y,
+                         float *const *pre, const int *m_dev, hipStream_t s, int *rc);                    // gemm_t.hip
 
 extern "C" {
 
@@ -708,6 +710,22 @@ int conan_linear_act_fwd(const float *x, const float *w, const float *bias, int 
     int rc = CONAN_OK;
     if (conan_linear_t_try(x, w, bias, nullptr, M, K, N, 0, act, y, m_dev, as_stream(stream), &rc, pre)) return rc;
     return CONAN_E_UNSUPPORTED;
+}
+
+int conan_linear_multi_fwd(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int num_layers, int act,
+                           const int *m_dev, float *const *y, float *const *pre, void *stream) {
+    if (!x || !w || !y || M < 0 || K <= 0 || N <= 0 || num_layers < 1 || (act != 0 && act != 1 && act != 3)) return CONAN_E_BADARG;
+    for (int q = 0; q < num_layers; ++q)
+        if (!w[q] || !y[q]) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    int rc = CONAN_OK;
+    if (conan_linear_t_multi(x, w, bias, M, K, N, num_layers, act, y, pre, m_dev, as_stream(stream), &rc)) return rc;
+    for (int q = 0; q < num_layers; ++q) {                        // shapes outside the one-launch form: one launch per layer
+        if (!conan_linear_t_try(x, w[q], bias ? bias[q] : nullptr, nullptr, M, K, N, 0, act, y[q], m_dev, as_stream(stream), &rc, pre ? pre[q] : nullptr))
+            return CONAN_E_UNSUPPORTED;
+        if (rc != CONAN_OK) return rc;
+    }
+    return CONAN_OK;
 }
 
 int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream) {

@@ -97,12 +97,19 @@ __device__ __forceinline__ void lt_store4(void *WBv, int N, int WS, int n, int k
 // ACT is a template parameter: the epilogue is straight-line code over 16*NB outputs per lane, and with a run-time
 // activation switch the kernel was 31 KB of code executed exactly once per wavefront at node-level sizes — rocprofv3
 // showed 45 % of the wave cycles waiting for instruction fetch (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).
+// Up to four Linear layers of the SAME input in one launch (q / k / v; dk / dv / f_proj of one f): chunk c of the nc > 1 mechanism below takes its
+// weight, bias and outputs from slot c here instead of from an offset into one wide layer.  w[0] == nullptr: not used.
+struct LtJobs {
+    const float *w[4], *bias[4];
+    float *y[4], *pre[4];
+};
+
 template <int K, int N, int ACT, int NT>
 __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, const float *__restrict__ w,
                                                            const float *__restrict__ bias, const float *__restrict__ residual,
                                                            int M, int w_kn, float *y,
                                                            const int *__restrict__ m_dev, int ldx, int ldw, int ldy,
-                                                           const float *accum, float *pre_out, int nc) {
+                                                           const float *accum, float *pre_out, int nc, const LtJobs J) {
     // ldx / ldw / ldy: row pitches of x, w and of y / residual / accum — the launcher tiles wider layers into 64/128-wide
     // (K, N) chunks of one strided problem; `accum` (may alias y) carries the partial sum of the previous K chunks and is
     // added BEFORE the activation.  pre_out (nullable): also store the pre-activation (bias and accum included), which the
@@ -125,7 +132,9 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     // (as separate launches every chunk streamed x from HBM again, and a node-level layer paid launch + staging per chunk).
     const int chunk = nc > 1 ? (int)blockIdx.x % nc : 0, slot = nc > 1 ? (int)blockIdx.x / nc : (int)blockIdx.x;
     const int nslots = nc > 1 ? (int)gridDim.x / nc : (int)gridDim.x;
-    if (nc > 1) {
+    if (nc > 1 && J.w[0]) {
+        w = J.w[chunk]; bias = J.bias[chunk]; y = J.y[chunk]; pre_out = J.pre[chunk];
+    } else if (nc > 1) {
         const int n0 = chunk * N;
         w += w_kn ? (size_t)n0 : (size_t)n0 * ldw;
         if (bias) bias += n0;
@@ -345,8 +354,10 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
 template <int K, int N>
 int launch_t(const float *x, const float *w, const float *bias, const float *residual, int M, int w_kn, int act, float *y,
              const int *m_dev, hipStream_t s, int ldx = K, int ldw = 0, int ldy = N, const float *accum = nullptr, float *pre_out = nullptr,
-             int nc = 1) {
+             int nc = 1, const LtJobs *jobs = nullptr) {
     if (ldw == 0) ldw = w_kn ? N : K;
+    LtJobs J{};
+    if (jobs) J = *jobs;
     const size_t lds_w = ((size_t)(LT_NPL * N * (K + 8)) / 2 + N) * 4;
     const int tiles16 = (M + 31) / 32;
     // 8 waves per workgroup (2 per SIMD cover each other's latencies) once every CU gets a full workgroup; below that 4-wave
@@ -362,12 +373,12 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
         if (narrow) {                                                                                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A, 256>),                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);                                   \
-            k_linear_t16<K, N, A, 256><<<grid16, 256, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out, nc); \
+            k_linear_t16<K, N, A, 256><<<grid16, 256, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, pre_out, nc, J); \
         } else {                                                                                                                 \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_t16<K, N, A, LT_THREADS>),                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);                                   \
             k_linear_t16<K, N, A, LT_THREADS><<<grid16, LT_THREADS, lds16, s>>>(x, w, bias, residual, M, w_kn, y, m_dev, ldx, ldw, ldy, accum, \
-                                                                                pre_out, nc);                                    \
+                                                                                pre_out, nc, J);                                 \
         }                                                                                                                        \
     } while (0)
     switch (act) {
@@ -403,6 +414,16 @@ static int chunk_launch(const float *x, const float *w, const float *bias, const
             if (rc != CONAN_OK) return rc;
         }
     return CONAN_OK;
+}
+
+// njobs (2..4) Linear layers K = 128 -> N = 128 of the same x in one launch; returns 0 when the shape is not covered (caller: one call per layer)
+int conan_linear_t_multi(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int njobs, int act, float *const *y,
+                         float *const *pre, const int *m_dev, hipStream_t s, int *rc) {
+    if (K != 128 || N != 128 || njobs < 2 || njobs > 4 || M < 1) return 0;
+    LtJobs J{};
+    for (int q = 0; q < njobs; ++q) { J.w[q] = w[q]; J.bias[q] = bias ? bias[q] : nullptr; J.y[q] = y[q]; J.pre[q] = pre ? pre[q] : nullptr; }
+    *rc = launch_t<128, 128>(x, w[0], nullptr, nullptr, M, 0, act, y[0], m_dev, s, 128, 0, 128, nullptr, nullptr, njobs, &J);
+    return 1;
 }
 
 int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,

@@ -100,16 +100,27 @@ class _MultiLinear(torch.autograd.Function):
         ws, bs = [_c(w) for w in wb[:n]], list(wb[n:])
         need = x.requires_grad or any(w.requires_grad for w in ws)
         ys, pres = [], []
-        for w, b in zip(ws, bs):
-            N = w.shape[0]
-            y = _tail0_shape(M, N, x.device, m_dev)
+        widths = {w.shape[0] for w in ws}
+        if 2 <= n <= 4 and K == 128 and widths == {128} and (all(b is not None for b in bs) or all(b is None for b in bs)):
+            # the layers' workgroups for the same rows run side by side in ONE launch: x is streamed once (conan_linear_multi_fwd)
+            import ctypes
+            ys = [_tail0_shape(M, 128, x.device, m_dev) for _ in range(n)]
             if act and need:
-                pre = torch.empty(M, N, dtype=f32, device=x.device)
-                call("conan_linear_act_fwd", ptr(x, f32), ptr(w, f32), ptr(b), M, K, N, 3, ptr(m_dev), ptr(y), ptr(pre), stream_ptr())
-                pres.append(pre)
-            else:
-                call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), None, M, K, N, 0, 3 if act else 0, ptr(m_dev), ptr(y), stream_ptr())
-            ys.append(y)
+                pres = [torch.empty(M, 128, dtype=f32, device=x.device) for _ in range(n)]
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            call("conan_linear_multi_fwd", ptr(x, f32), arr(ws), arr(bs) if bs[0] is not None else None, M, K, 128, n, 3 if act else 0, ptr(m_dev),
+                 arr(ys), arr(pres) if pres else None, stream_ptr())
+        else:
+            for w, b in zip(ws, bs):
+                N = w.shape[0]
+                y = _tail0_shape(M, N, x.device, m_dev)
+                if act and need:
+                    pre = torch.empty(M, N, dtype=f32, device=x.device)
+                    call("conan_linear_act_fwd", ptr(x, f32), ptr(w, f32), ptr(b), M, K, N, 3, ptr(m_dev), ptr(y), ptr(pre), stream_ptr())
+                    pres.append(pre)
+                else:
+                    call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), None, M, K, N, 0, 3 if act else 0, ptr(m_dev), ptr(y), stream_ptr())
+                ys.append(y)
         ctx.save_for_backward(x, *ws, *pres)
         ctx.n, ctx.act, ctx.m_dev, ctx.has_b, ctx.tap = n, act, m_dev, [b is not None for b in bs], bool(tap)
         # tap: x handed through as one more output, for a consumer that uses the same x as a residual (edge_update's f): the gradient of

@@ -154,6 +154,13 @@ int conan_linear_fwd(const float *x, const float *w, const float *bias, const fl
 int conan_linear_act_fwd(const float *x, const float *w, const float *bias, int M, int K, int N, int act, const int *m_dev,
                          float *y, float *pre, void *stream);
 
+/* num_layers Linear layers of the SAME input x [M,K] -> y[q] [M,N] (weights w[q] [N,K], biases bias[q] or bias == NULL, all of one width):
+ * y[q] = act(x w[q]^T + bias[q]), pre[q] (pre == NULL or entries NULL: not wanted) = the pre-activation.  K = N = 128 and 2..4 layers run as ONE
+ * launch whose workgroups for the same rows sit side by side (x is streamed from HBM once instead of once per layer); other shapes are
+ * one conan_linear_fwd per layer.  Replaces the q / k / v and dk / dv / f_proj projections of ViS_MP (torch_geometric_visnet.py:596-604,
+ * 623-640), which the reference evaluates as separate nn.Linear calls on one tensor.  The pointer arrays are host arrays. */
+int conan_linear_multi_fwd(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int num_layers, int act,
+                           const int *m_dev, float *const *y, float *const *pre, void *stream);
 /* g[rows,width] = dy * ssp'(v) computed from the layer OUTPUT y (ssp'(v) = sigmoid(v) = 1 - 0.5*exp(-y)). In place allowed. */
 int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream);
 /* dW[N,K] = g^T @ x and dbias[N] = column sums of g (dbias nullable), deterministic two-stage reduction (no float
