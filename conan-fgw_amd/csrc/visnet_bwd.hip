@@ -196,21 +196,30 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_x(const float *__restrict
         if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
     }
 }
-// per-chunk partial dgamma / dbeta (thread <-> column, rows of the chunk in order), then reduced in chunk order
-constexpr int LN_CHUNK = 256;
-__global__ void __launch_bounds__(128) k_layernorm_bwd_p(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ stats,
-                                                         int rows, int H, float *__restrict__ slabs) {
-    const int chunk = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
-    if (c >= H) return;
+// per-chunk partial dgamma / dbeta: thread <-> (column, one of LN_RL row lanes); a row lane takes rows r0 + lane, r0 + lane + LN_RL, ... of
+// the chunk in order, the LN_RL partial sums are combined through LDS in lane order, the chunks in chunk order (bitwise reproducible).
+// (Round 3: was one thread per column walking all 256 rows of its chunk — 80 workgroups of two wavefronts for 20 k rows, 72 us.)
+constexpr int LN_CHUNK = 256, LN_RL = 8;
+__global__ void __launch_bounds__(128 * LN_RL) k_layernorm_bwd_p(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ stats,
+                                                                 int rows, int H, float *__restrict__ slabs) {
+    __shared__ float sg[LN_RL][128], sb[LN_RL][128];
+    const int chunk = blockIdx.x, cl = threadIdx.x & 127, rl = threadIdx.x >> 7, c = blockIdx.y * 128 + cl;
     const int r0 = chunk * LN_CHUNK, r1 = min(rows, r0 + LN_CHUNK);
     float dg = 0.f, db = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const float g = dy[(size_t)r * H + c];
-        dg += g * (x[(size_t)r * H + c] - stats[2 * r]) * stats[2 * r + 1];
-        db += g;
+    if (c < H)
+        for (int r = r0 + rl; r < r1; r += LN_RL) {
+            const float g = dy[(size_t)r * H + c];
+            dg += g * (x[(size_t)r * H + c] - stats[2 * r]) * stats[2 * r + 1];
+            db += g;
+        }
+    sg[rl][cl] = dg; sb[rl][cl] = db;
+    __syncthreads();
+    if (rl == 0 && c < H) {
+#pragma unroll
+        for (int q = 1; q < LN_RL; ++q) { dg += sg[q][cl]; db += sb[q][cl]; }
+        slabs[((size_t)chunk * 2) * H + c] = dg;
+        slabs[((size_t)chunk * 2 + 1) * H + c] = db;
     }
-    slabs[((size_t)chunk * 2) * H + c] = dg;
-    slabs[((size_t)chunk * 2 + 1) * H + c] = db;
 }
 __global__ void k_layernorm_bwd_reduce(const float *__restrict__ slabs, int chunks, int H, float *__restrict__ dgamma, float *__restrict__ dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -701,7 +710,7 @@ int conan_layernorm_bwd(const float *x, const float *gamma, const float *dy, int
     const int chunks = (rows + LN_CHUNK - 1) / LN_CHUNK;
     if (rows > 0) {
         k_layernorm_bwd_x<<<nblk((long long)rows * 64), 256, 0, s>>>(x, gamma, dy, rows, H, eps, dx, stats);
-        k_layernorm_bwd_p<<<dim3(chunks, (H + 127) / 128), 128, 0, s>>>(x, dy, stats, rows, H, slabs);
+        k_layernorm_bwd_p<<<dim3(chunks, (H + 127) / 128), 128 * LN_RL, 0, s>>>(x, dy, stats, rows, H, slabs);
     }
     k_layernorm_bwd_reduce<<<(H + 255) / 256, 256, 0, s>>>(slabs, chunks, H, dgamma, dbeta);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
