@@ -208,7 +208,7 @@ static void scan_large(const int *in, int n, int *out, int *ws, hipStream_t s) {
 // The by-source lists of a graph fill exactly the edge range [e0, e1) of that graph, so the row pointers need no global
 // scan: t_rowptr[j] = e0 + (number of edges of the graph whose source is < j).  One wavefront per source atom scans the
 // graph's edges 64 at a time: ballot + popcount give the row start (scan 1) and the in-order write slots (scan 2).
-constexpr int TR_THREADS = 256;
+constexpr int TR_THREADS = 1024;     // 16 wavefronts per graph: a BACE / Lipophilicity-sized graph has 64-97 source atoms to place (4 wavefronts: 107 us per step at Lipophilicity B = 128)
 __global__ void __launch_bounds__(TR_THREADS) k_transpose_graph(const int *__restrict__ gptr, const int *__restrict__ rowptr,
                                                                 const int *__restrict__ col, int num_atoms,
                                                                 int *__restrict__ t_rowptr, int *__restrict__ t_eid) {
