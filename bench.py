@@ -51,6 +51,9 @@ def parse(argv=None):
     ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each (value = the median block; min / max are printed beside it)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the world > 1 step at any world size: graph A -> all_reduce of the flat gradient buffer -> graph B (1-GPU test of the RCCL path)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the ranks: nccl (= RCCL over xGMI, one GPU per rank) or gloo (collectives through host memory; "
+                         "ranks share the visible GPUs round-robin — exercises the whole world > 1 step on a ONE-GPU box, never a performance number)")
     ap.add_argument("--eager", action="store_true", help="time the eager Python step instead of the HIP-graph replay")
     ap.add_argument("--overlap", action="store_true", help="eager step: reduce the early gradient bucket while backward still runs (parallel.FlatGradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,16 +235,21 @@ def run_rank(args):
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()                    # gloo ranks may share a GPU (one-GPU test of the world > 1 step)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)              # "nccl" is RCCL on ROCm: one rank per GPU over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm: one rank per GPU over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from conan_fgw_amd import ops
     from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
-    from conan_fgw_amd.parallel import FlatGradients
+    from conan_fgw_amd.parallel import FlatGradients, all_reduce_group_stream, barrier_group_stream
     from conan_fgw_amd.synthetic import make_batch, make_bond_graph
     import types
 
@@ -291,8 +299,9 @@ def run_rank(args):
                 model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
 
     def barrier():
+        # (collectives that precede the HIP-graph capture never run on this stream: parallel.all_reduce_group_stream)
         if use_dist and world > 1:
-            dist.barrier()
+            barrier_group_stream(dev)
         torch.cuda.synchronize()
 
     def timed(step_fn, n):
@@ -304,7 +313,7 @@ def run_rank(args):
         dt = time.perf_counter() - t0
         if use_dist and world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce_group_stream(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
@@ -337,9 +346,15 @@ def run_rank(args):
         dt_graph, graph_err = None, None
         if not args.eager:
             flat.suspend_overlap(True)
+            # thread_local: only this thread's calls are policed during capture.  Other threads of the process make legal HIP calls
+            # meanwhile (ProcessGroupNCCL's watchdog polls its work events, the collator's copy thread) which "global" would turn into
+            # a failed capture.
+            cmode = "thread_local"
+            captured = False
             try:
+                barrier()                                            # every rank enters capture with its queue and its process group idle
                 gA = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gA, stream=side):
+                with torch.cuda.graph(gA, stream=side, capture_error_mode=cmode):
                     if train:
                         fwd_bwd()
                         flat.pack()
@@ -349,26 +364,47 @@ def run_rank(args):
                 gB = None
                 if train:
                     gB = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gB, stream=side, pool=gA.pool()):
+                    with torch.cuda.graph(gB, stream=side, pool=gA.pool(), capture_error_mode=cmode):
                         if collective:
                             flat.flat.mul_(inv_world)
                         opt.step()
+                captured = True
+            except Exception as e:                                   # capture is an optimisation of the launch path, never a requirement
+                graph_err = f"{type(e).__name__}: {e}"[:300]
+                import traceback
+                print(f"[bench rank {rank}] HIP-graph capture failed, falling back to the eager step:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+            if use_dist and world > 1:
+                # all ranks replay or none does: a rank stepping eagerly issues a different sequence of collectives
+                ok = torch.tensor([1.0 if captured else 0.0], device=dev)
+                all_reduce_group_stream(ok, op=dist.ReduceOp.MIN)
+                if captured and ok.item() == 0.0:
+                    captured, graph_err = False, "capture failed on another rank"
 
-                def graph_step():
-                    gA.replay()
-                    if train:
-                        if collective:
-                            dist.all_reduce(flat.flat, op=dist.ReduceOp.SUM)
-                        gB.replay()
+            def graph_step():
+                gA.replay()
+                if train:
+                    if collective:
+                        # synchronous form: the collective runs on THIS stream between the two replays (no event hop to the group's
+                        # stream and back).  Safe here because nothing is captured on this stream any more (parallel.py).
+                        dist.all_reduce(flat.flat, op=dist.ReduceOp.SUM)
+                    gB.replay()
+            if captured:
                 for _ in range(max(2, args.warmup)):
                     graph_step()
                 dt_blocks = [timed(graph_step, args.steps) for _ in range(max(1, args.blocks))]
                 dt_graph = float(np.median(dt_blocks))
-            except Exception as e:                                   # capture is an optimisation of the launch path, never a requirement
-                graph_err = f"{type(e).__name__}: {e}"[:300]
-                torch.cuda.synchronize()
             flat.suspend_overlap(False)
         loss_last = float(loss_out)
+        # every rank has applied the same averaged gradients: the parameters must agree across ranks bit for bit, the losses are the
+        # ranks' own (different shards)
+        per_rank = None
+        if use_dist:
+            mine = torch.stack([loss_out.detach().double().reshape(()), torch.cat([p.detach().reshape(-1) for p in flat.params]).double().sum()])
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            torch.cuda.synchronize()
+            per_rank = {"loss": [float(t[0]) for t in allr], "parameter_checksum": [float(t[1]) for t in allr]}
 
         # ---- the same step fed by the input pipeline: every step re-collates the batch on the host (C pack into a pinned
         # buffer), copies it (one H2D transfer on the copy stream, overlapping the previous step) and expands it on the device.
@@ -546,7 +582,9 @@ def run_rank(args):
                                    + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
                        "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
-            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "rccl_ranks": dist.get_world_size() if use_dist and args.backend == "nccl" else 0,
+            "dist": {"backend": ("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo (host memory; ranks may share a GPU: a functional run of the world > 1 step, not a rate)") if use_dist else None,
+                     "ranks": world, "distinct_gpus": min(world, torch.cuda.device_count()) if args.backend == "gloo" else world, "per_rank": per_rank},
             "allreduce_us": None if ar_us is None else round(ar_us, 1),
             "allreduce": {"payload_bytes": int(flat.flat.numel()) * 4, "calls_per_step": (1 if collective else 0) if use_graph else flat.last_allreduce_launches,
                           "in_timed_step": bool(collective), "forced": bool(args.force_collective and world == 1),

@@ -176,10 +176,25 @@ _LATE_STAGE1_ROWS = 65536   # below this row count a weight gradient's slab kern
 _flushed = {}              # weight data_ptr -> (dW data_ptr, db data_ptr | None) of the last flushes (cleared by whoever verifies them)
 
 
-# max |g| of pair-level filter gradients, keyed by the gradient's data pointer: produced by conan_cfconv_bwd_w_pairs (one device float per
-# backward of a CFConv), consumed by the filter network's backward, whose two MFMA kernels then run on two fp16 planes (half the
-# matrix-pipe work).  A gradient that was copied or accumulated on the way has another pointer and simply takes the bf16 path.
-_GMAX = {}
+# max |g| of pair-level filter gradients: produced by conan_cfconv_bwd_w_pairs (one device float per backward of a CFConv), consumed by
+# the filter network's backward, whose two MFMA kernels then run on two fp16 planes (half the matrix-pipe work).  It travels ON the
+# gradient tensor (attribute _conan_gmax = (device float, tensor version at production)): a gradient that autograd copied or summed into
+# a new tensor has no attribute, one it accumulated into IN PLACE has another version — both take the bf16 path, which needs no scale.
+# (Round 3 kept a module-level dict keyed by data_ptr: a pointer is not an identity — stale entries, in-place sums.)
+gmax_stats = {"tracked": 0, "used": 0}
+
+
+def _tag_gmax(t: Tensor, gmax: Tensor):
+    t._conan_gmax = (gmax, t._version)
+    gmax_stats["tracked"] += 1
+
+
+def _take_gmax(t: Tensor, g: Tensor):
+    tag = getattr(t, "_conan_gmax", None)
+    if tag is None or tag[1] != t._version or g.data_ptr() != t.data_ptr():
+        return None
+    gmax_stats["used"] += 1
+    return tag[0]
 
 
 def _wgrad(g, x, M, K, N, md, weight, has_bias, rbf=None, gmax=None):
@@ -604,7 +619,7 @@ class _FilterFn(torch.autograd.Function):
         ME = g_.max_edges
         dev = dW.device
         g = _c(dW)                                   # already multiplied by C(d): cfconv(..., pre_cutoff_grad=True)
-        gmax = _GMAX.pop(g.data_ptr(), None) if F == 128 else None      # max |g|, when the producer tracked it: the two kernels below run on fp16 planes
+        gmax = _take_gmax(dW, g) if F == 128 else None      # max |g|, when the producer tracked it and nothing touched g since: the two kernels below run on fp16 planes
         dw2, db2 = _wgrad(g, h1, ME, F, F, md, w2, True, gmax=gmax)
         if lib().conan_filter_bwd_supported(Gs, F):              # (g @ w2) * ssp'(h1) and its contraction with rbf(dist) in one pass
             dw1, db1 = _filter_bwd(g, h1, dist, _c(offset), ctx.coeff, w1, _c(w2), ME, md, gmax=gmax)
@@ -659,9 +674,7 @@ class _CFConvFn(torch.autograd.Function):
                 call("conan_cfconv_bwd_w_pairs", ptr(x), ptr(dout), ptr(g.num_pairs_dev), g.max_edges, ptr(g.pair_e0), ptr(g.pair_e1), ptr(g.col),
                      ptr(g.tgt), F, ptr(g.pair_dist), float(g.cutoff), ptr(dW), ptr(gmax), stream_ptr())
                 if gmax is not None:
-                    if len(_GMAX) > 64:
-                        _GMAX.clear()                      # (entries whose consumer never ran)
-                    _GMAX[dW.data_ptr()] = gmax
+                    _tag_gmax(dW, gmax)
             else:
                 call("conan_cfconv_bwd_w", ptr(x), ptr(dout), ptr(g.num_edges_dev), g.max_edges, ptr(g.col), ptr(g.tgt), F,
                      ptr(g.dist) if ctx.pre else None, float(g.cutoff or 0.0), ptr(dW), stream_ptr())

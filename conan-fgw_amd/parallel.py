@@ -27,6 +27,30 @@ def _world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def all_reduce_group_stream(t: torch.Tensor, op=None):
+    """All-reduce issued with async_op=True and waited for on the calling stream: the collective and the completion event of
+    its work object live on the process group's OWN stream, never on the caller's.
+
+    Why this matters (round-3 SIGABRT of the RCCL step, diagnosed in round 4): ProcessGroupNCCL runs a *synchronous* collective
+    directly on the caller's current stream and records the work's end event there; its watchdog thread polls that event
+    (hipEventQuery) every 100 ms until it retires the work.  If the caller starts a HIP-graph capture on the same stream inside
+    that window, HIP answers the watchdog's query with hipErrorCapturedEvent ("operation not permitted on an event last recorded
+    in a capturing stream": the check looks at the *stream's* capture state, not at when the event was recorded), the watchdog
+    thread throws and the process aborts.  Every collective issued before a capture on the same stream therefore goes through
+    here; the one between two graph *replays* may stay synchronous (a replay is a launch, not a capture)."""
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else op, async_op=True)
+    w.wait()
+    return t
+
+
+def barrier_group_stream(device: torch.device):
+    """dist.barrier() with the same property as all_reduce_group_stream (the NCCL barrier is an all-reduce on the caller's stream)."""
+    t = torch.zeros(1, device=device)
+    all_reduce_group_stream(t)
+    if t.is_cuda:
+        torch.cuda.synchronize(device)
+
+
 class FlatGradients:
     """One contiguous fp32 buffer for all gradients: packed with one concatenation kernel per bucket, averaged across ranks
     with one all-reduce per bucket, and aliased back as every parameter's .grad for the optimizer.
@@ -196,7 +220,7 @@ class FlatGradients:
             # (min == max of a layout checksum over the ranks), else fall back to the single all-reduce everywhere
             chk = float(sum((k + 1) * (i + 1) for k, i in enumerate(early)) % 1000003) if self._overlap else -1.0
             t = torch.tensor([chk, -chk], dtype=torch.float64, device=self.flat.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce_group_stream(t, op=dist.ReduceOp.MAX)
             if t[0].item() != chk or -t[1].item() != chk or chk < 0:
                 self._overlap = False
         self._layout(order, len(early) if self._overlap else len(order))
@@ -220,9 +244,11 @@ class FlatGradients:
         self._work = dist.all_reduce(self.flat[: self._split], op=dist.ReduceOp.SUM, async_op=True)
 
     # ------------------------------------------------------------------------------------------------ reduce
-    def all_reduce_mean(self, force: bool = False):
+    def all_reduce_mean(self, force: bool = False, group_stream: bool = True):
         """Pack, sum across ranks, divide by the world size.  `force`: issue the collective even in a 1-rank group (the same RCCL
-        call the multi-rank step makes; used to exercise the path on one GPU)."""
+        call the multi-rank step makes; used to exercise the path on one GPU).  `group_stream` (default): the collective runs on the
+        process group's own stream (all_reduce_group_stream: safe to follow with a HIP-graph capture on the calling stream);
+        False = synchronous call on the calling stream (two event hops fewer; only where no capture can follow)."""
         world = _world()
         self.last_allreduce_launches = 0
         if self._overlap and self._work is not None:
@@ -235,6 +261,9 @@ class FlatGradients:
             return
         self.pack()
         if world > 1 or (force and dist.is_available() and dist.is_initialized()):
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if group_stream:
+                all_reduce_group_stream(self.flat)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.last_allreduce_launches = 1
             self.flat.mul_(1.0 / world)

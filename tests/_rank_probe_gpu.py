@@ -1,4 +1,4 @@
-"""Child script of tests/test_gpu_rccl.py::test_overlapped_buckets_with_deferred_weight_gradients: one rank of a 2-rank job whose ranks
+"""Child script of tests/test_gpu_zz_rccl.py::test_overlapped_buckets_with_deferred_weight_gradients: one rank of a 2-rank job whose ranks
 share cuda:0 (the boxes have one GPU; gloo moves CUDA tensors through the host, RCCL needs one device per rank).  Each rank runs the
 real stage-2 model on its own shard with FlatGradients.backward() — deferred weight gradients — and the overlapped early bucket, and
 compares the averaged gradients with the plain (single all-reduce, immediate weight gradients) result on the same shards."""

@@ -189,6 +189,52 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs, wmag):
     assert rel(W[:E].detach().cpu(), W2[:E].cpu()) < 1e-6
 
 
+def test_filter_gradient_maximum_travels_with_the_tensor_and_is_dropped_when_the_gradient_was_touched():
+    """The fp16-plane filter backward scales g from max|g|, which the pair-gradient kernel tracks (ops._tag_gmax / _take_gmax).  (i) One
+    consumer per filter (every model): the tag survives the hop through the autograd engine, the fast kernels run.  (ii) ONE filter feeding
+    TWO CFConvs: autograd sums the two pair gradients (the first buffer may be reused in place) — the maximum of one addend is not the
+    maximum of the sum, so the backward must fall back to the scale-free kernels, and the result must still match fp64."""
+    b = make_batch("esol", 6, 5, seed=21)
+    g = _edges(b)
+    n, F_, Gs = g.num_atoms, 128, 50
+    torch.manual_seed(3)
+    gs = ps.GaussianSmearing(0.0, 10.0, Gs)
+    mlp = torch.nn.Sequential(torch.nn.Linear(Gs, F_), ps.ShiftedSoftplus(), torch.nn.Linear(F_, F_))
+    x1, x2 = torch.randn(n, F_), 30.0 * torch.randn(n, F_)          # the second consumer's gradient is 30x larger than the first's
+    gy = torch.randn(n, F_)
+
+    def run(two):
+        prm = [p.detach().to(dev).requires_grad_(True) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
+        W = ops.filter_generate(g, gs.offset.to(dev), gs.coeff, *prm, use_pairs=True)
+        out = ops.cfconv(x1.to(dev), W, g, pre_cutoff_grad=True, use_pairs=True)
+        if two:
+            out = out + ops.cfconv(x2.to(dev), W, g, pre_cutoff_grad=True, use_pairs=True)
+        before = dict(ops.gmax_stats)
+        out.backward(gy.to(dev))
+        torch.cuda.synchronize()
+        return prm, {k: ops.gmax_stats[k] - before[k] for k in before}
+
+    def ref(two):
+        m64 = torch.nn.Sequential(torch.nn.Linear(Gs, F_), ps.ShiftedSoftplus(), torch.nn.Linear(F_, F_)).double()
+        m64.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+        ei = torch.stack([g.col[: g.num_edges].cpu().long(), g.tgt[: g.num_edges].cpu().long()])
+        d = g.edge_weight().cpu().double()
+        Wr = m64(gs(d)) * (0.5 * (torch.cos(d * math.pi / 10.0) + 1.0))[:, None]
+        xs = x1.double() + (x2.double() if two else 0.0)
+        out = torch.zeros(n, F_, dtype=torch.float64).index_add_(0, ei[1], xs[ei[0]] * Wr)
+        out.backward(gy.double())
+        return [m64[0].weight.grad, m64[0].bias.grad, m64[2].weight.grad, m64[2].bias.grad]
+
+    prm, st = run(False)
+    assert st == {"tracked": 1, "used": 1}, st
+    for got, want in zip(prm, ref(False)):
+        assert rel(got.grad.cpu(), want) < 1e-5
+    prm, st = run(True)
+    assert st["tracked"] == 2 and st["used"] == 0, st
+    for got, want in zip(prm, ref(True)):
+        assert rel(got.grad.cpu(), want) < 1e-5
+
+
 @pytest.mark.parametrize("gscale", [1.0, 2e-6, 3e3])
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (40000, 128, 128), (33, 128, 128), (5000, 256, 128)])
 def test_wgrad_scaled_two_plane_fp16_matches_fp64(M, N, K, gscale):
