@@ -385,13 +385,10 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 //     Half the LDS (27.5 KB + vectors at N = 83) puts THREE 8-wavefront workgroups on a CU instead of two: the 640 couplings
 //     of a Lipophilicity-shaped shard of 128 molecules are resident at once (768 slots) instead of running 1.25 rounds.
 //   * The coupling itself lives in K's storage between iterations (fp32, the values that are returned).
-// A row / column sum outside [1e-150, 1e150] makes the workgroup give up without writing anything and raise redo[b, s]; the launcher then
-// runs k_fgw_coupling — which carries the exact log-domain path — on the flagged couplings only.
-#ifdef CONAN_FGW_NO_BLOCK22     // (A/B switch of tools/ab.py)
-#define FGW_MMG mm_f64_glb
-#else
-#define FGW_MMG mm_f64_glb22
-#endif
+// A row / column sum outside [1e-150, 1e150] — or a first-update row sum below 1e-28, i.e. a K row in or near the fp32 denormals — makes the
+// workgroup give up without writing anything and raise redo[b, s]; the launcher then runs k_fgw_coupling — which carries the exact
+// log-domain path — on the flagged couplings only.
+#define FGW_MMG mm_f64_glb22      // 2 x 2 register-blocked products (one operand load per MFMA instead of two: -9.5 % of the solve)
 // C2U8: the adjacency of the input graph is staged ONCE into LDS as bytes (caller's promise cs_small_int: integers in [0, 255]) and both
 // products that contract with it read it there instead of fetching fp32 from L2 in every projected-gradient iteration.
 template <int NW, bool C2U8>
@@ -556,7 +553,10 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
                 double r = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) r += part[w * N + i];
-                if (bad(r)) *bad_flag = 1.0;
+                // K is fp32: at the first u update (g = 1, f_j in [q_j / N, q_j]) the row sum brackets the row's largest K entry within N^2.
+                // Below 1e-28 that entry is within a few digits of the fp32 denormals (a row 87..103 e-folds under every column's best):
+                // the row would be returned with two or three significant bits.  Such couplings go to the exact pass like a zero sum.
+                if (bad(r) || (ii == 0 && r < 1e-28)) *bad_flag = 1.0;
                 gv[i] = pa[i] / r;
             }
             __syncthreads();
@@ -886,11 +886,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     // same grid for whatever it handed back (redo[b, s]; an early-exit launch otherwise)
     const bool c2b = params->cs_small_int != 0;
     const size_t lb = big_lds(N, c2b);
-#ifdef CONAN_FGW_NO_BIG       // (A/B switch of tools/ab.py: the round-2 kernel alone)
-    const bool big = false;
-#else
     const bool big = !small && !kl && lb <= LDS_LIMIT;
-#endif
     const FastConst fc = fast_const(*params, N);
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;

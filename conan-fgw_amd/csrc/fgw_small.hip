@@ -977,7 +977,6 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
     // Square loss: the round-3 kernel first; whatever it hands back (redo[b, s] = 1: a Sinkhorn sum left the fp64-safe range) is solved
     // by the kernel with the exact log-domain path, launched over the same grid with an early exit for everything else.
     const int *only = nullptr;
-#ifndef CONAN_FGW_NO_FAST      // (A/B switch of tools/ab.py: the round-2 kernel alone)
     if (!prm.loss_fun && redo && conan_fgw_fast_supported(D.N, D.d, prm.cs_small_int)) {
 #define FAST(RR)                                                                                                                     \
     do {                                                                                                                             \
@@ -991,7 +990,6 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
 #undef FAST
         only = redo;
     }
-#endif
 #define LAUNCH_(RR, SEC, GRID)                                                                                                  \
     do {                                                                                                                        \
         if (lds > 64 * 1024)                                                                                                    \

@@ -13,36 +13,20 @@
 //   GEMM2^T  W^T  = W2 . H1    : the B operand IS the accumulator of GEMM1 (after bias + ssp), register r of lane-half h
 //                                being row 32mb + (r&3) + 8(r>>2) + 4h, so the k order of the A fragments is permuted to
 //                                match: no LDS round trip, no cross-lane traffic between the two GEMMs.
-// The A operands (the two weight matrices as three bf16 images each: 54 + 102 KB at F = 128, of the CU's 160 KB) are staged once per
-// workgroup in LDS and read with conflict-free ds_read_b128 (one 16-wide k-step of one image per read).  Wavefronts never synchronise after staging: 8 independent waves per CU issue
-// MFMAs back to back, both GEMMs as exact 3-way bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy; there is no
-// other arithmetic mode and no environment switch).
+// The A operands (the two weight matrices as two fp16 planes each, pre-scaled by an exact power of two: 36 + 68 KB at F = 128, of the CU's
+// 160 KB) are staged once per workgroup in LDS and read with conflict-free ds_read_b128 (one 16-wide k-step of one plane per read).
+// Wavefronts never synchronise after staging: 8 independent waves per CU issue MFMAs back to back, both GEMMs as two-plane fp16 splits on
+// v_mfma_f32_32x32x16_f16 (three partial products per fp32 product, fp32-class accuracy; there is no other arithmetic mode and no
+// environment switch.  Round 2 used three bf16 planes and six partial products: same accuracy, 28 % slower, removed in round 4).
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// Exact 3-way bf16 split of 8 fp32 values: v = p1 + p2 + p3 up to 2^-24 |v| (each part is a round-to-nearest bf16 of the
-// running remainder, the remainders are exact in fp32).  With the six products p1q1, p1q2, p2q1, p1q3, p2q2, p3q1 a
-// bf16 MFMA chain reproduces the fp32 product to ~2^-24 relative (fp32 class, full fp32 exponent range) at 6 x 32 cycles
-// per 32x32x16 block instead of 8 x 64 cycles on the fp32 MFMA (2.7x).
-__device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h1 = (__bf16)v[j];
-        const float r1 = v[j] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
-    }
-}
-
 // Two-plane fp16 split of 8 fp32 values: v = h1 + h2 up to 2^-22 |v| while the remainder v - h1 is a normal fp16 number (|v| >~ 0.06),
 // and to 3e-8 absolute below that (fp16 subnormal spacing).  With the three products p1q1, p1q2, p2q1 (the dropped p2q2 is 2^-22
 // relative) an fp16 MFMA chain reproduces the fp32 product to ~2.4e-7 at HALF the matrix-pipe time and ~2/3 of the splitting work
-// of the three-plane bf16 form (6 products).  Range: the operands here are O(1e-2..1e2) — Gaussians in [0, 1], shifted-softplus
+// of a three-plane bf16 form (6 products).  Range: the operands here are O(1e-2..1e2) — Gaussians in [0, 1], shifted-softplus
 // outputs, weights pre-scaled by a power of two chosen from their maximum (exact, undone in the epilogue's FMA) — far inside fp16's 6e-5..65504.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2h(const float *v, f16x8 &p1, f16x8 &p2) {
@@ -72,15 +56,10 @@ __device__ __forceinline__ float block_absmax(float v, float *red) {      // red
 }
 
 constexpr int GP = 64;        // gaussians padded to four MFMA k-steps of 16 (zero weights beyond num_gaussians)
-constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (bf16 elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
+constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (16-bit elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
 constexpr int FF_THREADS = 512;
 
-#ifdef CONAN_FILTER_BF16X3      // (A/B switch of tools/ab.py: the round-2 three-plane bf16 form)
-constexpr bool FF_H16 = false;
-#else
-constexpr bool FF_H16 = true;
-#endif
-constexpr int FF_NPL = FF_H16 ? 2 : 3;                       // operand planes
+constexpr int FF_NPL = 2;                                    // operand planes: two fp16 planes (the round-2 three-plane bf16 form measured 28 % slower: DESIGN 3.1)
 constexpr int FF_OP = 36;                                    // pitch of the per-wave output slab (floats): 32 channels + 4
 
 template <int F>
@@ -89,12 +68,12 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     int Gs, float coeff, float cutoff, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out) {
     constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
-    constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (bf16 elements; 16-B slots stay distinct)
+    constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (16-bit elements; 16-B slots stay distinct)
     constexpr int W2WORDS = (FF_NPL * F * W2S) / 2;      // floats occupied by the 16-bit W2 images
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W1WORDS = (FF_NPL * F * W1S) / 2;      // floats occupied by the 16-bit W1 images
-    float *W1L = lds;                     // 3 x bf16 [F][W1S]
-    float *W2L = W1L + W1WORDS;           // 3 x bf16 [F][W2S], columns permuted per 16-group
+    float *W1L = lds;                     // 2 x fp16 [F][W1S]
+    float *W2L = W1L + W1WORDS;           // 2 x fp16 [F][W2S], columns permuted per 16-group
     float *B1L = W2L + W2WORDS;           // [F]
     float *B2L = B1L + F;                 // [F]
     float *OFL = B2L + F;                 // [GP]
@@ -109,7 +88,6 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     if ((int)blockIdx.x * (FF_THREADS / 64) >= tiles) return;
 
     {
-        __bf16 *W1B = reinterpret_cast<__bf16 *>(W1L);
         constexpr int PER1 = (F * GP + FF_THREADS - 1) / FF_THREADS;
         float wv[PER1];
 #pragma unroll
@@ -118,37 +96,25 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             wv[u] = (t < F * GP && k < Gs) ? w1[(size_t)f * Gs + k] : 0.f;
         }
         float sc1 = 1.0f;
-        if constexpr (FF_H16) {
-            float am = 0.f;
+        float am = 0.f;
 #pragma unroll
-            for (int u = 0; u < PER1; ++u) am = fmaxf(am, fabsf(wv[u]));
-            plane_scale(block_absmax<FF_THREADS>(am, wred), sc1, us1);
-        }
+        for (int u = 0; u < PER1; ++u) am = fmaxf(am, fabsf(wv[u]));
+        plane_scale(block_absmax<FF_THREADS>(am, wred), sc1, us1);
 #pragma unroll
         for (int u = 0; u < PER1; ++u) {
             const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
             if (t >= F * GP) continue;
-            if constexpr (FF_H16) {
-                _Float16 *W1H = reinterpret_cast<_Float16 *>(W1L);
-                const float v = wv[u] * sc1;
-                const _Float16 h1 = (_Float16)v;
-                W1H[(0 * F + f) * W1S + k] = h1;
-                W1H[(1 * F + f) * W1S + k] = (_Float16)(v - (float)h1);
-            } else {
-            const float v = wv[u];
-            const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
-            const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
-            W1B[(0 * F + f) * W1S + k] = h1;
-            W1B[(1 * F + f) * W1S + k] = h2;
-            W1B[(2 * F + f) * W1S + k] = (__bf16)r2;
-            }
+            _Float16 *W1H = reinterpret_cast<_Float16 *>(W1L);
+            const float v = wv[u] * sc1;
+            const _Float16 h1 = (_Float16)v;
+            W1H[(0 * F + f) * W1S + k] = h1;
+            W1H[(1 * F + f) * W1S + k] = (_Float16)(v - (float)h1);
         }
     }
     {
-        // three bf16 images of W2; inside every group of 16 input channels the columns are stored in the order the B
+        // two fp16 planes of W2; inside every group of 16 input channels the columns are stored in the order the B
         // fragment (GEMM1's accumulator registers 8s..8s+7 of lane-half h) enumerates them: position 8h + j holds
         // channel (j&3) + 8(j>>2) + 4h, so a lane reads its 8 k-values as one 16-byte access.
-        __bf16 *W2B = reinterpret_cast<__bf16 *>(W2L);
         // all of a thread's loads are issued before the first use: a load-convert-store loop serialises F*F/512 L2 round
         // trips (a fixed ~15 us per launch)
         constexpr int PER2 = (F * F + FF_THREADS - 1) / FF_THREADS;
@@ -156,12 +122,10 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
         for (int u = 0; u < PER2; ++u) { const int t = tid + u * FF_THREADS; wv[u] = t < F * F ? w2[t] : 0.f; }
         float sc2 = 1.0f;
-        if constexpr (FF_H16) {
-            float am = 0.f;
+        float am = 0.f;
 #pragma unroll
-            for (int u = 0; u < PER2; ++u) am = fmaxf(am, fabsf(wv[u]));
-            plane_scale(block_absmax<FF_THREADS>(am, wred), sc2, us2);
-        }
+        for (int u = 0; u < PER2; ++u) am = fmaxf(am, fabsf(wv[u]));
+        plane_scale(block_absmax<FF_THREADS>(am, wred), sc2, us2);
 #pragma unroll
         for (int u = 0; u < PER2; ++u) {
             const int t = tid + u * FF_THREADS;
@@ -169,20 +133,11 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             const int f2 = t / F, f = t - f2 * F;
             const int kk = f & 15, hh = (kk >> 2) & 1, jj = (kk & 3) + 4 * (kk >> 3);
             const int colp = (f & ~15) + 8 * hh + jj;
-            if constexpr (FF_H16) {
-                _Float16 *W2H = reinterpret_cast<_Float16 *>(W2L);
-                const float v = wv[u] * sc2;
-                const _Float16 h1 = (_Float16)v;
-                W2H[(0 * F + f2) * W2S + colp] = h1;
-                W2H[(1 * F + f2) * W2S + colp] = (_Float16)(v - (float)h1);
-            } else {
-            const float v = wv[u];
-            const __bf16 h1 = (__bf16)v; const float r1 = v - (float)h1;
-            const __bf16 h2 = (__bf16)r1; const float r2 = r1 - (float)h2;
-            W2B[(0 * F + f2) * W2S + colp] = h1;
-            W2B[(1 * F + f2) * W2S + colp] = h2;
-            W2B[(2 * F + f2) * W2S + colp] = (__bf16)r2;
-            }
+            _Float16 *W2H = reinterpret_cast<_Float16 *>(W2L);
+            const float v = wv[u] * sc2;
+            const _Float16 h1 = (_Float16)v;
+            W2H[(0 * F + f2) * W2S + colp] = h1;
+            W2H[(1 * F + f2) * W2S + colp] = (_Float16)(v - (float)h1);
         }
     }
     for (int t = tid; t < F; t += FF_THREADS) { B1L[t] = b1[t]; B2L[t] = b2[t]; }
@@ -203,10 +158,9 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[mb][r] = 0.f;
         {
-            // both operands as exact 3-way bf16 splits (as GEMM2): the B fragment of k-step s is rbf_k(d_e) for k = 16s + 8h .. +7,
-            // evaluated and split in registers; the A fragments are the three W1 images.  6 x 32 cycles per 32x32x16 block instead
+            // both operands as two-plane fp16 splits (as GEMM2): the B fragment of k-step s is rbf_k(d_e) for k = 16s + 8h .. +7,
+            // evaluated and split in registers; the A fragments are the two W1 planes.  3 x 32 cycles per 32x32x16 block instead
             // of 8 x 64 on the fp32 MFMA.
-            const __bf16 *W1B = reinterpret_cast<const __bf16 *>(W1L);
 #pragma unroll
             for (int s = 0; s < GP / 16; ++s) {
                 const int kb = 16 * s + 8 * h;
@@ -215,36 +169,17 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 float rb[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float t0 = d - of[j]; rb[j] = exp_neg_f(coeff * (t0 * t0)); }
-                if constexpr (FF_H16) {
-                    const _Float16 *W1H = reinterpret_cast<const _Float16 *>(W1L);
-                    f16x8 q1, q2;
-                    split2h(rb, q1, q2);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const int row = 32 * mb + l31;
-                        const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&W1H[(0 * F + row) * W1S + kb]);
-                        const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&W1H[(1 * F + row) * W1S + kb]);
-                        acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc1[mb], 0, 0, 0);      // smallest terms first
-                        acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc1[mb], 0, 0, 0);
-                        acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc1[mb], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    continue;
-                }
-                bf16x8 q1, q2, q3;
-                split3(rb, q1, q2, q3);
+                const _Float16 *W1H = reinterpret_cast<const _Float16 *>(W1L);
+                f16x8 q1, q2;
+                split2h(rb, q1, q2);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     const int row = 32 * mb + l31;
-                    const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&W1B[(0 * F + row) * W1S + kb]);
-                    const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&W1B[(1 * F + row) * W1S + kb]);
-                    const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&W1B[(2 * F + row) * W1S + kb]);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc1[mb], 0, 0, 0);
-                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc1[mb], 0, 0, 0);
+                    const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&W1H[(0 * F + row) * W1S + kb]);
+                    const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&W1H[(1 * F + row) * W1S + kb]);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc1[mb], 0, 0, 0);      // smallest terms first
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc1[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc1[mb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -255,7 +190,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&B1L[32 * mb + 8 * q + 4 * h]);
-                const float us = us1;                                // the fp16 planes of W1 carry its plane scale (1 in the bf16 form)
+                const float us = us1;                                // the fp16 planes of W1 carry its plane scale
                 acc1[mb][4 * q + 0] = ssp_f(fmaf(acc1[mb][4 * q + 0], us, bb.x));
                 acc1[mb][4 * q + 1] = ssp_f(fmaf(acc1[mb][4 * q + 1], us, bb.y));
                 acc1[mb][4 * q + 2] = ssp_f(fmaf(acc1[mb][4 * q + 2], us, bb.z));
@@ -267,24 +202,16 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                if constexpr (FF_H16) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) =
-                            make_float4(acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]);
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) =
+                        make_float4(acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
-                        const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
-                        const f4 hv4 = {o.x, o.y, o.z, o.w};
-                        if ((tile << 5) + r < E) __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)((tile << 5) + r) * F + 32 * mb + c));
-                    }
-                } else if (valid) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f4 hv4 = {acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]};
-                        __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)e * F + 32 * mb + 8 * q + 4 * h));
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
+                    const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
+                    const f4 hv4 = {o.x, o.y, o.z, o.w};
+                    if ((tile << 5) + r < E) __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)((tile << 5) + r) * F + 32 * mb + c));
                 }
             }
         }
@@ -300,7 +227,6 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
             {
-                const __bf16 *W2B = reinterpret_cast<const __bf16 *>(W2L);
 #pragma unroll
                 for (int ms = 0; ms < 2 * MB; ++ms) {
                     const int mb = ms >> 1, sgrp = ms & 1;
@@ -308,37 +234,17 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
 #pragma unroll
                     for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
                     const int colp = 32 * mb + 16 * sgrp + 8 * h;
-                    if constexpr (FF_H16) {
-                        const _Float16 *W2H = reinterpret_cast<const _Float16 *>(W2L);
-                        f16x8 q1, q2;
-                        split2h(hv, q1, q2);
-#pragma unroll
-                        for (int nb = 0; nb < NG; ++nb) {
-                            const int row = 32 * (n0 + nb) + l31;
-                            const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&W2H[(0 * F + row) * W2S + colp]);
-                            const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&W2H[(1 * F + row) * W2S + colp]);
-                            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc2[nb], 0, 0, 0);
-                            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc2[nb], 0, 0, 0);
-                            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc2[nb], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
-                    bf16x8 q1, q2, q3;
-                    split3(hv, q1, q2, q3);
+                    const _Float16 *W2H = reinterpret_cast<const _Float16 *>(W2L);
+                    f16x8 q1, q2;
+                    split2h(hv, q1, q2);
 #pragma unroll
                     for (int nb = 0; nb < NG; ++nb) {
                         const int row = 32 * (n0 + nb) + l31;
-                        const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&W2B[(0 * F + row) * W2S + colp]);
-                        const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&W2B[(1 * F + row) * W2S + colp]);
-                        const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&W2B[(2 * F + row) * W2S + colp]);
-                        // smallest terms first
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc2[nb], 0, 0, 0);
-                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc2[nb], 0, 0, 0);
+                        const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&W2H[(0 * F + row) * W2S + colp]);
+                        const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&W2H[(1 * F + row) * W2S + colp]);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc2[nb], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -355,16 +261,13 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     o.y = fmaf(acc2[nb][4 * q + 1], us, bb.y) * C;
                     o.z = fmaf(acc2[nb][4 * q + 2], us, bb.z) * C;
                     o.w = fmaf(acc2[nb][4 * q + 3], us, bb.w) * C;
-                    if constexpr (FF_H16) *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) = o;
-                    else if (valid) *reinterpret_cast<float4 *>(Wout + (size_t)e * F + 32 * (n0 + nb) + 8 * q + 4 * h) = o;
+                    *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) = o;
                 }
-                if constexpr (FF_H16) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
-                        const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
-                        if ((tile << 5) + r < E) *reinterpret_cast<float4 *>(Wout + (size_t)((tile << 5) + r) * F + 32 * (n0 + nb) + c) = o;
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
+                    const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
+                    if ((tile << 5) + r < E) *reinterpret_cast<float4 *>(Wout + (size_t)((tile << 5) + r) * F + 32 * (n0 + nb) + c) = o;
                 }
             }
         }
@@ -375,7 +278,7 @@ template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP + (FF_H16 ? (FF_THREADS / 64) * 32 * FF_OP : 0)) * 4;
+    const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP + (FF_THREADS / 64) * 32 * FF_OP) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (max_edges + 31) / 32;
     int grid = (tiles + 7) / 8;

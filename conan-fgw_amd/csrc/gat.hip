@@ -571,7 +571,6 @@ int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alph
     hipStream_t s = as_stream(stream);
     const int PW = 3 * channels + edge_dim;
     float *dpre_self = ws, *da_dst = ws + n, *dpre = ws + 2 * (size_t)n, *part = dpre + (num_edges > 0 ? num_edges : 1);
-#ifndef CONAN_GAT_NO_GROUP16     // (A/B switch of tools/ab.py: the round-2 wavefront-per-node kernels)
     if (edge_dim <= 4 && (channels == 64 || channels == 128 || channels == 256)) {
         const int wgs16 = gat_g_wgs(n);
 #define GAT_G16(CHN)                                                                                                                          \
@@ -591,7 +590,6 @@ int conan_gat_aggregate_bwd(const float *h, const float *dout, const float *alph
         CONAN_LAUNCH_CHECK();
         return CONAN_OK;
     }
-#endif
     if (edge_dim <= 4)
         k_gat_bwd_target<4><<<GAT_BW_WGS, 256, 0, s>>>(h, dout, alpha, alpha_self, a_src, a_dst, rowptr, col, eid, edge_attr, edge_dim, v, negative_slope, n,
                                                           channels, dpre, dpre_self, da_dst, part, PW);

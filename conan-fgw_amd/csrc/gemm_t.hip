@@ -15,17 +15,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LT_THREADS = 512;
 
-// exact 3-way bf16 split (see filter_fused.hip): v = p1 + p2 + p3 up to 2^-24 |v|
-__device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h1 = (__bf16)v[j];
-        const float r1 = v[j] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
-    }
-}
 
 // Two-plane fp16 form (default; see filter_fused.hip): v = h1 + h2 with the three products p1q1, p1q2, p2q1 on v_mfma_f32_32x32x16_f16 —
 // half the matrix-pipe time and 2/3 of the splitting work of the three-plane bf16 form.  fp16's narrow exponent range is met by exact
@@ -35,12 +24,7 @@ __device__ __forceinline__ void split3(const float *v, bf16x8 &p1, bf16x8 &p2, b
 // maximum keep 22 bits; below that the absolute error is 3e-8 / 256 of the row maximum.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-#ifdef CONAN_LINEAR_BF16X3      // (A/B switch of tools/ab.py: the round-2 three-plane bf16 form)
-constexpr bool LT_H16 = false;
-#else
-constexpr bool LT_H16 = true;
-#endif
-constexpr int LT_NPL = LT_H16 ? 2 : 3;
+constexpr int LT_NPL = 2;                                      // operand planes
 constexpr int LT_OP = 68;                                      // pitch of the per-wave output slab (floats): 64 channels + 4
 __device__ __forceinline__ void split2h(const float *v, float sc, f16x8 &p1, f16x8 &p2) {
 #pragma unroll
@@ -69,30 +53,16 @@ __device__ __forceinline__ float lt_block_absmax(float v, float *red) {      // 
 }
 // four consecutive k of image row n: 8-byte stores, one per plane
 __device__ __forceinline__ void lt_store4(void *WBv, int N, int WS, int n, int k, const float *v4, float sc) {
-    if constexpr (LT_H16) {
-        _Float16 *WB = reinterpret_cast<_Float16 *>(WBv);
-        f16x4 h1, h2;
+    _Float16 *WB = reinterpret_cast<_Float16 *>(WBv);
+    f16x4 h1, h2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = v4[e] * sc; h1[e] = (_Float16)t; h2[e] = (_Float16)(t - (float)h1[e]); }
-        *reinterpret_cast<f16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
-        *reinterpret_cast<f16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
-    } else {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        __bf16 *WB = reinterpret_cast<__bf16 *>(WBv);
-        bf16x4 h1, h2, h3;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h1[e] = (__bf16)v4[e]; const float r1 = v4[e] - (float)h1[e];
-            h2[e] = (__bf16)r1; h3[e] = (__bf16)(r1 - (float)h2[e]);
-        }
-        *reinterpret_cast<bf16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
-        *reinterpret_cast<bf16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
-        *reinterpret_cast<bf16x4 *>(&WB[(2 * N + n) * WS + k]) = h3;
-    }
+    for (int e = 0; e < 4; ++e) { const float t = v4[e] * sc; h1[e] = (_Float16)t; h2[e] = (_Float16)(t - (float)h1[e]); }
+    *reinterpret_cast<f16x4 *>(&WB[(0 * N + n) * WS + k]) = h1;
+    *reinterpret_cast<f16x4 *>(&WB[(1 * N + n) * WS + k]) = h2;
 }
 
-// SPLIT variant: both operands are split into three bf16 parts and the product is formed from the six significant
-// partial products on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy, 2.7x the fp32 MFMA rate).  W's three images are
+// SPLIT variant: both operands are split into two fp16 planes (above) and the product is formed from the three significant
+// partial products on v_mfma_f32_32x32x16_f16 (fp32-class accuracy).  W's two planes are
 // staged once per workgroup; x is split in registers after the global load.
 // ACT is a template parameter: the epilogue is straight-line code over 16*NB outputs per lane, and with a run-time
 // activation switch the kernel was 31 KB of code executed exactly once per wavefront at node-level sizes — rocprofv3
@@ -117,9 +87,9 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
     constexpr int act = ACT;
     constexpr int NB = N / 32;
     constexpr int S = K / 16;             // MFMA k-steps
-    constexpr int WS = K + 8;             // LDS pitch (bf16 elements)
+    constexpr int WS = K + 8;             // LDS pitch (16-bit elements)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [planes][N][WS] (bf16 or fp16)
+    __bf16 *WB = reinterpret_cast<__bf16 *>(lds);               // [planes][N][WS] (fp16 planes; the pointer type is only a 16-bit carrier)
     float *BL = lds + (LT_NPL * N * WS) / 2;                    // [N]
     float *OT = BL + N + (threadIdx.x >> 6) * (32 * LT_OP);    // fp16 form: this wave's [32][LT_OP] output slab
     __shared__ float wred[NT / 64];
@@ -160,7 +130,7 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
         }
     };
     if (slot * (NT / 64) + wave < tiles) load_x(slot * (NT / 64) + wave);
-    // Staging of the three bf16 images of W as [n][k]; all of a thread's loads are in flight before the first use.
+    // Staging of the two fp16 planes of W as [n][k]; all of a thread's loads are in flight before the first use.
     if (!w_kn) {                                              // w is [N][K]: float4 = 4 consecutive k -> one 8-byte store per image
         constexpr int V4 = N * K / 4, PER = (V4 + NT - 1) / NT;
         float4 wv[PER];
@@ -171,12 +141,10 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
             wv[u] = q < V4 ? *reinterpret_cast<const float4 *>(w + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float wsc = 1.0f;
-        if constexpr (LT_H16) {
-            float am = 0.f;
+        float am = 0.f;
 #pragma unroll
-            for (int u = 0; u < PER; ++u) am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u].x), fabsf(wv[u].y)), fmaxf(fabsf(wv[u].z), fabsf(wv[u].w))));
-            pow2_scale(lt_block_absmax<NT>(am, wred), wsc, wun);
-        }
+        for (int u = 0; u < PER; ++u) am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u].x), fabsf(wv[u].y)), fmaxf(fabsf(wv[u].z), fabsf(wv[u].w))));
+        pow2_scale(lt_block_absmax<NT>(am, wred), wsc, wun);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int q = tid + u * NT;
@@ -202,15 +170,13 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
                 wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * ldw + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float wsc = 1.0f;
-        if constexpr (LT_H16) {
-            float am = 0.f;
+        float am = 0.f;
 #pragma unroll
-            for (int u = 0; u < PERW; ++u)
+        for (int u = 0; u < PERW; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u][j].x), fabsf(wv[u][j].y)), fmaxf(fabsf(wv[u][j].z), fabsf(wv[u][j].w))));
-            pow2_scale(lt_block_absmax<NT>(am, wred), wsc, wun);
-        }
+            for (int j = 0; j < 4; ++j)
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u][j].x), fabsf(wv[u][j].y)), fmaxf(fabsf(wv[u][j].z), fabsf(wv[u][j].w))));
+        pow2_scale(lt_block_absmax<NT>(am, wred), wsc, wun);
 #pragma unroll
         for (int u = 0; u < PERW; ++u) {
             const int pt = wave + u * (NT / 64);
@@ -238,67 +204,41 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
         float xun = 1.0f;                                      // inverse of this lane's row scale x inverse weight scale
-        if constexpr (LT_H16) {
-            float am = 0.f;
+        float am = 0.f;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                am = fmaxf(am, fmaxf(fmaxf(fabsf(xa[s].x), fabsf(xa[s].y)), fmaxf(fabsf(xa[s].z), fabsf(xa[s].w))));
-                am = fmaxf(am, fmaxf(fmaxf(fabsf(xb[s].x), fabsf(xb[s].y)), fmaxf(fabsf(xb[s].z), fabsf(xb[s].w))));
-            }
-            am = fmaxf(am, __shfl_xor(am, 32));                // the other half of the row sits on lane ^ 32
-            float xsc, xu;
-            pow2_scale(am, xsc, xu);
-            xun = xu * wun;
-            const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB);
-            // the whole tile becomes fp16 planes first (same register count as the fp32 rows): the fp32 registers are then free for the
-            // NEXT tile's rows, whose loads fly during this tile's MFMA loop and epilogue instead of during the epilogue alone
-            f16x8 q1[S], q2[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
-                split2h(xv, xsc, q1[s], q2[s]);
-            }
-            if (tile + wave_stride < tiles) load_x(tile + wave_stride);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int colp = 16 * s + 8 * h;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int row = 32 * nb + l31;
-                    const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * N + row) * WS + colp]);
-                    const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * N + row) * WS + colp]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1[s], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2[s], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1[s], acc[nb], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+        for (int s = 0; s < S; ++s) {
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(xa[s].x), fabsf(xa[s].y)), fmaxf(fabsf(xa[s].z), fabsf(xa[s].w))));
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(xb[s].x), fabsf(xb[s].y)), fmaxf(fabsf(xb[s].z), fabsf(xb[s].w))));
+        }
+        am = fmaxf(am, __shfl_xor(am, 32));                // the other half of the row sits on lane ^ 32
+        float xsc, xu;
+        pow2_scale(am, xsc, xu);
+        xun = xu * wun;
+        const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB);
+        // the whole tile becomes fp16 planes first (same register count as the fp32 rows): the fp32 registers are then free for the
+        // NEXT tile's rows, whose loads fly during this tile's MFMA loop and epilogue instead of during the epilogue alone
+        f16x8 q1[S], q2[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
-            bf16x8 q1, q2, q3;
-            split3(xv, q1, q2, q3);
+            split2h(xv, xsc, q1[s], q2[s]);
+        }
+        if (tile + wave_stride < tiles) load_x(tile + wave_stride);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
             const int colp = 16 * s + 8 * h;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int row = 32 * nb + l31;
-                const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&WB[(0 * N + row) * WS + colp]);
-                const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&WB[(1 * N + row) * WS + colp]);
-                const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&WB[(2 * N + row) * WS + colp]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc[nb], 0, 0, 0);
+                const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * N + row) * WS + colp]);
+                const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * N + row) * WS + colp]);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1[s], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2[s], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1[s], acc[nb], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        }
-        if (!LT_H16 && tile + wave_stride < tiles) load_x(tile + wave_stride);
         const int mc = valid ? m : M - 1;                      // rows beyond M compute on a clamped row and are not stored
-        float *yr = y + (size_t)mc * ldy + 4 * h;
         const float *rr = residual ? residual + (size_t)mc * ldy + 4 * h : nullptr;
         const float *ar = accum ? accum + (size_t)mc * ldy + 4 * h : nullptr;
         float4 rv[NB][4];
@@ -328,23 +268,18 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
                     if (act == 2) v[u] *= 1.0f - 0.5f * __expf(-r4[u]);
                     else if (rr) v[u] += r4[u];
                 }
-                if constexpr (LT_H16)
-                    *reinterpret_cast<float4 *>(&OT[l31 * LT_OP + 32 * (nb & 1) + 8 * q + 4 * h]) = make_float4(v[0], v[1], v[2], v[3]);
-                else if (valid)
-                    *reinterpret_cast<float4 *>(yr + 32 * nb + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(&OT[l31 * LT_OP + 32 * (nb & 1) + 8 * q + 4 * h]) = make_float4(v[0], v[1], v[2], v[3]);
             }
             // fp16 form: the planes leave room in LDS for a [32][64] slab per wave — the outputs cross it so that a store instruction
             // writes 4 rows x 256 contiguous bytes instead of 32 rows x 32 bytes (partial lines that L2 has to merge; with the loads
             // switched off the kernel took 86 us of its 128 for the stores alone: 128 -> 116 us).  The slab is private to the wave: no barrier.
-            if constexpr (LT_H16) {
-                if (nb & 1) {
-                    const int rbase = tile << 5;
+            if (nb & 1) {
+                const int rbase = tile << 5;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int r = 4 * i + (lane >> 4), c = 4 * (lane & 15);
-                        const float4 o = *reinterpret_cast<const float4 *>(&OT[r * LT_OP + c]);
-                        if (rbase + r < M) *reinterpret_cast<float4 *>(y + (size_t)(rbase + r) * ldy + 32 * (nb - 1) + c) = o;
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    const int r = 4 * i + (lane >> 4), c = 4 * (lane & 15);
+                    const float4 o = *reinterpret_cast<const float4 *>(&OT[r * LT_OP + c]);
+                    if (rbase + r < M) *reinterpret_cast<float4 *>(y + (size_t)(rbase + r) * ldy + 32 * (nb - 1) + c) = o;
                 }
             }
         }
@@ -363,7 +298,7 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     // 8 waves per workgroup (2 per SIMD cover each other's latencies) once every CU gets a full workgroup; below that 4-wave
     // workgroups spread the tiles over twice as many CUs (node-level layers: 790 tiles -> 198 instead of 99 CUs).
     const bool narrow = tiles16 < 8 * 256;
-    const size_t lds16 = lds_w + (LT_H16 ? (size_t)(narrow ? 4 : 8) * 32 * LT_OP * 4 : 0);
+    const size_t lds16 = lds_w + (size_t)(narrow ? 4 : 8) * 32 * LT_OP * 4;
     const int per = narrow ? 4 : 8;
     int grid16 = (tiles16 + per - 1) / per;
     if (grid16 > 256 / nc) grid16 = 256 / nc;          // (nc chunks: 256 / nc tile slots x nc)
@@ -400,10 +335,8 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
 template <int KC, int NC>
 static int chunk_launch(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn, int act,
                         float *y, const int *m_dev, hipStream_t s, float *pre_out) {
-#ifndef CONAN_LINEAR_NO_NCHUNK      // (A/B switch: one launch per chunk, as in round 2)
     if (K == KC && N / NC > 1 && N / NC <= 4)              // one contraction chunk: the N / NC output chunks share their x tiles in ONE launch
         return launch_t<KC, NC>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, K, w_kn ? N : K, N, nullptr, pre_out, N / NC);
-#endif
     for (int n0 = 0; n0 < N; n0 += NC)
         for (int k0 = 0; k0 < K; k0 += KC) {
             const bool first = k0 == 0, last = k0 + KC >= K;

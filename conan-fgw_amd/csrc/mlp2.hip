@@ -16,8 +16,8 @@
 // the second weight is staged with the matching column permutation) — nothing crosses lanes or LDS between the two GEMMs.  Both
 // products are two-plane fp16 splits on v_mfma_f32_32x32x16_f16 (fp32-class; gemm_t.hip describes the form and its exact power-of-two
 // scales: one per weight matrix, one per x row — and here one per row of the intermediate, taken from the accumulators).  Both weights
-// (2 x 70 KB of planes) sit in LDS from the start: one staging phase, one barrier.  (The three-plane bf16 form of round 2, kept behind
-// -DCONAN_LINEAR_BF16X3 for A/B runs, needed 104 KB per weight and staged them one after the other with two more barriers.)  `mid`
+// (2 x 70 KB of planes) sit in LDS from the start: one staging phase, one barrier.  (The three-plane bf16 form of round 2
+// needed 104 KB per weight and staged them one after the other with two more barriers.)  `mid`
 // (h forward, dh backward) is also written out: the weight gradients of the two layers need it.
 #include "common.h"
 
@@ -28,12 +28,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int M2_THREADS = 256, M2_WAVES = 4;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-#ifdef CONAN_LINEAR_BF16X3
-constexpr bool M2_H16 = false;
-#else
-constexpr bool M2_H16 = true;
-#endif
-constexpr int M2_NPL = M2_H16 ? 2 : 3;
+constexpr int M2_NPL = 2;                                      // operand planes (two fp16 planes, gemm_t.hip)
 __device__ __forceinline__ void m2_split2h(const float *v, float sc, f16x8 &p1, f16x8 &p2) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -53,49 +48,25 @@ __device__ __forceinline__ float m2_absmax4(float m, const float4 &v) {
     return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 
-__device__ __forceinline__ void m2_split3(const float *v, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h1 = (__bf16)v[j];
-        const float r1 = v[j] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        p1[j] = h1; p2[j] = h2; p3[j] = (__bf16)r2;
-    }
-}
-
-// Three bf16 images of a weight as [n][k] (pitch KD + 8), staged by all threads in two steps so that the global loads of BOTH weights can
+// Two fp16 planes of a weight as [n][k] (pitch KD + 8), staged by all threads in two steps so that the global loads of BOTH weights can
 // be in flight from the start of the kernel: m2_fetch (float4 loads into registers) and m2_park (split + 8-byte LDS stores).
 // src is [n][k] (TRANS = false: forward; a float4 = 4 consecutive k of one row) or [k][n] (TRANS = true: the backward reads the forward
 // weights transposed; a thread owns a 4(k) x 4(n) block, transposed in registers — lane mapping as gemm_t.hip: every 16-lane group covers
 // 16 distinct 8-byte bank slots).  PERM: inside every group of 16 k's the columns are stored in the order in which a lane-half
 // enumerates the accumulator registers of the previous GEMM (position 8h + j <-> (j&3) + 8(j>>2) + 4h); four consecutive, 4-aligned k's
 // stay consecutive under that permutation, so the 8-byte stores survive it.
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int m2_perm4(int k, bool perm) {
     if (!perm) return k;
     const int a = (k & 15) >> 2;
     return (k & ~15) + 8 * (a & 1) + 4 * (a >> 1);
 }
 __device__ __forceinline__ void m2_store4(__bf16 *WB, int NO, int WS, int n, int kp, const float *v4, float sc) {
-    if constexpr (M2_H16) {
-        _Float16 *WH = reinterpret_cast<_Float16 *>(WB);
-        f16x4 h1, h2;
+    _Float16 *WH = reinterpret_cast<_Float16 *>(WB);
+    f16x4 h1, h2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = v4[e] * sc; h1[e] = (_Float16)t; h2[e] = (_Float16)(t - (float)h1[e]); }
-        *reinterpret_cast<f16x4 *>(&WH[(0 * NO + n) * WS + kp]) = h1;
-        *reinterpret_cast<f16x4 *>(&WH[(1 * NO + n) * WS + kp]) = h2;
-        return;
-    }
-    bf16x4 h1, h2, h3;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h1[e] = (__bf16)v4[e]; const float r1 = v4[e] - (float)h1[e];
-        h2[e] = (__bf16)r1; h3[e] = (__bf16)(r1 - (float)h2[e]);
-    }
-    *reinterpret_cast<bf16x4 *>(&WB[(0 * NO + n) * WS + kp]) = h1;
-    *reinterpret_cast<bf16x4 *>(&WB[(1 * NO + n) * WS + kp]) = h2;
-    *reinterpret_cast<bf16x4 *>(&WB[(2 * NO + n) * WS + kp]) = h3;
+    for (int e = 0; e < 4; ++e) { const float t = v4[e] * sc; h1[e] = (_Float16)t; h2[e] = (_Float16)(t - (float)h1[e]); }
+    *reinterpret_cast<f16x4 *>(&WH[(0 * NO + n) * WS + kp]) = h1;
+    *reinterpret_cast<f16x4 *>(&WH[(1 * NO + n) * WS + kp]) = h2;
 }
 template <int NO, int KD, bool TRANS>
 struct M2Weight {
@@ -172,10 +143,10 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     constexpr int SA = KA / 16, SB = NA / 16, MBA = NA / 32, MBB = NB / 32;
     constexpr int WSA = KA + 8, WSB = NA + 8;
     constexpr int WORDS_A = (M2_NPL * NA * WSA) / 2, WORDS_B = (M2_NPL * NB * WSB) / 2;
-    constexpr int WORDS = M2_H16 ? WORDS_A + WORDS_B : (WORDS_A > WORDS_B ? WORDS_A : WORDS_B);
+    constexpr int WORDS = WORDS_A + WORDS_B;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16 *WB = reinterpret_cast<__bf16 *>(lds);
-    __bf16 *WB2 = M2_H16 ? reinterpret_cast<__bf16 *>(lds + WORDS_A) : WB;      // the second weight: its own buffer (fp16 form) or the first one's, reused
+    __bf16 *WB2 = reinterpret_cast<__bf16 *>(lds + WORDS_A);      // the second weight has its own buffer
     float *BL = lds + WORDS;                                   // [NA + NB] biases
     __shared__ float wred[2 * M2_WAVES];
     float unA = 1.0f, unB = 1.0f;                              // inverse plane scales of the two weights (fp16 form)
@@ -216,22 +187,18 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     M2Weight<NA, KA, BWD> stA;
     M2Weight<NB, NA, BWD> stB;
     stA.fetch(wA, tid);
-    stB.fetch(wB, tid);                                        // bf16 form: in flight during the first GEMM
-    if constexpr (M2_H16) {
-        const float ma = wave_max(stA.absmax()), mb = wave_max(stB.absmax());
-        if (lane == 0) { wred[wave] = ma; wred[M2_WAVES + wave] = mb; }
-        __syncthreads();
-        float a = wred[0], b = wred[M2_WAVES];
+    stB.fetch(wB, tid);                                        // in flight during the first GEMM
+    const float ma = wave_max(stA.absmax()), mb = wave_max(stB.absmax());
+    if (lane == 0) { wred[wave] = ma; wred[M2_WAVES + wave] = mb; }
+    __syncthreads();
+    float a = wred[0], b = wred[M2_WAVES];
 #pragma unroll
-        for (int w = 1; w < M2_WAVES; ++w) { a = fmaxf(a, wred[w]); b = fmaxf(b, wred[M2_WAVES + w]); }
-        float scA, scB;
-        m2_pow2_scale(a, scA, unA);
-        m2_pow2_scale(b, scB, unB);
-        stA.park(WB, tid, false, scA);
-        stB.park(WB2, tid, true, scB);
-    } else {
-        stA.park(WB, tid, false);
-    }
+    for (int w = 1; w < M2_WAVES; ++w) { a = fmaxf(a, wred[w]); b = fmaxf(b, wred[M2_WAVES + w]); }
+    float scA, scB;
+    m2_pow2_scale(a, scA, unA);
+    m2_pow2_scale(b, scB, unB);
+    stA.park(WB, tid, false, scA);
+    stB.park(WB2, tid, true, scB);
     for (int t = tid; t < NA + NB; t += M2_THREADS) BL[t] = BWD ? 0.f : (t < NA ? bA[t] : bB[t - NA]);
     if (MODE == 3) {                                           // g = dy * ssp'(pre) from the saved output, in place and out for the weight gradient
 #pragma unroll
@@ -255,60 +222,38 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
     for (int nb = 0; nb < MBA; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
-    float un1 = 1.0f;                                          // fp16 form: inverse of (row scale of x) x (scale of the first weight)
-    if constexpr (M2_H16) {
-        float am = 0.f;
+    float un1 = 1.0f;                                          // inverse of (row scale of x) x (scale of the first weight)
+    {
+    float am = 0.f;
 #pragma unroll
-        for (int s = 0; s < SA; ++s) { am = m2_absmax4(am, xa[s]); am = m2_absmax4(am, xb[s]); }
-        am = fmaxf(am, __shfl_xor(am, 32));                    // the other half of the row sits on lane ^ 32
-        float xsc, xu;
-        m2_pow2_scale(am, xsc, xu);
-        un1 = xu * unA;
-        const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB);
-#pragma unroll
-        for (int s = 0; s < SA; ++s) {
-            const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
-            f16x8 q1, q2;
-            m2_split2h(xv, xsc, q1, q2);
-            const int colp = 16 * s + 8 * h;
-#pragma unroll
-            for (int nb = 0; nb < MBA; ++nb) {
-                const int row = 32 * nb + l31;
-                const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * NA + row) * WSA + colp]);
-                const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * NA + row) * WSA + colp]);
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc1[nb], 0, 0, 0);
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc1[nb], 0, 0, 0);
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc1[nb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int nb = 0; nb < MBA; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[nb][r] *= un1;
-    } else {
+    for (int s = 0; s < SA; ++s) { am = m2_absmax4(am, xa[s]); am = m2_absmax4(am, xb[s]); }
+    am = fmaxf(am, __shfl_xor(am, 32));                    // the other half of the row sits on lane ^ 32
+    float xsc, xu;
+    m2_pow2_scale(am, xsc, xu);
+    un1 = xu * unA;
+    const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB);
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
         const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
-        bf16x8 q1, q2, q3;
-        m2_split3(xv, q1, q2, q3);
+        f16x8 q1, q2;
+        m2_split2h(xv, xsc, q1, q2);
         const int colp = 16 * s + 8 * h;
 #pragma unroll
         for (int nb = 0; nb < MBA; ++nb) {
             const int row = 32 * nb + l31;
-            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&WB[(0 * NA + row) * WSA + colp]);
-            const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&WB[(1 * NA + row) * WSA + colp]);
-            const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&WB[(2 * NA + row) * WSA + colp]);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc1[nb], 0, 0, 0);
+            const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * NA + row) * WSA + colp]);
+            const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * NA + row) * WSA + colp]);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc1[nb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     }
+#pragma unroll
+    for (int nb = 0; nb < MBA; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[nb][r] *= un1;
     // element-wise step on the accumulators (register r of half h is channel 32nb + (r&3) + 8(r>>2) + 4h) and the `mid` output
 #pragma unroll
     for (int nb = 0; nb < MBA; ++nb)
@@ -333,10 +278,6 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
             if (mid_out && valid)
                 *reinterpret_cast<float4 *>(mid_out + (size_t)m * NA + 32 * nb + 8 * q + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
         }
-    if constexpr (!M2_H16) {
-        __syncthreads();                                       // every wave is done with the first weight
-        stB.park(WB, tid, true);
-    }
     float4 rv[MODE == 0 ? MBB : 1][4];
     if (MODE == 0 && residual) {
         const float *rr = residual + (size_t)mr * NB + 4 * h;
@@ -345,7 +286,6 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
 #pragma unroll
             for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
     }
-    if constexpr (!M2_H16) __syncthreads();
 
     // ---------------- GEMM2^T: acc2[nb] = WB[32nb.., :] . mid^T, B operand = acc1 (k order of the A fragments permuted to match)
     f32x16 acc2[MBB];
@@ -354,59 +294,34 @@ __global__ void __launch_bounds__(M2_THREADS) k_mlp2(const float *__restrict__ x
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
     float un2 = 1.0f;
-    if constexpr (M2_H16) {
-        float am = 0.f;                                        // the row of `mid`: 64 channels here, 64 on lane ^ 32
+    {
+    float am = 0.f;                                        // the row of `mid`: 64 channels here, 64 on lane ^ 32
 #pragma unroll
-        for (int nb = 0; nb < MBA; ++nb)
+    for (int nb = 0; nb < MBA; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc1[nb][r]));
-        am = fmaxf(am, __shfl_xor(am, 32));
-        float msc, mu;
-        m2_pow2_scale(am, msc, mu);
-        un2 = mu * unB;
-        const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB2);
-#pragma unroll
-        for (int ms = 0; ms < SB; ++ms) {
-            const int mb = ms >> 1, sgrp = ms & 1;
-            float hv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
-            f16x8 q1, q2;
-            m2_split2h(hv, msc, q1, q2);
-            const int colp = 32 * mb + 16 * sgrp + 8 * h;
-#pragma unroll
-            for (int nb = 0; nb < MBB; ++nb) {
-                const int row = 32 * nb + l31;
-                const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * NB + row) * WSB + colp]);
-                const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * NB + row) * WSB + colp]);
-                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc2[nb], 0, 0, 0);
-                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc2[nb], 0, 0, 0);
-                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc2[nb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
+        for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc1[nb][r]));
+    am = fmaxf(am, __shfl_xor(am, 32));
+    float msc, mu;
+    m2_pow2_scale(am, msc, mu);
+    un2 = mu * unB;
+    const _Float16 *WH = reinterpret_cast<const _Float16 *>(WB2);
 #pragma unroll
     for (int ms = 0; ms < SB; ++ms) {
         const int mb = ms >> 1, sgrp = ms & 1;
         float hv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) hv[j] = acc1[mb][8 * sgrp + j];
-        bf16x8 q1, q2, q3;
-        m2_split3(hv, q1, q2, q3);
+        f16x8 q1, q2;
+        m2_split2h(hv, msc, q1, q2);
         const int colp = 32 * mb + 16 * sgrp + 8 * h;
 #pragma unroll
         for (int nb = 0; nb < MBB; ++nb) {
             const int row = 32 * nb + l31;
-            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(&WB[(0 * NB + row) * WSB + colp]);
-            const bf16x8 p2 = *reinterpret_cast<const bf16x8 *>(&WB[(1 * NB + row) * WSB + colp]);
-            const bf16x8 p3 = *reinterpret_cast<const bf16x8 *>(&WB[(2 * NB + row) * WSB + colp]);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p3, q1, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q2, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q3, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p2, q1, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q2, acc2[nb], 0, 0, 0);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, q1, acc2[nb], 0, 0, 0);
+            const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&WH[(0 * NB + row) * WSB + colp]);
+            const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&WH[(1 * NB + row) * WSB + colp]);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1, acc2[nb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -429,7 +344,7 @@ template <int KA, int NA, int NB, int MODE>
 int m2_launch(const float *x, const float *wA, const float *bA, const float *wB, const float *bB, const float *aux, const float *residual, int M,
               float *mid_out, float *y, float *in_out, hipStream_t s) {
     constexpr int WA = (M2_NPL * NA * (KA + 8)) / 2, WBw = (M2_NPL * NB * (NA + 8)) / 2;
-    const size_t lds = ((size_t)(M2_H16 ? WA + WBw : (WA > WBw ? WA : WBw)) + NA + NB) * 4;
+    const size_t lds = ((size_t)(WA + WBw) + NA + NB) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp2<KA, NA, NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int tiles = (M + 31) / 32;
     k_mlp2<KA, NA, NB, MODE><<<(tiles + M2_WAVES - 1) / M2_WAVES, M2_THREADS, lds, s>>>(x, wA, bA, wB, bB, aux, residual, M, mid_out, y, in_out);

@@ -71,11 +71,7 @@ __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]
 #ifndef CONAN_V_EB
 #define CONAN_V_EB 4
 #endif
-#ifdef CONAN_V_NO_HALF      // (A/B switch: a whole wavefront per edge at H = 128, float2 per lane)
-constexpr bool V_HALF = false;
-#else
 constexpr bool V_HALF = true;     // H = 128: a half-wavefront per edge (32 lanes x float4 = one 512-byte row), two edges per instruction
-#endif
 constexpr int VN_EB = CONAN_V_EB;      // edges in flight per wavefront
 #ifndef CONAN_VB_RUN
 #define CONAN_VB_RUN 16
@@ -208,7 +204,7 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = ll * CPL;
+    const int c0 = (int)blockIdx.y * (HALF ? 32 : 64) * CPL + ll * CPL;      // blockIdx.y: block of 64 CPL (HALF: 32 CPL) channels — whole heads (H > 128)
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;                                       // idle lanes (H < 64 CPL) read column 0 and store nothing
     for (int i = wave; i < n; i += nw) {
@@ -498,13 +494,16 @@ int conan_visnet_attn_message(const float *q, const float *k, const float *v, co
                               float *xagg, void *stream) {
     VN_CHECK(q && k && v && dk && dv && rowptr && col && dist && vmsg && xagg && n >= 0 && H > 0 && num_heads > 0 && H % num_heads == 0);
     const int hd = H / num_heads;
+    // H a multiple of 128 (the classification backbone's 512, common.py:444-446): blocks of 128 channels on blockIdx.y, each a half-wavefront
+    // per edge — heads must not straddle a block (hd divides 128) and span a power-of-two number of 4-channel lanes
+    const bool blocks128 = H % 128 == 0 && V_HALF && hd % 4 == 0 && (((hd / 4) & (hd / 4 - 1)) == 0) && 128 % hd == 0;
     const int cpl = H > 64 ? (H + 63) / 64 : 1;
-    if (H > 128 || (H > 64 && H != 128) || hd % cpl != 0) return CONAN_E_UNSUPPORTED;
-    const int lph = hd / cpl;
+    if (!blocks128 && (H > 128 || (H > 64 && H != 128) || hd % cpl != 0)) return CONAN_E_UNSUPPORTED;
+    const int lph = blocks128 ? hd / 4 : hd / cpl;
     if (lph & (lph - 1)) return CONAN_E_UNSUPPORTED;
     if (n == 0) return CONAN_OK;
-    if (H == 128 && V_HALF && hd % 4 == 0 && (((hd / 4) & (hd / 4 - 1)) == 0))
-        k_attn_msg<4, true><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, hd / 4, pre_act, vmsg, xagg);
+    if (blocks128)
+        k_attn_msg<4, true><<<dim3(nblk((long long)n * 64), H / 128), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, hd / 4, pre_act, vmsg, xagg);
     else if (cpl == 2) k_attn_msg<2><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
     else k_attn_msg<1><<<nblk((long long)n * 64), 256, 0, as_stream(stream)>>>(q, k, v, dk, dv, rowptr, col, dist, cutoff, n, H, lph, pre_act, vmsg, xagg);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;

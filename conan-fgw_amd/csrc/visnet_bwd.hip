@@ -76,11 +76,7 @@ __device__ __forceinline__ void vst(float *__restrict__ p, const float (&r)[CPL]
 #ifndef CONAN_V_EB
 #define CONAN_V_EB 4
 #endif
-#ifdef CONAN_V_NO_HALF
-constexpr bool V_HALF = false;
-#else
 constexpr bool V_HALF = true;     // H = 128: a half-wavefront per edge (visnet.hip)
-#endif
 constexpr int VB_EB = CONAN_V_EB;
 #ifndef CONAN_VB_RUN
 #define CONAN_VB_RUN 16
@@ -272,7 +268,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = ll * CPL;
+    const int c0 = (int)blockIdx.y * (HALF ? 32 : 64) * CPL + ll * CPL;      // blockIdx.y: channel block of whole heads (H > 128, visnet.hip)
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;                                       // idle lanes read column 0 and store nothing
     for (int i = wave; i < n; i += nw) {
@@ -334,7 +330,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const int c0 = ll * CPL;
+    const int c0 = (int)blockIdx.y * (HALF ? 32 : 64) * CPL + ll * CPL;
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;
     for (int j = wave; j < n; j += nw) {
@@ -727,15 +723,17 @@ int conan_visnet_attn_message_bwd(const float *q, const float *k, const float *v
     VB_CHECK(q && k && v && dk && dv && dvmsg && dxagg && rowptr && col && tgt && t_rowptr && t_eid && dist && dq && dkn && dvn && ddk && ddv);
     VB_CHECK(n >= 0 && H > 0 && num_heads > 0 && H % num_heads == 0);
     const int hd = H / num_heads, cpl = H > 64 ? (H + 63) / 64 : 1;
-    if (H > 128 || (H > 64 && H != 128) || hd % cpl != 0) return CONAN_E_UNSUPPORTED;
-    const int lph = hd / cpl;
+    const bool blocks128 = H % 128 == 0 && V_HALF && hd % 4 == 0 && (((hd / 4) & (hd / 4 - 1)) == 0) && 128 % hd == 0;      // as conan_visnet_attn_message
+    if (!blocks128 && (H > 128 || (H > 64 && H != 128) || hd % cpl != 0)) return CONAN_E_UNSUPPORTED;
+    const int lph = blocks128 ? hd / 4 : hd / cpl;
     if (lph & (lph - 1)) return CONAN_E_UNSUPPORTED;
     if (n == 0) return CONAN_OK;
     hipStream_t s = as_stream(stream);
     const int g = nblk((long long)n * 64);
-    if (H == 128 && V_HALF && hd % 4 == 0 && (((hd / 4) & (hd / 4 - 1)) == 0)) {
-        k_attn_bwd_target<4, true><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, hd / 4, pre_act, dq, ddk, ddv);
-        k_attn_bwd_source<4, true><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, hd / 4, pre_act, dkn, dvn);
+    if (blocks128) {
+        const dim3 gb(g, H / 128);
+        k_attn_bwd_target<4, true><<<gb, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, hd / 4, pre_act, dq, ddk, ddv);
+        k_attn_bwd_source<4, true><<<gb, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, hd / 4, pre_act, dkn, dvn);
     } else if (cpl == 2) {
         k_attn_bwd_target<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, rowptr, col, dist, cutoff, n, H, lph, pre_act, dq, ddk, ddv);
         k_attn_bwd_source<2><<<g, 256, 0, s>>>(q, k, v, dk, dv, dvmsg, dxagg, t_rowptr, t_eid, tgt, dist, cutoff, n, H, lph, pre_act, dkn, dvn);

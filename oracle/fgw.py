@@ -60,7 +60,7 @@ def fgw_barycenter(Ys, Cs, ps=None, lambdas=None, init_C=None, N=None, p=None, d
     rc = fn(ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(n), ctypes.c_int(d), _p(Ys), _p(Cs), _p(ps), _p(p_arr),
             _p(lambdas), _p(init_C), cr(o["alpha"]), cr(o["epsilon"]), ctypes.c_int(mi), cr(o["tol"]),
             cr(o["inner_tol"]), ctypes.c_int(int(o["numItermax"])), cr(o["stopThr"]),
-            ctypes.c_int(int(bool(o["fixed_structure"]))), ctypes.c_int(int(bool(o["fixed_features"]))),
+            ctypes.c_int(int(bool(o["fixed_structure"]))), ctypes.c_int(int(bool(o["fixed_features"])) | (2 if o.get("init_Y") is not None else 0)),
             _p(Y), _p(C), _p(T), _p(ef), _p(es), _p(iters), ctypes.c_int(loss))
     if rc != 0:
         raise RuntimeError("oracle fgw_barycenter failed rc=%d" % rc)

@@ -176,7 +176,8 @@ REAL FN(conan_oracle_fgw_dist)(int n1, int n2, const REAL *M, const REAL *C1, co
 }
 
 /* barycenter.py:7-225 (fgw_barycenters) restricted to: loss_fun="square_loss" or "kl_loss", solver="PGD",
- * stop_criterion="barycenter", warmstartT=True, symmetric=True, init_C given, init_Y=None, p given or
+ * stop_criterion="barycenter", warmstartT=True, symmetric=True, init_C given, init_Y=None or given (bit 1 of
+ * fixed_features: Y holds init_Y on entry, barycenter.py:69-80; bit 0 = fixed_features itself), p given or
  * uniform, every input graph of the same size n (the production glue always pads to N_max,
  * schnet_no_sum.py:242-252) — n may differ from N.
  *
@@ -205,7 +206,9 @@ int FN(conan_oracle_fgw_barycenter_loss)(int N, int K, int n, int d, const REAL 
     if (!p || !Ms || !Yprev || !Cprev || !TC || !work || !have_T || !init_C) return -1;
     for (i = 0; i < N; ++i) p[i] = p_in ? p_in[i] : (REAL)1 / (REAL)N;
     for (i = 0; i < N * N; ++i) C[i] = init_C[i];        /* :54-67 */
-    if (!fixed_features) for (i = 0; i < N * d; ++i) Y[i] = 0;   /* :76-77 ; fixed_features => Y holds init_Y on entry */
+    const int have_init_Y = (fixed_features & 2) != 0;   /* :78-80: Y = init_Y */
+    fixed_features &= 1;
+    if (!fixed_features && !have_init_Y) for (i = 0; i < N * d; ++i) Y[i] = 0;   /* :76-77 ; otherwise Y holds init_Y on entry */
     for (s = 0; s < K; ++s) FN(sqdist)(N, n, d, Y, Ys + (size_t)s * n * d, Ms + s * nn);   /* :82 */
     if (iters) iters[0] = 0;
     while ((ef > tol || es > tol) && cpt < max_iter) {   /* :112 (err_rel_loss == 0) */

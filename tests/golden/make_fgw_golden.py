@@ -96,6 +96,8 @@ def run_ref(Ys, Cs, dtype, _init_first=True, **over):
     K, N, d = Ys.shape
     t = lambda a: torch.from_numpy(np.asarray(a)).to(dtype)
     args = dict(PROD); args.update(over)
+    if args.get("init_Y") is not None:
+        args["init_Y"] = t(args["init_Y"])
     Ysl = [t(y).requires_grad_(True) for y in Ys]
     Csl = [t(c) for c in Cs]
     ps = [torch.ones(N, dtype=dtype) / N for _ in range(K)]
@@ -203,6 +205,32 @@ def main_kl():
               f"relC={rel(r32['C'], r64['C']):.2e} relT={rel(r32['T'], r64['T']):.2e} finite={np.isfinite(r64['C']).all()}")
 
 
+def starved_row_inputs(N, K=2, d=16, i0=5, seed=11):
+    """Inputs whose barycenter node i0 starts ~95 e-folds (at eps = 0.1, alpha = 0.1) above every column's best cost: near-identical features
+    everywhere, init_Y[i0] displaced by |.|^2 = 10.5.  In an fp32 kernel matrix that row is all denormals (tests/test_gpu_fgw.py)."""
+    rng = np.random.default_rng(seed)
+    Ys = (0.6 + 0.01 * rng.standard_normal((K, N, d))).astype(np.float32)
+    Y0 = (0.6 + 0.01 * rng.standard_normal((N, d))).astype(np.float32)
+    Y0[i0] += np.float32(np.sqrt(10.5 / d))
+    A = (rng.random((K, N, N)) < 0.3).astype(np.float32); Cs = np.triu(A, 1); Cs = Cs + Cs.transpose(0, 2, 1)
+    return Ys, Cs, Y0
+
+
+def main_inity():
+    """init_Y given (barycenter.py:78-80) with a starved row, one outer iteration: run as `python make_fgw_golden.py inity`; writes fgw_inity_*.npz."""
+    for N in (40, 70, 96):
+        Ys, Cs, Y0 = starved_row_inputs(N)
+        rec = dict(Ys=Ys, Cs=Cs.astype(np.uint8), init_Y=Y0, i0=np.int64(5), max_iter=np.int64(1))
+        for tag, dt in (("r32", torch.float32), ("r64", torch.float64)):
+            rr = run_ref(Ys, Cs, dt, init_Y=Y0, max_iter=1)
+            for k in ("Y", "C", "T", "err_feature", "err_structure", "pgd", "sinkhorn"):
+                rec[f"{tag}_{k}"] = rr[k].astype(np.float32) if (tag == "r32" and rr[k].dtype.kind == "f") else rr[k]
+        np.savez_compressed(os.path.join(HERE, f"fgw_inity_n{N}.npz"), **rec)
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        print(f"inity n{N}: relY={rel(rec['r32_Y'], rec['r64_Y']):.2e} relT={rel(rec['r32_T'], rec['r64_T']):.2e} row i0 * N = {rec['r64_T'][0, 5].sum() * N:.6f} "
+              f"pgd={rec['r64_pgd'].ravel()} sk={rec['r64_sinkhorn'].ravel()}")
+
+
 def main_randinit():
     """init_C=None: the reference draws its own initial structure (barycenter.py:61-65: torch.manual_seed(seed); randn(N, 2); dist).
     Run as `python make_fgw_golden.py randinit`; writes fgw_randinit_*.npz only."""
@@ -220,4 +248,4 @@ def main_randinit():
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else ""
-    {"kl": main_kl, "randinit": main_randinit}.get(mode, main)()
+    {"kl": main_kl, "randinit": main_randinit, "inity": main_inity}.get(mode, main)()

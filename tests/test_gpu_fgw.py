@@ -89,6 +89,31 @@ def test_second_pass_on_the_exact_path_when_the_scaling_form_leaves_its_range(N,
         assert rel(Y[b].cpu().numpy(), ref["Y"]) < 1e-4 and rel(C[b].cpu().numpy(), ref["C"]) < 1e-4
 
 
+@pytest.mark.parametrize("N", [40, 70, 96], ids=["n40_small_kernel", "n70", "n96"])
+def test_row_in_the_fp32_denormal_window_goes_to_the_exact_path(N, golden_dir):
+    """k_fgw_coupling_big (N > 64) keeps K = exp(Mr - column best) as fp32 in LDS.  A barycenter node whose costs sit ~95 e-folds above every
+    column's best has a K row of fp32 DENORMALS (5e-42: two or three significant bits): its row sum is ~1e-43, inside the fp64 range the
+    round-3 guard tested, so the coupling was returned with a garbage row although the reference's log-domain Sinkhorn handles it exactly
+    (sinkhorn.py:318-450).  The guard now also tests the row sums of the first u update against 1e-28 (g = 1, f_j in [q_j / N, q_j]: the sum
+    brackets the row's largest K entry within a factor N^2) and hands such couplings to the exact second pass (info bit 0).  Expected values:
+    the reference itself run on these inputs (tests/golden/fgw_inity_*.npz, make_fgw_golden.py inity).  N = 40 runs the N <= 64 kernel, whose
+    K is fp64 (no hand-back needed): it pins init_Y on that path."""
+    g = np.load(os.path.join(golden_dir, f"fgw_inity_n{N}.npz"))
+    i0, kw = int(g["i0"]), dict(epsilon=0.1, alpha=0.1, max_iter=int(g["max_iter"]))
+    Ys, Cs, Y0 = g["Ys"][None], g["Cs"].astype(np.float32)[None], g["init_Y"][None]
+    for small_int in (False, True):
+        Y, C, T, info, errs = ops.fgw_barycenter_batched(torch.from_numpy(Ys).to(dev), torch.from_numpy(Cs).to(dev), init_Y=torch.from_numpy(Y0).to(dev),
+                                                         cs_small_int=small_int, **kw)
+        Tg = T[0].cpu().numpy().astype(np.float64)
+        if N > 64:
+            assert int(info[0, 3]) & 1, "the starved row did not send its coupling to the exact path"
+        assert int(info[0, 1]) == int(g["r64_pgd"].sum()) and int(info[0, 2]) == int(g["r64_sinkhorn"].sum())
+        for s in range(Tg.shape[0]):
+            row, want = Tg[s, i0], g["r64_T"][s, i0]
+            assert np.linalg.norm(row - want) <= 1e-4 * np.linalg.norm(want), (s, np.linalg.norm(row - want) / np.linalg.norm(want))
+        assert rel(Tg, g["r64_T"]) < 1e-4 and rel(Y[0].cpu().numpy(), g["r64_Y"]) < 1e-4 and rel(C[0].cpu().numpy(), g["r64_C"]) < 1e-4
+
+
 def test_cfm_log_known_answer(golden_dir):
     """The reference's only stored answer (notebooks/data/cfm_log.pt) through the mirror of its own signature."""
     g = np.load(os.path.join(golden_dir, "cfm_log.npz"))

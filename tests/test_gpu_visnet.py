@@ -62,10 +62,12 @@ def test_production_width_vs_oracle_and_invariance():
     assert rel(out2.detach().cpu().numpy(), out1.detach().cpu().numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("H,shape,B,K", [(32, "esol", 2, 3), (64, "bace", 2, 3), (128, "esol", 2, 5)])
+@pytest.mark.parametrize("H,shape,B,K", [(32, "esol", 2, 3), (64, "bace", 2, 3), (128, "esol", 2, 5), (512, "esol", 2, 3), (256, "bace", 1, 2)])
 def test_backward_matches_oracle_autograd(H, shape, B, K):
     """Gradients of every trainable ViSNet parameter (trunk, both heads, atomref priors) through forward_w_barycenter,
-    against torch autograd of the fp64 oracle (the oracle's FGW backward is the reference's: T held constant)."""
+    against torch autograd of the fp64 oracle (the oracle's FGW backward is the reference's: T held constant).
+    H = 512 is the width the reference's classification head instantiates its backbone with (common.py:444-446, feat_dim = 512; not
+    reachable from the reference's CLI with ViSNet, reachable from the class API): attention runs in blocks of 128 channels."""
     b = make_batch(shape, B, K, seed=55, box=7.0 if shape == "esol" else None)
     torch.manual_seed(H)
     m = ViSNet(dev, hidden_channels=H).to(dev)

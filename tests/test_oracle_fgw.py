@@ -40,6 +40,23 @@ def test_cfm_log_pins_glue(golden_dir):
         assert np.abs(out - g["Ys"][k]).max() <= 2.4e-7
 
 
+@pytest.mark.parametrize("N", [40, 70, 96])
+def test_oracle_takes_an_initial_feature_matrix_like_the_reference(N, golden_dir):
+    """init_Y given (barycenter.py:78-80), with a barycenter node ~95 e-folds above every column's best cost: the reference's log-domain
+    Sinkhorn gives that node its full mass (row sum 1/N).  Until round 4 the oracle silently started from Y = 0 whatever init_Y said."""
+    g = np.load(os.path.join(golden_dir, f"fgw_inity_n{N}.npz"))
+    i0 = int(g["i0"])
+    assert abs(g["r64_T"][0, i0].sum() * N - 1.0) < 1e-9
+    r = fgw.fgw_barycenter(g["Ys"], g["Cs"], dtype=np.float64, init_Y=g["init_Y"], max_iter=int(g["max_iter"]))
+    assert np.array_equal(r["pgd"], g["r64_pgd"]) and np.array_equal(r["sinkhorn"][..., : g["r64_sinkhorn"].shape[-1]], g["r64_sinkhorn"])
+    assert rel(r["T"], g["r64_T"]) < 1e-9 and rel(r["T"][:, i0], g["r64_T"][:, i0]) < 1e-9
+    assert rel(r["Y"], g["r64_Y"]) < 1e-9 and rel(r["C"], g["r64_C"]) < 1e-9
+    r0 = fgw.fgw_barycenter(g["Ys"], g["Cs"], dtype=np.float64, max_iter=int(g["max_iter"]))          # Y = 0 start: a different problem
+    assert rel(r0["T"][:, i0], g["r64_T"][:, i0]) > 0.1
+    r32 = fgw.fgw_barycenter(g["Ys"], g["Cs"], dtype=np.float32, init_Y=g["init_Y"], max_iter=int(g["max_iter"]))
+    assert rel(r32["T"], g["r32_T"]) < 1e-4
+
+
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
 def test_oracle_f64_matches_ref64(path):
     g = np.load(path)
