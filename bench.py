@@ -306,7 +306,7 @@ def run_rank(args):
     def fwd_bwd():
         flat.zero()
         pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
-        loss = torch.nn.functional.binary_cross_entropy(pred, y) if classify else torch.nn.functional.mse_loss(pred, y)   # common.py: BCE / MSE
+        loss = torch.nn.functional.binary_cross_entropy(pred, y) if classify else ops.mse_loss(pred, y)   # common.py: BCE / MSE (MSE and its gradient: one launch)
         flat.backward(loss)                        # = loss.backward() with the slab sums of all weight gradients batched into one launch
         loss_out.copy_(loss.detach())
 

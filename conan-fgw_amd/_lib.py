@@ -83,6 +83,7 @@ SIGNATURES = {
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_stage2_head_supported": (c_int, [c_int]),
+    "conan_mse_loss_fwd": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "conan_stage2_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "conan_stage2_head_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_mlp2_supported": (c_int, [c_int, c_int, c_int, c_int]),

@@ -115,9 +115,37 @@ __global__ void __launch_bounds__(HD_THREADS) k_stage2_head_bwd(const float *__r
     }
 }
 
+// Mean-squared-error loss of the stage-2 step (the reference's criterion for regression, common.py: nn.MSELoss) and its gradient in ONE launch:
+// loss = mean((pred - target)^2), dpred = 2 (pred - target) / n.  One workgroup; the sum runs in a fixed order (bitwise reproducible).
+// torch's mse_loss + backward are five launches of ~4.7 us each on the critical path between the forward and the backward of the step.
+__global__ void __launch_bounds__(256) k_mse_loss(const float *__restrict__ pred, const float *__restrict__ target, int n, float *__restrict__ loss,
+                                                  float *__restrict__ dpred) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const float inv = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float d = pred[i] - target[i];
+        acc += d * d;
+        dpred[i] = 2.0f * d * inv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
+}
+
 }  // namespace
 
 extern "C" {
+
+int conan_mse_loss_fwd(const float *pred, const float *target, int n, float *loss, float *dpred, void *stream) {
+    if (!pred || !target || !loss || !dpred || n <= 0) return CONAN_E_BADARG;
+    k_mse_loss<<<1, 256, 0, as_stream(stream)>>>(pred, target, n, loss, dpred);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
 
 int conan_stage2_head_supported(int D) { return (D >= 1 && D <= HD_MAXD) ? 1 : 0; }
 

@@ -670,7 +670,14 @@ class _CFConvFn(torch.autograd.Function):
             if ctx.pairs:
                 if not ctx.pre:
                     raise RuntimeError("use_pairs requires pre_cutoff_grad=True (the pair gradient includes the cosine cutoff)")
-                gmax = torch.zeros(1, dtype=f32, device=x.device) if F == 128 else None      # raised to max |dW| by the kernel
+                gmax = None
+                if F == 128:                               # one device float per CFConv backward, raised to max |dW| by the kernel: slots of a
+                    pool = getattr(g, "_gmax_pool", None)  # zeroed pool that lives on the graph (one fill per backward pass instead of one per block)
+                    if pool is None or pool[1] >= pool[0].numel():
+                        pool = [torch.zeros(8, dtype=f32, device=x.device), 0]
+                        g._gmax_pool = pool
+                    gmax = pool[0][pool[1]:pool[1] + 1]
+                    pool[1] += 1
                 call("conan_cfconv_bwd_w_pairs", ptr(x), ptr(dout), ptr(g.num_pairs_dev), g.max_edges, ptr(g.pair_e0), ptr(g.pair_e1), ptr(g.col),
                      ptr(g.tgt), F, ptr(g.pair_dist), float(g.cutoff), ptr(dW), ptr(gmax), stream_ptr())
                 if gmax is not None:
@@ -726,10 +733,13 @@ class _DensifyFn(torch.autograd.Function):
         ctx.save_for_backward(feat, minmax)
         ctx.graph, ctx.args = graph, (N, shift, a, b)
         ctx.mark_non_differentiable(Cs)
+        ctx.set_materialize_grads(False)          # no [G,N,N] zero tensor for the adjacency's "gradient" (a 5 us fill per step)
         return Ys, Cs
 
     @staticmethod
     def backward(ctx, dYs, _dCs):
+        if dYs is None:
+            return None, None, None, None, None, None
         feat, minmax = ctx.saved_tensors
         N, shift, a, b = ctx.args
         g = ctx.graph
@@ -770,6 +780,7 @@ class _FgwBarycenterFn(torch.autograd.Function):
              B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(T_iter), ptr(info), ptr(errs), ptr(ws), stream_ptr())
         ctx.save_for_backward(T, p, lambdas)
         ctx.dims = (B, K, N, d)
+        ctx.set_materialize_grads(False)          # C, T, info, errs carry no gradient: without this autograd fills four zero tensors per backward
         if T_iter is None:
             ctx.mark_non_differentiable(C, T, info, errs)
             return Y, C, T, info, errs
@@ -778,6 +789,8 @@ class _FgwBarycenterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dY, *_):
+        if dY is None:
+            return (None,) * 8
         T, p, lambdas = ctx.saved_tensors
         B, K, N, d = ctx.dims
         dYs = torch.empty(B, K, N, d, dtype=f32, device=dY.device)
@@ -795,6 +808,29 @@ def fgw_barycenter_batched(Ys: Tensor, Cs: Tensor, ps: Optional[Tensor] = None, 
     prm.update(params)
     opt = lambda t: _c(t) if t is not None else None
     return _FgwBarycenterFn.apply(Ys, Cs, opt(ps), opt(p), opt(lambdas), opt(init_C), opt(init_Y), prm)
+
+
+class _MseLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = _c(pred), _c(target)
+        if pred.shape != target.shape:
+            raise RuntimeError(f"mse_loss: pred {tuple(pred.shape)} and target {tuple(target.shape)} must have the same shape")
+        loss = torch.empty((), dtype=f32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        call("conan_mse_loss_fwd", ptr(pred, f32), ptr(target, f32), pred.numel(), ptr(loss), ptr(dpred), stream_ptr())
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None
+
+
+def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """mean((pred - target)^2) with its gradient formed in the same launch (the reference's nn.MSELoss criterion, common.py)."""
+    return _MseLossFn.apply(pred, target)
 
 
 class _ReadoutFn(torch.autograd.Function):

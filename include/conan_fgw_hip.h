@@ -250,6 +250,11 @@ int conan_stage2_head_bwd(const float *dout, const float *W3, const float *Wb, c
                           float agg_weight, int num_molecules, int K, int D, float *dx3, float *dxc, float *dxb, float *dW3, float *db3, float *dWb,
                           float *dbb, float *dwreg, float *dbreg, void *stream);
 
+/* Regression criterion of the training step and its gradient in one launch: loss[0] = mean((pred - target)^2), dpred[i] = 2 (pred[i] -
+ * target[i]) / n.  Replaces torch.nn.functional.mse_loss + its backward (nn.MSELoss of the reference's Lightning module, common.py) — five
+ * small launches on the critical path between the forward and the backward of a step.  Fixed summation order. */
+int conan_mse_loss_fwd(const float *pred, const float *target, int n, float *loss, float *dpred, void *stream);
+
 /* Two chained node-level Linear layers in one launch (mlp2.hip):
  *   forward : mid = ssp(x w1^T + b1) [M,N1];  y = mid w2^T + b2 (+ residual) [M,N2]
  *             = InteractionBlock's  conv.lin2 -> act -> lin (+ x)  (schnet_no_sum.py:164 with PyG's InteractionBlock.forward)

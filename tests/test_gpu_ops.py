@@ -506,6 +506,24 @@ def test_linear_wide_layers_are_tiled_into_strided_chunks(M, K, N, act, w_kn):
     assert torch.isnan(y[M:]).all()                                 # rows beyond the device-side count are not touched
 
 
+@pytest.mark.parametrize("n", [1, 256, 1000])
+def test_mse_loss_and_its_gradient_in_one_launch(n):
+    g = torch.Generator().manual_seed(n)
+    pred, y = torch.randn(n, 1, generator=g), torch.randn(n, 1, generator=g)
+    pd = pred.to(dev).requires_grad_(True)
+    loss = ops.mse_loss(pd, y.to(dev))
+    (3.0 * loss).backward()
+    p64 = pred.double().requires_grad_(True)
+    ref = F.mse_loss(p64, y.double())
+    (3.0 * ref).backward()
+    assert loss.shape == () and abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert rel(pd.grad.cpu(), p64.grad) < 1e-6
+    l2 = ops.mse_loss(pd.detach(), y.to(dev))
+    assert float(l2) == float(loss)                                   # fixed summation order
+    with pytest.raises(RuntimeError):
+        ops.mse_loss(pd, y.to(dev)[:, 0])
+
+
 def test_embedding_out_of_range_index_is_nan_not_out_of_bounds():
     """torch.nn.Embedding device-asserts on an index outside [0, num_embeddings); here the row is NaN and the backward skips it."""
     w = torch.randn(100, 64, device=dev, requires_grad=True)
