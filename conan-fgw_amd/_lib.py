@@ -80,6 +80,10 @@ SIGNATURES = {
     "conan_filter_bwd_slices": (c_int, [c_int]),
     "conan_filter_bwd_ws": (c_ll, [c_int, c_int, c_int]),
     "conan_filter_bwd": (c_int, [_P, _P, _P, c_int, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "conan_filter_bwd2_supported": (c_int, [c_int, c_int]),
+    "conan_filter_bwd2_slices": (c_int, [c_int]),
+    "conan_filter_bwd2_ws": (c_ll, [c_int, c_int, c_int]),
+    "conan_filter_bwd2": (c_int, [_P, _P, _P, c_int, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_rbf_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P]),
     "conan_cutoff_scale": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "conan_stage2_head_supported": (c_int, [c_int]),

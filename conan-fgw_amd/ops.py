@@ -300,6 +300,30 @@ def _filter_bwd(g, h1, dist, offset, coeff, w1, w2, M, md, gmax=None):
     return dw, db
 
 
+def _filter_bwd2(g, h1, dist, offset, coeff, w1, w2, M, md, gmax):
+    """(dW1 [F,Gs], db1 [F]), (dW2 [F,F], db2 [F]) of the filter network from the gradient g of its output in ONE pass over g and h1
+    (conan_filter_bwd2: _filter_bwd and the second layer's _wgrad fused).  Immediate, or slabs now + batched sum later (see _wgrad)."""
+    F, Gs = w1.shape
+    dev = g.device
+    ws = torch.empty(int(lib().conan_filter_bwd2_ws(M, Gs, F)), dtype=f32, device=dev)
+    slices = int(lib().conan_filter_bwd2_slices(M))
+    dw1, db1 = torch.empty(F, Gs, dtype=f32, device=dev), torch.empty(F, dtype=f32, device=dev)
+    dw2, db2 = torch.empty(F, F, dtype=f32, device=dev), torch.empty(F, dtype=f32, device=dev)
+    p1, p2 = w1.data_ptr(), w2.data_ptr()
+    defer = _pending is not None
+    if defer and any(j["weight_ptr"] in (p1, p2) for j in _pending):
+        flush_weight_gradients()
+        defer = False
+    call("conan_filter_bwd2", ptr(g), ptr(h1), ptr(dist), M, ptr(offset, f32), Gs, coeff, ptr(w2), F, ptr(md), ptr(gmax),
+         None if defer else ptr(dw1), None if defer else ptr(db1), None if defer else ptr(dw2), None if defer else ptr(db2), ptr(ws), stream_ptr())
+    if defer:
+        cut = slices * (F * Gs + F)
+        for wsv, dw, db, K, wp in ((ws[:cut], dw1, db1, Gs, p1), (ws[cut:], dw2, db2, F, p2)):
+            _pending.append(dict(ws=wsv, dw_ptr=dw.data_ptr(), db_ptr=db.data_ptr(), keep=(dw.untyped_storage(), db.untyped_storage()),
+                                 M=M, K=K, N=F, slices=slices, weight_ptr=wp, stream=torch.cuda.current_stream()))
+    return (dw1, db1), (dw2, db2)
+
+
 # ------------------------------------------------------------------------------------------------ linear / activation
 class _LinearFn(torch.autograd.Function):
     @staticmethod
@@ -591,6 +615,9 @@ def cutoff_scale(w_raw: Tensor, graph: RadiusGraph) -> Tensor:
     return _CutoffScaleFn.apply(w_raw, graph)
 
 
+FUSED_FILTER_BACKWARD = True      # tools / tests switch the round-3 pair of kernels back on to compare (never read from the environment)
+
+
 class _FilterFn(torch.autograd.Function):
     """Fused filter generator (conan_filter_fwd).  Its output must be consumed by `cfconv(..., pre_cutoff_grad=True)`:
     the incoming gradient g is then w.r.t. the un-scaled filter.  Backward: dw2 = g^T h1 (conan_linear_wgrad), then ONE pass
@@ -620,6 +647,9 @@ class _FilterFn(torch.autograd.Function):
         dev = dW.device
         g = _c(dW)                                   # already multiplied by C(d): cfconv(..., pre_cutoff_grad=True)
         gmax = _take_gmax(dW, g) if F == 128 else None      # max |g|, when the producer tracked it and nothing touched g since: the two kernels below run on fp16 planes
+        if gmax is not None and FUSED_FILTER_BACKWARD and lib().conan_filter_bwd2_supported(Gs, F):      # both layers' gradients in one pass over g and h1
+            (dw1, db1), (dw2, db2) = _filter_bwd2(g, h1, dist, _c(offset), ctx.coeff, w1, _c(w2), ME, md, gmax)
+            return None, None, None, dw1, db1, dw2, db2, None
         dw2, db2 = _wgrad(g, h1, ME, F, F, md, w2, True, gmax=gmax)
         if lib().conan_filter_bwd_supported(Gs, F):              # (g @ w2) * ssp'(h1) and its contraction with rbf(dist) in one pass
             dw1, db1 = _filter_bwd(g, h1, dist, _c(offset), ctx.coeff, w1, _c(w2), ME, md, gmax=gmax)

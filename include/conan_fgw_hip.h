@@ -226,6 +226,20 @@ long long conan_filter_bwd_ws(int M, int num_gaussians, int num_filters);
 int conan_filter_bwd(const float *g, const float *h1, const float *dist, int M, const float *offset, int num_gaussians, float coeff,
                      const float *w2, int num_filters, const int *m_dev, float *dW1, float *db1, float *ws, const float *gmax, void *stream);
 
+/* Backward of the WHOLE filter network in one pass over the pair rows (filter_bwd2.hip, round 4): conan_filter_bwd plus the weight / bias
+ * gradient of the second Linear, dW2 [F,F] = g^T h1, db2 [F] = column sums of g — g and h1 cross HBM once instead of twice.  Requires the
+ * device-side maximum of |g| (`gmax`, see conan_cfconv_bwd_w_pairs): both products run on two fp16 planes.  ws holds
+ * conan_filter_bwd2_ws(M, Gs, F) floats = [slabs1 | bias1 | slabs2 | bias2] with conan_filter_bwd2_slices(M) slabs each.
+ * dW1 == dW2 == NULL: slabs only, to be reduced by two conan_wgrad_reduce_batch jobs — (ws, K = Gs, N = F) and
+ * (ws + slices * (F * Gs + F), K = F, N = F), both with job.slices = conan_filter_bwd2_slices(M).
+ * Supported: conan_filter_bwd2_supported(Gs, F) (F = 128, Gs <= 63); reference: schnet_no_sum.py:161-164,209-212 (the filter network's backward). */
+int conan_filter_bwd2_supported(int num_gaussians, int num_filters);
+int conan_filter_bwd2_slices(int M);
+long long conan_filter_bwd2_ws(int M, int num_gaussians, int num_filters);
+int conan_filter_bwd2(const float *g, const float *h1, const float *dist, int M, const float *offset, int num_gaussians, float coeff,
+                      const float *w2, int num_filters, const int *m_dev, const float *gmax, float *dW1, float *db1, float *dW2, float *db2,
+                      float *ws, void *stream);
+
 /* rbf[e,k] = exp(coeff * (dist[e] - offset[k])^2): GaussianSmearing (PyG; schnet_no_sum.py:161,209).  `offset` is the
  * module's buffer (distance_expansion.offset), coeff = -0.5/(offset[1]-offset[0])^2.  num_edges_dev (nullable) = device
  * int with the edge count (rowptr[num_atoms]); at most max_edges rows are written. */

@@ -475,6 +475,62 @@ def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs, gscale):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("gscale", [1.0, 3e-7, 4e4], ids=["g1", "tiny_grad", "huge_grad"])
+@pytest.mark.parametrize("M,Gs", [(1, 50), (31, 50), (33, 50), (4133, 50), (40000, 50), (300000, 50), (3000, 20), (2500, 63)])
+def test_filter_network_backward_in_one_pass(M, Gs, gscale):
+    """conan_filter_bwd2: both layers' weight / bias gradients of the filter network from ONE pass over g and h1 (dw2 = g^T h1, db2 = colsum g,
+    dh1 = (g w2) * ssp'(h1) on chip, dw1 = dh1^T rbf, db1 = colsum dh1), against the fp64 formulas and against the two kernels it replaces
+    (conan_filter_bwd + conan_linear_wgrad_scaled: same arithmetic, summed in another order); rows beyond the device-side count are masked;
+    the slab form reduced by two conan_wgrad_reduce_batch jobs gives the same bits; repeat runs are bitwise equal.  M = 300000 makes every
+    workgroup walk several tiles (double-buffered images, 256 workgroups)."""
+    from conan_fgw_amd._lib import WgradJob, call, lib, ptr, stream_ptr
+    Fh, pad = 128, 37
+    assert lib().conan_filter_bwd2_supported(Gs, Fh) == 1 and lib().conan_filter_bwd2_supported(64, Fh) == 0 and lib().conan_filter_bwd2_supported(50, 64) == 0
+    gen = torch.Generator().manual_seed(M + Gs)
+    g = (torch.randn(M + pad, Fh, generator=gen) * gscale).to(dev)
+    g[M:] = float("nan")                                                                    # rows beyond the count must never be touched
+    gmax = g[:M].abs().max().reshape(1).contiguous()
+    h1 = (torch.rand(M + pad, Fh, generator=gen) * 3 - 0.6).to(dev)                        # ssp output range (> -ln 2)
+    h1[M:] = float("nan")
+    dist = (torch.rand(M + pad, generator=gen) * 10).to(dev)
+    w2 = (torch.randn(Fh, Fh, generator=gen) / 11).to(dev)
+    off = torch.linspace(0, 10, Gs).to(dev)
+    coeff = -0.5 / float(off[1] - off[0]) ** 2
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib().conan_filter_bwd2_ws(M + pad, Gs, Fh)), device=dev)
+    out = lambda: (torch.empty(Fh, Gs, device=dev), torch.empty(Fh, device=dev), torch.empty(Fh, Fh, device=dev), torch.empty(Fh, device=dev))
+    dW1, db1, dW2, db2 = out()
+    args = (ptr(g), ptr(h1), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), ptr(gmax))
+    call("conan_filter_bwd2", *args, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(ws), stream_ptr())
+    g64, h64 = g[:M].double(), h1[:M].double()
+    dh = (g64 @ w2.double()) * (1 - 0.5 * torch.exp(-h64))
+    rbf = torch.exp(coeff * (dist[:M, None].double() - off[None].double()) ** 2)
+    for got, want in ((dW1, dh.T @ rbf), (db1, dh.sum(0)), (dW2, g64.T @ h64), (db2, g64.sum(0))):
+        assert torch.isfinite(got).all()
+        assert rel(got.double().cpu().numpy(), want.cpu().numpy()) < 1e-5
+    # the pair of kernels it replaces
+    wsa = torch.empty(int(lib().conan_filter_bwd_ws(M + pad, Gs, Fh)), device=dev)
+    dWa, dba = torch.empty_like(dW1), torch.empty_like(db1)
+    g0, h0 = g.clone(), h1.clone(); g0[M:] = 0; h0[M:] = 0
+    call("conan_filter_bwd", ptr(g0), ptr(h0), ptr(dist), M + pad, ptr(off), Gs, coeff, ptr(w2), Fh, ptr(md), ptr(dWa), ptr(dba), ptr(wsa), ptr(gmax), stream_ptr())
+    assert rel(dW1.cpu().numpy(), dWa.cpu().numpy()) < 1e-5 and rel(db1.cpu().numpy(), dba.cpu().numpy()) < 1e-5
+    wsb = torch.empty(int(lib().conan_linear_wgrad_ws(M + pad, Fh, Fh)), device=dev)
+    dWb, dbb = torch.empty_like(dW2), torch.empty_like(db2)
+    call("conan_linear_wgrad_scaled", ptr(g0), ptr(h0), M + pad, Fh, Fh, ptr(md), ptr(dWb), ptr(dbb), ptr(wsb), ptr(gmax), stream_ptr())
+    assert rel(dW2.cpu().numpy(), dWb.cpu().numpy()) < 1e-5 and rel(db2.cpu().numpy(), dbb.cpu().numpy()) < 1e-5
+    # slab form + batched reduction; bitwise reproducibility
+    e1, eb1, e2, eb2 = out()
+    call("conan_filter_bwd2", *args, None, None, None, None, ptr(ws), stream_ptr())
+    slices = int(lib().conan_filter_bwd2_slices(M + pad))
+    job = (WgradJob * 2)()
+    job[0].ws, job[0].dW, job[0].dbias = ws.data_ptr(), e1.data_ptr(), eb1.data_ptr()
+    job[0].M, job[0].K, job[0].N, job[0].slices = M + pad, Gs, Fh, slices
+    job[1].ws, job[1].dW, job[1].dbias = ws.data_ptr() + 4 * slices * (Fh * Gs + Fh), e2.data_ptr(), eb2.data_ptr()
+    job[1].M, job[1].K, job[1].N, job[1].slices = M + pad, Fh, Fh, slices
+    call("conan_wgrad_reduce_batch", job, 2, stream_ptr())
+    assert torch.equal(dW1, e1) and torch.equal(db1, eb1) and torch.equal(dW2, e2) and torch.equal(db2, eb2)
+
+
 @pytest.mark.parametrize("M,K,N,act,w_kn", [(3000, 128, 384, 0, 0), (3000, 384, 128, 0, 1), (1777, 128, 256, 3, 0), (2048, 256, 128, 1, 1),
                                             (999, 512, 256, 1, 0), (640, 192, 320, 0, 0), (1500, 256, 256, 2, 1)])
 def test_linear_wide_layers_are_tiled_into_strided_chunks(M, K, N, act, w_kn):
