@@ -29,6 +29,24 @@
 // accumulation; g scaled from its device-side maximum, w2 planes carrying their own power-of-two scale) — the same tests, same tolerances.
 #include "common.h"
 
+// Phase timing (tools/f2_phase_profile.py builds a private library with -DCONAN_F2_PROFILE; the product library contains none of this): lane 0
+// of every wavefront accumulates shader-clock ticks between marks and adds them to 16 global slots at the end (slots 0-7: A wavefronts, 8-15: B).
+#ifdef CONAN_F2_PROFILE
+static __device__ long long g_f2_prof[16];
+extern "C" int conan_debug_f2_prof(long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f2_prof), sizeof(long long) * 16) != hipSuccess) return -2;
+    if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_f2_prof), z, sizeof(z)) != hipSuccess) return -2; }
+    return 0;
+}
+#define F2_PROF_DECL long long prof_t = clock64(); long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define F2_PROF(k) do { const long long t_ = clock64(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
+#define F2_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(reinterpret_cast<unsigned long long *>(&g_f2_prof[(threadIdx.x >= 256 ? 8 : 0) + k_]), (unsigned long long)prof_acc[k_]); } while (0)
+#else
+#define F2_PROF_DECL
+#define F2_PROF(k)
+#define F2_PROF_FLUSH
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,6 +54,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
+#ifndef CONAN_F2_RING
+#define CONAN_F2_RING 1
+#endif
+constexpr int F2_RING = CONAN_F2_RING;                         // tiles in flight per workgroup (staging registers: 16 + 8 per tile and thread)
 constexpr int F2_THREADS = 512, F2_WAVES = 8, F2_F = 128, F2_WS = F2_F + 8, F2_JP = 64, F2_GRID_MAX = 256;
 constexpr int F2_WH_BYTES = 2 * F2_F * F2_WS * 2;            // w2 planes [2][k][WS] fp16
 constexpr int F2_IMG_PLANE = 32 * 256;                         // one plane of a tile image
@@ -156,34 +178,13 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
     const int G = gridDim.x;
     auto phys = [&](int t) { return tiles - 1 - (int)(blockIdx.x + t * G); };      // < 0: no such tile
     const int srow = tid >> 4, sch = tid & 15;                                        // staging role: row of the tile, 16-byte chunk (8 channels)
-    float4 ga, gb, ha, hb;
+    // Staging registers: a ring of F2_RING tiles per thread — the rows of tile t + 1 + F2_RING are requested when tile t + 1 is stored, so
+    // F2_RING tiles (32 KB each per workgroup) are in flight at any time.
+    struct Rows { float4 ga, gb, ha, hb; float dv[8]; bool ok; };      // (dv: B wavefronts, the 8 distances of their rbf fragment; ok: the row exists)
+    Rows R[F2_RING];
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
-    auto load_rows = [&](int t) {
-        const int pt = phys(t);
-        const int m = (pt << 5) + srow;
-        const bool ok = pt >= 0 && m < M;
-        const size_t o = (size_t)(ok ? m : 0) * F + 8 * sch;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 a0 = *reinterpret_cast<const float4 *>(g + o), a1 = *reinterpret_cast<const float4 *>(g + o + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(h1 + o), b1 = *reinterpret_cast<const float4 *>(h1 + o + 4);
-        ga = ok ? a0 : z; gb = ok ? a1 : z; ha = ok ? b0 : z; hb = ok ? b1 : z;
-    };
-    auto store_rows = [&](int buf) {
-        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        const float hv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cs[j] += gv[j];
-        f16x8 p1, p2;
-        const int o = buf * F2_IMG_BYTES + f2_off(srow, sch);
-        f2_split2h(gv, gsc, p1, p2);
-        *reinterpret_cast<f16x8 *>(GI + o) = p1;
-        *reinterpret_cast<f16x8 *>(GI + o + F2_IMG_PLANE) = p2;
-        f2_split2h(hv, 1.0f, p1, p2);
-        *reinterpret_cast<f16x8 *>(HI + o) = p1;
-        *reinterpret_cast<f16x8 *>(HI + o + F2_IMG_PLANE) = p2;
-    };
     // B wavefront u = wave - 4 generates the rbf fragment (s2, jb) = (u >> 1, u & 1) of a tile: lane (column 32 jb + l31, row group h) holds the
     // 8 rows 16 s2 + 4h + {0..3, 8..11} — the order in which a lane-half enumerates the dx accumulator's registers 8 s2 .. 8 s2 + 7
     const int bu = wave - 4, b_s2 = bu >> 1, b_jb = bu & 1;
@@ -194,26 +195,49 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
         jkind = j < Gs ? 0 : (j == F2_JP - 1 ? 2 : 1);
         mu = j < Gs ? offset[j] : 0.f;
     }
-    float dv[8];
-    auto load_dist = [&](int t) {
+    auto load_rows = [&](int t, Rows &r) {
         const int pt = phys(t);
-        const int e0 = (max(pt, 0) << 5) + 16 * b_s2 + 4 * h;
+        const int m = (pt << 5) + srow;
+        const bool ok = pt >= 0 && m < M;
+        const size_t o = (size_t)(ok ? m : 0) * F + 8 * sch;
+        // (rows that do not exist read row 0 and are zeroed when they are STORED: a select here would make the loads synchronous)
+        r.ga = *reinterpret_cast<const float4 *>(g + o); r.gb = *reinterpret_cast<const float4 *>(g + o + 4);
+        r.ha = *reinterpret_cast<const float4 *>(h1 + o); r.hb = *reinterpret_cast<const float4 *>(h1 + o + 4);
+        r.ok = ok;
+        if (wave >= 4) {
+            const int e0 = (max(pt, 0) << 5) + 16 * b_s2 + 4 * h;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dv[j] = dist[min(e0 + (j & 3) + 8 * (j >> 2), M - 1)];
-    };
-    auto store_rbf = [&](int buf) {
-        float rv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = dv[j] - mu;
-            const float ex = exp_neg_f(coeff * (t * t));
-            rv[j] = jkind == 0 ? ex : (jkind == 2 ? 1.0f : 0.0f);
+            for (int j = 0; j < 8; ++j) r.dv[j] = dist[min(e0 + (j & 3) + 8 * (j >> 2), M - 1)];
         }
+    };
+    auto store_rows = [&](int buf, const Rows &r) {
+        float gv[8] = {r.ga.x, r.ga.y, r.ga.z, r.ga.w, r.gb.x, r.gb.y, r.gb.z, r.gb.w};
+        float hv[8] = {r.ha.x, r.ha.y, r.ha.z, r.ha.w, r.hb.x, r.hb.y, r.hb.z, r.hb.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gv[j] = r.ok ? gv[j] : 0.f; hv[j] = r.ok ? hv[j] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += gv[j];
         f16x8 p1, p2;
-        f2_split2h(rv, 1.0f, p1, p2);
-        char *o = RB + buf * F2_RB_BYTES + (bu * 2) * F2_RB_FRAG + lane * 16;
-        *reinterpret_cast<f16x8 *>(o) = p1;
-        *reinterpret_cast<f16x8 *>(o + F2_RB_FRAG) = p2;
+        const int o = buf * F2_IMG_BYTES + f2_off(srow, sch);
+        f2_split2h(gv, gsc, p1, p2);
+        *reinterpret_cast<f16x8 *>(GI + o) = p1;
+        *reinterpret_cast<f16x8 *>(GI + o + F2_IMG_PLANE) = p2;
+        f2_split2h(hv, 1.0f, p1, p2);
+        *reinterpret_cast<f16x8 *>(HI + o) = p1;
+        *reinterpret_cast<f16x8 *>(HI + o + F2_IMG_PLANE) = p2;
+        if (wave >= 4) {
+            float rv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = r.dv[j] - mu;
+                const float ex = exp_neg_f(coeff * (t * t));
+                rv[j] = jkind == 0 ? ex : (jkind == 2 ? 1.0f : 0.0f);
+            }
+            f2_split2h(rv, 1.0f, p1, p2);
+            char *ro = RB + buf * F2_RB_BYTES + (bu * 2) * F2_RB_FRAG + lane * 16;
+            *reinterpret_cast<f16x8 *>(ro) = p1;
+            *reinterpret_cast<f16x8 *>(ro + F2_RB_FRAG) = p2;
+        }
     };
 
     f32x16 accs[4];                                            // A: [jb] = dw1[32kb.., 32jb..] (two of them)      B: [nb] = dw2[32nb.., 32(wave-4)..]
@@ -223,26 +247,40 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
         for (int r = 0; r < 16; ++r) accs[a][r] = 0.f;
 
     const int my_tiles = tiles > (int)blockIdx.x ? (tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
-    if (my_tiles > 0) {
-        load_rows(0);
-        if (wave >= 4) load_dist(0);
-        store_rows(0);
-        if (wave >= 4) store_rbf(0);
-        if (my_tiles > 1) { load_rows(1); if (wave >= 4) load_dist(1); }
-    }
+#pragma unroll
+    for (int i = 0; i < F2_RING; ++i) load_rows(i, R[i]);
+    store_rows(0, R[0]);
+    load_rows(F2_RING, R[0]);
     __syncthreads();                                           // w2 planes, tile 0
 
-    for (int t = 0; t < my_tiles; ++t) {
+    F2_PROF_DECL;
+    for (int t0 = 0; t0 < my_tiles; t0 += F2_RING) {
+#pragma unroll
+    for (int u = 0; u < F2_RING; ++u) {
+        const int t = t0 + u;
+        if (t >= my_tiles) break;
         const int buf = t & 1;
         const char *Gp = GI + buf * F2_IMG_BYTES, *Hp = HI + buf * F2_IMG_BYTES;
-        // the next tile goes into the other buffer (free since the barrier that ended iteration t - 1) before this tile's matrix work, so
-        // that the split's vector instructions and the LDS stores run under the MFMAs of the SIMD's other wavefront
-        if (t + 1 < my_tiles) {
-            store_rows(buf ^ 1);
-            if (wave >= 4) store_rbf(buf ^ 1);
-            if (t + 2 < my_tiles) { load_rows(t + 2); if (wave >= 4) load_dist(t + 2); }
-        }
+        // The next tile goes into the other buffer (free since the barrier that ended iteration t - 1).  The B wavefronts stage it BEFORE their
+        // matrix work, the A wavefronts AFTER theirs: the two wavefronts of a SIMD are an A and a B, so one splits and stores while the other
+        // feeds the matrix pipe (with both staging first, the barrier lined the vector phase and the matrix phase of all eight up one behind
+        // the other: 41 % vector issue, 26 % matrix pipe, 42 % of the wave cycles waiting).
+        auto stage_next = [&]() {
+            if (t + 1 < my_tiles) {
+                Rows &r = R[(u + 1) % F2_RING];                // ring slot of tile t + 1 (t0 is a multiple of F2_RING)
+                store_rows(buf ^ 1, r);
+                load_rows(t + 1 + F2_RING, r);                 // unconditionally (a tile past the end reads row 0 and is never stored): the same number
+                                                               // of loads on every path lets the compiler wait for exactly the ring slot it stores
+            }
+        };
+        F2_PROF(0);            // (loop overhead)
+        if (wave >= 4) stage_next();
+        F2_PROF(1);            // B: staging
+#ifdef CONAN_F2_NOCOMPUTE
+        if (false) {
+#else
         if (wave < 4) {
+#endif
             const int kb = wave;
             // ---- dx strip: acc[r] = sum_n g[e][n] w2[n][32kb + l31], e = (r&3) + 8(r>>2) + 4h ---------------------------------
             // the three partial products of the fp16 planes accumulate in THREE accumulators (accs[2], accs[3] are free in an A wavefront): back-to-back
@@ -262,6 +300,7 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = (accs[2][r] + accs[3][r]) + acc[r];      // the two small cross terms first
+            F2_PROF(2);        // A: dx strip
             // ---- dh1 = acc / (w2 scale) * ssp'(h1): h1 of (row e(r), channel 32kb + l31) by transposed reads of H -----------------
             float dh[16];
 #pragma unroll
@@ -275,6 +314,7 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
                     dh[4 * q + j] = acc[4 * q + j] * wun * (1.0f - 0.5f * __expf(-hvv));      // ssp'(pre) from the saved output
                 }
             }
+            F2_PROF(3);        // A: h1 by transposed reads, ssp'
             // ---- dw1[32kb.., :] += dh1^T rbf ---------------------------------------------------------------------------------
             const char *Rp = RB + buf * F2_RB_BYTES + lane * 16;
 #pragma unroll
@@ -290,7 +330,12 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
                     accs[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, r1, accs[jb], 0, 0, 0);
                 }
             }
-        } else {
+        }
+#ifdef CONAN_F2_NOCOMPUTE
+        else if (false) {
+#else
+        else {
+#endif
             // ---- dw2[:, 32kb..] += g^T h1: both operands column-wise out of the row-major images -----------------------------------
             const int kb = wave - 4;
 #pragma unroll
@@ -306,9 +351,15 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
                 }
             }
         }
+        F2_PROF(4);            // A: dw1 products / B: dw2 products
+        if (wave < 4) stage_next();
+        F2_PROF(5);            // A: staging
         __syncthreads();                                       // the other buffer is complete; this one may be overwritten
+        F2_PROF(6);            // barrier
+    }
     }
 
+    F2_PROF_FLUSH;
     // ---- slabs of this workgroup: every strip comes from exactly one wavefront ---------------------------------------------------------
     if (wave < 4) {
         float *slab = slabs1 + (size_t)blockIdx.x * F * Gs;
