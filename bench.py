@@ -282,7 +282,7 @@ def run_rank(args):
     # tensor addresses, which the captured HIP graphs below need.  The timed steps run on this resident batch.
     from conan_fgw_amd.collate import DeviceCollator, molecules_from_synthetic
     items = molecules_from_synthetic(b, bg)
-    collator = DeviceCollator(dev, K, depth=2, static=True)
+    collator = DeviceCollator(dev, K, depth=4, static=True)
     data = collator(items).wait()
     z, pos, batch = data.z, data.pos, data.batch
     y = torch.from_numpy(b.y).to(dev)[:, None]
@@ -432,21 +432,44 @@ def run_rank(args):
         # PCIe-inclusive rate: reported beside `value`, never as `value`.
         pipe = None
         try:
+            from conan_fgw_amd.collate import CollatePipeline
+            import itertools, threading
             step_fn = graph_step if dt_graph is not None else eager_step
+            feed = CollatePipeline(collator, itertools.repeat(items), prefetch=2)      # host half on a worker thread, two batches ahead
+
             def pipe_step():
-                collator(items).wait()
+                next(feed).wait()
                 step_fn()
-            for _ in range(2):
+            for _ in range(3):
                 pipe_step()
-            n_pipe = max(5, args.steps // 2)
+            n_pipe = max(5, args.steps)
             dt_pipe = timed(pipe_step, n_pipe)
+            feed.close()
+            torch.cuda.synchronize()
+            time.sleep(0.05)                                             # (the worker finishes the pack it was in)
             t0 = time.perf_counter()
             for _ in range(5):
                 collator.pack(items)
             host_ms = 1e3 * (time.perf_counter() - t0) / 5
+            # eight packers at once on this host — what the eight ranks of one node do: eight fresh processes (no GPU), each packing the same
+            # batch 20 times into host memory through the same C entry points; the slowest one's mean is reported
+            pack8 = None
+            if rank == 0 and world == 1:
+                code = ("import sys, time, ctypes, numpy as np; sys.path.insert(0, %r); "
+                        "from conan_fgw_amd.synthetic import make_batch, make_bond_graph; from conan_fgw_amd import collate as C; "
+                        "b = make_batch(%r, %d, %d, seed=1236); items = C.molecules_from_synthetic(b, make_bond_graph(b, seed=2236)); "
+                        "t = C.host_pack_benchmark(items, %d, 20); print('PACKMS', t)") % (ROOT, args.shape, args.batch, K, K)
+                procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(8)]
+                vals = []
+                for pr in procs:
+                    out_, _ = pr.communicate(timeout=120)
+                    vals += [float(l.split()[1]) for l in out_.splitlines() if l.startswith("PACKMS")]
+                pack8 = round(max(vals), 4) if len(vals) == 8 else None
             pipe = {"molecules_per_s": round(args.batch * world * n_pipe / dt_pipe, 1), "ms_per_step": round(1e3 * dt_pipe / n_pipe, 4), "steps": n_pipe,
                     "packed_bytes_per_batch": collator.last_packed_bytes, "host_pack_ms": round(host_ms, 4),
-                    "what": "collate (C pack, pinned) + 1 H2D copy + device expansion + the step, per step; copy overlaps the previous step"}
+                    "host_pack_ms_8_concurrent_processes": pack8,
+                    "what": "collate on a worker thread two batches ahead (item records cached, C pack into a pinned ring) + 1 H2D copy + device expansion + "
+                            "the step, per step; the copy overlaps the previous step, the expansion waits for it (static input addresses)"}
         except Exception as e:
             pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.synchronize()

@@ -61,12 +61,47 @@ class DeviceBatch(types.SimpleNamespace):
     `num_graphs`, `max_nodes`, `num_molecules`.  `ready` is recorded on the copy stream behind the unpack kernel."""
 
     def wait(self, stream: Optional[torch.cuda.Stream] = None):
-        (stream or torch.cuda.current_stream()).wait_event(self.ready)
+        stream = stream or torch.cuda.current_stream()
+        stream.wait_event(self.ready)
+        pair = getattr(self, "_static_pair", None)
+        if pair is not None:
+            # static collator: the expansion kernel wrote a landing copy; ONE device-to-device copy moves it to the fixed addresses the
+            # model (a captured HIP graph) reads.  The next batch may be expanded as soon as this copy is done — not only when the step
+            # that reads these tensors is — so expansion and step overlap.
+            collator, fixed, landing = pair
+            with torch.cuda.stream(stream):
+                fixed.copy_(landing, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            collator._consumed = ev
+            collator._landing_busy = False
+            self._static_pair = None
         return self
 
     def as_model_input(self):
         """`(data_batch, batch_node_index)`: exactly what the reference's collate_fn returns (datasets.py:199)."""
         return self, self.batch_node_index
+
+
+def _item_record(it: ConformerMolecule, K: int, x_dim: int, ea_dim: int):
+    """(n_atoms, n_bonds, five array addresses, the arrays themselves) of one dataset item, validated and made contiguous ONCE and kept on
+    the item: a dataset hands the same objects out every epoch, and five `np.ascontiguousarray` calls per molecule per batch were the
+    whole cost of the host half (1.3 of 1.4 ms per 256-molecule batch, round 4)."""
+    rec = getattr(it, "_conan_record", None)
+    if rec is not None and rec[0] == (K, x_dim, ea_dim, id(it.z), id(it.pos), id(it.x), id(it.edge_index), id(it.edge_attr)):
+        return rec[1]
+    n, nb = len(it.z), it.edge_index.shape[1]
+
+    def arr(a, dtype, shape):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"collate: expected shape {tuple(shape)}, got {tuple(a.shape)}")
+        return a
+    arrays = (arr(it.z, np.int64, (n,)), arr(it.pos, np.float32, (K, n, 3)), arr(it.x, np.float32, (n, x_dim)),
+              arr(it.edge_index, np.int64, (2, nb)), arr(it.edge_attr, np.float32, (nb, ea_dim)))
+    out = (n, nb, tuple(a.ctypes.data for a in arrays), arrays)
+    it._conan_record = ((K, x_dim, ea_dim, id(it.z), id(it.pos), id(it.x), id(it.edge_index), id(it.edge_attr)), out)
+    return out
 
 
 def _as_items(batch_items: Sequence) -> List[ConformerMolecule]:
@@ -76,8 +111,9 @@ def _as_items(batch_items: Sequence) -> List[ConformerMolecule]:
 class DeviceCollator:
     """collate_fn for the HIP path.  Holds `depth` pinned host buffers and device staging buffers (grown on demand) and a copy
     stream; `__call__(items)` packs on the host, enqueues the H2D copy and the expansion kernel on the copy stream and returns
-    immediately.  With `static=True` the expanded tensors are allocated once (worst case over the batches seen so far must not
-    grow) and re-used, which is what a captured HIP graph needs: fixed input addresses."""
+    immediately.  With `static=True` the expanded tensors are allocated once (the batch shape must not change) and re-used, which is
+    what a captured HIP graph needs: fixed input addresses.  The kernel then expands into a landing copy and `DeviceBatch.wait()` moves
+    it to the fixed addresses with one device-to-device transfer, so the expansion of batch i+1 overlaps the step on batch i."""
 
     def __init__(self, device, num_conformers: int, depth: int = 2, static: bool = False):
         self.device = torch.device(device)
@@ -89,41 +125,34 @@ class DeviceCollator:
         self._pinned = [None] * depth
         self._staged = [None] * depth
         self._events = [None] * depth
-        self._slot = 0
+        self._pack_slot = 0
         self._out = None
+        self._consumed = None                                # static mode: event behind the last landing -> fixed copy
+        self._landing_busy = False
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.last_packed_bytes = 0
 
     # ---------------------------------------------------------------------------------------------- host half
     def pack(self, batch_items: Sequence):
-        """Host half only: returns (layout, pinned uint8 tensor holding the packed batch, smiles)."""
+        """Host half only: returns (layout, pinned uint8 tensor holding the packed batch, smiles, ring slot).  Safe to call from a worker
+        thread while the calling thread runs `enqueue` for earlier batches (CollatePipeline): the slots are handed out round-robin and a slot
+        is reused only after the copy that last read it has finished."""
         items = _as_items(batch_items)
         B, K = len(items), self.K
-        n_atoms = np.fromiter((len(it.z) for it in items), dtype=np.int32, count=B)
-        n_bonds = np.fromiter((it.edge_index.shape[1] for it in items), dtype=np.int32, count=B)
         x_dim = items[0].x.shape[1] if items[0].x.ndim == 2 else 0
         ea_dim = items[0].edge_attr.shape[1] if items[0].edge_attr.ndim == 2 else 0
-        keep = []                                            # keeps converted arrays alive until the C call returns
-
-        def arr(a, dtype, shape=None):
-            a = np.ascontiguousarray(a, dtype=dtype)
-            if shape is not None and tuple(a.shape) != tuple(shape):
-                raise ValueError(f"collate: expected shape {tuple(shape)}, got {tuple(a.shape)}")
-            keep.append(a)
-            return a.ctypes.data
-
+        recs = [_item_record(it, K, x_dim, ea_dim) for it in items]      # (the arrays stay alive on the items until the C call returns)
+        n_atoms = np.fromiter((r[0] for r in recs), dtype=np.int32, count=B)
+        n_bonds = np.fromiter((r[1] for r in recs), dtype=np.int32, count=B)
         PP = ctypes.c_void_p * B
-        zs = PP(*[arr(it.z, np.int64, (n_atoms[m],)) for m, it in enumerate(items)])
-        ps = PP(*[arr(it.pos, np.float32, (K, n_atoms[m], 3)) for m, it in enumerate(items)])
-        xs = PP(*[arr(it.x, np.float32, (n_atoms[m], x_dim)) for m, it in enumerate(items)])
-        es = PP(*[arr(it.edge_index, np.int64, (2, n_bonds[m])) for m, it in enumerate(items)])
-        eas = PP(*[arr(it.edge_attr, np.float32, (n_bonds[m], ea_dim)) for m, it in enumerate(items)])
+        zs, ps, xs, es, eas = (PP(*[r[2][q] for r in recs]) for q in range(5))
         ys = np.fromiter((it.y for it in items), dtype=np.float32, count=B)
         L = BatchLayout()
         rc = lib().conan_collate_layout(B, K, n_atoms.ctypes.data, n_bonds.ctypes.data, x_dim, ea_dim, ctypes.byref(L))
         if rc != 0:
             raise RuntimeError(f"conan_collate_layout failed ({rc})")
-        slot = self._slot
+        slot = self._pack_slot
+        self._pack_slot = (slot + 1) % self.depth
         if self._events[slot] is not None:
             self._events[slot].synchronize()                 # the copy that last used this pinned buffer has finished
         if self._pinned[slot] is None or self._pinned[slot].numel() < L.bytes:
@@ -134,54 +163,159 @@ class DeviceCollator:
         if rc != 0:
             raise ValueError("collate: bad item (a bond leaves its molecule, or an array is missing)")
         self.last_packed_bytes = int(L.bytes)
-        return L, pinned, [it.smiles for it in items]
+        return L, pinned, [it.smiles for it in items], slot
 
     # ---------------------------------------------------------------------------------------------- device half
     def _outputs(self, L: BatchLayout):
+        """The expanded tensors of a batch.  static=True: allocated once as views of ONE buffer — in fact two of them: `fixed`, the addresses
+        the model reads, and `landing`, where the expansion kernel writes (DeviceBatch.wait copies landing -> fixed in one transfer)."""
         dev = self.device
         A, E, G = L.num_atoms, L.num_bond_edges, L.num_graphs
         if self.static and self._out is not None:
-            o = self._out
+            o = self._out[0]
             if (o["z"].shape[0], o["edge_index"].shape[1], o["y"].shape[0]) != (A, E, G):
                 raise RuntimeError("static DeviceCollator: the batch shape changed (atoms / bond edges / graphs); "
                                    "captured-graph replay needs shape-stable batches")
-            return o
-        o = dict(z=torch.empty(A, dtype=torch.int64, device=dev), pos=torch.empty(A, 3, dtype=torch.float32, device=dev),
-                 batch=torch.empty(A, dtype=torch.int64, device=dev), x=torch.empty(A, L.x_dim, dtype=torch.float32, device=dev),
-                 edge_index=torch.empty(2, E, dtype=torch.int64, device=dev), edge_attr=torch.empty(E, L.ea_dim, dtype=torch.float32, device=dev),
-                 y=torch.empty(G, dtype=torch.float32, device=dev), graph_ptr=torch.empty(G + 1, dtype=torch.int32, device=dev),
-                 conformers_index=torch.empty(G, dtype=torch.int64, device=dev), conf_node_batch=torch.empty(A, dtype=torch.int64, device=dev))
-        if self.static:
-            self._out = o
-        return o
+            return self._out
+        spec = [("z", (A,), torch.int64), ("pos", (A, 3), torch.float32), ("batch", (A,), torch.int64), ("x", (A, L.x_dim), torch.float32),
+                ("edge_index", (2, E), torch.int64), ("edge_attr", (E, L.ea_dim), torch.float32), ("y", (G,), torch.float32),
+                ("graph_ptr", (G + 1,), torch.int32), ("conformers_index", (G,), torch.int64), ("conf_node_batch", (A,), torch.int64)]
+        if not self.static:
+            return {k: torch.empty(*shp, dtype=dt, device=dev) for k, shp, dt in spec}, None, None, None
+        offs, total = [], 0
+        for _k, shp, dt in spec:
+            nbytes = int(np.prod(shp)) * torch.empty((), dtype=dt).element_size()
+            offs.append(total)
+            total += (nbytes + 255) & ~255
+        flats = [torch.empty(max(total, 256), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+        def views(flat):
+            out = {}
+            for (k, shp, dt), off in zip(spec, offs):
+                n = int(np.prod(shp))
+                out[k] = flat[off: off + n * torch.empty((), dtype=dt).element_size()].view(dt).view(*shp)
+            return out
+        for f in flats:
+            f.record_stream(self._main_stream)               # (allocated under the copy stream by enqueue; both are also used on the caller's)
+        self._out = (views(flats[0]), views(flats[1]), flats[0], flats[1])      # (fixed views, landing views, fixed, landing)
+        return self._out
 
     def __call__(self, batch_items: Sequence) -> DeviceBatch:
-        L, pinned, smiles = self.pack(batch_items)
-        slot = self._slot
-        self._slot = (slot + 1) % self.depth
+        return self.enqueue(*self.pack(batch_items))
+
+    def enqueue(self, L: BatchLayout, pinned, smiles, slot: int) -> DeviceBatch:
+        """Device half: the H2D copy and the expansion kernel of a packed batch on the copy stream; returns immediately."""
         cs = self.copy_stream
-        main = torch.cuda.current_stream(self.device)
+        main = self._main_stream = torch.cuda.current_stream(self.device)
         if self._staged[slot] is None or self._staged[slot].numel() < L.bytes:
             with torch.cuda.stream(cs):                      # allocated on the stream that writes it: the caching allocator orders a
                 self._staged[slot] = torch.empty(pinned.numel(), dtype=torch.uint8, device=self.device)      # reused block behind its last use there
         staged = self._staged[slot]
         with torch.cuda.stream(cs):
             staged[: L.bytes].copy_(pinned[: L.bytes], non_blocking=True)      # overlaps whatever the caller's stream is running
-        if self.static and self._out is not None:
-            cs.wait_stream(main)                             # the shared output tensors may still be read by work already queued
         with torch.cuda.stream(cs):
-            o = self._outputs(L)
-            call("conan_collate_unpack", ptr(staged), ctypes.byref(L), ptr(o["z"]), ptr(o["pos"]), ptr(o["batch"]), ptr(o["x"]) if L.x_dim else None,
-                 ptr(o["edge_index"]) if L.num_bond_edges else None, ptr(o["edge_attr"]) if (L.num_bond_edges and L.ea_dim) else None,
-                 ptr(o["y"]), ptr(o["graph_ptr"]), ptr(o["conformers_index"]), ptr(o["conf_node_batch"]), stream_ptr())
+            o, landing_views, fixed, landing = self._outputs(L)
+            w = landing_views if self.static else o           # static: the kernel writes the landing copy (see DeviceBatch.wait)
+            if self.static:
+                if self._landing_busy:
+                    raise RuntimeError("static DeviceCollator: call .wait() on the previous batch before assembling the next one "
+                                       "(there is one landing copy)")
+                if self._consumed is not None:
+                    cs.wait_event(self._consumed)             # the previous batch has left the landing copy
+                self._landing_busy = True
+            call("conan_collate_unpack", ptr(staged), ctypes.byref(L), ptr(w["z"]), ptr(w["pos"]), ptr(w["batch"]), ptr(w["x"]) if L.x_dim else None,
+                 ptr(w["edge_index"]) if L.num_bond_edges else None, ptr(w["edge_attr"]) if (L.num_bond_edges and L.ea_dim) else None,
+                 ptr(w["y"]), ptr(w["graph_ptr"]), ptr(w["conformers_index"]), ptr(w["conf_node_batch"]), stream_ptr())
             ev = torch.cuda.Event()
             ev.record(cs)
         self._events[slot] = ev
-        for t in o.values():
-            t.record_stream(main)                            # allocated on the copy stream, consumed on the caller's
+        if not self.static:
+            for t in o.values():
+                t.record_stream(main)                        # allocated on the copy stream, consumed on the caller's
         staged.record_stream(cs)
-        return DeviceBatch(**o, batch_node_index=o["batch"], smiles=[s for s in smiles for _ in range(L.K)], num_graphs=int(L.num_graphs), max_nodes=int(L.max_nodes),
-                           num_molecules=int(L.B), num_conformers=int(L.K), ready=ev)
+        b = DeviceBatch(**o, batch_node_index=o["batch"], smiles=[s for s in smiles for _ in range(L.K)], num_graphs=int(L.num_graphs), max_nodes=int(L.max_nodes),
+                        num_molecules=int(L.B), num_conformers=int(L.K), ready=ev)
+        if self.static:
+            b._static_pair = (self, fixed, landing)
+        return b
+
+
+class CollatePipeline:
+    """Batches ready on the device, assembled ahead of the consumer: a worker thread runs the host half (`DeviceCollator.pack`: C memcpy into a
+    pinned ring, the GIL released) `prefetch` batches ahead while the calling thread enqueues copies / expansion kernels and launches steps.
+    Iterating yields `DeviceBatch` objects in source order (call `.wait()` on each, as with the collator itself).  The reference gets the same
+    overlap from DataLoader worker processes (datamodules.py); here one thread suffices: the host half of a 256-molecule batch is ~0.2 ms.
+
+        for batch in CollatePipeline(collator, loader):      # loader yields lists of dataset items
+            step(batch.wait())
+    """
+
+    def __init__(self, collator: DeviceCollator, source, prefetch: int = 2):
+        import queue
+        import threading
+        if collator.depth < prefetch + 2:
+            raise ValueError(f"CollatePipeline(prefetch={prefetch}) needs a DeviceCollator with depth >= {prefetch + 2} pinned buffers")
+        self.collator, self._q, self._src, self._stop = collator, queue.Queue(maxsize=prefetch), iter(source), False
+        self._thread = threading.Thread(target=self._run, name="conan-collate", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            for items in self._src:
+                if self._stop:
+                    return
+                self._q.put(self.collator.pack(items))
+            self._q.put(None)
+        except BaseException as e:                           # noqa: BLE001 - re-raised in the consumer
+            self._q.put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> DeviceBatch:
+        p = self._q.get()
+        if p is None:
+            raise StopIteration
+        if isinstance(p, BaseException):
+            raise p
+        return self.collator.enqueue(*p)
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:                                     # noqa: BLE001 - queue.Empty
+            pass
+
+
+def host_pack_benchmark(batch_items: Sequence, num_conformers: int, reps: int = 20) -> float:
+    """Milliseconds per host-side pack of one batch (item records cached, conan_collate_layout + conan_collate_pack into plain host memory):
+    the host half of the collator without a GPU — bench.py runs it in eight processes at once to see what eight ranks of one node cost each
+    other."""
+    import time
+    items = _as_items(batch_items)
+    B, K = len(items), int(num_conformers)
+    x_dim, ea_dim = items[0].x.shape[1], items[0].edge_attr.shape[1]
+    buf = None
+    t0 = 0.0
+    for r in range(reps + 2):
+        if r == 2:
+            t0 = time.perf_counter()
+        recs = [_item_record(it, K, x_dim, ea_dim) for it in items]
+        n_atoms = np.fromiter((q[0] for q in recs), dtype=np.int32, count=B)
+        n_bonds = np.fromiter((q[1] for q in recs), dtype=np.int32, count=B)
+        PP = ctypes.c_void_p * B
+        zs, ps, xs, es, eas = (PP(*[q[2][c] for q in recs]) for c in range(5))
+        ys = np.fromiter((it.y for it in items), dtype=np.float32, count=B)
+        L = BatchLayout()
+        if lib().conan_collate_layout(B, K, n_atoms.ctypes.data, n_bonds.ctypes.data, x_dim, ea_dim, ctypes.byref(L)) != 0:
+            raise RuntimeError("conan_collate_layout failed")
+        if buf is None or buf.size < L.bytes:
+            buf = np.empty(int(L.bytes) + 256, dtype=np.uint8)
+        if lib().conan_collate_pack(ctypes.byref(L), n_atoms.ctypes.data, n_bonds.ctypes.data, zs, ps, xs, es, eas, ys.ctypes.data, buf.ctypes.data) != 0:
+            raise ValueError("collate: bad item")
+    return 1e3 * (time.perf_counter() - t0) / reps
 
 
 def collate_fn(batch_items: Sequence, device=None, num_conformers: Optional[int] = None):

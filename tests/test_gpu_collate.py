@@ -60,8 +60,49 @@ def test_static_collator_keeps_addresses_and_rejects_shape_changes():
     cb = make_batch("esol", 3, K, seed=4); bg = make_bond_graph(cb, seed=5)
     items = molecules_from_synthetic(cb, bg)
     a = coll(items).wait(); p0 = a.pos.data_ptr()
-    b = coll(items).wait()
+    ref = {k: getattr(a, k).clone() for k in ("z", "pos", "batch", "x", "edge_index", "edge_attr", "y", "graph_ptr")}
+    b = coll(items)
+    with pytest.raises(RuntimeError, match="wait"):          # one landing copy: the previous batch must have been taken over first
+        coll(items)
+    b.wait()
     assert b.pos.data_ptr() == p0
+    torch.cuda.synchronize()
+    assert all(torch.equal(getattr(b, k), ref[k]) for k in ref)
+    # a different batch of the SAME shape lands at the same addresses with its own values
+    items2 = molecules_from_synthetic(cb, make_bond_graph(cb, seed=5))
+    items2[0].pos = items2[0].pos + 1.0
+    c = coll(items2).wait()
+    torch.cuda.synchronize()
+    assert c.pos.data_ptr() == p0 and not torch.equal(c.pos, ref["pos"]) and torch.equal(c.z, ref["z"])
     cb2 = make_batch("esol", 4, K, seed=6); bg2 = make_bond_graph(cb2, seed=7)
     with pytest.raises(RuntimeError, match="shape"):
         coll(molecules_from_synthetic(cb2, bg2))
+
+
+def test_pipeline_on_a_worker_thread_yields_the_same_batches_in_order():
+    """CollatePipeline: the host half runs on a worker thread `prefetch` batches ahead; the batches arrive in source order and equal what the
+    collator produces when called directly (item records are cached on the items: the second epoch takes the cached path)."""
+    from conan_fgw_amd.collate import CollatePipeline
+    K = 3
+    sets = []
+    for seed in (3, 4, 5, 6, 7):
+        cb = make_batch("esol", 5, K, seed=seed); bg = make_bond_graph(cb, seed=seed + 50)
+        sets.append(molecules_from_synthetic(cb, bg))
+    direct = DeviceCollator(dev, K, depth=2)
+    want = []
+    for items in sets:
+        b = direct(items).wait()
+        torch.cuda.synchronize()
+        want.append({k: getattr(b, k).clone() for k in ("z", "pos", "batch", "x", "edge_index", "edge_attr", "y", "graph_ptr")})
+    coll = DeviceCollator(dev, K, depth=4)
+    with pytest.raises(ValueError):
+        CollatePipeline(DeviceCollator(dev, K, depth=2), [], prefetch=2)
+    for epoch in range(2):
+        got = []
+        for b in CollatePipeline(coll, sets, prefetch=2):
+            b.wait()
+            torch.cuda.synchronize()
+            got.append({k: getattr(b, k).clone() for k in want[0]})
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert all(torch.equal(g[k], w[k]) for k in w)
