@@ -44,6 +44,14 @@ __device__ __forceinline__ float ssp_f(float v) {
 }
 
 // exp(x) for x <= 0 with |x| up to ~1e3 on v_exp_f32: absolute error <= ~4e-8 (|x| e^x <= 0.37 scales the argument rounding).
+// Wave-private LDS hand-off (a lane stores, ANOTHER lane of the same wavefront loads): one wavefront's LDS operations execute in order in
+// hardware, but nothing told the compiler not to move the loads above the stores (or the next round's stores above these loads).  A
+// wavefront-scope release / acquire pair around a wave barrier does; it costs no instruction beyond the s_waitcnt the data dependence needs.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ float exp_neg_f(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8) and every XCD has a private 4 MB L2.  The gather

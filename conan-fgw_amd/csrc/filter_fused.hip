@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) =
                         make_float4(acc1[mb][4 * q], acc1[mb][4 * q + 1], acc1[mb][4 * q + 2], acc1[mb][4 * q + 3]);
+                wave_lds_fence();                              // slab rows are read by other lanes of this wavefront
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     const f4 hv4 = {o.x, o.y, o.z, o.w};
                     if ((tile << 5) + r < E) __builtin_nontemporal_store(hv4, reinterpret_cast<f4 *>(h1_out + (size_t)((tile << 5) + r) * F + 32 * mb + c));
                 }
+                wave_lds_fence();                              // ... and rewritten for the next block
             }
         }
 
@@ -263,12 +265,14 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     o.w = fmaf(acc2[nb][4 * q + 3], us, bb.w) * C;
                     *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) = o;
                 }
+                wave_lds_fence();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
                     const float4 o = *reinterpret_cast<const float4 *>(&OT[r * FF_OP + c]);
                     if ((tile << 5) + r < E) *reinterpret_cast<float4 *>(Wout + (size_t)((tile << 5) + r) * F + 32 * (n0 + nb) + c) = o;
                 }
+                wave_lds_fence();
             }
         }
     }

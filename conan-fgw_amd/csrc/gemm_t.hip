@@ -275,12 +275,14 @@ __global__ void __launch_bounds__(NT) k_linear_t16(const float *__restrict__ x, 
             // switched off the kernel took 86 us of its 128 for the stores alone: 128 -> 116 us).  The slab is private to the wave: no barrier.
             if (nb & 1) {
                 const int rbase = tile << 5;
+                wave_lds_fence();                              // the slab rows below were written by other lanes of this wavefront
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int r = 4 * i + (lane >> 4), c = 4 * (lane & 15);
                     const float4 o = *reinterpret_cast<const float4 *>(&OT[r * LT_OP + c]);
                     if (rbase + r < M) *reinterpret_cast<float4 *>(y + (size_t)(rbase + r) * ldy + 32 * (nb - 1) + c) = o;
                 }
+                wave_lds_fence();                              // ... and are overwritten by the next pair of blocks
             }
         }
     }

@@ -232,7 +232,11 @@ int conan_filter_bwd(const float *g, const float *h1, const float *dist, int M, 
  * conan_filter_bwd2_ws(M, Gs, F) floats = [slabs1 | bias1 | slabs2 | bias2] with conan_filter_bwd2_slices(M) slabs each.
  * dW1 == dW2 == NULL: slabs only, to be reduced by two conan_wgrad_reduce_batch jobs — (ws, K = Gs, N = F) and
  * (ws + slices * (F * Gs + F), K = F, N = F), both with job.slices = conan_filter_bwd2_slices(M).
- * Supported: conan_filter_bwd2_supported(Gs, F) (F = 128, Gs <= 63); reference: schnet_no_sum.py:161-164,209-212 (the filter network's backward). */
+ * Supported: conan_filter_bwd2_supported(Gs, F) (F = 128, Gs <= 63); reference: schnet_no_sum.py:161-164,209-212 (the filter network's backward).
+ * Precision floor of the single global scale (also conan_filter_bwd / conan_linear_wgrad_scaled with gmax): an element of g carries an absolute
+ * error of up to ~2^-29 max|g| once it is smaller than ~2^-19 max|g| — fp32-class while |g| spans fewer than ~five decades, a bounded floor
+ * beyond that (tests/test_gpu_ops.py pins it with a 1e6 outlier).  Callers whose gradients can span more pass gmax = NULL to
+ * conan_filter_bwd + conan_linear_wgrad (three bf16 planes, no scale, full fp32 exponent range, twice the matrix work). */
 int conan_filter_bwd2_supported(int num_gaussians, int num_filters);
 int conan_filter_bwd2_slices(int M);
 long long conan_filter_bwd2_ws(int M, int num_gaussians, int num_filters);
