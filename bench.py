@@ -469,7 +469,8 @@ def run_rank(args):
                     "packed_bytes_per_batch": collator.last_packed_bytes, "host_pack_ms": round(host_ms, 4),
                     "host_pack_ms_8_concurrent_processes": pack8,
                     "what": "collate on a worker thread two batches ahead (item records cached, C pack into a pinned ring) + 1 H2D copy + device expansion + "
-                            "the step, per step; the copy overlaps the previous step, the expansion waits for it (static input addresses)"}
+                            "the step, per step; copy and expansion (into a landing copy) overlap the previous step, one device-to-device transfer moves the batch to the "
+                            "fixed addresses the captured step reads"}
         except Exception as e:
             pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.synchronize()
