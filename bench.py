@@ -364,7 +364,7 @@ def run_rank(args):
 
         # ---- HIP-graph capture of the same step: A = forward + backward + pack | all-reduce (eager RCCL call between the two
         # replays, world > 1 only) | B = mean + Adam.  Same kernels as the eager step, zero host work between them.
-        dt_graph, graph_err = None, None
+        dt_graph, graph_err, host_launch_ms = None, None, None
         if not args.eager:
             flat.suspend_overlap(True)
             # thread_local: only this thread's calls are policed during capture.  Other threads of the process make legal HIP calls
@@ -410,9 +410,16 @@ def run_rank(args):
                         # stream and back).  Safe here because nothing is captured on this stream any more (parallel.py).
                         dist.all_reduce(flat.flat, op=dist.ReduceOp.SUM)
                     gB.replay()
+            host_launch_ms = None
             if captured:
                 for _ in range(max(2, args.warmup)):
                     graph_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    graph_step()
+                host_launch_ms = 1e3 * (time.perf_counter() - t0) / 5      # host time to ENQUEUE one step's replays (the queue is empty: nothing blocks)
+                torch.cuda.synchronize()
                 dt_blocks = [timed(graph_step, args.steps) for _ in range(max(1, args.blocks))]
                 dt_graph = float(np.median(dt_blocks))
             flat.suspend_overlap(False)
@@ -663,6 +670,7 @@ def run_rank(args):
             "eager": {"molecules_per_s": round(args.batch * world * n_eager / dt_eager, 1), "ms_per_step": round(1e3 * dt_eager / n_eager, 4), "steps": n_eager},
             "with_input_pipeline": pipe,
             "graph_capture_error": graph_err,
+            "graph_launch_host_ms": None if (args.eager or host_launch_ms is None) else round(host_launch_ms, 4),
             "loss": {"after_eager_phase": loss_eager, "last": loss_last},
             "roofline": roofline,
         }
