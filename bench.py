@@ -475,9 +475,9 @@ def run_rank(args):
             pipe = {"molecules_per_s": round(args.batch * world * n_pipe / dt_pipe, 1), "ms_per_step": round(1e3 * dt_pipe / n_pipe, 4), "steps": n_pipe,
                     "packed_bytes_per_batch": collator.last_packed_bytes, "host_pack_ms": round(host_ms, 4),
                     "host_pack_ms_8_concurrent_processes": pack8,
-                    "what": "collate on a worker thread two batches ahead (item records cached, C pack into a pinned ring) + 1 H2D copy + device expansion + "
-                            "the step, per step; copy and expansion (into a landing copy) overlap the previous step, one device-to-device transfer moves the batch to the "
-                            "fixed addresses the captured step reads"}
+                    "what": "per step: collate on a worker thread (item records cached, C pack into a pinned ring, then the H2D copy and the expansion kernel enqueued by "
+                            "that thread once the GPU has released the landing copy: no device-side wait is queued ahead) + one device-to-device transfer to the fixed "
+                            "addresses the captured step reads + the step; copy and expansion overlap the previous step"}
         except Exception as e:
             pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.synchronize()

@@ -76,6 +76,8 @@ class DeviceBatch(types.SimpleNamespace):
             collator._consumed = ev
             collator._landing_busy = False
             self._static_pair = None
+            if collator._landing_released is not None:
+                collator._landing_released.release()          # CollatePipeline's worker may assemble the next batch
         return self
 
     def as_model_input(self):
@@ -126,6 +128,7 @@ class DeviceCollator:
         self._staged = [None] * depth
         self._events = [None] * depth
         self._pack_slot = 0
+        self._landing_released = None                        # set by CollatePipeline (static collators): a semaphore the consumer's wait() releases
         self._out = None
         self._consumed = None                                # static mode: event behind the last landing -> fixed copy
         self._landing_busy = False
@@ -203,10 +206,13 @@ class DeviceCollator:
     def __call__(self, batch_items: Sequence) -> DeviceBatch:
         return self.enqueue(*self.pack(batch_items))
 
-    def enqueue(self, L: BatchLayout, pinned, smiles, slot: int) -> DeviceBatch:
-        """Device half: the H2D copy and the expansion kernel of a packed batch on the copy stream; returns immediately."""
+    def enqueue(self, L: BatchLayout, pinned, smiles, slot: int, main: Optional[torch.cuda.Stream] = None, host_wait: bool = False) -> DeviceBatch:
+        """Device half: the H2D copy and the expansion kernel of a packed batch on the copy stream; returns immediately.  `main`: the stream
+        that will consume the batch (default: the calling thread's current stream).  `host_wait` (static collators): wait on the HOST until the
+        previous batch has left the landing copy instead of queueing a device-side wait for it — for a caller that runs ahead of the GPU, see
+        CollatePipeline."""
         cs = self.copy_stream
-        main = self._main_stream = torch.cuda.current_stream(self.device)
+        main = self._main_stream = main if main is not None else torch.cuda.current_stream(self.device)
         if self._staged[slot] is None or self._staged[slot].numel() < L.bytes:
             with torch.cuda.stream(cs):                      # allocated on the stream that writes it: the caching allocator orders a
                 self._staged[slot] = torch.empty(pinned.numel(), dtype=torch.uint8, device=self.device)      # reused block behind its last use there
@@ -221,7 +227,10 @@ class DeviceCollator:
                     raise RuntimeError("static DeviceCollator: call .wait() on the previous batch before assembling the next one "
                                        "(there is one landing copy)")
                 if self._consumed is not None:
-                    cs.wait_event(self._consumed)             # the previous batch has left the landing copy
+                    if host_wait:
+                        self._consumed.synchronize()
+                    else:
+                        cs.wait_event(self._consumed)         # the previous batch has left the landing copy
                 self._landing_busy = True
             call("conan_collate_unpack", ptr(staged), ctypes.byref(L), ptr(w["z"]), ptr(w["pos"]), ptr(w["batch"]), ptr(w["x"]) if L.x_dim else None,
                  ptr(w["edge_index"]) if L.num_bond_edges else None, ptr(w["edge_attr"]) if (L.num_bond_edges and L.ea_dim) else None,
@@ -242,13 +251,18 @@ class DeviceCollator:
 
 class CollatePipeline:
     """Batches ready on the device, assembled ahead of the consumer: a worker thread runs the host half (`DeviceCollator.pack`: C memcpy into a
-    pinned ring, the GIL released) `prefetch` batches ahead while the calling thread enqueues copies / expansion kernels and launches steps.
-    Iterating yields `DeviceBatch` objects in source order (call `.wait()` on each, as with the collator itself).  The reference gets the same
-    overlap from DataLoader worker processes (datamodules.py); here one thread suffices: the host half of a 256-molecule batch is ~0.2 ms.
+    pinned ring, the GIL released) AND enqueues the copy + expansion kernel on the copy stream, `prefetch` batches ahead (non-static collators)
+    or one batch ahead (static: there is one landing copy), while the calling thread only launches steps.  Iterating yields `DeviceBatch`
+    objects in source order (call `.wait()` on each, as with the collator itself).  The reference gets the same overlap from DataLoader worker
+    processes (datamodules.py); here one thread suffices: the host half of a 256-molecule batch is ~0.2 ms.
 
         for batch in CollatePipeline(collator, loader):      # loader yields lists of dataset items
             step(batch.wait())
-    """
+
+    Static collators: the worker waits ON THE HOST for the previous batch to have left the landing copy before it enqueues the next expansion.
+    A consumer that replays captured steps runs several steps ahead of the GPU; a device-side wait queued that far ahead sits at the head of
+    the copy stream's hardware queue for milliseconds, and every variant of that measured slower (round 4: fed step 2.69 ms against 2.50 resident
+    with the copy stream sharing a hardware queue, 3.7 ms with a queue of its own) than never queueing a wait that is not already satisfied."""
 
     def __init__(self, collator: DeviceCollator, source, prefetch: int = 2):
         import queue
@@ -256,15 +270,27 @@ class CollatePipeline:
         if collator.depth < prefetch + 2:
             raise ValueError(f"CollatePipeline(prefetch={prefetch}) needs a DeviceCollator with depth >= {prefetch + 2} pinned buffers")
         self.collator, self._q, self._src, self._stop = collator, queue.Queue(maxsize=prefetch), iter(source), False
+        self._consumer_stream = torch.cuda.current_stream(collator.device)
+        self._free = None
+        if collator.static:
+            if collator._landing_busy:
+                raise RuntimeError("CollatePipeline: call .wait() on the collator's outstanding batch first")
+            self._free = collator._landing_released = threading.Semaphore(1)
         self._thread = threading.Thread(target=self._run, name="conan-collate", daemon=True)
         self._thread.start()
 
     def _run(self):
         try:
+            torch.cuda.set_device(self.collator.device)
             for items in self._src:
                 if self._stop:
                     return
-                self._q.put(self.collator.pack(items))
+                p = self.collator.pack(items)
+                if self._free is not None:
+                    self._free.acquire()                       # the consumer has called wait() on the previous batch ...
+                    if self._stop:
+                        return
+                self._q.put(self.collator.enqueue(*p, main=self._consumer_stream, host_wait=True))      # ... and the GPU has executed its landing copy
             self._q.put(None)
         except BaseException as e:                           # noqa: BLE001 - re-raised in the consumer
             self._q.put(e)
@@ -273,20 +299,32 @@ class CollatePipeline:
         return self
 
     def __next__(self) -> DeviceBatch:
-        p = self._q.get()
-        if p is None:
+        b = self._q.get()
+        if b is None:
             raise StopIteration
-        if isinstance(p, BaseException):
-            raise p
-        return self.collator.enqueue(*p)
+        if isinstance(b, BaseException):
+            raise b
+        return b
 
     def close(self):
+        """Stop the worker.  A static collator's batch that was already assembled is handed back by marking the landing copy free."""
         self._stop = True
+        if self._free is not None:
+            self._free.release()
         try:
             while True:
                 self._q.get_nowait()
         except Exception:                                     # noqa: BLE001 - queue.Empty
             pass
+        self._thread.join(timeout=5.0)
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:                                     # noqa: BLE001
+            pass
+        if self.collator.static:
+            self.collator._landing_released = None
+            self.collator._landing_busy = False                # (an assembled, never consumed batch: the landing copy is simply overwritten next time)
 
 
 def host_pack_benchmark(batch_items: Sequence, num_conformers: int, reps: int = 20) -> float:

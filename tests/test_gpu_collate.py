@@ -106,3 +106,48 @@ def test_pipeline_on_a_worker_thread_yields_the_same_batches_in_order():
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert all(torch.equal(g[k], w[k]) for k in w)
+
+
+def test_pipeline_with_a_static_collator_hands_over_one_landing_copy_at_a_time():
+    """static=True (captured-step replay): the worker enqueues the expansion of batch i + 1 only after the consumer's wait() on batch i has
+    been executed by the GPU (host-side wait, no device-side wait queued ahead); the fixed tensors keep their addresses, every batch arrives
+    intact even when the consumer is slow or fast, and close() in mid-stream leaves the collator usable."""
+    import copy
+    import time
+    from conan_fgw_amd.collate import CollatePipeline
+    K = 3
+    cb = make_batch("esol", 6, K, seed=11); bg = make_bond_graph(cb, seed=61)
+    base = molecules_from_synthetic(cb, bg)
+    sets = []
+    for v in range(6):                                       # same shapes, different coordinates and targets
+        items = copy.deepcopy(base)
+        for it in items:
+            it.pos = (it.pos + np.float32(0.25 * v)).astype(np.float32)
+            it.y = float(it.y) + v
+        sets.append(items)
+    direct = DeviceCollator(dev, K, depth=2)
+    want = []
+    for items in sets:
+        b = direct(items).wait()
+        torch.cuda.synchronize()
+        want.append({k: getattr(b, k).clone() for k in ("z", "pos", "batch", "x", "edge_index", "edge_attr", "y", "graph_ptr")})
+    coll = DeviceCollator(dev, K, depth=4, static=True)
+    addr = None
+    for delay in (0.0, 0.01):
+        feed = CollatePipeline(coll, sets, prefetch=2)
+        for i, b in enumerate(feed):
+            b.wait()
+            if addr is None:
+                addr = b.pos.data_ptr()
+            assert b.pos.data_ptr() == addr
+            got = {k: getattr(b, k).clone() for k in want[0]}       # (on the consumer's stream, behind the landing copy)
+            torch.cuda.synchronize()
+            assert all(torch.equal(got[k], want[i][k]) for k in got), (delay, i)
+            time.sleep(delay)
+        assert i == len(sets) - 1
+    feed = CollatePipeline(coll, sets, prefetch=2)
+    next(feed).wait()
+    feed.close()                                              # the worker may hold an assembled batch: it is dropped
+    b = coll(sets[3]).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(b.pos, want[3]["pos"]) and torch.equal(b.y, want[3]["y"])
