@@ -148,8 +148,12 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         base[i * P + j] = 2.0 * alpha * (ra[i] + rb[j]) + (1.0 - alpha) * m;
     }
     __syncthreads();
-    for (int i = tid; i < N; i += NT) { ra[i] = exp(loga[i]); rb[i] = exp(logb[i]); }      // p_i, q_j for the scaling form (r1 / r2 are consumed)
+    int zero_mass = 0;
+    for (int i = tid; i < N; i += NT) { ra[i] = exp(loga[i]); rb[i] = exp(logb[i]); zero_mass |= (loga[i] < -1.0e300 || logb[i] < -1.0e300) ? 1 : 0; }      // p_i, q_j for the scaling form (r1 / r2 are consumed)
     double *pa = ra, *qb = rb;
+    // nodes without mass (fgw.py embeds n != N problems with such nodes): the scaling form's first half-step would count them (g = 1 on every
+    // row), so such couplings take the log-domain path, whose potentials start at -inf there
+    const bool massless = __syncthreads_or(zero_mass) != 0;
     FGW_PROF(2);      // base
 
     // ---- projected gradient loop (bregman.py:119-157)
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
         static_assert(NW < 15, "red[15] is the range flag: block_sum_d<NW> must not reach it");
         double *bad_flag = red + 15;                                      // set by whoever sees a sum out of range; read after the next barrier
         for (int j = tid; j < N; j += NT) v[j] = Mr[j * P + j];          // column references (the diagonal), before K overwrites them
-        if (tid == 0) *bad_flag = 0.0;
+        if (tid == 0) *bad_flag = massless ? 1.0 : 0.0;
         __syncthreads();
         for (int j = lane; j < N; j += 64) {                              // K = exp(Mr - ref_j), partial column sums
             const double ref = v[j];
@@ -252,7 +256,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
             // ---- exact log-domain Sinkhorn (sinkhorn.py:393-433), restarted from u = v = 0 on a re-formed Mr
             __syncthreads();
             form_mr();
-            for (int i = tid; i < N; i += NT) { u[i] = 0.0; v[i] = 0.0; }     // sinkhorn.py:393-394
+            // (a node without mass has log-weight -inf and its potential is -inf after its first update; it starts there, so that it never
+            // enters the other side's first log-sum-exp: the rectangular problem fgw.py embeds has no such node at all)
+            for (int i = tid; i < N; i += NT) { u[i] = loga[i] < -1.0e300 ? loga[i] : 0.0; v[i] = logb[i] < -1.0e300 ? logb[i] : 0.0; }     // sinkhorn.py:393-394
             __syncthreads();
             for (ii = 0; ii < prm.num_iter_max; ++ii) {
                 // v_j = logb_j - logsumexp_i(Mr_ij + u_i).  lane <-> column (consecutive lanes read consecutive LDS words), the
@@ -426,12 +432,16 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     float *Tg = Tw + ((size_t)b * D.K + s) * NN;
     const bool warm = outer > 0 && prm.warmstart;
 
+    int zero_mass = 0;
     for (int i = tid; i < N; i += NT) {
         pa[i] = pb ? (double)pb[(size_t)b * N + i] : fc.inv_n;
         qb[i] = ps ? (double)ps[((size_t)b * D.K + s) * N + i] : fc.inv_n;
+        zero_mass |= (pa[i] <= 0.0 || qb[i] <= 0.0) ? 1 : 0;
     }
     if (tid == 0) *bad_flag = 0.0;
-    __syncthreads();
+    // A node without mass (fgw.py embeds n != N problems with such nodes) must not enter the first Sinkhorn half-step, which this kernel takes
+    // with g = 1 on every row: such couplings go to the exact pass, whose potentials start at -inf on those nodes.
+    const bool massless = __syncthreads_or(zero_mass) != 0;
     // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
     for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
@@ -493,8 +503,8 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
 
     int cpt = 0, sk_total = 0;
     double err = 1.0;
-    bool bail = false;
-    while (err > fc.inner_tol && cpt < prm.max_iter) {                  // bregman.py:119
+    bool bail = massless;
+    while (!bail && err > fc.inner_tol && cpt < prm.max_iter) {         // bregman.py:119
         // per-lane and uniform offsets of this iteration are derived from laundered copies: hoisted out of the loop they spill
         int tq = tid, N = D.N, P = D.P;
         asm volatile("" : "+v"(tq), "+s"(N), "+s"(P));
@@ -643,7 +653,7 @@ __global__ void __launch_bounds__(256) k_fgw_bwd(const float *__restrict__ T, co
         for (int t = threadIdx.x; t < N * N; t += 256) Tl[t] = Ts[t];
         for (int t = threadIdx.x; t < N * d; t += 256) {
             const int i = t / d;
-            const float pinv = pb ? 1.0f / pb[(size_t)b * N + i] : (float)N;
+            const float pinv = pb ? (pb[(size_t)b * N + i] > 0.f ? 1.0f / pb[(size_t)b * N + i] : 0.f) : (float)N;      // (massless node: no gradient)
             gl[t] = pinv * g[t];
         }
         __syncthreads();
@@ -659,7 +669,7 @@ __global__ void __launch_bounds__(256) k_fgw_bwd(const float *__restrict__ T, co
         const int j = t / d, c = t - j * d;
         float a = 0.f;
         for (int i = 0; i < N; ++i) {
-            const float pinv = pb ? 1.0f / pb[(size_t)b * N + i] : (float)N;
+            const float pinv = pb ? (pb[(size_t)b * N + i] > 0.f ? 1.0f / pb[(size_t)b * N + i] : 0.f) : (float)N;
             a += Ts[i * N + j] * pinv * g[i * d + c];
         }
         dYs[((size_t)b * K + s) * N * d + t] = lam * a;

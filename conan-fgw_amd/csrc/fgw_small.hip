@@ -124,6 +124,9 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
     }
     // ---- ... then the LDS stores
     if (tid < 64) { pq[tid] = p_own; pq[64 + tid] = q_own; }
+    // a node without mass (fgw.py embeds n != N problems with such nodes) must not enter the scaling form's first half-step (g = 1 on every
+    // row): such couplings take the log-domain path below, whose potentials start at -inf on those nodes
+    const bool massless = __syncthreads_or(tid < N && (p_own <= 0.0 || q_own <= 0.0)) != 0;
     vec4[tid] = vec_own;
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
         auto mrB = [&](int r) { const int q = wq + 4 * r, qc = q < N ? q : N - 1; const double m = -(Bl[lc * P + qc] - 2.0 * alpha * Gl[lc * P + qc]) * inv_eps; return (q < N && lane_ok) ? m : -1.0e300; };
         double kA[R], kB[R];                                            // the coupling in both layouts
         int ii = 0;
-        bool exact = false;                                             // workgroup-uniform
+        bool exact = massless;                                          // workgroup-uniform
         {
             // ---- first column step (u = v = 0): K = exp(Mr - ref_j), f_j = b_j / sum_i K.  The stabiliser is the column's DIAGONAL
             // entry Mr_jj, which every wave reads for itself (no combine, no barrier); any reference within ~ +-600 of the column
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
             double *xm = bufC, *xs = bufK, *uc = fcp, *vc = gcp;        // [4][64] max, [4][64] sum, [64] u, [64] v
             const double loga = log(pi_l), logb = log(qj);
             double u_l = 0.0, v_l = 0.0;
-            uc[lane] = 0.0;
+            uc[lane] = (lane_ok && !(pi_l > 0.0)) ? loga : 0.0;        // (massless row: -inf from the start, see `massless`)
             for (ii = 0; ii < prm.num_iter_max; ++ii) {
                 // v_j = logb_j - logsumexp_i(Mr_ij + u_i): serial over my rows, then ONE 4-way combine of (partial max, partial
                 // sum) pairs: sum = sum_w s_w * exp(m_w - M)
@@ -600,8 +603,10 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
 
     int cpt = 0, sk_total = 0;
     double err = 1.0;
-    bool bail = false;                                                  // workgroup-uniform
-    while (err > fc.inner_tol && cpt < prm.max_iter) {                  // bregman.py:119
+    // A node without mass (fgw.py embeds n != N problems with such nodes) must not enter the first Sinkhorn half-step, which the scaling form
+    // takes with g = 1 on every row: such couplings are handed to the exact pass, whose potentials start at -inf on those nodes.
+    bool bail = __syncthreads_or(tid < N && (p_own <= 0.0 || q_own <= 0.0)) != 0;      // workgroup-uniform
+    while (!bail && err > fc.inner_tol && cpt < prm.max_iter) {         // bregman.py:119
         // Everything per-lane below (LDS offsets, tile indices, fragment pointers) is derived from THIS copy of the thread index, which the
         // optimiser cannot see through: left alone it hoists some sixty loop-invariant offsets out of the loop and spills them.
         int tq = tid, N = D.N, P = D.P;                                 // (shadow the kernel-wide N, P on purpose)
@@ -852,7 +857,8 @@ __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
                     for (int s = 0; s < K; ++s) {
                         const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
                         const int i = t / d;
-                        const double pinv = 1.0 / (pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N);
+                        const double pw = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+                        const double pinv = pw > 0.0 ? 1.0 / pw : 0.0;       // a node without mass (fgw.py embeds n != N problems with such nodes) keeps a zero row
                         acc[u] += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;          // utils.py:94
                     }
                 }
@@ -892,7 +898,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
                     const int i = t / N, j = t - i * N;
                     const double pi = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
                     const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
-                    const double cn = prm.loss_fun ? exp(acc[u] / (pi * pj)) : acc[u] / (pi * pj);     // :72-73 / :86-87
+                    const double cn = pi * pj > 0.0 ? (prm.loss_fun ? exp(acc[u] / (pi * pj)) : acc[u] / (pi * pj)) : 0.0;     // :72-73 / :86-87 (massless nodes: zero)
                     const double df = cn - old[u];
                     es2 += df * df;
                     Cb[t] = cn;

@@ -4,7 +4,8 @@
 Same argument names, defaults and error behaviour (`ValueError` for unknown `loss_fun` / `stop_criterion` / `solver`,
 barycenter.py:33-44).  `loss_fun` = "square_loss" (every model) or "kl_loss" (utils.py:20-32,76-87).  Option values that exist in
 the reference but are not reached by any model (`BAPG`, `PPA`, `stop_criterion="loss"` — the latter is broken in the reference
-itself, SURVEY.md 8c — and input graphs whose node count differs from N) raise `NotImplementedError`.  Runs on the GPU only.
+itself) raise `NotImplementedError`.  Input graphs of any size (n_s != N, ragged lists) are solved by embedding them in a
+square problem with massless nodes (below).  Runs on the GPU only.
 """
 from __future__ import annotations
 
@@ -41,11 +42,34 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
     if fixed_features and init_Y is None:
         raise ValueError("If Y is fixed it must be initialized")
 
-    Ys_t = torch.stack([y.to(torch.float32) for y in Ys]) if not torch.is_tensor(Ys) else Ys
-    Cs_t = torch.stack([c.to(torch.float32) for c in Cs]) if not torch.is_tensor(Cs) else Cs
-    K, n, d = Ys_t.shape
-    if n != N or Cs_t.shape[1] != N:
-        raise NotImplementedError("input graphs must all have N nodes (the ConAN glue pads them, schnet_no_sum.py:242-252)")
+    N = int(N)
+    Ys_l = [y.to(torch.float32) for y in (Ys.unbind(0) if torch.is_tensor(Ys) else Ys)]
+    Cs_l = [c.to(torch.float32) for c in (Cs.unbind(0) if torch.is_tensor(Cs) else Cs)]
+    K, d = len(Ys_l), Ys_l[0].shape[1]
+    sizes = [int(y.shape[0]) for y in Ys_l]
+    if len(Cs_l) != K or any(tuple(c.shape) != (n, n) for c, n in zip(Cs_l, sizes)):
+        raise ValueError("Cs[s] must be a square matrix over the nodes of Ys[s]")
+    # Input graphs whose node counts differ from N or from each other (barycenter.py:50-67 takes any; no ConAN model does this: the glue pads
+    # every conformer to N, schnet_no_sum.py:242-252).  The kernels solve square problems, so the call is embedded in one of size
+    # Np = max(N, max n_s): the extra nodes carry NO mass (p_i = 0 / ps[s]_j = 0), zero features and no edges.  A massless node's row / column of
+    # every coupling is exactly zero in the Sinkhorn scaling (u_i = p_i / (K v)_i), it adds nothing to any product, and the barycenter update
+    # keeps its row of Y and its row / column of C at zero (fgw_small.hip: the divisions by p are guarded) — the leading N x N / N x n_s blocks
+    # are the reference's rectangular problem, term for term.
+    Np = max([N] + sizes)
+    embedded = Np != N or any(n != N for n in sizes)
+    dev = Ys_l[0].device
+    if embedded:
+        def pad(t, *shape):
+            out = torch.zeros(*shape, dtype=torch.float32, device=dev)
+            out[tuple(slice(0, k) for k in t.shape)] = t
+            return out
+        ps_l = [torch.ones(n, device=dev) / n for n in sizes] if ps is None else [q.to(torch.float32).to(dev) for q in (ps.unbind(0) if torch.is_tensor(ps) else ps)]
+        p_full = (torch.ones(N, device=dev) / N) if p is None else p.to(torch.float32).to(dev)
+        Ys_l = [pad(y, Np, d) for y in Ys_l]
+        Cs_l = [pad(c, Np, Np) for c in Cs_l]
+        ps = [pad(q, Np) for q in ps_l]
+        p_embedded = pad(p_full, Np)
+    Ys_t, Cs_t = torch.stack(Ys_l), torch.stack(Cs_l)
     if init_C is None:
         # barycenter.py:61-65: torch.manual_seed(seed); xalea = torch.randn(N, 2); C = dist(xalea, xalea) — a host-side random
         # squared-distance matrix (utils.py:154-171 with X is Y: clamped at 0, zero diagonal).  Reproduced draw for draw,
@@ -57,10 +81,18 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
         c0 += a2[:, None]
         c0 += a2[None, :]
         init_C = (torch.clamp(c0, min=0) * (1 - torch.eye(N))).to(Ys_t.device)
+    N_user = N
+    if embedded:
+        ic = torch.zeros(Np, Np, dtype=torch.float32, device=dev); ic[:N, :N] = init_C.to(torch.float32)
+        init_C = ic
+        if init_Y is not None:
+            iy = torch.zeros(Np, d, dtype=torch.float32, device=dev); iy[:N] = init_Y.to(torch.float32)
+            init_Y = iy
+        N = Np
     ps_t = None
     if ps is not None:
         ps_t = (torch.stack(list(ps)) if not torch.is_tensor(ps) else ps).to(torch.float32).view(1, K, N)
-    p_t = p.to(torch.float32).view(1, N) if p is not None else None
+    p_t = p_embedded.view(1, N) if embedded else (p.to(torch.float32).view(1, N) if p is not None else None)
     lam = None
     if lambdas is not None:
         lam = torch.as_tensor(lambdas, dtype=torch.float32, device=Ys_t.device)
@@ -73,6 +105,8 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
         fixed_structure=fixed_structure, fixed_features=fixed_features, warmstart=warmstartT, loss_fun=loss_fun, keep_iterates=bool(log),
         cs_small_int=small_int)
     Y, C, T, info, errs = res[:5]
+    if embedded:
+        Y, C = Y[:, :N_user], C[:, :N_user, :N_user]
     if not log:
         return Y[0], C[0]
     outer = int(info[0, 0].item())
@@ -81,11 +115,12 @@ def fgw_barycenters(N, Ys: Sequence[Tensor], Cs: Sequence[Tensor], ps=None, p=No
     # euclidean distances (utils.py:154-171); a by-product for the caller's inspection, formed here from the outputs
     Yd = Y[0]
     y2 = (Yd * Yd).sum(1)
-    Ms = [torch.clamp(y2[:, None] + (Ys_t[s] * Ys_t[s]).sum(1)[None, :] - 2.0 * (Yd @ Ys_t[s].T), min=0) for s in range(K)]
+    Yin = [Ys_t[s, :sizes[s]] for s in range(K)]              # (an embedded call: the caller's own nodes)
+    Ms = [torch.clamp(y2[:, None] + (Yin[s] * Yin[s]).sum(1)[None, :] - 2.0 * (Yd @ Yin[s].T), min=0) for s in range(K)]
     log_ = {"err_feature": [errs[0, 0, i] for i in range(outer)], "err_structure": [errs[0, 1, i] for i in range(outer)],
-            "Ts_iter": [[T_iter[i, 0, s] for s in range(K)] for i in range(outer)],           # barycenter.py:196
-            "T": [T[0, s] for s in range(K)],
-            "p": p if p is not None else torch.ones(N, device=Y.device) / N,
+            "Ts_iter": [[T_iter[i, 0, s, :N_user, :sizes[s]] for s in range(K)] for i in range(outer)],           # barycenter.py:196
+            "T": [T[0, s, :N_user, :sizes[s]] for s in range(K)],
+            "p": p if p is not None else torch.ones(N_user, device=Y.device) / N_user,
             "Ms": Ms,
             "n_outer": outer, "n_pgd": int(info[0, 1].item()), "n_sinkhorn": int(info[0, 2].item())}
     return Y[0], C[0], log_

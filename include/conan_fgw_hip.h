@@ -472,6 +472,10 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d);
  * always does; schnet_no_sum.py:281-306).  Replaces the Python loop over molecules (schnet_no_sum.py:259-312).
  * Ys[B,K,N,d], Cs[B,K,N,N], ps[B,K,N] or NULL (uniform), p[B,N] or NULL (uniform), lambdas[K] or NULL (1/K),
  * init_C[B,N,N] or NULL (= Cs[b,0], schnet_no_sum.py:303), init_Y[B,N,d] or NULL (zeros).
+ * Entries of ps / p may be ZERO: a node without mass takes no part in the problem (its row / column of every coupling, its row of Y and
+ * its row / column of C are exactly zero).  That is how input graphs with fewer than N nodes, or a barycenter with fewer nodes than its
+ * inputs (barycenter.py:50-67 takes any sizes), are passed: zero rows in Ys / Cs / init_C and zero weights (conan-fgw_amd/fgw.py does
+ * this); couplings with massless nodes are solved on the log-domain path (flags bit 0).
  * Outputs: Y[B,N,d], C[B,N,N], T[B,K,N,N] (final couplings, saved for the backward),
  * T_iter[max_iter,B,K,N,N] or NULL: the couplings after every outer iteration (the reference's log["Ts_iter"], barycenter.py:196;
  * a molecule that stopped early keeps its last couplings in the later slots),

@@ -246,6 +246,56 @@ def main_randinit():
         print(f"randinit {name}: outer={len(rec['r64_err_feature'])} relY={rel(rec['r32_Y'], rec['r64_Y']):.2e} relC={rel(rec['r32_C'], rec['r64_C']):.2e}")
 
 
+RECT_CASES = [
+    # name, seed, N (barycenter nodes), sizes of the input graphs, d
+    ("N6_n9", 31, 6, (9, 9, 9), 8),
+    ("N10_n7", 32, 10, (7, 7, 7, 7), 8),
+    ("N6_ragged", 33, 6, (5, 8, 7), 8),
+    ("N40_n33", 34, 40, (33, 33), 16),
+    ("N70_n80", 35, 70, (80, 80), 16),
+]
+
+
+def main_rect():
+    """Input graphs whose node counts differ from N and from each other (barycenter.py:50-67 takes any): `python make_fgw_golden.py rect`
+    writes fgw_rect_*.npz — inputs zero-padded to the largest graph with their sizes beside them, the reference's outputs as they are.
+    init_C=None: the reference draws its own N x N start (seed 3)."""
+    for name, seed, N, sizes, d in RECT_CASES:
+        K, nmax = len(sizes), max(sizes)
+        Ysp = np.zeros((K, nmax, d), np.float32); Csp = np.zeros((K, nmax, nmax), np.float32)
+        for s, n in enumerate(sizes):
+            y, c = make_inputs(seed + 100 * s, 1, n, 0, d, 10.0)
+            Ysp[s, :n] = y[0]; Csp[s, :n, :n] = c[0]
+        rec = dict(Ys=Ysp, Cs=Csp.astype(np.uint8), sizes=np.array(sizes, np.int64), N=np.int64(N), seed=np.int64(3))
+        for tag, dt in (("r32", torch.float32), ("r64", torch.float64)):
+            t = lambda a: torch.from_numpy(np.asarray(a)).to(dt)
+            Ysl = [t(Ysp[s, :n]) for s, n in enumerate(sizes)]
+            Csl = [t(Csp[s, :n, :n]) for s, n in enumerate(sizes)]
+            ps = [torch.ones(n, dtype=dt) / n for n in sizes]
+            lambdas = torch.ones(K, dtype=dt) / K
+            args = dict(PROD); args["seed"] = 3
+            with Counter() as cnt:
+                Y, C, log = ref_bary.fgw_barycenters(N=N, Ys=Ysl, Cs=Csl, ps=ps, lambdas=lambdas, init_C=None, **args)
+            outer = len(log["err_feature"])
+            mi = args["max_iter"]
+            pgd = np.zeros((outer, K), np.int32); sk = np.zeros((outer, K, mi), np.int32)
+            for o in range(outer):
+                for s in range(K):
+                    c = cnt.calls[o * K + s]
+                    pgd[o, s] = len(c); sk[o, s, : len(c)] = c
+            T = np.zeros((K, N, nmax)); 
+            for s, n in enumerate(sizes):
+                T[s, :, :n] = log["T"][s].detach().numpy()
+            rr = dict(Y=Y.detach().numpy(), C=C.detach().numpy(), T=T, err_feature=np.array([float(e) for e in log["err_feature"]]),
+                      err_structure=np.array([float(e) for e in log["err_structure"]]), pgd=pgd, sinkhorn=sk)
+            for k, v in rr.items():
+                rec[f"{tag}_{k}"] = v.astype(np.float32) if (tag == "r32" and v.dtype.kind == "f") else v
+        np.savez_compressed(os.path.join(HERE, f"fgw_rect_{name}.npz"), **rec)
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        print(f"rect {name}: outer={len(rec['r64_err_feature'])} relY={rel(rec['r32_Y'], rec['r64_Y']):.2e} relC={rel(rec['r32_C'], rec['r64_C']):.2e} "
+              f"pgd={rec['r64_pgd'].sum()} sk={rec['r64_sinkhorn'].sum()}")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else ""
-    {"kl": main_kl, "randinit": main_randinit, "inity": main_inity}.get(mode, main)()
+    {"kl": main_kl, "randinit": main_randinit, "inity": main_inity, "rect": main_rect}.get(mode, main)()

@@ -314,3 +314,64 @@ def test_densify_with_a_too_small_node_hint_poisons_instead_of_corrupting():
             assert torch.equal(Cs[k], Cs_ok[k, :N, :N])
     Ys.nan_to_num().sum().backward()
     assert feat.grad is not None and feat.grad.shape == feat.shape
+
+
+RECT = golden_files("fgw_rect_")
+
+
+@pytest.mark.parametrize("path", RECT, ids=[os.path.basename(p)[9:-4] for p in RECT])
+def test_input_graphs_of_any_size_through_the_reference_signature(path):
+    """barycenter.py:50-67 takes input graphs whose node counts differ from N and from each other (no model does: the glue pads to N).
+    `fgw_barycenters` embeds such a call in a square problem whose extra nodes carry no mass (conan-fgw_amd/fgw.py); expected values: the
+    reference itself on the ragged lists (make_fgw_golden.py rect; init_C=None, its own seeded start).  Same contract as the square goldens:
+    iteration counts of ref64, Y / C within 1e-4, the couplings' leading N x n_s blocks, massless rows and columns exactly zero."""
+    g = np.load(path)
+    N, sizes = int(g["N"]), [int(n) for n in g["sizes"]]
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev)
+    Ys = [t(g["Ys"][s, :n]) for s, n in enumerate(sizes)]
+    Cs = [t(g["Cs"][s, :n, :n]) for s, n in enumerate(sizes)]
+    K = len(sizes)
+    Y, C, log = pfgw.fgw_barycenters(N=N, Ys=Ys, Cs=Cs, ps=[torch.ones(n, device=dev) / n for n in sizes], lambdas=torch.ones(K) / K,
+                                     warmstartT=True, symmetric=True, method="sinkhorn_log", alpha=0.1, solver="PGD", fixed_structure=False,
+                                     fixed_features=False, epsilon=0.1, p=None, loss_fun="square_loss", max_iter=5, tol=1e-2, numItermax=5,
+                                     stopThr=1e-2, verbose=False, log=True, init_C=None, seed=int(g["seed"]), init_X=None, random_state=None)
+    assert tuple(Y.shape) == (N, g["Ys"].shape[2]) and tuple(C.shape) == (N, N)
+    assert log["n_outer"] == len(g["r64_err_feature"]) and log["n_pgd"] == int(g["r64_pgd"].sum()) and log["n_sinkhorn"] == int(g["r64_sinkhorn"].sum())
+    Yn, Cn = Y.cpu().numpy(), C.cpu().numpy()
+    assert np.isfinite(Yn).all() and np.isfinite(Cn).all()
+    for key, val in (("Y", Yn), ("C", Cn)):
+        yard = rel(g["r32_" + key], g["r64_" + key])
+        e64 = rel(val, g["r64_" + key])
+        assert e64 <= max(1e-4, yard), (key, e64, yard)
+    for s, n in enumerate(sizes):
+        Ts = log["T"][s].cpu().numpy()
+        assert Ts.shape == (N, n)
+        want = g["r64_T"][s, :, :n]
+        assert rel(Ts, want) <= max(1e-4, 2 * rel(g["r32_T"][s, :, :n], want)), (s, rel(Ts, want))
+        np.testing.assert_allclose(Ts.sum(1), np.full(N, 1.0 / N), rtol=2e-2)          # marginals of the caller's problem (stopThr = 1e-2)
+        assert tuple(log["Ms"][s].shape) == (N, n)
+    # without log, default weights (uniform lambdas / ps formed in fp64 by the kernel instead of the caller's fp32 tensors): the two-tuple, same values
+    Y2, C2 = pfgw.fgw_barycenters(N=N, Ys=Ys, Cs=Cs, ps=None, lambdas=None, alpha=0.1, epsilon=0.1, max_iter=5, tol=1e-2, numItermax=5, stopThr=1e-2,
+                                  warmstartT=True, init_C=None, seed=int(g["seed"]))
+    assert rel(Y2.cpu().numpy(), Yn) < 1e-6 and rel(C2.cpu().numpy(), Cn) < 1e-6
+
+
+@pytest.mark.parametrize("N,n", [(12, 17), (17, 12), (70, 75)], ids=["N12_n17", "N17_n12", "N70_n75_large_kernel"])
+def test_massless_nodes_survive_the_exact_second_pass(N, n):
+    """The embedding of an n != N call (massless nodes: log p = -inf on the log-domain path) driven through the exact second pass by a small
+    epsilon, against the fp64 oracle solving the rectangular problem itself."""
+    K, d = 3, 8
+    rng = np.random.default_rng(9)
+    Ys = (rng.random((K, n, d)) * 1.9 + 0.1).astype(np.float32)
+    A = (rng.random((K, n, n)) < 0.4).astype(np.float32); Cs = np.triu(A, 1); Cs = Cs + Cs.transpose(0, 2, 1)
+    A0 = (rng.random((N, N)) < 0.4).astype(np.float32); C0 = np.triu(A0, 1); C0 = C0 + C0.T
+    kw = dict(epsilon=2e-3, alpha=0.1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    Y, C, log = pfgw.fgw_barycenters(N=N, Ys=[t(y) for y in Ys], Cs=[t(c) for c in Cs], init_C=t(C0), max_iter=5, tol=1e-2, numItermax=5, stopThr=1e-2,
+                                     warmstartT=True, log=True, **kw)
+    ref = ofgw.fgw_barycenter(Ys, Cs, N=N, init_C=C0, dtype=np.float64, **kw)
+    assert log["n_outer"] == ref["outer"] and log["n_pgd"] == int(ref["pgd"].sum()) and log["n_sinkhorn"] == int(ref["sinkhorn"].sum())
+    assert np.isfinite(Y.cpu().numpy()).all() and np.isfinite(C.cpu().numpy()).all()
+    assert rel(Y.cpu().numpy(), ref["Y"]) < 1e-4 and rel(C.cpu().numpy(), ref["C"]) < 1e-4
+    for s in range(K):
+        assert rel(log["T"][s].cpu().numpy(), ref["T"][s]) < 1e-3

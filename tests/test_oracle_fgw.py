@@ -116,3 +116,24 @@ def test_oracle_kl_loss_matches_reference_goldens():
             yard = rel(g["r32_" + k].astype(np.float64), g["r64_" + k])
             assert rel(o32[k].astype(np.float64), g["r32_" + k].astype(np.float64)) <= 1e-4 or \
                 rel(o32[k].astype(np.float64), g["r64_" + k]) <= 2.0 * yard + 1e-6, (f, k)
+
+
+RECT = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fgw_rect_*.npz"))) if "ragged" not in p]
+
+
+@pytest.mark.parametrize("path", RECT, ids=[os.path.basename(p)[9:-4] for p in RECT])
+def test_oracle_rectangular_problems_match_the_reference(path):
+    """Input graphs with n != N nodes (barycenter.py:50-67): the restatement is written for N x n couplings throughout; the reference run on
+    the same lists (make_fgw_golden.py rect) pins it — same iteration counts, fp64 results to 1e-9.  The start is the reference's own seeded
+    draw (barycenter.py:61-65), reproduced here with torch's generator."""
+    import torch
+    g = np.load(path)
+    N, n = int(g["N"]), int(g["sizes"][0])
+    torch.manual_seed(int(g["seed"]))
+    xa = torch.randn(N, 2).double().numpy()
+    a2 = (xa * xa).sum(1)
+    c0 = np.maximum(a2[:, None] + a2[None, :] - 2 * xa @ xa.T, 0) * (1 - np.eye(N))
+    r = fgw.fgw_barycenter(g["Ys"][:, :n], g["Cs"][:, :n, :n], N=N, init_C=c0, dtype=np.float64)
+    assert r["outer"] == len(g["r64_err_feature"]) and np.array_equal(r["pgd"], g["r64_pgd"])
+    assert np.array_equal(r["sinkhorn"][..., : g["r64_sinkhorn"].shape[-1]], g["r64_sinkhorn"])
+    assert rel(r["Y"], g["r64_Y"]) < 1e-7 and rel(r["C"], g["r64_C"]) < 1e-7 and rel(r["T"], g["r64_T"][:, :, :n]) < 1e-7
