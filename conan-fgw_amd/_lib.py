@@ -140,6 +140,9 @@ SIGNATURES = {
     "conan_fgw_workspace_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
     "conan_fgw_barycenter_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(FgwParams),
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+    "conan_fgw_workspace_bytes_ragged": (c_ll, [c_int, c_int, c_int, c_int]),
+    "conan_fgw_barycenter_fwd_ragged": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, ctypes.POINTER(FgwParams),
+                                                _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_fgw_barycenter_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "conan_fgw_readout_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "conan_fgw_readout_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),

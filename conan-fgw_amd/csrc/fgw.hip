@@ -31,11 +31,25 @@ namespace {
 // ------------------------------------------------------------------------------------------------ init
 __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict__ init_C, const float *__restrict__ init_Y,
                            FgwDims D, int max_iter, double *__restrict__ Cw, double *__restrict__ Yw, int *__restrict__ active,
-                           int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout) {
+                           int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout, FgwAdj adj) {
     const int b = blockIdx.x;
     const int NN = D.N * D.N, Nd = D.N * D.d;
+    if (!init_C && adj.rowptr) {                                          // init_C = adjacency of the molecule's first graph, from its ragged lists
+        const int N = D.N, g = b * D.K;
+        for (int t = threadIdx.x; t < NN; t += blockDim.x) Cout[(size_t)b * NN + t] = 0.f;
+        __syncthreads();
+        const int lo = adj.gptr[g], n = min(adj.gptr[g + 1] - lo, N);
+        for (int e = adj.rowptr[lo] + (int)threadIdx.x; e < adj.rowptr[lo + n]; e += blockDim.x) {
+            const int i = adj.tgt[e] - lo, j = adj.col[e] - lo;
+            if (i >= 0 && i < N && j >= 0 && j < N) atomicAdd(&Cout[(size_t)b * NN + j * N + i], 1.0f);
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int t = threadIdx.x; t < NN; t += blockDim.x) Cw[(size_t)b * NN + t] = (double)Cout[(size_t)b * NN + t];
+    } else {
     const float *c0 = init_C ? init_C + (size_t)b * NN : Cs + (size_t)b * D.K * NN;   // init_C = Cs[0] (schnet_no_sum.py:303)
     for (int t = threadIdx.x; t < NN; t += blockDim.x) { Cw[(size_t)b * NN + t] = (double)c0[t]; Cout[(size_t)b * NN + t] = c0[t]; }
+    }
     for (int t = threadIdx.x; t < Nd; t += blockDim.x) {
         float y = init_Y ? init_Y[(size_t)b * Nd + t] : 0.f;                            // barycenter.py:76-77
         Yw[(size_t)b * Nd + t] = (double)y; Yout[(size_t)b * Nd + t] = y;
@@ -58,7 +72,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
-    fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, const int *__restrict__ only) {
+    fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, const int *__restrict__ only, FgwAdj adj) {
     constexpr bool LDS_MODE = MODE == 2, MR_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
@@ -85,7 +99,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     float *Tl = reinterpret_cast<float *>(base + NP);
 
     const float *Z = Ys + ((size_t)b * D.K + s) * N * d;        // features of input graph s      [N,d]
-    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;          // structure of input graph s     [N,N]
+    // structure of input graph s [N,N]; with the ragged structure (FgwAdj) this kernel is only the exact pass behind k_fgw_coupling_big, and a
+    // flagged coupling expands its graph into its own slice of the dense scratch first
+    const float *C2 = adj.rowptr ? adj_dense_slice<NT>(adj, cid, N, tid) : Cs + ((size_t)b * D.K + s) * NN;
     const double *C1 = Cw + (size_t)b * NN;                     // current barycenter structure   [N,N]
     const double *Y = Yw + (size_t)b * N * d;                   // current barycenter features    [N,d]
     float *Tg = Tw + ((size_t)b * D.K + s) * NN;
@@ -402,7 +418,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
-    fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, int *__restrict__ redo) {
+    fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, int *__restrict__ redo, FgwAdj adj) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
@@ -442,11 +458,19 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     // A node without mass (fgw.py embeds n != N problems with such nodes) must not enter the first Sinkhorn half-step, which this kernel takes
     // with g = 1 on every row: such couplings go to the exact pass, whose potentials start at -inf on those nodes.
     const bool massless = __syncthreads_or(zero_mass) != 0;
+    const bool ragged = C2U8 && adj.rowptr != nullptr;
     // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
     for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
         Kf[i * P + j] = warm ? Tg[t] : (float)(pa[i] * qb[j]);
-        if constexpr (C2U8) C2b[i * P + j] = (unsigned char)C2[t];
+        if constexpr (C2U8) C2b[i * P + j] = ragged ? (unsigned char)0 : (unsigned char)C2[t];
+    }
+    if constexpr (C2U8) {
+        if (ragged) {                                                     // the graph's adjacency counts straight from its neighbour lists (FgwAdj)
+            __syncthreads();
+            adj_scatter_lds_bytes<NT>(adj, (int)blockIdx.x, N, P, C2b, tid);
+            __syncthreads();
+        }
     }
     {   // init_matrix vectors (utils.py:39-43) and squared feature norms: 8 lanes per index (see k_fgw_coupling)
         constexpr int LPI = 8;
@@ -455,7 +479,10 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
             double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
             if (i < N) {
                 for (int k = sub; k < N; k += LPI) {
-                    const double c1 = C1[i * N + k], c2 = (double)C2[i * N + k];
+                    double c2;
+                    if constexpr (C2U8) c2 = ragged ? (double)C2b[i * P + k] : (double)C2[i * N + k];
+                    else c2 = (double)C2[i * N + k];
+                    const double c1 = C1[i * N + k];
                     r1 += c1 * c1 * pa[k];
                     r2 += qb[k] * c2 * c2;
                 }
@@ -707,6 +734,7 @@ __global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat,
         const float x = (t < n * d ? feat[(size_t)lo * d + t] : 0.f) + shift;
         Yg[t] = a + __fdiv_rn((x - mn) * scale, range);                 // a + (t - min) * (b - a) / (max - min)
     }
+    if (!Cs) return;                                                     // features only: the solver reads the structure from the ragged lists (conan_fgw_barycenter_fwd_ragged)
     float *Cg = Cs + (size_t)g * N * N;
     for (int t = tid; t < N * N; t += 256) Cg[t] = 0.f;
     __syncthreads();
@@ -730,6 +758,9 @@ __global__ void __launch_bounds__(256) k_densify(const float *__restrict__ feat,
     }
     (void)e0; (void)e1;
 }
+
+// to_dense_adj of every graph into the dense scratch (shapes / losses whose kernels have no ragged load stage): one workgroup per graph
+__global__ void __launch_bounds__(256) k_adj_dense(FgwAdj adj, int N) { (void)adj_dense_slice<256>(adj, (int)blockIdx.x, N, (int)threadIdx.x); }
 
 // Backward of the feature half: y = a + (x + shift - mn) * s / r, r = mx - mn, through min() and max() like autograd
 // (the gradient of a full-tensor min/max is split evenly among ties; padded entries absorb their share).
@@ -845,12 +876,15 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d) {
     return (long long)bytes;
 }
 
-int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
-                             const float *init_C, const float *init_Y, int B, int K, int N, int d,
-                             const conan_fgw_params *params, float *Y, float *C, float *T, float *T_iter, int *info,
-                             float *errs, void *workspace, void *stream) {
-    if (!Ys || !Cs || !params || !Y || !C || !T || !info || !errs || !workspace || B <= 0 || K <= 0 || N <= 0 || d <= 0)
+static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
+                        const float *init_C, const float *init_Y, int B, int K, int N, int d,
+                        const conan_fgw_params *params_in, float *Y, float *C, float *T, float *T_iter, int *info,
+                        float *errs, void *workspace, void *stream, FgwAdj adj) {
+    if (!Ys || (!Cs && !adj.rowptr) || !params_in || !Y || !C || !T || !info || !errs || !workspace || B <= 0 || K <= 0 || N <= 0 || d <= 0)
         return CONAN_E_BADARG;
+    conan_fgw_params params_v = *params_in;
+    if (adj.rowptr) params_v.cs_small_int = 1;                          // adjacency counts are small integers by construction
+    const conan_fgw_params *params = &params_v;
     if (params->max_iter <= 0 || params->num_iter_max <= 0) return CONAN_E_BADARG;
     if (params->fixed_features && !init_Y) return CONAN_E_BADARG;      // barycenter.py:70-72
     hipStream_t s = as_stream(stream);
@@ -870,9 +904,21 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
     const bool small = conan_fgw_small_supported(N, d);
     const bool kl = params->loss_fun != 0;
     if (params->loss_fun != 0 && params->loss_fun != 1) return CONAN_E_BADARG;
+    if (adj.rowptr) {
+        // ragged structure: the dense scratch sits behind the regular workspace (conan_fgw_workspace_bytes_ragged).  The kernels with a ragged
+        // load stage are the square-loss ones of the model path (k_fgw_coupling_fast for N <= 64, k_fgw_coupling_big above); any other shape /
+        // loss expands the graphs into the scratch once and continues on the dense path.
+        adj.dense = reinterpret_cast<float *>(static_cast<char *>(workspace) + conan_fgw_workspace_bytes(B, K, N, d));
+        const bool ragged_ok = !kl && (small ? conan_fgw_fast_supported(N, d, 1) : big_lds(N, true) <= LDS_LIMIT);
+        if (!ragged_ok) {
+            k_adj_dense<<<B * K, 256, 0, s>>>(adj, N);
+            Cs = adj.dense;
+            adj.rowptr = nullptr;
+        }
+    }
 
-    if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, init_C, init_Y, active, info, errs, Y, C, s);
-    else k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C);
+    if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, init_C, init_Y, active, info, errs, Y, C, adj, s);
+    else k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C, adj);
     const size_t lc = coupling_lds(N);
     const bool c_lds = lc <= LDS_LIMIT;
     const size_t vec_c = (size_t)((6 + 2 * GEN_NW) * N + 16) * 8;
@@ -885,7 +931,7 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling<M, KLV, GEN_NW, SEC>),                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                  \
         k_fgw_coupling<M, KLV, GEN_NW, SEC><<<GRID, 64 * GEN_NW, lds_bytes, s>>>(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, \
-                                                                              info, sc_c, Ypart, Cpart, only);                      \
+                                                                              info, sc_c, Ypart, Cpart, only, adj);                 \
     } while (0)
 #define CONAN_CPL(M, KLV)                                                                                                           \
     do {                                                                                                                            \
@@ -908,14 +954,14 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW, U8>),                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);                                         \
         k_fgw_coupling_big<GEN_NW, U8><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
-                                                                       Ypart, Cpart, redo);                                          \
+                                                                       Ypart, Cpart, redo, adj);                                     \
     } while (0)
             if (c2b) CONAN_BIG(true); else CONAN_BIG(false);
 #undef CONAN_BIG
             only = redo;
         }
         if (small)
-            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, redo, s);
+            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, redo, adj, s);
         else if (mode == 2) { if (kl) CONAN_CPL(2, true); else CONAN_CPL(2, false); }
         else if (mode == 1) { if (kl) CONAN_CPL(1, true); else CONAN_CPL(1, false); }
         else { if (kl) CONAN_CPL(0, true); else CONAN_CPL(0, false); }
@@ -927,6 +973,29 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
 #undef CONAN_CPL_
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
+}
+
+int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,
+                             const float *init_C, const float *init_Y, int B, int K, int N, int d,
+                             const conan_fgw_params *params, float *Y, float *C, float *T, float *T_iter, int *info,
+                             float *errs, void *workspace, void *stream) {
+    if (!Cs) return CONAN_E_BADARG;
+    return fgw_fwd_impl(Ys, Cs, ps, p, lambdas, init_C, init_Y, B, K, N, d, params, Y, C, T, T_iter, info, errs, workspace, stream,
+                        FgwAdj{nullptr, nullptr, nullptr, nullptr, nullptr});
+}
+
+long long conan_fgw_workspace_bytes_ragged(int B, int K, int N, int d) {
+    const long long w = conan_fgw_workspace_bytes(B, K, N, d);
+    return w <= 0 ? 0 : w + (long long)al256((size_t)B * K * N * N * sizeof(float));
+}
+
+int conan_fgw_barycenter_fwd_ragged(const float *Ys, const int *graph_ptr, const int *rowptr, const int *col, const int *tgt, const float *ps,
+                                    const float *p, const float *lambdas, const float *init_C, const float *init_Y, int B, int K, int N, int d,
+                                    const conan_fgw_params *params, float *Y, float *C, float *T, float *T_iter, int *info, float *errs,
+                                    void *workspace, void *stream) {
+    if (!graph_ptr || !rowptr || !col || !tgt) return CONAN_E_BADARG;
+    return fgw_fwd_impl(Ys, nullptr, ps, p, lambdas, init_C, init_Y, B, K, N, d, params, Y, C, T, T_iter, info, errs, workspace, stream,
+                        FgwAdj{graph_ptr, rowptr, col, tgt, nullptr});
 }
 
 int conan_fgw_barycenter_bwd(const float *T, const float *dY, const float *p, const float *lambdas, int B, int K,
@@ -941,7 +1010,7 @@ int conan_fgw_barycenter_bwd(const float *T, const float *dY, const float *p, co
 
 int conan_fgw_densify(const float *feat, const int *graph_ptr, const int *rowptr, const int *col, int num_graphs,
                       int N, int d, float shift, float a, float b, float *Ys, float *Cs, float *minmax, void *stream) {
-    if (!feat || !graph_ptr || !rowptr || !col || !Ys || !Cs || !minmax || num_graphs <= 0 || N <= 0 || d <= 0) return CONAN_E_BADARG;
+    if (!feat || !graph_ptr || !Ys || !minmax || num_graphs <= 0 || N <= 0 || d <= 0 || (Cs && (!rowptr || !col))) return CONAN_E_BADARG;
     k_densify<<<num_graphs, 256, 0, as_stream(stream)>>>(feat, graph_ptr, rowptr, col, N, d, shift, a, b, Ys, Cs, minmax);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;

@@ -55,6 +55,46 @@ struct FgwDims {
     int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
 };
 
+// The input graphs' structure straight from the ragged neighbour lists ("never materialise [G, N_max, N_max]"): CSR by target
+// over the whole batch + the target of every edge, as the radius-graph kernel leaves them (graph.hip).  Graph g owns the nodes gptr[g] ..
+// gptr[g + 1] - 1 and the edges rowptr[lo] .. rowptr[lo + n] - 1 (n clamped to N like k_densify).  rowptr == nullptr: dense Cs [B,K,N,N].
+// `dense`: [B,K,N,N] fp32 scratch that only the exact second pass (and kernels without a ragged load stage) fill, each workgroup its own slice.
+struct FgwAdj {
+    const int *gptr, *rowptr, *col, *tgt;
+    float *dense;
+};
+// to_dense_adj (schnet_no_sum.py:249; orientation of k_densify: entry [source][target] += 1) of graph g into a ZEROED LDS byte matrix with row
+// pitch P (4-byte aligned): one thread per edge, counts packed four to a word (an entry above 255 would carry: a radius graph has no repeated
+// pair at all).  The caller's barriers bracket it.
+template <int NT>
+__device__ __forceinline__ void adj_scatter_lds_bytes(const FgwAdj &A, int g, int N, int P, unsigned char *m, int tid) {
+    const int lo = A.gptr[g], n = min(A.gptr[g + 1] - lo, N);
+    const int e0 = A.rowptr[lo], e1 = A.rowptr[lo + n];
+    for (int e = e0 + tid; e < e1; e += NT) {
+        const int i = A.tgt[e] - lo, j = A.col[e] - lo;
+        if (i >= 0 && i < N && j >= 0 && j < N) {
+            const unsigned o = (unsigned)(j * P + i);
+            atomicAdd(reinterpret_cast<unsigned *>(m + (o & ~3u)), 1u << (8 * (o & 3u)));
+        }
+    }
+}
+// the same into this workgroup's slice of the dense scratch (global memory; exact second pass only): returns the slice.  Contains barriers.
+template <int NT>
+__device__ __forceinline__ const float *adj_dense_slice(const FgwAdj &A, int g, int N, int tid) {
+    float *dst = A.dense + (size_t)g * N * N;
+    for (int t = tid; t < N * N; t += NT) dst[t] = 0.f;
+    __syncthreads();
+    const int lo = A.gptr[g], n = min(A.gptr[g + 1] - lo, N);
+    const int e0 = A.rowptr[lo], e1 = A.rowptr[lo + n];
+    for (int e = e0 + tid; e < e1; e += NT) {
+        const int i = A.tgt[e] - lo, j = A.col[e] - lo;
+        if (i >= 0 && i < N && j >= 0 && j < N) atomicAdd(&dst[j * N + i], 1.0f);
+    }
+    __threadfence_block();
+    __syncthreads();
+    return dst;
+}
+
 // Uniform fp64 constants of the round-3 coupling kernels, formed on the host: the scalar unit has no fp64 conversions, so the same
 // values derived in the kernel from the fp32 parameters live in VECTOR registers for the whole kernel (the register budgets of
 // those kernels have no room for them).
@@ -788,16 +828,17 @@ __device__ __forceinline__ void mm_lds2(int M, int Nn, int Kd, const TX *__restr
 
 // Launchers of the register-resident path (fgw_small.hip), N <= 64.
 bool conan_fgw_small_supported(int N, int d);
+bool conan_fgw_fast_supported(int N, int d, int small_int);
 size_t conan_fgw_small_part_bytes(int B, int K, int N, int d);
 size_t conan_fgw_part_offset(int B, int K, int N, int d);      // bytes of Ypart + Cpart (16-byte aligned): where the fp64 vectors start
 // (also initialises the molecules: the N <= 64 path launches no k_fgw_init)
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
                              double *Cw, double *Yw, double *zvec, double *yvec, const float *init_C, const float *init_Y, int *active, int *info,
-                             float *errs, float *Yout, float *Cout, hipStream_t s);
+                             float *errs, float *Yout, float *Cout, FgwAdj adj, hipStream_t s);
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
                               const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart, const double *zvec,
-                              const double *yvec, int *redo, hipStream_t s);
+                              const double *yvec, int *redo, FgwAdj adj, hipStream_t s);
 // yvec (nullable): the register-resident path's per-molecule vectors, refreshed after every update
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
                             const fgw_part_t *Ypart, const fgw_part_t *Cpart, double *Cw, double *Yw, int *active, int *info,

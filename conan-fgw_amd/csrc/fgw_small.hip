@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, fgw_part_t *__restrict__ Ypart,
-    fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, const int *__restrict__ only) {
+    fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, const int *__restrict__ only, FgwAdj adj) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // SECOND (the pass behind k_fgw_coupling_fast): a SMALL grid walks all couplings and solves the ones that were handed back (only[]) —
     // an empty pass then costs a few dozen workgroups instead of B * K.  Otherwise: one workgroup per coupling, no loop (inside a loop
@@ -86,7 +86,9 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
     const bool z_lds = (size_t)N * d * sizeof(float) <= (size_t)NP * sizeof(double);
 
     const float *Z = Ys + ((size_t)b * D.K + s) * N * d;
-    const float *C2 = Cs + ((size_t)b * D.K + s) * NN;
+    // (ragged structure: this kernel is then only the exact pass behind k_fgw_coupling_fast, and a flagged coupling expands its graph into its
+    // own slice of the dense scratch first)
+    const float *C2 = adj.rowptr ? adj_dense_slice<FGW_THREADS>(adj, cid, N, tid) : Cs + ((size_t)b * D.K + s) * NN;
     const double *C1 = Cw + (size_t)b * NN;
     const double *Y = Yw + (size_t)b * N * d;
     float *Tg = Tw + ((size_t)b * D.K + s) * NN;
@@ -470,7 +472,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, fgw_part_t *__restrict__ Ypart,
-    fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo) {
+    fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo, FgwAdj adj) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     if (!active[b]) return;
@@ -520,9 +522,11 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     };
     const bool warm = outer > 0 && prm.warmstart;
     const bool stage_yz = d <= 2 * P && !y_zero;                          // Y / Z through LDS for the prologue's dot(Y, Z)
+    // the input graph's structure: dense [N,N] floats, or (C2T = bytes) straight from the ragged neighbour lists (FgwAdj)
+    const bool ragged = sizeof(C2T) == 1 && adj.rowptr != nullptr;
     float c2v[EPT];
 #pragma unroll
-    for (int u = 0; u < EPT; ++u) { const int t = tid + u * FGW_THREADS; c2v[u] = C2[t < NN ? t : NN - 1]; }
+    for (int u = 0; u < EPT; ++u) { const int t = tid + u * FGW_THREADS; c2v[u] = ragged ? 0.f : C2[t < NN ? t : NN - 1]; }
     // C1 (and the warm-start coupling) cannot go to LDS before the dot product has consumed Z, which is staged over C1's storage: they
     // are requested when the product's MFMAs are done (below) instead of being parked in registers across it.
     double c1v[EPT];
@@ -557,6 +561,12 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     if (tid < 64) { pq[tid] = p_own; pq[64 + tid] = q_own; }
     vec4[tid] = vec_own;
     for_entries([&](int u, int o) { C2l[o] = (C2T)c2v[u]; if (!stage_yz) C1l[o] = c1v[u]; });
+    if constexpr (sizeof(C2T) == 1) {
+        if (ragged) {                                                   // (workgroup-uniform) zeros are in place: one thread per edge adds its count
+            __syncthreads();
+            adj_scatter_lds_bytes<FGW_THREADS>(adj, (int)blockIdx.x, N, P, reinterpret_cast<unsigned char *>(C2l), tid);
+        }
+    }
     __syncthreads();
     FGW_PROF(0);      // staging
     const double qj = pq[64 + lane];                                    // b_j with j = lane (layout A)
@@ -793,13 +803,25 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
                                                            double *__restrict__ Yw, double *__restrict__ zvec, double *__restrict__ yvec,
                                                            const float *__restrict__ init_C, const float *__restrict__ init_Y, int max_iter,
                                                            int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs,
-                                                           float *__restrict__ Yout, float *__restrict__ Cout) {
+                                                           float *__restrict__ Yout, float *__restrict__ Cout, FgwAdj adj) {
     const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
     const int N = D.N, d = D.d;
+    // ragged structure (FgwAdj): this graph's adjacency counts as bytes in LDS (N <= 64), built once here; the dense Cs is never read
+    __shared__ __attribute__((aligned(16))) unsigned char cm[64 * 65 + 16];
+    const int Pm = D.P;
+    if (adj.rowptr) {
+        for (int t = threadIdx.x; t < (64 * 65 + 16) / 4; t += 256) reinterpret_cast<unsigned *>(cm)[t] = 0u;
+        __syncthreads();
+        adj_scatter_lds_bytes<256>(adj, (int)blockIdx.x, N, Pm, cm, (int)threadIdx.x);
+        __syncthreads();
+    }
     if (s == 0) {                                                       // (workgroup-uniform)
         const int NN = N * N, Nd = N * d;
         const float *c0 = init_C ? init_C + (size_t)b * NN : Cs + (size_t)b * D.K * NN;      // init_C = Cs[0] (schnet_no_sum.py:303)
-        for (int t = threadIdx.x; t < NN; t += 256) { Cw[(size_t)b * NN + t] = (double)c0[t]; Cout[(size_t)b * NN + t] = c0[t]; }
+        for (int t = threadIdx.x; t < NN; t += 256) {
+            const float cv = (!init_C && adj.rowptr) ? (float)cm[(t / N) * Pm + (t % N)] : c0[t];
+            Cw[(size_t)b * NN + t] = (double)cv; Cout[(size_t)b * NN + t] = cv;
+        }
         for (int t = threadIdx.x; t < Nd; t += 256) {
             const float y = init_Y ? init_Y[(size_t)b * Nd + t] : 0.f;                          // barycenter.py:76-77
             Yw[(size_t)b * Nd + t] = (double)y; Yout[(size_t)b * Nd + t] = y;
@@ -816,7 +838,7 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
     if (j < N) {
         for (int c = sub; c < d; c += 4) { const double v = (double)Z[(size_t)j * d + c]; z2 += v * v; }
         for (int k = sub; k < N; k += 4) {
-            const double c2 = (double)C2[j * N + k], qk = q ? (double)q[k] : 1.0 / (double)N;
+            const double c2 = adj.rowptr ? (double)cm[j * Pm + k] : (double)C2[j * N + k], qk = q ? (double)q[k] : 1.0 / (double)N;
             r2 += qk * (kl ? c2 : c2 * c2);
         }
     }
@@ -938,29 +960,29 @@ size_t conan_fgw_small_part_bytes(int B, int K, int N, int d) {
 
 void conan_fgw_small_prepare(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm,
                              double *Cw, double *Yw, double *zvec, double *yvec, const float *init_C, const float *init_Y, int *active, int *info,
-                             float *errs, float *Yout, float *Cout, hipStream_t s) {
+                             float *errs, float *Yout, float *Cout, FgwAdj adj, hipStream_t s) {
     k_fgw_small_vectors<<<D.B * D.K, 256, 0, s>>>(Ys, Cs, ps, pb, D, prm.loss_fun, Cw, Yw, zvec, yvec, init_C, init_Y, prm.max_iter, active, info,
-                                                 errs, Yout, Cout);
+                                                 errs, Yout, Cout, adj);
 }
 
 template <int R, int MAXT, typename C2T>
 static void launch_fast_t(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm, int outer, int y_zero,
                         const double *Cw, const double *Yw, const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart,
-                        const double *zvec, const double *yvec, int *redo, hipStream_t s) {
+                        const double *zvec, const double *yvec, int *redo, FgwAdj adj, hipStream_t s) {
     const size_t lds = fast_lds<C2T>(D.N).bytes;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_fast<R, MAXT, C2T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     const FastConst fc = fast_const(prm, D.N);
     k_fgw_coupling_fast<R, MAXT, C2T><<<D.B * D.K, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, fc, outer, y_zero, Cw, Yw, active, Tw, info, Ypart,
-                                                                          Cpart, zvec, yvec, redo);
+                                                                          Cpart, zvec, yvec, redo, adj);
 }
 template <int R, typename C2T>
 static void launch_fast(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D, conan_fgw_params prm, int outer, int y_zero,
                         const double *Cw, const double *Yw, const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart,
-                        const double *zvec, const double *yvec, int *redo, hipStream_t s) {
+                        const double *zvec, const double *yvec, int *redo, FgwAdj adj, hipStream_t s) {
     const int tpw = fast_tiles_per_wave(D.N);                          // <= ceil(ceil(4R / 16)^2 / 4)
-#define ARGS Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s
+#define ARGS Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, adj, s
     if constexpr (R <= 6) launch_fast_t<R, 1, C2T>(ARGS);
     else if constexpr (R <= 12) { if (tpw <= 1) launch_fast_t<R, 1, C2T>(ARGS); else launch_fast_t<R, 3, C2T>(ARGS); }
     else { if (tpw <= 1) launch_fast_t<R, 1, C2T>(ARGS); else if (tpw <= 3) launch_fast_t<R, 3, C2T>(ARGS); else launch_fast_t<R, 4, C2T>(ARGS); }
@@ -976,7 +998,7 @@ bool conan_fgw_fast_supported(int N, int d, int small_int) {
 void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps, const float *pb, FgwDims D,
                               conan_fgw_params prm, int outer, int y_zero, const double *Cw, const double *Yw,
                               const int *active, float *Tw, int *info, fgw_part_t *Ypart, fgw_part_t *Cpart, const double *zvec,
-                              const double *yvec, int *redo, hipStream_t s) {
+                              const double *yvec, int *redo, FgwAdj adj, hipStream_t s) {
     const size_t lds = small_lds(D.N, D.d);
     const int R = (D.N + 3) / 4;
     const int grid = D.B * D.K;
@@ -986,8 +1008,8 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
     if (!prm.loss_fun && redo && conan_fgw_fast_supported(D.N, D.d, prm.cs_small_int)) {
 #define FAST(RR)                                                                                                                     \
     do {                                                                                                                             \
-        if (prm.cs_small_int) launch_fast<RR, unsigned char>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s); \
-        else launch_fast<RR, float>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, s);     \
+        if (prm.cs_small_int) launch_fast<RR, unsigned char>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, adj, s); \
+        else launch_fast<RR, float>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, info, Ypart, Cpart, zvec, yvec, redo, adj, s);     \
     } while (0)
         if (R <= 6) FAST(6);
         else if (R <= 9) FAST(9);
@@ -1002,7 +1024,7 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_small<RR, KLV, SEC>),                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
         k_fgw_coupling_small<RR, KLV, SEC><<<GRID, FGW_THREADS, lds, s>>>(Ys, Cs, ps, pb, D, prm, outer, y_zero, Cw, Yw, active, Tw, \
-                                                                info, Ypart, Cpart, zvec, yvec, only);                          \
+                                                                info, Ypart, Cpart, zvec, yvec, only, adj);                     \
     } while (0)
 #define LAUNCH(RR)                                                                                                              \
     do {                                                                                                                        \

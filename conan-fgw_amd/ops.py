@@ -751,15 +751,16 @@ def segment_sum(x: Tensor, graph_ptr: Tensor, num_graphs: int) -> Tensor:
 # ------------------------------------------------------------------------------------------------ FGW barycenter
 class _DensifyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, graph, N, shift, a, b):
+    def forward(ctx, feat, graph, N, shift, a, b, adjacency=True):
         feat = _c(feat)
         G, d = graph.num_graphs, feat.shape[1]
         dev = feat.device
         Ys = torch.empty(G, N, d, dtype=f32, device=dev)
-        Cs = torch.empty(G, N, N, dtype=f32, device=dev)
+        # adjacency=False: features only — the solver reads the structure from the graph's ragged lists (fgw_barycenter_batched(adjacency=graph))
+        Cs = torch.empty(G, N, N, dtype=f32, device=dev) if adjacency else torch.empty(0, dtype=f32, device=dev)
         minmax = torch.empty(G, 2, dtype=f32, device=dev)
         call("conan_fgw_densify", ptr(feat, f32), ptr(graph.graph_ptr), ptr(graph.rowptr), ptr(graph.col), G, N, d, shift, a, b,
-             ptr(Ys), ptr(Cs), ptr(minmax), stream_ptr())
+             ptr(Ys), ptr(Cs) if adjacency else None, ptr(minmax), stream_ptr())
         ctx.save_for_backward(feat, minmax)
         ctx.graph, ctx.args = graph, (N, shift, a, b)
         ctx.mark_non_differentiable(Cs)
@@ -769,19 +770,20 @@ class _DensifyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dYs, _dCs):
         if dYs is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         feat, minmax = ctx.saved_tensors
         N, shift, a, b = ctx.args
         g = ctx.graph
         dfeat = torch.empty_like(feat)
         call("conan_fgw_densify_bwd", ptr(feat), ptr(_c(dYs)), ptr(g.graph_ptr), ptr(minmax), g.num_graphs, N, feat.shape[1],
              shift, a, b, ptr(dfeat), stream_ptr())
-        return dfeat, None, None, None, None, None
+        return dfeat, None, None, None, None, None, None
 
 
-def fgw_densify(feat: Tensor, graph: RadiusGraph, max_nodes: int, shift: float, a: float = 0.1, b: float = 2.0):
-    """to_dense_batch + shift + normalize_tensor per conformer slab, and to_dense_adj (schnet_no_sum.py:242-252)."""
-    return _DensifyFn.apply(feat, graph, max_nodes, float(shift), float(a), float(b))
+def fgw_densify(feat: Tensor, graph: RadiusGraph, max_nodes: int, shift: float, a: float = 0.1, b: float = 2.0, adjacency: bool = True):
+    """to_dense_batch + shift + normalize_tensor per conformer slab, and to_dense_adj (schnet_no_sum.py:242-252).  adjacency=False: the [G,N,N]
+    adjacency tensors are not built (the second result is empty) — pass the graph itself to `fgw_barycenter_batched(adjacency=graph)`."""
+    return _DensifyFn.apply(feat, graph, max_nodes, float(shift), float(a), float(b), bool(adjacency))
 
 
 PROD_FGW = dict(alpha=0.1, epsilon=0.1, max_iter=5, tol=1e-2, inner_tol=1e-4, num_iter_max=5, stop_thr=1e-2,
@@ -791,8 +793,12 @@ PROD_FGW = dict(alpha=0.1, epsilon=0.1, max_iter=5, tol=1e-2, inner_tol=1e-4, nu
 class _FgwBarycenterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Ys, Cs, ps, p, lambdas, init_C, init_Y, params):
-        Ys, Cs = _c(Ys), _c(Cs)
+        adj = params.get("adjacency")             # a RadiusGraph: the input graphs' structure straight from its ragged lists, Cs unused
+        Ys = _c(Ys)
+        Cs = _c(Cs) if adj is None else None
         B, K, N, d = Ys.shape
+        if adj is not None and adj.num_graphs != B * K:
+            raise RuntimeError(f"adjacency graph holds {adj.num_graphs} conformer graphs, Ys holds {B} x {K}")
         dev = Ys.device
         prm = FgwParams(float(params["alpha"]), float(params["epsilon"]), int(params["max_iter"]), float(params["tol"]),
                         float(params["inner_tol"]), int(params["num_iter_max"]), float(params["stop_thr"]),
@@ -804,10 +810,16 @@ class _FgwBarycenterFn(torch.autograd.Function):
         T_iter = torch.empty(prm.max_iter, B, K, N, N, dtype=f32, device=dev) if params.get("keep_iterates") else None
         info = torch.empty(B, 4, dtype=i32, device=dev)
         errs = torch.empty(B, 2, prm.max_iter, dtype=f32, device=dev)
-        ws = torch.empty(int(lib().conan_fgw_workspace_bytes(B, K, N, d)), dtype=torch.uint8, device=dev)
         import ctypes
-        call("conan_fgw_barycenter_fwd", ptr(Ys, f32), ptr(Cs, f32), ptr(ps), ptr(p), ptr(lambdas), ptr(init_C), ptr(init_Y),
-             B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(T_iter), ptr(info), ptr(errs), ptr(ws), stream_ptr())
+        if adj is None:
+            ws = torch.empty(int(lib().conan_fgw_workspace_bytes(B, K, N, d)), dtype=torch.uint8, device=dev)
+            call("conan_fgw_barycenter_fwd", ptr(Ys, f32), ptr(Cs, f32), ptr(ps), ptr(p), ptr(lambdas), ptr(init_C), ptr(init_Y),
+                 B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(T_iter), ptr(info), ptr(errs), ptr(ws), stream_ptr())
+        else:
+            ws = torch.empty(int(lib().conan_fgw_workspace_bytes_ragged(B, K, N, d)), dtype=torch.uint8, device=dev)
+            call("conan_fgw_barycenter_fwd_ragged", ptr(Ys, f32), ptr(adj.graph_ptr, i32), ptr(adj.rowptr, i32), ptr(adj.col, i32), ptr(adj.tgt, i32),
+                 ptr(ps), ptr(p), ptr(lambdas), ptr(init_C), ptr(init_Y), B, K, N, d, ctypes.byref(prm), ptr(Y), ptr(C), ptr(T), ptr(T_iter),
+                 ptr(info), ptr(errs), ptr(ws), stream_ptr())
         ctx.save_for_backward(T, p, lambdas)
         ctx.dims = (B, K, N, d)
         ctx.set_materialize_grads(False)          # C, T, info, errs carry no gradient: without this autograd fills four zero tensors per backward
@@ -833,7 +845,9 @@ def fgw_barycenter_batched(Ys: Tensor, Cs: Tensor, ps: Optional[Tensor] = None, 
                            **params):
     """B independent FGW barycenters.  Ys [B,K,N,d], Cs [B,K,N,N] -> Y [B,N,d], C [B,N,N], T [B,K,N,N], info [B,4], errs [B,2,max_iter]
     (+ T_iter [max_iter,B,K,N,N] with keep_iterates=True: the couplings after every outer iteration, barycenter.py:196).
-    Gradient flows to Ys only (through the final couplings as constants), like the reference."""
+    Gradient flows to Ys only (through the final couplings as constants), like the reference.
+    `adjacency=graph` (a RadiusGraph with B * K conformer graphs, Cs=None): the input structures are to_dense_adj of those graphs, read by the
+    coupling kernels from the ragged neighbour lists — no [B,K,N,N] tensor exists (what the models do)."""
     prm = dict(PROD_FGW)
     prm.update(params)
     opt = lambda t: _c(t) if t is not None else None

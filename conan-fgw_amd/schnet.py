@@ -233,10 +233,10 @@ class SchNetNoSum(torch.nn.Module):
         if max_nodes is None:
             gp = graph.graph_ptr
             max_nodes = int((gp[1:] - gp[:-1]).max().item())                # host sync (to_dense_batch does the same, :242)
-        Ys, Cs = ops.fgw_densify(node_feature, graph, max_nodes, self.FEATURE_SHIFT)       # :242-252 with :41-87
+        Ys, _ = ops.fgw_densify(node_feature, graph, max_nodes, self.FEATURE_SHIFT, adjacency=False)      # (to_dense_adj, :249-252, is read by the solver from the graph's ragged lists)       # :242-252 with :41-87
         N, d = max_nodes, node_feature.shape[1]
-        Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), Cs.view(batch_size, K, N, N), cs_small_int=True)   # :259-306
-        self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs, Ys=Ys, Cs=Cs)
+        Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), None, adjacency=graph)   # :259-306
+        self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs, Ys=Ys)
         F_bary_batch = ops.fgw_readout(Y, K, self.READOUT_MODE)                            # :308-312
         node_out = ops.segment_sum(node_feature, graph.graph_ptr, G) if _want_node_out else None    # :314
         return node_out, F_bary_batch

@@ -244,9 +244,9 @@ class ViSNet(torch.nn.Module):
         if max_nodes is None:
             gp = graph.graph_ptr
             max_nodes = int((gp[1:] - gp[:-1]).max().item())
-        Ys, Cs = ops.fgw_densify(node_feature, graph, max_nodes, self.FEATURE_SHIFT)
+        Ys, _ = ops.fgw_densify(node_feature, graph, max_nodes, self.FEATURE_SHIFT, adjacency=False)      # (to_dense_adj, :249-252, is read by the solver from the graph's ragged lists)
         N, d = max_nodes, node_feature.shape[1]
-        Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), Cs.view(batch_size, K, N, N), cs_small_int=True)
+        Y, C, T, info, errs = ops.fgw_barycenter_batched(Ys.view(batch_size, K, N, d), None, adjacency=graph)
         self.last_fgw = dict(Y=Y, C=C, T=T, info=info, errs=errs)
         return ops.segment_sum(node_feature, graph.graph_ptr, G), ops.fgw_readout(Y, K, self.READOUT_MODE)
 

@@ -440,7 +440,8 @@ int conan_visnet_gate_bwd(const float *u, const float *v2, const float *dxo, con
 /* Glue of _compute_barycenter (schnet_no_sum.py:242-252 with :41-87; visnet.py:168-176 with :32-79):
  * to_dense_batch + shift + normalize_tensor(.,a,b) per conformer slab (min/max over the WHOLE padded [N,d] slab,
  * barycenter.py:393-399) and to_dense_adj.  Ys[G,N,d], Cs[G,N,N] (Cs[g, src, tgt] = multiplicity of edge src->tgt),
- * minmax[G,2] saved for the backward. */
+ * minmax[G,2] saved for the backward.  Cs == NULL: features only (rowptr / col are then unused) — the structure goes to
+ * conan_fgw_barycenter_fwd_ragged as neighbour lists. */
 int conan_fgw_densify(const float *feat, const int *graph_ptr, const int *rowptr, const int *col, int num_graphs,
                       int N, int d, float shift, float a, float b, float *Ys, float *Cs, float *minmax, void *stream);
 /* Backward of the feature half of conan_fgw_densify (autograd through +shift, min(), max() and the affine map). */
@@ -488,6 +489,19 @@ int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, 
                              const float *init_C, const float *init_Y, int B, int K, int N, int d,
                              const conan_fgw_params *params /* (host) */, float *Y, float *C, float *T, float *T_iter,
                              int *info, float *errs, void *workspace, void *stream);
+/* The same solve with the input graphs' structure read straight from the ragged neighbour lists instead of Cs[B,K,N,N] (SURVEY.md 2.2 / 7:
+ * the reference materialises to_dense_adj per conformer, schnet_no_sum.py:249-252; here no [G,N,N] tensor exists): graph g = b * K + s owns the
+ * nodes graph_ptr[g] .. graph_ptr[g+1]-1 and the edges rowptr[lo] .. rowptr[lo+n]-1 of the by-target CSR that conan_radius_graph_csr leaves
+ * (col = source, tgt = target of every edge; n clamped to N as in conan_fgw_densify); structure entry [source][target] = multiplicity of the edge.
+ * The coupling kernels of the model path (square loss; N <= 64, or N > 64 within the LDS budget) build the adjacency counts as bytes in LDS in
+ * their load stage; any other shape / loss, and the exact second pass of a flagged coupling, expand graphs into a scratch behind the regular
+ * workspace (conan_fgw_workspace_bytes_ragged; untouched otherwise).  cs_small_int is implied.  Same outputs, same arithmetic: results equal
+ * conan_fgw_barycenter_fwd on the densified inputs bit for bit. */
+long long conan_fgw_workspace_bytes_ragged(int B, int K, int N, int d);
+int conan_fgw_barycenter_fwd_ragged(const float *Ys, const int *graph_ptr, const int *rowptr, const int *col, const int *tgt, const float *ps,
+                                    const float *p, const float *lambdas, const float *init_C, const float *init_Y, int B, int K, int N, int d,
+                                    const conan_fgw_params *params /* (host) */, float *Y, float *C, float *T, float *T_iter, int *info,
+                                    float *errs, void *workspace, void *stream);
 
 /* dYs[b,s,j,:] = lambdas[s] * sum_i T[b,s,i,j] * (1/p[b,i]) * dY[b,i,:]  — the whole backward of the block given the
  * saved couplings (the reference solves them under torch.no_grad(), barycenter.py:120). */

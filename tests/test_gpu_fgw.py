@@ -375,3 +375,34 @@ def test_massless_nodes_survive_the_exact_second_pass(N, n):
     assert rel(Y.cpu().numpy(), ref["Y"]) < 1e-4 and rel(C.cpu().numpy(), ref["C"]) < 1e-4
     for s in range(K):
         assert rel(log["T"][s].cpu().numpy(), ref["T"][s]) < 1e-3
+
+
+@pytest.mark.parametrize("shape,B,K,kw", [
+    ("esol", 6, 5, {}),                                   # N <= 64: k_fgw_small_vectors + k_fgw_coupling_fast build the adjacency bytes in LDS
+    ("esol", 4, 3, {"epsilon": 2e-4}),                    # ... and flagged couplings expand their graph for the exact second pass
+    ("esol", 3, 4, {"loss_fun": "kl_loss"}),              # a loss without a ragged load stage: graphs expanded once, dense path
+    ("bace", 6, 5, {}),                                   # N > 64: k_fgw_init + k_fgw_coupling_big
+    ("bace", 6, 3, {"epsilon": 2e-4}),
+], ids=["n_le_64", "n_le_64_exact_pass", "kl_dense_fallback", "n_gt_64", "n_gt_64_exact_pass"])
+def test_structure_read_from_the_ragged_neighbour_lists_equals_the_dense_adjacency(shape, B, K, kw):
+    """The models hand the solver the radius graph itself (`adjacency=graph`): no [G,N,N] tensor is built.  The coupling
+    kernels' load stage forms the same adjacency counts from the graph's CSR, so every output equals the solve on `to_dense_adj` bit for
+    bit — including the init_C = Cs[0] start, the iteration counts and the couplings saved for the backward."""
+    b = make_batch(shape, B, K, seed=77)
+    pos = torch.from_numpy(b.pos).to(dev); batch = torch.from_numpy(b.batch).to(dev)
+    gp = ops.graph_ptr_from_batch(batch, b.num_graphs)
+    g = ops.RadiusGraph(pos, gp, b.num_graphs, 10.0 if shape == "esol" else 5.0, 32)
+    N, d = b.max_nodes, 64
+    assert (N <= 64) == (shape == "esol")
+    torch.manual_seed(3)
+    feat = torch.nn.functional.softplus(torch.randn(len(b.z), d, device=dev))
+    Ys, Cs = ops.fgw_densify(feat, g, N, 0.5)
+    Ys2, none = ops.fgw_densify(feat, g, N, 0.5, adjacency=False)
+    assert torch.equal(Ys, Ys2) and none.numel() == 0
+    dense = ops.fgw_barycenter_batched(Ys.view(B, K, N, d), Cs.view(B, K, N, N), cs_small_int=True, **kw)
+    ragged = ops.fgw_barycenter_batched(Ys.view(B, K, N, d), None, adjacency=g, **kw)
+    if "epsilon" in kw:
+        assert int(dense[3][:, 3].max()) & 1, "the shape no longer sends a coupling to the exact pass"
+    for a, r, name in zip(dense, ragged, ("Y", "C", "T", "info", "errs")):
+        assert torch.equal(a, r) or (name == "errs" and torch.equal(torch.nan_to_num(a), torch.nan_to_num(r))), name
+    assert torch.isfinite(ragged[0]).all()
