@@ -275,8 +275,8 @@ def test_training_steps_on_ragged_batches_follow_the_oracle():
         cb = make_batch("esol", B, K, seed=seed); bg = make_bond_graph(cb, seed=seed + 100)
         sets.append(molecules_from_synthetic(cb, bg)); raw.append((cb, bg))
     flat = FlatGradients(m.parameters())
-    opt = torch.optim.SGD(flat.params, lr=0.02, momentum=0.9)
-    opt_ref = torch.optim.SGD(ref.parameters(), lr=0.02, momentum=0.9)
+    opt = torch.optim.SGD(flat.params, lr=1e-6, momentum=0.9)        # (the untrained model predicts O(10): gradients are O(1e3), the steps O(1e-3))
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=1e-6, momentum=0.9)
     p0 = {k: v.detach().clone() for k, v in ref.named_parameters()}
     losses, losses_ref = [], []
     feed = CollatePipeline(DeviceCollator(dev, K, depth=4), sets, prefetch=2)
@@ -290,13 +290,13 @@ def test_training_steps_on_ragged_batches_follow_the_oracle():
         flat.backward(loss)
         flat.all_reduce_mean()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         opt_ref.zero_grad()
         r = ref(t(cb.z), t(cb.pos).double(), t(cb.batch), t(bg.x), t(bg.edge_index), t(bg.edge_attr))
         lr_ = torch.nn.functional.mse_loss(r, t(cb.y)[:, None].double())
         lr_.backward()
         opt_ref.step()
-        losses_ref.append(float(lr_))
+        losses_ref.append(float(lr_.detach()))
     np.testing.assert_allclose(losses, losses_ref, rtol=2e-4)
     gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
     num = sum(float((gp[k].detach().cpu().double() - rp[k].detach()).pow(2).sum()) for k in rp)
