@@ -16,11 +16,7 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd(const float *__restrict__ x,
                                                     float *__restrict__ out, const int *__restrict__ pid) {
     constexpr int F = 128 * VEC;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-#ifdef CF_REVERSE
-    const int lb = (int)gridDim.x - 1 - xcd_contiguous_block(blockIdx.x, gridDim.x);
-#else
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
-#endif
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
     const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
     for (int i = a_lo; i < a_hi; i += 4) {

@@ -54,10 +54,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
-#ifndef CONAN_F2_RING
-#define CONAN_F2_RING 1
-#endif
-constexpr int F2_RING = CONAN_F2_RING;                         // tiles in flight per workgroup (staging registers: 16 + 8 per tile and thread)
+constexpr int F2_RING = 1;                                     // tiles in flight per workgroup beyond the one being stored (staging registers: 16 + 8 per tile and thread; 2 measured no faster)
 constexpr int F2_THREADS = 512, F2_WAVES = 8, F2_F = 128, F2_WS = F2_F + 8, F2_JP = 64, F2_GRID_MAX = 256;
 constexpr int F2_WH_BYTES = 2 * F2_F * F2_WS * 2;            // w2 planes [2][k][WS] fp16
 constexpr int F2_IMG_PLANE = 32 * 256;                         // one plane of a tile image
@@ -276,11 +273,7 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
         F2_PROF(0);            // (loop overhead)
         if (wave >= 4) stage_next();
         F2_PROF(1);            // B: staging
-#ifdef CONAN_F2_NOCOMPUTE
-        if (false) {
-#else
         if (wave < 4) {
-#endif
             const int kb = wave;
             // ---- dx strip: acc[r] = sum_n g[e][n] w2[n][32kb + l31], e = (r&3) + 8(r>>2) + 4h ---------------------------------
             // the three partial products of the fp16 planes accumulate in THREE accumulators (accs[2], accs[3] are free in an A wavefront): back-to-back
@@ -331,11 +324,7 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
                 }
             }
         }
-#ifdef CONAN_F2_NOCOMPUTE
-        else if (false) {
-#else
         else {
-#endif
             // ---- dw2[:, 32kb..] += g^T h1: both operands column-wise out of the row-major images -----------------------------------
             const int kb = wave - 4;
 #pragma unroll
