@@ -474,7 +474,10 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, fgw_part_t *__restrict__ Ypart,
     fgw_part_t *__restrict__ Cpart, const double *__restrict__ zvec, const double *__restrict__ yvec, int *__restrict__ redo, FgwAdj adj) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    // The K workgroups of a molecule read the same C (28 KB), Y and vectors: with the plain numbering they sit on K different XCDs (workgroups are
+    // dealt round-robin) and each pulls its own copy through its own L2.  XCD k takes the k-th contiguous eighth of the couplings instead.
+    const int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int b = cid / D.K, s = cid % D.K;
     if (!active[b]) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N;
@@ -564,7 +567,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     if constexpr (sizeof(C2T) == 1) {
         if (ragged) {                                                   // (workgroup-uniform) zeros are in place: one thread per edge adds its count
             __syncthreads();
-            adj_scatter_lds_bytes<FGW_THREADS>(adj, (int)blockIdx.x, N, P, reinterpret_cast<unsigned char *>(C2l), tid);
+            adj_scatter_lds_bytes<FGW_THREADS>(adj, cid, N, P, reinterpret_cast<unsigned char *>(C2l), tid);
         }
     }
     __syncthreads();
@@ -725,7 +728,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         FGW_PROF(7);  // T store + err
     }
     if (bail) {                                                         // nothing has been written: the launcher re-runs this coupling on the exact path
-        if (tid == 0) { redo[blockIdx.x] = 1; atomicOr(&info[b * 4 + 3], 1); }      // info flag bit 0: a coupling of this molecule took the second pass
+        if (tid == 0) { redo[cid] = 1; atomicOr(&info[b * 4 + 3], 1); }      // info flag bit 0: a coupling of this molecule took the second pass
         return;
     }
     __syncthreads();
@@ -740,7 +743,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             if (j >= N) { j -= N; ++i; }
         }
     }
-    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[blockIdx.x] = 0; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; }
     FGW_PROF(8);      // T -> global
 
     // ---- contributions to the barycenter update while T is resident
