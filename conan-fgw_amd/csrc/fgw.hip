@@ -421,7 +421,9 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     fgw_part_t *__restrict__ Ypart, fgw_part_t *__restrict__ Cpart, int *__restrict__ redo, FgwAdj adj) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
-    const int b = blockIdx.x / D.K, s = blockIdx.x % D.K;
+    // XCD k owns the k-th contiguous eighth of the couplings (see k_fgw_coupling_fast): the K workgroups of a molecule share C in one L2
+    const int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int b = cid / D.K, s = cid % D.K;
     if (!active[b]) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     unsigned char *C2b = reinterpret_cast<unsigned char *>(part + NW * N);      // C2U8: [N,P] adjacency bytes
     double *bad_flag = red + 15;
     static_assert(NW < 15, "red[15] is the range flag");
-    char *gs = scratch + (size_t)blockIdx.x * coupling_scratch_stride(NP);
+    char *gs = scratch + (size_t)cid * coupling_scratch_stride(NP);
     double *Al = reinterpret_cast<double *>(gs) + NP;                     // [N,P] fp64, L2-resident scratch (same carve as k_fgw_coupling)
     double *base = Al + NP;
 
@@ -468,7 +470,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     if constexpr (C2U8) {
         if (ragged) {                                                     // the graph's adjacency counts straight from its neighbour lists (FgwAdj)
             __syncthreads();
-            adj_scatter_lds_bytes<NT>(adj, (int)blockIdx.x, N, P, C2b, tid);
+            adj_scatter_lds_bytes<NT>(adj, cid, N, P, C2b, tid);
             __syncthreads();
         }
     }
@@ -642,12 +644,12 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
         FGW_PROF(7);  // T store + err
     }
     if (bail) {
-        if (tid == 0) { redo[blockIdx.x] = 1; atomicOr(&info[b * 4 + 3], 1); }      // info flag bit 0: a coupling of this molecule took the second pass
+        if (tid == 0) { redo[cid] = 1; atomicOr(&info[b * 4 + 3], 1); }      // info flag bit 0: a coupling of this molecule took the second pass
         return;
     }
     __syncthreads();
     for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Kf[i * P + j]; }
-    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[blockIdx.x] = 0; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; }
     FGW_PROF(8);      // T -> global
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
