@@ -54,7 +54,7 @@ __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict
         float y = init_Y ? init_Y[(size_t)b * Nd + t] : 0.f;                            // barycenter.py:76-77
         Yw[(size_t)b * Nd + t] = (double)y; Yout[(size_t)b * Nd + t] = y;
     }
-    if (threadIdx.x == 0) { active[b] = 1; info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
+    if (threadIdx.x == 0) { fgw_active_init(active, D.B, b); info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
     for (int t = threadIdx.x; t < 2 * max_iter; t += blockDim.x) errs[(size_t)b * 2 * max_iter + t] = __builtin_nanf("");
 }
 
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     constexpr int NT = 64 * NW;
     auto solve = [&](const int cid) {
     const int b = cid / D.K, s = cid % D.K;
-    if (!active[b]) return;
+    if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
     // XCD k owns the k-th contiguous eighth of the couplings (see k_fgw_coupling_fast): the K workgroups of a molecule share C in one L2
     const int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int b = cid / D.K, s = cid % D.K;
-    if (!active[b]) return;
+    if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -871,7 +871,7 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d) {
     size_t bytes = 0;
     bytes += al256((size_t)B * NN * 8);               // Cw          (every region starts 256-byte aligned)
     bytes += al256((size_t)B * N * d * 8);            // Yw
-    bytes += al256((size_t)B * 4);                    // active
+    bytes += al256((size_t)B * 16);                   // active: [parity][features | structure][B] (fgw_active)
     bytes += al256((size_t)B * K * coupling_scratch_stride(NP));    // coupling scratch (global mode)
     bytes += al256((size_t)B * NP * 16);              // update scratch (global mode)
     bytes += conan_fgw_small_part_bytes(B, K, N, d);   // per-graph update contributions (register-resident path)
@@ -895,7 +895,7 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
     char *w = static_cast<char *>(workspace);
     double *Cw = reinterpret_cast<double *>(w); w += al256((size_t)B * NN * 8);
     double *Yw = reinterpret_cast<double *>(w); w += al256((size_t)B * N * d * 8);
-    int *active = reinterpret_cast<int *>(w); w += al256((size_t)B * 4);
+    int *active = reinterpret_cast<int *>(w); w += al256((size_t)B * 16);
     char *sc_c = w; w += al256((size_t)B * K * coupling_scratch_stride(NP));
     w += al256((size_t)B * NP * 16);        // (reserved)
     fgw_part_t *Ypart = reinterpret_cast<fgw_part_t *>(w);
@@ -946,6 +946,9 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
     const size_t lb = big_lds(N, c2b);
     const bool big = !small && !kl && lb <= LDS_LIMIT;
     const FastConst fc = fast_const(*params, N);
+    // N <= 64: the update kernel forms the feature contributions T_s Z_s itself (fgw_small.hip); the coupling kernels then skip that product
+    const bool y_from_t = small && !params->fixed_features && conan_fgw_update_chunk(K, N, d, B) > 0;
+    fgw_part_t *Ypart_c = y_from_t ? nullptr : Ypart;
     for (int outer = 0; outer < params->max_iter; ++outer) {
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         const int *only = nullptr;
@@ -963,13 +966,13 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
             only = redo;
         }
         if (small)
-            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart, Cpart, zvec, yvec, redo, adj, s);
+            conan_fgw_small_coupling(Ys, Cs, ps, p, D, *params, outer, y_zero, Cw, Yw, active, T, info, Ypart_c, Cpart, zvec, yvec, redo, adj, s);
         else if (mode == 2) { if (kl) CONAN_CPL(2, true); else CONAN_CPL(2, false); }
         else if (mode == 1) { if (kl) CONAN_CPL(1, true); else CONAN_CPL(1, false); }
         else { if (kl) CONAN_CPL(0, true); else CONAN_CPL(0, false); }
         if (T_iter)      // log["Ts_iter"] (barycenter.py:196): a snapshot per outer iteration, only when the caller asks for the log
             (void)hipMemcpyAsync(T_iter + (size_t)outer * B * K * NN, T, (size_t)B * K * NN * sizeof(float), hipMemcpyDeviceToDevice, s);
-        conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, small ? yvec : nullptr, s);
+        conan_fgw_small_update(p, lambdas, D, *params, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Y, C, small ? yvec : nullptr, y_from_t ? T : nullptr, y_from_t ? Ys : nullptr, s);
     }
 #undef CONAN_CPL
 #undef CONAN_CPL_

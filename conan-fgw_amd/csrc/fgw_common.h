@@ -41,7 +41,8 @@ static __device__ long long g_fgw_prof[32];            // one copy per translati
 constexpr int FGW_THREADS = 256;
 constexpr int FGW_WAVES = FGW_THREADS / 64;
 
-// Per-graph contributions to the barycenter update (T_s Z_s and T_s C_s T_s^T, summed over s by k_fgw_update_parts).  fp64: they are the
+// Per-graph contributions to the barycenter update (T_s Z_s — N > 64 only: the N <= 64 update kernel forms it from T itself — and T_s C_s T_s^T,
+// summed over s by k_fgw_update_parts).  fp64: they are the
 // largest HBM streams of a solve (41 MB written + 41 MB read per outer iteration at cfg2), but as fp32 (measured: coupling launch
 // 132.3 -> 130.8 us, update 16.3 -> 15.3 us) their rounding — 6e-8 relative per outer iteration — is amplified by the scheme like every
 // other perturbation: tests/test_gpu_fgw.py::test_large_graphs_vs_oracle[64-2-16] moved from < 1e-4 to 1.6e-4 of the fp64 reference on
@@ -54,6 +55,15 @@ __host__ __device__ inline int fgw_pitch(int N) { return N | 1; }
 struct FgwDims {
     int B, K, N, d, P;      // P = row pitch of the LDS/scratch matrices (odd => conflict-free column access)
 };
+
+// "Molecule b still moves" flags of the outer loop (barycenter.py:112): [parity of the outer iteration][features | structure][B] ints.  The update
+// kernel of iteration o writes the flags of parity o & 1 — one from each of the molecule's two workgroups — and everything that runs in iteration
+// o (coupling kernels, the update itself) reads the flags of iteration o - 1, i.e. parity (o + 1) & 1; the init kernels raise parity 1.
+__device__ __forceinline__ bool fgw_active(const int *__restrict__ active, int B, int b, int outer) {
+    const int *a = active + ((outer + 1) & 1) * 2 * B;
+    return (a[b] | a[B + b]) != 0;
+}
+__device__ __forceinline__ void fgw_active_init(int *__restrict__ active, int B, int b) { active[2 * B + b] = 1; active[3 * B + b] = 1; }
 
 // The input graphs' structure straight from the ragged neighbour lists ("never materialise [G, N_max, N_max]"): CSR by target
 // over the whole batch + the target of every edge, as the radius-graph kernel leaves them (graph.hip).  Graph g owns the nodes gptr[g] ..
@@ -842,4 +852,5 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
 // yvec (nullable): the register-resident path's per-molecule vectors, refreshed after every update
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
                             const fgw_part_t *Ypart, const fgw_part_t *Cpart, double *Cw, double *Yw, int *active, int *info,
-                            float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s);
+                            float *errs, float *Yout, float *Cout, double *yvec, const float *Tw, const float *Ys, hipStream_t s);
+int conan_fgw_update_chunk(int K, int N, int d, int B);

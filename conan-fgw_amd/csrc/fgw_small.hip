@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
     // the optimiser hoists the body's invariants and the kernel spills).
     auto solve = [&](const int cid) {
     const int b = cid / D.K, s = cid % D.K;
-    if (!active[b]) return;
+    if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
     FGW_PROF(8);      // T -> global
 
     // ---- contributions to the barycenter update while T is resident
-    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
+    if (!prm.fixed_features && Ypart) {                                 // Ypart = T @ Z (utils.py:90-95); nullptr: the update kernel forms it from T itself
         fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
         if (z_lds) {                                                    // G's storage is idle again: Z through LDS, one coalesced pass
             const int Nd = N * d;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     // dealt round-robin) and each pulls its own copy through its own L2.  XCD k takes the k-th contiguous eighth of the couplings instead.
     const int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int b = cid / D.K, s = cid % D.K;
-    if (!active[b]) return;
+    if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     FGW_PROF(8);      // T -> global
 
     // ---- contributions to the barycenter update while T is resident
-    if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
+    if (!prm.fixed_features && Ypart) {                                 // Ypart = T @ Z (utils.py:90-95); nullptr: the update kernel forms it from T itself
         fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
         if (yz_lds) {                                                   // C1 is dead: Z through its storage, one coalesced pass
             const int Nd = N * d;
@@ -781,20 +781,22 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
 // LPI = NT / 64 lanes per index (N <= 64), strided partial sums combined by xor-shuffles: a fixed order, bitwise reproducible.
 template <int NT>
 __device__ __forceinline__ void molecule_vectors(const double *__restrict__ Y, const double *__restrict__ C, const float *__restrict__ p, int N,
-                                                 int d, bool kl, double *__restrict__ out) {
+                                                 int d, bool kl, double *__restrict__ out, int which = 2) {      // which: 0 = |y|^2 only, 1 = r1 only, 2 = both
     constexpr int LPI = NT / 64;
     const int i = (int)threadIdx.x / LPI, sub = (int)threadIdx.x % LPI;
     double y2 = 0.0, r1 = 0.0;
     if (i < N) {
-        for (int c = sub; c < d; c += LPI) { const double v = Y[(size_t)i * d + c]; y2 += v * v; }
-        for (int k = sub; k < N; k += LPI) {
-            const double c1 = C[i * N + k], pk = p ? (double)p[k] : 1.0 / (double)N;
-            r1 += (kl ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * pk;
-        }
+        if (which != 1)
+            for (int c = sub; c < d; c += LPI) { const double v = Y[(size_t)i * d + c]; y2 += v * v; }
+        if (which != 0)
+            for (int k = sub; k < N; k += LPI) {
+                const double c1 = C[i * N + k], pk = p ? (double)p[k] : 1.0 / (double)N;
+                r1 += (kl ? c1 * log(c1 + 1e-15) - c1 : c1 * c1) * pk;
+            }
     }
 #pragma unroll
     for (int o = 1; o < LPI; o <<= 1) { y2 += __shfl_xor(y2, o, 64); r1 += __shfl_xor(r1, o, 64); }
-    if (i < N && sub == 0) { out[i] = y2; out[N + i] = r1; }
+    if (i < N && sub == 0) { if (which != 1) out[i] = y2; if (which != 0) out[N + i] = r1; }
 }
 
 // One workgroup per (molecule, input graph): the static vectors |z_j|^2 and r2_j = sum_k q_k f2(C2[j,k]) (f2(b) = b^2, or b for kl),
@@ -829,7 +831,7 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
             const float y = init_Y ? init_Y[(size_t)b * Nd + t] : 0.f;                          // barycenter.py:76-77
             Yw[(size_t)b * Nd + t] = (double)y; Yout[(size_t)b * Nd + t] = y;
         }
-        if (threadIdx.x == 0) { active[b] = 1; info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
+        if (threadIdx.x == 0) { fgw_active_init(active, D.B, b); info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
         for (int t = threadIdx.x; t < 2 * max_iter; t += 256) errs[(size_t)b * 2 * max_iter + t] = __builtin_nanf("");
         __syncthreads();                                                // Cw / Yw of this molecule are read back below (same workgroup)
     }
@@ -853,54 +855,137 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
         molecule_vectors<256>(Yw + (size_t)b * N * d, Cw + (size_t)b * N * N, pb ? pb + (size_t)b * N : nullptr, N, d, kl != 0, yvec + (size_t)b * 2 * N);
 }
 
-// Barycenter update from the per-graph contributions: elementwise, one workgroup per molecule.
-constexpr int UPD_THREADS = 1024;       // the kernel is a few dependent L2 round trips per molecule: more threads, fewer trips each
+// Barycenter update from the per-graph contributions (utils.py:67-95, barycenter.py:112).  TWO workgroups per molecule (round 4), because the two
+// halves share nothing: block b updates the FEATURES Y (and |y_i|^2), block B + b the STRUCTURE C (and r1_i); each logs its own error and raises
+// its own "still moving" flag.  A molecule is active in outer iteration o + 1 if either flag of iteration o is set (fgw_active): the flags are
+// double-buffered by the parity of the outer iteration, so that a workgroup of iteration o never reads a flag its sibling is writing.
+//
+// Y_FROM_T (the N <= 64 path): the feature contributions T_s Z_s are formed HERE, from the couplings the coupling kernels wrote and the input
+// features, instead of being written as fp64 [N,d] matrices by every coupling workgroup and read back: that product was the largest phase of
+// k_fgw_coupling_fast (23 of 124 us per workgroup and launch: Z fetched a second time at the kernel's tail, behind its own stores, 17 KB of fp64
+// results per coupling) and 2 x 21.6 MB of traffic per launch at cfg2.  `chunk` graphs at a time are staged in LDS (T_s, Z_s as fp32: 12.8 KB per
+// graph at N = 33, d = 64); a wavefront owns one padded 16 x 16 output tile per round and sums the graphs' products (fp64 MFMA, the same
+// converted operands as in the coupling kernel) in registers in the order s = 0 .. K - 1.
+constexpr int UPD_THREADS = 512;        // eight wavefronts: with <= 102 VGPRs the two halves of a molecule are resident on one CU together
+template <bool Y_FROM_T>
 __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
     const float *__restrict__ pb, const float *__restrict__ lambdas, FgwDims D, conan_fgw_params prm, int outer,
     const fgw_part_t *__restrict__ Ypart, const fgw_part_t *__restrict__ Cpart, double *__restrict__ Cw, double *__restrict__ Yw,
     int *__restrict__ active, int *__restrict__ info, float *__restrict__ errs, float *__restrict__ Yout, float *__restrict__ Cout,
-    double *__restrict__ yvec) {
+    double *__restrict__ yvec, const float *__restrict__ Tw, const float *__restrict__ Ys, int chunk) {
     __shared__ double red[UPD_THREADS / 64 + 1];
-    const int b = blockIdx.x;
-    if (!active[b]) return;
+    extern __shared__ __attribute__((aligned(16))) char usmem[];
+    const int part = (int)blockIdx.x >= D.B ? 1 : 0;                    // 0: features, 1: structure
+    const int b = (int)blockIdx.x - part * D.B;
     const int N = D.N, d = D.d, K = D.K, NN = N * N, Nd = N * d;
     const int tid = threadIdx.x;
-    double ef2 = 0.0, es2 = 0.0;
-    // The K contributions of U consecutive elements per thread are requested together (K * U loads in flight): the kernel is a
-    // handful of L2 round trips per molecule, so its time is the number of dependent trips, not the byte count.
+    int *flag_out = active + (outer & 1) * 2 * D.B + part * D.B + b;
+    if (!fgw_active(active, D.B, b, outer)) {                           // converged earlier: stays converged
+        if (tid == 0) *flag_out = 0;
+        return;
+    }
     constexpr int U = 4;
-    if (!prm.fixed_features) {
-        double *Yb = Yw + (size_t)b * Nd;
-        for (int t0 = tid; t0 < Nd; t0 += U * UPD_THREADS) {
-            double acc[U], old[U];
+    double e2 = 0.0;
+    if (part == 0) {
+        if (!prm.fixed_features) {
+            double *Yb = Yw + (size_t)b * Nd;
+            if constexpr (Y_FROM_T) {
+                float *Tl = reinterpret_cast<float *>(usmem), *Zl = Tl + (size_t)chunk * NN;
+                const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+                const int Mq = (N + 15) >> 4, Nq = (d + 15) >> 4;
+                constexpr int NWU = UPD_THREADS / 64, TW = 2;                          // two padded 16 x 16 output tiles per wavefront and round: one round up to N = 64, d = 64
+                for (int t0 = 0; t0 < Mq * Nq; t0 += NWU * TW) {
+                    int ti0[TW], tj0[TW], tic[TW], tjc[TW];
+                    bool mine[TW];                                                  // (wave-uniform)
+                    f64x4 sum[TW];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = t0 + u * UPD_THREADS;
-                acc[u] = 0.0; old[u] = 0.0;
-                if (t < Nd) {
-                    old[u] = Yb[t];
-                    for (int s = 0; s < K; ++s) {
-                        const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
-                        const int i = t / d;
-                        const double pw = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
-                        const double pinv = pw > 0.0 ? 1.0 / pw : 0.0;       // a node without mass (fgw.py embeds n != N problems with such nodes) keeps a zero row
-                        acc[u] += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;          // utils.py:94
+                    for (int w = 0; w < TW; ++w) {
+                        const int t = t0 + wave + w * NWU;
+                        mine[w] = t < Mq * Nq;
+                        ti0[w] = mine[w] ? (t / Nq) << 4 : 0; tj0[w] = mine[w] ? (t % Nq) << 4 : 0;
+                        tic[w] = min(ti0[w] + li, N - 1); tjc[w] = min(tj0[w] + li, d - 1);      // clamped: outputs beyond N / d are not stored
+                        sum[w] = f64x4{0.0, 0.0, 0.0, 0.0};
+                    }
+                    for (int s0 = 0; s0 < K; s0 += chunk) {
+                        const int cs = min(chunk, K - s0);
+                        __syncthreads();                                            // the previous stage is consumed
+                        const float *tg = Tw + ((size_t)b * K + s0) * NN, *zg = Ys + ((size_t)b * K + s0) * Nd;
+                        // (every load of a batch is requested before the first LDS store: one memory round trip per batch, not one per element)
+                        auto stage = [&](const float *__restrict__ src, float *dst, int n) {
+                            constexpr int SB = 12;
+                            for (int base = 0; base < n; base += SB * UPD_THREADS) {
+                                float v[SB];
+#pragma unroll
+                                for (int u = 0; u < SB; ++u) { const int q = base + u * UPD_THREADS + tid; v[u] = src[q < n ? q : n - 1]; }
+#pragma unroll
+                                for (int u = 0; u < SB; ++u) { const int q = base + u * UPD_THREADS + tid; if (q < n) dst[q] = v[u]; }
+                            }
+                        };
+                        stage(tg, Tl, cs * NN);
+                        stage(zg, Zl, cs * Nd);
+                        __syncthreads();
+#pragma unroll
+                        for (int w = 0; w < TW; ++w)
+                            if (mine[w])
+                                for (int q = 0; q < cs; ++q) {
+                                    const double lam = lambdas ? (double)lambdas[s0 + q] : 1.0 / (double)K;
+                                    const f64x4 r = mm2_tile<0, false>(Tl + (size_t)q * NN + tic[w] * N + lk, Zl + (size_t)q * Nd + lk * d + tjc[w], d, N, lk);
+                                    sum[w] = sum[w] + lam * r;                      // utils.py:94, s = 0 .. K - 1
+                                }
+                    }
+#pragma unroll
+                    for (int w = 0; w < TW; ++w) {
+                        const int jb = tj0[w] + li;
+                        if (mine[w] && jb < d) {
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                const int i = ti0[w] + lk + 4 * qq;
+                                if (i < N) {
+                                    const double pw = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+                                    const double yn = sum[w][qq] * (pw > 0.0 ? 1.0 / pw : 0.0);      // a node without mass (fgw.py embeds n != N problems with such nodes) keeps a zero row
+                                    const double df = yn - Yb[i * d + jb];
+                                    e2 += df * df;
+                                    Yb[i * d + jb] = yn;
+                                    Yout[(size_t)b * Nd + i * d + jb] = (float)yn;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                // The K contributions of U consecutive elements per thread are requested together (K * U loads in flight): the kernel is a
+                // handful of L2 round trips per molecule, so its time is the number of dependent trips, not the byte count.
+                for (int t0 = tid; t0 < Nd; t0 += U * UPD_THREADS) {
+                    double acc[U], old[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int t = t0 + u * UPD_THREADS;
+                        acc[u] = 0.0; old[u] = 0.0;
+                        if (t < Nd) {
+                            old[u] = Yb[t];
+                            for (int s = 0; s < K; ++s) {
+                                const double lam = lambdas ? (double)lambdas[s] : 1.0 / (double)K;
+                                const int i = t / d;
+                                const double pw = pb ? (double)pb[(size_t)b * N + i] : 1.0 / (double)N;
+                                const double pinv = pw > 0.0 ? 1.0 / pw : 0.0;       // a node without mass keeps a zero row
+                                acc[u] += lam * Ypart[((size_t)b * K + s) * Nd + t] * pinv;          // utils.py:94
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int t = t0 + u * UPD_THREADS;
+                        if (t < Nd) {
+                            const double df = acc[u] - old[u];
+                            e2 += df * df;
+                            Yb[t] = acc[u];
+                            Yout[(size_t)b * Nd + t] = (float)acc[u];
+                        }
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = t0 + u * UPD_THREADS;
-                if (t < Nd) {
-                    const double df = acc[u] - old[u];
-                    ef2 += df * df;
-                    Yb[t] = acc[u];
-                    Yout[(size_t)b * Nd + t] = (float)acc[u];
-                }
-            }
         }
-    }
-    if (!prm.fixed_structure) {
+    } else if (!prm.fixed_structure) {
         double *Cb = Cw + (size_t)b * NN;
         for (int t0 = tid; t0 < NN; t0 += U * UPD_THREADS) {
             double acc[U], old[U];
@@ -925,22 +1010,20 @@ __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
                     const double pj = pb ? (double)pb[(size_t)b * N + j] : 1.0 / (double)N;
                     const double cn = pi * pj > 0.0 ? (prm.loss_fun ? exp(acc[u] / (pi * pj)) : acc[u] / (pi * pj)) : 0.0;     // :72-73 / :86-87 (massless nodes: zero)
                     const double df = cn - old[u];
-                    es2 += df * df;
+                    e2 += df * df;
                     Cb[t] = cn;
                     Cout[(size_t)b * NN + t] = (float)cn;
                 }
             }
         }
     }
-    const double ef = sqrt(block_sum_d<UPD_THREADS / 64>(ef2, red));       // (its barriers also publish Yb / Cb to the whole workgroup)
-    const double es = sqrt(block_sum_d<UPD_THREADS / 64>(es2, red));
+    const double err = sqrt(block_sum_d<UPD_THREADS / 64>(e2, red));       // (its barriers also publish Yb / Cb to the whole workgroup)
     if (yvec) molecule_vectors<UPD_THREADS>(Yw + (size_t)b * Nd, Cw + (size_t)b * NN, pb ? pb + (size_t)b * N : nullptr, N, d, prm.loss_fun != 0,
-                                            yvec + (size_t)b * 2 * N);
+                                            yvec + (size_t)b * 2 * N, part);
     if (tid == 0) {
-        errs[((size_t)b * 2 + 0) * prm.max_iter + outer] = (float)ef;
-        errs[((size_t)b * 2 + 1) * prm.max_iter + outer] = (float)es;
-        info[b * 4 + 0] = outer + 1;
-        active[b] = (ef > (double)prm.tol || es > (double)prm.tol) ? 1 : 0;           // barycenter.py:112
+        errs[((size_t)b * 2 + part) * prm.max_iter + outer] = (float)err;  // err_feature / err_structure
+        info[b * 4 + 0] = outer + 1;                                       // (both halves write the same value)
+        *flag_out = err > (double)prm.tol ? 1 : 0;                         // barycenter.py:112: the loop continues while either error exceeds tol
     }
 }
 
@@ -1054,6 +1137,26 @@ void conan_fgw_small_coupling(const float *Ys, const float *Cs, const float *ps,
 
 void conan_fgw_small_update(const float *pb, const float *lambdas, FgwDims D, conan_fgw_params prm, int outer,
                             const fgw_part_t *Ypart, const fgw_part_t *Cpart, double *Cw, double *Yw, int *active, int *info,
-                            float *errs, float *Yout, float *Cout, double *yvec, hipStream_t s) {
-    k_fgw_update_parts<<<D.B, UPD_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout, yvec);
+                            float *errs, float *Yout, float *Cout, double *yvec, const float *Tw, const float *Ys, hipStream_t s) {
+    // Tw / Ys given: the feature contributions are formed in this kernel from the couplings (conan_fgw_update_chunk > 0; the coupling kernels were
+    // then launched with Ypart = nullptr)
+    const int chunk = Tw ? conan_fgw_update_chunk(D.K, D.N, D.d, D.B) : 0;
+    if (chunk > 0) {
+        const size_t lds = (size_t)chunk * ((size_t)D.N * D.N + (size_t)D.N * D.d) * 4;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_update_parts<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_fgw_update_parts<true><<<2 * D.B, UPD_THREADS, lds, s>>>(pb, lambdas, D, prm, outer, nullptr, Cpart, Cw, Yw, active, info, errs, Yout, Cout, yvec, Tw, Ys, chunk);
+    } else {
+        k_fgw_update_parts<false><<<2 * D.B, UPD_THREADS, 0, s>>>(pb, lambdas, D, prm, outer, Ypart, Cpart, Cw, Yw, active, info, errs, Yout, Cout, yvec, nullptr, nullptr, 0);
+    }
+}
+
+// graphs per LDS stage of the update kernel's own T_s Z_s products (0: not on that path — N > 64, or one graph does not fit)
+int conan_fgw_update_chunk(int K, int N, int d, int B) {
+    if (N > 64) return 0;
+    // two workgroups per CU (the molecule's two halves run side by side) — unless the launch has no more workgroups than the chip has CUs
+    const size_t per = ((size_t)N * N + (size_t)N * d) * 4, budget = (2 * B <= 256 ? 144 : 72) * 1024;
+    if (per > budget) return 0;
+    const int c = (int)(budget / per);
+    return c < K ? c : K;
 }
