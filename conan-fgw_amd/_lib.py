@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libconan_fgw_hip.so")
 _LIB = None
-ABI_VERSION = 3            # == CONAN_FGW_ABI_VERSION of include/conan_fgw_hip.h (tests/test_abi.py compares the two)
+ABI_VERSION = 4            # == CONAN_FGW_ABI_VERSION of include/conan_fgw_hip.h (tests/test_abi.py compares the two)
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 
@@ -99,7 +99,7 @@ SIGNATURES = {
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
-    "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     "conan_cfconv_bwd_w_pairs": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, _P]),
     "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_float, _P, _P]),
     "conan_segment_sum_fwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
@@ -212,7 +212,19 @@ def ptr(t, dtype=None):
     return t.data_ptr()
 
 
+_TRACE = None      # optional callable(name, fn, args) -> rc wrapped around EVERY entry-point call (bench.py / tools: per-entry-point HIP-event brackets)
+
+
+def set_call_trace(fn):
+    """Install (or, with None, remove) a wrapper around every C-ABI call of this process: `fn(name, cfunc, args)` must call `cfunc(*args)` and
+    return its result.  Every module binds `call` by name at import, so the hook lives inside the function, not in a module attribute."""
+    global _TRACE
+    prev, _TRACE = _TRACE, fn
+    return prev
+
+
 def call(name: str, *args):
-    rc = getattr(lib(), name)(*args)
+    fn = getattr(lib(), name)
+    rc = fn(*args) if _TRACE is None else _TRACE(name, fn, args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -93,8 +93,11 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd_generic(const float *__restr
 __global__ void __launch_bounds__(256) k_cfconv_bwd_x128(const float *__restrict__ W, const float *__restrict__ dout,
                                                          const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                          const int *__restrict__ tgt, int num_atoms, float *__restrict__ dx,
-                                                         const int *__restrict__ pid) {
+                                                         const int *__restrict__ pid, float *__restrict__ zero_slot) {
     constexpr int F = 128;
+    // zero_slot: the max |g| word that the NEXT kernel of this backward (k_cfconv_bwd_wp128, same stream) raises with atomicMax — cleared here,
+    // by a kernel that is launched anyway, instead of by a fill launch of its own (and fresh on every backward pass, captured or not)
+    if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
@@ -135,7 +138,8 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_x128(const float *__restrict
 __global__ void __launch_bounds__(256) k_cfconv_bwd_x(const float *__restrict__ W, const float *__restrict__ dout,
                                                       const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
                                                       const int *__restrict__ tgt, int num_atoms, int F, float *__restrict__ dx,
-                                                      const int *__restrict__ pid) {
+                                                      const int *__restrict__ pid, float *__restrict__ zero_slot) {
+    if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;      // see k_cfconv_bwd_x128
     const int lane = threadIdx.x & 63;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
@@ -280,14 +284,17 @@ int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const in
 }
 
 int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt,
-                       const int *pid, int num_atoms, int num_filters, float *dx, void *stream) {
+                       const int *pid, int num_atoms, int num_filters, float *dx, float *zero_slot, void *stream) {
     if (!W || !dout || !t_rowptr || !t_eid || !tgt || !dx || num_atoms < 0 || num_filters <= 0 || (num_filters & 3)) return CONAN_E_BADARG;
-    if (num_atoms == 0) return CONAN_OK;
+    if (num_atoms == 0) {
+        if (zero_slot && hipMemsetAsync(zero_slot, 0, sizeof(float), as_stream(stream)) != hipSuccess) return CONAN_E_LAUNCH;
+        return CONAN_OK;
+    }
     int blocks = (num_atoms + 3) / 4;
     if (blocks > 65536) blocks = 65536;
     blocks = round_up8(blocks);
-    if (num_filters == 128) k_cfconv_bwd_x128<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, dx, pid);
-    else k_cfconv_bwd_x<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, num_filters, dx, pid);
+    if (num_filters == 128) k_cfconv_bwd_x128<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, dx, pid, zero_slot);
+    else k_cfconv_bwd_x<<<blocks, 256, 0, as_stream(stream)>>>(W, dout, t_rowptr, t_eid, tgt, num_atoms, num_filters, dx, pid, zero_slot);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

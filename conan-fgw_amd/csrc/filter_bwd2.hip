@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(F2_THREADS, 1) k_filter_bwd2(const float *__re
         if (wave >= 4) {
             const int e0 = (max(pt, 0) << 5) + 16 * b_s2 + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r.dv[j] = dist[min(e0 + (j & 3) + 8 * (j >> 2), M - 1)];
+            for (int j = 0; j < 8; ++j) r.dv[j] = dist[max(min(e0 + (j & 3) + 8 * (j >> 2), M - 1), 0)];      // (M == 0: a batch without pairs reads dist[0], unused)
         }
     };
     auto store_rows = [&](int buf, const Rows &r) {

@@ -133,6 +133,8 @@ class GATBased(nn.Module):
         h = self.gat_conv1(x, graph, edge_attr)
         h = self.gat_conv2(h, graph, edge_attr)
         if num_graphs is None:
+            num_graphs = ops.batch_hints(batch)[0]                     # DeviceCollator's host-known count
+        if num_graphs is None:
             num_graphs = int(batch.max().item()) + 1                   # host sync, as inside PyG's SumAggregation
         gp = ops.graph_ptr_from_batch(batch, num_graphs)
         return ops.segment_sum(h, gp, num_graphs)                      # self.node_aggregation(h, batch)

@@ -100,6 +100,13 @@ def empty_rows(rows: int, width: int, device, m_dev: Optional[Tensor]) -> Tensor
     return t
 
 
+def batch_hints(batch: Optional[Tensor]):
+    """(num_graphs, max_nodes) that DeviceCollator attached to the node -> graph index tensor it produced (host-known from the item sizes), or
+    (None, None): a caller that passes no size arguments — the reference's call shape — then needs no device -> host read to size anything."""
+    h = getattr(batch, "_conan_hints", None) if batch is not None else None
+    return h if h is not None else (None, None)
+
+
 def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
     batch = _c(batch)
     out = torch.empty(num_graphs + 1, dtype=i32, device=batch.device)
@@ -690,24 +697,23 @@ class _CFConvFn(torch.autograd.Function):
         dout = _c(dout)
         dx = dW = None
         F = x.shape[1]
+        # max |dW| of the pair gradient (F = 128): one device float per CFConv backward, raised by conan_cfconv_bwd_w_pairs with atomicMax.  It is
+        # cleared by the dx kernel that runs right before it on this stream (zero_slot) — fresh on every backward pass, no fill launch, and
+        # nothing lives on the graph object (round 4 kept a zeroed pool there: stale once a graph object outlived one backward).
+        want_gmax = ctx.needs_input_grad[1] and ctx.pairs and F == 128
+        gmax = torch.empty(1, dtype=f32, device=x.device) if want_gmax else None
         if ctx.needs_input_grad[0]:
             t_rowptr, t_eid = g.transpose()
             dx = torch.empty_like(x)
             call("conan_cfconv_bwd_x", ptr(W), ptr(dout), ptr(t_rowptr), ptr(t_eid), ptr(g.tgt), ptr(g.pid) if ctx.pairs else None,
-                 g.num_atoms, F, ptr(dx), stream_ptr())
+                 g.num_atoms, F, ptr(dx), ptr(gmax), stream_ptr())
+        elif gmax is not None:
+            gmax.zero_()
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
             if ctx.pairs:
                 if not ctx.pre:
                     raise RuntimeError("use_pairs requires pre_cutoff_grad=True (the pair gradient includes the cosine cutoff)")
-                gmax = None
-                if F == 128:                               # one device float per CFConv backward, raised to max |dW| by the kernel: slots of a
-                    pool = getattr(g, "_gmax_pool", None)  # zeroed pool that lives on the graph (one fill per backward pass instead of one per block)
-                    if pool is None or pool[1] >= pool[0].numel():
-                        pool = [torch.zeros(8, dtype=f32, device=x.device), 0]
-                        g._gmax_pool = pool
-                    gmax = pool[0][pool[1]:pool[1] + 1]
-                    pool[1] += 1
                 call("conan_cfconv_bwd_w_pairs", ptr(x), ptr(dout), ptr(g.num_pairs_dev), g.max_edges, ptr(g.pair_e0), ptr(g.pair_e1), ptr(g.col),
                      ptr(g.tgt), F, ptr(g.pair_dist), float(g.cutoff), ptr(dW), ptr(gmax), stream_ptr())
                 if gmax is not None:

@@ -180,10 +180,12 @@ class SchNetNoSum(torch.nn.Module):
         if not z.is_cuda:
             raise RuntimeError("SchNetNoSum (MI355X) runs on the GPU only: move the inputs to the device; there is no CPU fallback")
         batch = torch.zeros_like(z) if batch is None else batch            # schnet_no_sum.py:157
+        hint_g, hint_n = ops.batch_hints(batch)                            # sizes DeviceCollator left on the tensor (reference-shaped calls carry no size arguments)
         if num_graphs is None:
-            num_graphs = int(batch[-1].item()) + 1                         # host sync; pass num_graphs= to avoid it
+            num_graphs = hint_g if hint_g is not None else int(batch[-1].item()) + 1      # host sync only for foreign tensors; pass num_graphs= to avoid it
         gptr = ops.graph_ptr_from_batch(batch, num_graphs)
         graph = self.interaction_graph.csr(pos, gptr, num_graphs)
+        graph.max_nodes_hint = hint_n if hint_g == num_graphs else None
         return batch, gptr, graph, num_graphs
 
     def _trunk(self, z: Tensor, graph: ops.RadiusGraph) -> Tensor:
@@ -230,6 +232,8 @@ class SchNetNoSum(torch.nn.Module):
             graph = edge_index
         else:
             graph = _graph_from_edge_index(edge_index, batch, G)
+        if max_nodes is None:
+            max_nodes = getattr(graph, "max_nodes_hint", None)
         if max_nodes is None:
             gp = graph.graph_ptr
             max_nodes = int((gp[1:] - gp[:-1]).max().item())                # host sync (to_dense_batch does the same, :242)

@@ -216,7 +216,8 @@ class ViSNet(torch.nn.Module):
             raise RuntimeError("ViSNet (MI355X) runs on the GPU only: move the inputs to the device; there is no CPU fallback")
         batch = torch.zeros_like(z) if batch is None else batch
         if num_graphs is None:
-            num_graphs = int(batch[-1].item()) + 1
+            hint_g, _ = ops.batch_hints(batch)                             # DeviceCollator's host-known count (no sync), else one read
+            num_graphs = hint_g if hint_g is not None else int(batch[-1].item()) + 1
         return batch, ops.graph_ptr_from_batch(batch, num_graphs), num_graphs
 
     def _head(self, xs, vs, z, output_model, prior):
@@ -241,6 +242,9 @@ class ViSNet(torch.nn.Module):
         from .schnet import _graph_from_edge_index
         K, G = num_conformers, batch_size * num_conformers
         graph = edge_index if isinstance(edge_index, ops.RadiusGraph) else _graph_from_edge_index(edge_index, batch, G)
+        if max_nodes is None:
+            hint_g, hint_n = ops.batch_hints(batch)
+            max_nodes = hint_n if hint_g == G else None
         if max_nodes is None:
             gp = graph.graph_ptr
             max_nodes = int((gp[1:] - gp[:-1]).max().item())

@@ -37,7 +37,7 @@ extern "C" {
 /* Library / device probe.  Returns CONAN_FGW_ABI_VERSION of the build.  The version changes whenever an existing export changes its
  * signature or meaning (v2: num_embeddings / pre_act arguments of round 2; v3: round-3 signatures), so a consumer compiled against
  * this header can detect a stale library: compare the return value with the macro. */
-#define CONAN_FGW_ABI_VERSION 3
+#define CONAN_FGW_ABI_VERSION 4
 int conan_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- batch assembly */
@@ -316,9 +316,11 @@ int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges,
  * NULL = row e. */
 int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const int *col, const int *pid, int num_atoms,
                      int num_filters, float *out, void *stream);
-/* Backward: dx[j,:] = sum_{e: col[e]==j} W[e,:]*dout[tgt[e],:] (via the by-source CSR), dW[e,:] = x[col[e],:]*dout[tgt[e],:]. */
+/* Backward: dx[j,:] = sum_{e: col[e]==j} W[e,:]*dout[tgt[e],:] (via the by-source CSR), dW[e,:] = x[col[e],:]*dout[tgt[e],:].
+ * zero_slot (nullable, ABI 4): one device float that this launch clears — the `gmax` word of the conan_cfconv_bwd_w_pairs call that follows on
+ * the same stream, so that no fill launch of its own is needed and the word is fresh on every backward pass (captured graphs included). */
 int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt,
-                       const int *pid, int num_atoms, int num_filters, float *dx, void *stream);
+                       const int *pid, int num_atoms, int num_filters, float *dx, float *zero_slot, void *stream);
 /* Pair-level filter gradient (before the cosine cutoff): dWp[p,:] = C(d_p) * sum over the (1 or 2) edges of pair p of
  * x[src(e),:] * dout[tgt(e),:].  gmax (nullable, num_filters = 128 only): one device float, ZEROED by the caller before the call; the
  * kernel raises it to max |dWp| as it writes.  conan_filter_bwd / conan_linear_wgrad take that word to run their products on two

@@ -54,6 +54,36 @@ def test_double_buffered_collator_and_model_run():
         assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)       # same molecules; only the order of the bond edges inside a graph differs
 
 
+@pytest.mark.parametrize("model_name", ["schnet", "visnet"])
+def test_reference_shaped_call_on_a_collated_batch_never_syncs(model_name):
+    """The reference calls `model(batch, conformers_index, node_index)` with no size arguments (schnet_based_models.py:135-173).  On a batch from
+    DeviceCollator the sizes ride on the index tensors (ops.batch_hints), so forward AND backward run without one device -> host read:
+    torch's sync debug mode turns any such read into an error.  Same prediction as the call with explicit hints."""
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    K = 3
+    cb = make_batch("esol", 5, K, seed=21); bg = make_bond_graph(cb, seed=22)
+    torch.manual_seed(1)
+    model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=model_name).to(dev)
+    data, node_index = DeviceCollator(dev, K, depth=2)(molecules_from_synthetic(cb, bg)).wait().as_model_input()
+    cidx = data.conformers_index
+    y_hint = model(data, cidx, node_index, num_graphs=data.num_graphs, max_nodes=data.max_nodes).detach().clone()       # (warm-up: lazy allocations, side stream)
+    torch.cuda.synchronize()
+    prev = torch.cuda.get_sync_debug_mode()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        y = model(data, cidx, node_index)                          # the reference's call, unchanged
+        y.square().mean().backward()
+    finally:
+        torch.cuda.set_sync_debug_mode(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(y.detach(), y_hint)
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 10 and all(bool(torch.isfinite(g).all()) for g in grads)
+    # a foreign index tensor (no hints) still works: it pays the reference's two host reads instead
+    y_foreign = model(data, cidx, node_index.clone())
+    assert torch.equal(y_foreign.detach(), y_hint)
+
+
 def test_static_collator_keeps_addresses_and_rejects_shape_changes():
     K = 2
     coll = DeviceCollator(dev, K, depth=2, static=True)

@@ -90,6 +90,23 @@ def test_two_rank_step_end_to_end_on_one_gpu():
     assert d["value"] > 0 and abs(d["value"] - 2 * 64 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-3 * d["value"]
 
 
+def test_eight_rank_dry_run_of_cfg3_on_one_gpu():
+    """BASELINE.json configs[2] (Lipophilicity + SchNet, K=5, sharded over 8 ranks) as the driver would start it — `--config cfg3`, 8 ranks of
+    torch.distributed.run — with the ranks sharing this box's one GPU over gloo and 16 molecules each instead of 128 (eight processes' worth of
+    workspaces on one device): every rank captures and replays its own shard (N_max per rank, datamodules.py:40-41), one collective per step,
+    identical parameters on all eight ranks afterwards, per-rank step times in the line.  A functional run of the 8-rank code path, not a rate."""
+    d = _bench(["--gpus", "8", "--config", "cfg3", "--batch", "16", "--steps", "3", "--warmup", "2", "--blocks", "1", "--no-cpu-baseline", "--backend", "gloo"],
+               distributed=True, tag="gloo8_cfg3", nproc=8)
+    assert d["n_gpus"] == 8 and d["dist"]["ranks"] == 8 and d["config"]["parallelism"] == "dp8"
+    assert "LIPO" in d["config"]["workload"] and d["config"]["molecules_per_gpu"] == 16 and d["config"]["max_nodes"] > 64      # the large-N FGW kernels
+    assert d["allreduce"]["in_timed_step"] and d["allreduce"]["calls_per_step"] == 1
+    assert d["graph_capture_error"] is None
+    pr = d["dist"]["per_rank"]
+    assert len(pr["loss"]) == 8 and len(set(pr["loss"])) == 8                            # eight different shards
+    assert len(set(pr["parameter_checksum"])) == 1                                        # one model
+    assert len(pr["ms_per_step"]) == 8 and pr["ms_per_step_min"] > 0 and d["allreduce_exposed_us"] is not None
+
+
 def test_overlapped_buckets_with_deferred_weight_gradients():
     """2 ranks (gloo, both on cuda:0): FlatGradients.backward() with deferred weight gradients AND the overlapped early bucket.  The
     early-bucket hook must not mistake not-yet-accumulated siblings of a multi-output autograd node for copied gradients."""

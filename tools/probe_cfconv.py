@@ -26,7 +26,7 @@ def timed(fn, reps=20):
 out = torch.empty(n, F, device=dev)
 def fwd(): ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(W), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), ops.stream_ptr())
 tr, te = g.transpose(); dx = torch.empty(n, F, device=dev); dW = torch.empty(g.max_edges, F, device=dev)
-def bx(): ops.call("conan_cfconv_bwd_x", ops.ptr(W), ops.ptr(gy), ops.ptr(tr), ops.ptr(te), ops.ptr(g.tgt), ops.ptr(g.pid), n, F, ops.ptr(dx), ops.stream_ptr())
+def bx(): ops.call("conan_cfconv_bwd_x", ops.ptr(W), ops.ptr(gy), ops.ptr(tr), ops.ptr(te), ops.ptr(g.tgt), ops.ptr(g.pid), n, F, ops.ptr(dx), None, ops.stream_ptr())
 def bw(): ops.call("conan_cfconv_bwd_w_pairs", ops.ptr(x), ops.ptr(gy), ops.ptr(g.num_pairs_dev), g.max_edges, ops.ptr(g.pair_e0), ops.ptr(g.pair_e1), ops.ptr(g.col), ops.ptr(g.tgt), F, ops.ptr(g.pair_dist), 10.0, ops.ptr(dW), None, ops.stream_ptr())
 tf, tx, tw = timed(fwd), timed(bx), timed(bw)
 # in-model cache state: the filter kernel writes W (and h1) right before the gather reads W
