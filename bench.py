@@ -316,17 +316,19 @@ def run_rank(args):
     inv_world = 1.0 / world
     collective = train and use_dist and (world > 1 or args.force_collective)      # the step contains the RCCL all-reduce
 
+    seed = torch.full((), inv_world if collective else 1.0, device=dev)      # gradient seed of every backward pass (no scaling pass over the flat buffer afterwards)
+
     def fwd_bwd():
         flat.zero()
         pred = model(data, cidx, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
         loss = torch.nn.functional.binary_cross_entropy(pred, y) if classify else ops.mse_loss(pred, y)   # common.py: BCE / MSE (MSE and its gradient: one launch)
-        flat.backward(loss)                        # = loss.backward() with the slab sums of all weight gradients batched into one launch
+        flat.backward(loss, grad_scale=seed)       # = loss.backward(seed) with the slab sums of all weight gradients batched into one launch; seed = 1 / world: the SUM all-reduce yields the mean
         loss_box[0] = loss.detach()
 
     def eager_step():
         if train:
             fwd_bwd()
-            flat.all_reduce_mean(force=args.force_collective)      # pack + (world > 1 or forced) RCCL all-reduce(s) + mean
+            flat.all_reduce_mean(force=args.force_collective, prescaled=collective)      # pack + (world > 1 or forced) RCCL all-reduce(s); the mean comes from the seed
             opt.step()
         else:
             with torch.no_grad():
@@ -402,9 +404,7 @@ def run_rank(args):
                 if train:
                     gB = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gB, stream=side, pool=gA.pool(), capture_error_mode=cmode):
-                        if collective:
-                            flat.flat.mul_(inv_world)
-                        opt.step()
+                        opt.step()                                   # (the gradients were seeded with 1 / world: the summed buffer is the mean)
                 captured = True
             except Exception as e:                                   # capture is an optimisation of the launch path, never a requirement
                 graph_err = f"{type(e).__name__}: {e}"[:300]
@@ -441,13 +441,6 @@ def run_rank(args):
                 dt_graph = float(np.median(dt_blocks))
                 local_value_ms = 1e3 * float(np.median(local_dts[n0:]))
                 loss_after_blocks = float(loss_box[0])
-                if collective:
-                    # what the collective costs the step where it sits (between the two replays, nothing overlapped): the same replays without it,
-                    # timing only — the parameters of this leg are not what training would produce, it runs after the timed blocks
-                    def graph_step_no_collective():
-                        gA.replay(); gB.replay()
-                    dt_nc = timed(graph_step_no_collective, args.steps)
-                    allreduce_exposed_us = 1e6 * (dt_graph - dt_nc) / args.steps
             flat.suspend_overlap(False)
         loss_last = loss_after_blocks if loss_after_blocks is not None else float(loss_box[0])
         # every rank has applied the same averaged gradients: the parameters must agree across ranks bit for bit, the losses are the
@@ -468,6 +461,15 @@ def run_rank(args):
                         "ms_per_step": [round(v, 4) for v in ms], "ms_per_step_min": round(min(ms), 4), "ms_per_step_max": round(max(ms), 4),
                         "ms_per_step_note": "each rank's own clock around its median timed block (value uses the MAX over ranks per block); a wide max / min spread "
                                             "points at one slow rank (host contention, a throttled GPU), a uniform rise over the 1-rank step at the collective"}
+
+        # ---- what the collective costs the step where it sits (between the two replays, nothing overlapped): the same replays without it.  Timing
+        # only, and only here — AFTER the per-rank checksums were taken: without the all-reduce every rank applies its own gradients, so from
+        # this point on the ranks' parameters differ (nothing below depends on them being equal)
+        if collective and dt_graph is not None:
+            def graph_step_no_collective():
+                gA.replay(); gB.replay()
+            dt_nc = timed(graph_step_no_collective, args.steps)
+            allreduce_exposed_us = 1e6 * (dt_graph - dt_nc) / args.steps
 
         # ---- the same step fed by the input pipeline: every step re-collates the batch on the host (C pack into a pinned
         # buffer), copies it (one H2D transfer on the copy stream, overlapping the previous step) and expands it on the device.

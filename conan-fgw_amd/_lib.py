@@ -98,6 +98,8 @@ SIGNATURES = {
     "conan_mlp2_outact_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "conan_filter_fused_supported": (c_int, [c_int, c_int]),
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "conan_filter_cfconv_fwd_supported": (c_int, [c_int, c_int]),
+    "conan_filter_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     "conan_cfconv_bwd_w_pairs": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, _P]),

@@ -410,7 +410,10 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 // A row / column sum outside [1e-150, 1e150] — or a first-update row sum below 1e-28, i.e. a K row in or near the fp32 denormals — makes the
 // workgroup give up without writing anything and raise redo[b, s]; the launcher then runs k_fgw_coupling — which carries the exact
 // log-domain path — on the flagged couplings only.
-#define FGW_MMG mm_f64_glb22      // 2 x 2 register-blocked products (one operand load per MFMA instead of two: -9.5 % of the solve)
+// 2 x 2 register-blocked products (one operand load per MFMA instead of two: -9.5 % of the solve).  Round 5 built the exact-tile
+// form — whole tiles + v_mfma_f64_4x4x4_4b_f64 strips for the ragged edge (N = 85: 25 tiles + strips instead of 36 padded tiles) — twice and
+// measured it slower both times (profiles/r5_ab_fgw_large_strips_v1.txt, _v2.txt; DESIGN 3.3 has the numbers and why): removed again.
+#define FGW_MMG mm_f64_glb22
 // C2U8: the adjacency of the input graph is staged ONCE into LDS as bytes (caller's promise cs_small_int: integers in [0, 255]) and both
 // products that contract with it read it there instead of fetching fp32 from L2 in every projected-gradient iteration.
 template <int NW, bool C2U8>

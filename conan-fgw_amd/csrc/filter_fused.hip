@@ -57,16 +57,24 @@ __device__ __forceinline__ float block_absmax(float v, float *red) {      // red
 
 constexpr int GP = 64;        // gaussians padded to four MFMA k-steps of 16 (zero weights beyond num_gaussians)
 constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (16-bit elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
-constexpr int FF_THREADS = 512;
+constexpr int FF_THREADS = 512;      // eight wavefronts per workgroup (training form); the inference form (no h1 output) runs twelve: FF_THREADS_INFER
 
 constexpr int FF_NPL = 2;                                    // operand planes: two fp16 planes (the round-2 three-plane bf16 form measured 28 % slower: DESIGN 3.1)
 constexpr int FF_OP = 36;                                    // pitch of the per-wave output slab (floats): 32 channels + 4
 
-template <int F>
-__global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
+// CF = true (round 5, forward-only): the filter rows never reach HBM — the tile's rows are the DIRECTED edges e0 .. e0 + 31 in CSR order (grouped
+// by target), each row is multiplied by its source's features x[col[e], :] as it leaves the accumulators and the products are summed per
+// target (CFConv.propagate: out[i] = sum_{e in row i} x[col[e]] * W[e]) through the per-wave slab: lane <-> channel walks the 32 rows in edge
+// order and adds each finished target segment to `out` (pre-zeroed by the entry point).  A target with <= 33 edges spans at most two tiles, so
+// its row of `out` is 0 + a (+ b): the result does not depend on which tile's add lands first (bitwise reproducible at cap 32).
+constexpr int FF_THREADS_INFER = 768; // three wavefronts per SIMD: 154 KB of LDS, <= 168 registers.  W-only 74-76 -> 67-69 us at cfg2 (profiles/r5_ab_filter_fwd_768_threads.txt);
+                                      // with the h1 stream the kernel sits on its stores either way (67-69 us both), so training keeps eight
+template <int F, bool CF = false, int NT = FF_THREADS>
+__global__ void __launch_bounds__(NT) k_filter_fused(
     const float *__restrict__ dist, const int *__restrict__ num_edges_dev, int max_edges, const float *__restrict__ offset,
     int Gs, float coeff, float cutoff, const float *__restrict__ w1, const float *__restrict__ b1,
-    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out) {
+    const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ Wout, float *__restrict__ h1_out,
+    const float *__restrict__ xin = nullptr, const int *__restrict__ col = nullptr, const int *__restrict__ tgt = nullptr) {
     constexpr int MB = F / 32;            // 32-row blocks of the channel dimension
     constexpr int W2S = F + 8;            // LDS pitch of a W2 row in the split images (16-bit elements; 16-B slots stay distinct)
     constexpr int W2WORDS = (FF_NPL * F * W2S) / 2;      // floats occupied by the 16-bit W2 images
@@ -80,29 +88,30 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     // fp16 form: a [32][FF_OP] output slab per wave — the outputs of a 32-channel block cross it so that a store instruction writes 8 rows
     // x 128 contiguous bytes (whole lines) instead of 32 rows x 32 bytes that L2 has to merge (gemm_t.hip measured the effect)
     float *OT = OFL + GP + (threadIdx.x >> 6) * (32 * FF_OP);
-    __shared__ float wred[FF_THREADS / 64];
+    __shared__ float wred[NT / 64];
     float us1 = 1.0f, us2 = 1.0f;                                 // inverse plane scales of W1 / W2 (fp16 form)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int E = num_edges_dev ? min(*num_edges_dev, max_edges) : max_edges;
     const int tiles = (E + 31) >> 5;
-    if ((int)blockIdx.x * (FF_THREADS / 64) >= tiles) return;
+    if (!CF && (int)blockIdx.x * (NT / 64) >= tiles) return;
+    if (CF && tiles == 0) return;
 
     {
-        constexpr int PER1 = (F * GP + FF_THREADS - 1) / FF_THREADS;
+        constexpr int PER1 = (F * GP + NT - 1) / NT;
         float wv[PER1];
 #pragma unroll
         for (int u = 0; u < PER1; ++u) {
-            const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
+            const int t = tid + u * NT, f = t / GP, k = t - f * GP;
             wv[u] = (t < F * GP && k < Gs) ? w1[(size_t)f * Gs + k] : 0.f;
         }
         float sc1 = 1.0f;
         float am = 0.f;
 #pragma unroll
         for (int u = 0; u < PER1; ++u) am = fmaxf(am, fabsf(wv[u]));
-        plane_scale(block_absmax<FF_THREADS>(am, wred), sc1, us1);
+        plane_scale(block_absmax<NT>(am, wred), sc1, us1);
 #pragma unroll
         for (int u = 0; u < PER1; ++u) {
-            const int t = tid + u * FF_THREADS, f = t / GP, k = t - f * GP;
+            const int t = tid + u * NT, f = t / GP, k = t - f * GP;
             if (t >= F * GP) continue;
             _Float16 *W1H = reinterpret_cast<_Float16 *>(W1L);
             const float v = wv[u] * sc1;
@@ -117,18 +126,18 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
         // channel (j&3) + 8(j>>2) + 4h, so a lane reads its 8 k-values as one 16-byte access.
         // all of a thread's loads are issued before the first use: a load-convert-store loop serialises F*F/512 L2 round
         // trips (a fixed ~15 us per launch)
-        constexpr int PER2 = (F * F + FF_THREADS - 1) / FF_THREADS;
+        constexpr int PER2 = (F * F + NT - 1) / NT;
         float wv[PER2];
 #pragma unroll
-        for (int u = 0; u < PER2; ++u) { const int t = tid + u * FF_THREADS; wv[u] = t < F * F ? w2[t] : 0.f; }
+        for (int u = 0; u < PER2; ++u) { const int t = tid + u * NT; wv[u] = t < F * F ? w2[t] : 0.f; }
         float sc2 = 1.0f;
         float am = 0.f;
 #pragma unroll
         for (int u = 0; u < PER2; ++u) am = fmaxf(am, fabsf(wv[u]));
-        plane_scale(block_absmax<FF_THREADS>(am, wred), sc2, us2);
+        plane_scale(block_absmax<NT>(am, wred), sc2, us2);
 #pragma unroll
         for (int u = 0; u < PER2; ++u) {
-            const int t = tid + u * FF_THREADS;
+            const int t = tid + u * NT;
             if (t >= F * F) continue;
             const int f2 = t / F, f = t - f2 * F;
             const int kk = f & 15, hh = (kk >> 2) & 1, jj = (kk & 3) + 4 * (kk >> 3);
@@ -140,16 +149,24 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             W2H[(1 * F + f2) * W2S + colp] = (_Float16)(v - (float)h1);
         }
     }
-    for (int t = tid; t < F; t += FF_THREADS) { B1L[t] = b1[t]; B2L[t] = b2[t]; }
-    for (int t = tid; t < GP; t += FF_THREADS) OFL[t] = t < Gs ? offset[t] : 0.f;
+    for (int t = tid; t < F; t += NT) { B1L[t] = b1[t]; B2L[t] = b2[t]; }
+    for (int t = tid; t < GP; t += NT) OFL[t] = t < Gs ? offset[t] : 0.f;
     __syncthreads();
 
     const int l31 = lane & 31, h = lane >> 5;
-    const int wave_stride = gridDim.x * (FF_THREADS / 64);
-    for (int tile = blockIdx.x * (FF_THREADS / 64) + wave; tile < tiles; tile += wave_stride) {
+    // CF: every workgroup owns a CONTIGUOUS range of tiles, XCD k the k-th eighth of the edges (the x rows of a conformer are gathered by ~20
+    // neighbouring targets: they meet in one L2); the plain generator deals tiles round-robin as before
+    const int per_wg = CF ? (tiles + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int lb = CF ? ((gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) : 0;
+    const int t_begin = CF ? lb * per_wg + wave : blockIdx.x * (NT / 64) + wave;
+    const int t_end = CF ? min(tiles, (lb + 1) * per_wg) : tiles;
+    const int wave_stride = CF ? NT / 64 : gridDim.x * (NT / 64);
+    for (int tile = t_begin; tile < t_end; tile += wave_stride) {
         const int e = (tile << 5) + l31;
         const bool valid = e < E;
         const float d = valid ? dist[e] : 0.f;
+        int src = 0, trg = -1;
+        if constexpr (CF) { if (valid) { src = col[e]; trg = tgt[e]; } }
 
         // ---------------- GEMM1^T: acc1[mb] = W1[32mb.., :] . rbf^T
         f32x16 acc1[MB];
@@ -196,7 +213,7 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                 acc1[mb][4 * q + 2] = ssp_f(fmaf(acc1[mb][4 * q + 2], us, bb.z));
                 acc1[mb][4 * q + 3] = ssp_f(fmaf(acc1[mb][4 * q + 3], us, bb.w));
             }
-        if (h1_out) {
+        if (!CF && h1_out) {
             // streaming stores: h1 is not read again before the backward pass, W is read by the very next kernel — without the hint
             // the two 132 MB streams together overflow the 256 MiB Infinity Cache and the gather finds none of W there
             typedef float f4 __attribute__((ext_vector_type(4)));
@@ -228,6 +245,14 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
             for (int nb = 0; nb < NG; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+            float4 xg[CF ? NG : 1][4];
+            if constexpr (CF) {                                        // the source's features for this lane's channels: requested BEFORE the group's MFMAs
+#pragma unroll
+                for (int nb = 0; nb < NG; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        xg[nb][q] = valid ? *reinterpret_cast<const float4 *>(xin + (size_t)src * F + 32 * (n0 + nb) + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             {
 #pragma unroll
                 for (int ms = 0; ms < 2 * MB; ++ms) {
@@ -263,9 +288,42 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
                     o.y = fmaf(acc2[nb][4 * q + 1], us, bb.y) * C;
                     o.z = fmaf(acc2[nb][4 * q + 2], us, bb.z) * C;
                     o.w = fmaf(acc2[nb][4 * q + 3], us, bb.w) * C;
+                    if constexpr (CF) { o.x *= xg[nb][q].x; o.y *= xg[nb][q].y; o.z *= xg[nb][q].z; o.w *= xg[nb][q].w; }
                     *reinterpret_cast<float4 *>(&OT[l31 * FF_OP + 8 * q + 4 * h]) = o;
                 }
                 wave_lds_fence();
+                if constexpr (CF) {
+                    // segment sums: lane <-> channel (the lower half-wavefront), rows in edge order; a row's target is wave-uniform (read from
+                    // the lane that owns the edge), so the segment test is a scalar branch.  One add to `out` per (target, tile).
+                    // Both half-wavefronts walk: lanes 0..31 rows 0..15, lanes 32..63 rows 16..31, lane & 31 = channel.  When rows 15 and 16 belong to
+                    // the same target the upper half does not flush its first segment: it hands the sum down (carry) and the lower half adds it to
+                    // its last segment — one add per (target, tile), partial sums combined in a fixed order.
+                    {
+                        const int c = lane & 31, r0 = 16 * h;
+                        float *ocol = Wout + 32 * (n0 + nb) + c;           // (Wout = out [n, F] in this mode)
+                        const bool joined = __shfl(trg, 15, 64) == __shfl(trg, 16, 64);      // wave-uniform
+                        float accs = 0.f, carry = 0.f;
+                        int cur = h ? __shfl(trg, 16, 64) : __shfl(trg, 0, 64);            // uniform per half: the branches below diverge by half only
+                        bool first = true;                                                   // still inside the half's first segment
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int tl = __shfl(trg, r, 64), th = __shfl(trg, 16 + r, 64);
+                            const int tr = h ? th : tl;
+                            if (tr != cur) {
+                                if (h && first && joined) carry = accs;
+                                else if (cur >= 0) unsafeAtomicAdd(ocol + (size_t)cur * F, accs);
+                                accs = 0.f; cur = tr; first = false;
+                            }
+                            accs += OT[(r0 + r) * FF_OP + c];
+                        }
+                        if (h && first && joined) { carry = accs; cur = -1; }               // the whole upper half continues the lower half's last target
+                        const float down = __shfl(carry, (lane & 31) + 32, 64);              // upper half's carried sum of this channel
+                        if (!h && joined) accs += down;
+                        if (cur >= 0) unsafeAtomicAdd(ocol + (size_t)cur * F, accs);
+                    }
+                    wave_lds_fence();
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 8 * i + (lane >> 3), c = 4 * (lane & 7);
@@ -278,22 +336,51 @@ __global__ void __launch_bounds__(FF_THREADS) k_filter_fused(
     }
 }
 
+template <int F, int NT>
+int launch_nt(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
+              float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1, hipStream_t s) {
+    const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP + (NT / 64) * 32 * FF_OP) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F, false, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (max_edges + 31) / 32;
+    int grid = (tiles + NT / 64 - 1) / (NT / 64);
+    if (grid > 256) grid = 256;                           // one persistent workgroup per CU
+    k_filter_fused<F, false, NT><<<grid, NT, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1);
+    return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+}
 template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
+    if (F == 128 && !h1) return launch_nt<F, FF_THREADS_INFER>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, s);
+    return launch_nt<F, FF_THREADS>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, s);
+}
+
+template <int F>
+int launch_cf(const float *x, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges, const float *offset, int Gs,
+              float coeff, float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, int num_atoms, float *out, hipStream_t s) {
     const size_t lds = ((size_t)(FF_NPL * F * W1S) / 2 + (size_t)(FF_NPL * F * (F + 8)) / 2 + 2 * F + GP + (FF_THREADS / 64) * 32 * FF_OP) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int tiles = (max_edges + 31) / 32;
-    int grid = (tiles + 7) / 8;
-    if (grid > 256) grid = 256;                           // one persistent 8-wave workgroup per CU
-    k_filter_fused<F><<<grid, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fused<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipMemsetAsync(out, 0, (size_t)num_atoms * F * sizeof(float), s) != hipSuccess) return CONAN_E_LAUNCH;      // every target's row starts at 0 (targets without edges stay there)
+    k_filter_fused<F, true><<<256, FF_THREADS, lds, s>>>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, out, nullptr, x, col, tgt);
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
 }  // namespace
 
 extern "C" {
+
+int conan_filter_cfconv_fwd_supported(int num_gaussians, int num_filters) { return (num_gaussians >= 2 && num_gaussians <= GP && num_filters == 128) ? 1 : 0; }
+
+int conan_filter_cfconv_fwd(const float *x, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges,
+                            const float *offset, int num_gaussians, float coeff, float cutoff, int num_filters, const float *w1,
+                            const float *b1, const float *w2, const float *b2, int num_atoms, float *out, void *stream) {
+    if (!x || !dist || !col || !tgt || !offset || !w1 || !b1 || !w2 || !b2 || !out || max_edges < 0 || num_atoms < 0) return CONAN_E_BADARG;
+    if (!conan_filter_cfconv_fwd_supported(num_gaussians, num_filters)) return CONAN_E_UNSUPPORTED;
+    if (num_atoms == 0) return CONAN_OK;
+    hipStream_t s = as_stream(stream);
+    if (max_edges == 0) return hipMemsetAsync(out, 0, (size_t)num_atoms * num_filters * sizeof(float), s) == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+    return launch_cf<128>(x, dist, col, tgt, num_edges_dev, max_edges, offset, num_gaussians, coeff, cutoff, w1, b1, w2, b2, num_atoms, out, s);
+}
 
 int conan_filter_fused_supported(int num_gaussians, int num_filters) {
     return (num_gaussians >= 2 && num_gaussians <= GP && (num_filters == 32 || num_filters == 64 || num_filters == 128)) ? 1 : 0;

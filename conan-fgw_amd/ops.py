@@ -678,6 +678,24 @@ def filter_generate(graph: "RadiusGraph", offset: Tensor, coeff: float, w1: Tens
     return _FilterFn.apply(graph, offset, coeff, w1, b1, w2, b2, use_pairs)
 
 
+def filter_cfconv_supported(num_gaussians: int, num_filters: int) -> bool:
+    return bool(lib().conan_filter_cfconv_fwd_supported(int(num_gaussians), int(num_filters)))
+
+
+def filter_cfconv(x: Tensor, graph: "RadiusGraph", offset: Tensor, coeff: float, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """CFConv's edge half in ONE launch, forward only (conan_filter_cfconv_fwd): out[i] = sum_{j in N(i)} x[j] * (mlp(rbf(d_ij)) * C(d_ij)) with the
+    filter rows generated per directed edge and consumed on the spot — no [E, F] tensor exists.  Inference only: raises when a gradient is
+    required (the training step's backward reads the filter tensor that `filter_generate` + `cfconv` save)."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (x, w1, b1, w2, b2)):
+        raise RuntimeError("filter_cfconv is forward-only: use filter_generate + cfconv when gradients are needed")
+    x = _c(x)
+    out = torch.empty_like(x)
+    call("conan_filter_cfconv_fwd", ptr(x, f32), ptr(graph.dist), ptr(graph.col), ptr(graph.tgt), ptr(graph.num_edges_dev), graph.max_edges,
+         ptr(_c(offset), f32), offset.shape[0], float(coeff), graph.cutoff, w1.shape[0], ptr(_c(w1), f32), ptr(_c(b1), f32), ptr(_c(w2), f32),
+         ptr(_c(b2), f32), graph.num_atoms, ptr(out), stream_ptr())
+    return out
+
+
 class _CFConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, graph, pre_cutoff_grad=False, use_pairs=False):
@@ -875,6 +893,10 @@ class _MseLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
+        if g.is_cuda and g.dtype == f32 and g.numel() == 1:        # the seed of loss.backward() (1, or 1 / world_size): one HIP launch, no aten kernel in the step
+            out = torch.empty_like(dpred)
+            call("conan_scale_scalar", ptr(dpred), ptr(_c(g)), dpred.numel(), ptr(out), stream_ptr())
+            return out, None
         return dpred * g, None
 
 

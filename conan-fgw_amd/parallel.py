@@ -159,16 +159,18 @@ class FlatGradients:
             if only is None:
                 ops._flushed.clear()
 
-    def backward(self, loss: torch.Tensor):
+    def backward(self, loss: torch.Tensor, grad_scale: Optional[torch.Tensor] = None):
         """loss.backward() with the slab reductions of all weight gradients batched into one launch (flushed before any gradient is
-        packed or reduced).  Equivalent to `loss.backward()` in results."""
+        packed or reduced).  Equivalent to `loss.backward()` in results.  `grad_scale` (a 0-dim tensor, e.g. 1 / world_size): the seed of the
+        backward pass — the ranks' SUM all-reduce then yields the mean directly and no scaling pass over the flat buffer is needed
+        (`all_reduce_mean(prescaled=True)`)."""
         if self.flat.is_cuda:
             from . import ops
             with ops.deferred_weight_gradients():
-                loss.backward()
+                loss.backward(grad_scale)
             self._flush_deferred()                               # (the context flushed; this verifies the adoption)
         else:
-            loss.backward()
+            loss.backward(grad_scale)
 
     # ------------------------------------------------------------------------------------------------ overlap
     def enable_overlap(self, early_fraction: float = 0.5):
@@ -244,8 +246,9 @@ class FlatGradients:
         self._work = dist.all_reduce(self.flat[: self._split], op=dist.ReduceOp.SUM, async_op=True)
 
     # ------------------------------------------------------------------------------------------------ reduce
-    def all_reduce_mean(self, force: bool = False, group_stream: bool = True):
-        """Pack, sum across ranks, divide by the world size.  `force`: issue the collective even in a 1-rank group (the same RCCL
+    def all_reduce_mean(self, force: bool = False, group_stream: bool = True, prescaled: bool = False):
+        """Pack, sum across ranks, divide by the world size (`prescaled`: the backward pass was seeded with 1 / world_size — `backward(loss,
+        grad_scale=...)` — so the sum already is the mean and the scaling pass is skipped).  `force`: issue the collective even in a 1-rank group (the same RCCL
         call the multi-rank step makes; used to exercise the path on one GPU).  `group_stream` (default): the collective runs on the
         process group's own stream (all_reduce_group_stream: safe to follow with a HIP-graph capture on the calling stream);
         False = synchronous call on the calling stream (two event hops fewer; only where no capture can follow)."""
@@ -257,7 +260,8 @@ class FlatGradients:
             self._work.wait(); w2.wait()
             self._work = None
             self.last_allreduce_launches = 2
-            self.flat.mul_(1.0 / world)
+            if not prescaled:
+                self.flat.mul_(1.0 / world)
             return
         self.pack()
         if world > 1 or (force and dist.is_available() and dist.is_initialized()):
@@ -266,4 +270,5 @@ class FlatGradients:
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.last_allreduce_launches = 1
-            self.flat.mul_(1.0 / world)
+            if not prescaled:
+                self.flat.mul_(1.0 / world)

@@ -72,6 +72,19 @@ class RadiusInteractionGraph(torch.nn.Module):
         return g.edge_index(), g.edge_weight()
 
 
+FUSE_FILTER_INTO_GATHER = True      # inference path of CFConv: tools / tests switch it off to compare (never read from the environment)
+FUSE_MIN_FILTER_BYTES = 192 << 20   # fuse when the pair-shared filter tensor would not stay in the 256 MiB Infinity Cache between its two kernels
+
+
+def _filter_tensor_outgrows_cache(graph: "ops.RadiusGraph", num_filters: int) -> bool:
+    """Measured (profiles/r5_filter_cfconv_fused_v2.txt): the fused forward generates one filter row per DIRECTED edge (twice the matrix work of the
+    pair-shared generator), which pays once the [pairs, F] tensor the two-kernel form writes and re-reads no longer fits the Infinity Cache —
+    Lipophilicity-sized batches: stage-2 forward 3.99 -> 3.80 ms — and does not below that (cfg2: 132 MB, 1.32 ms either way).  The edge count is
+    device-side; the host-known estimate is atoms x min(cap, atoms per conformer - 1), no sync."""
+    n, G = graph.num_atoms, max(1, graph.num_graphs)
+    est_pairs = 0.5 * n * min(float(graph.cap), max(0.0, n / G - 1.0))
+    return est_pairs * num_filters * 4 >= FUSE_MIN_FILTER_BYTES
+
 class CFConv(torch.nn.Module):
     def __init__(self, in_channels: int, out_channels: int, num_filters: int, nn: Sequential, cutoff: float):
         super().__init__()
@@ -94,6 +107,13 @@ class CFConv(torch.nn.Module):
             W = ops.cutoff_scale(w_raw, graph)                                            # * C(d)
         else:                                                                             # fused: rbf -> mlp -> * C(d) in one kernel
             offset, coeff = rbf
+            if (FUSE_FILTER_INTO_GATHER and not torch.is_grad_enabled() and _filter_tensor_outgrows_cache(graph, self.nn[2].weight.shape[0])
+                    and ops.filter_cfconv_supported(offset.shape[0], self.nn[2].weight.shape[0])):
+                # inference: the filter rows are consumed where they are generated — no [E, F] tensor, one launch for the whole edge half
+                x_in = x if tap else None
+                x = ops.linear(x, self.lin1.weight)
+                x = ops.filter_cfconv(x, graph, offset, coeff, self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias)
+                return (x, x_in) if tap else x
             W = ops.filter_generate(graph, offset, coeff, self.nn[0].weight, self.nn[0].bias, self.nn[2].weight, self.nn[2].bias)
         x_in = None
         if tap:                                                                           # lin1 (no bias), handing x through for the residual

@@ -310,6 +310,19 @@ int conan_filter_fwd(const float *dist, const int *num_edges_dev, int max_edges,
                      float coeff, float cutoff, int num_filters, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *W, float *h1_out, void *stream);
 
+/* Forward-only fusion of conan_filter_fwd and conan_cfconv_fwd (round 5): out[i,:] = sum_{e in row i} x[col[e],:] * W[e,:] with W[e,:] generated
+ * from dist[e] inside the kernel and consumed from the accumulators — the [E,F] filter tensor (and h1) never reaches HBM.  Rows are the DIRECTED
+ * edges in CSR order (tgt[e] ascending); one filter row per directed edge, i.e. twice the matrix work of the pair-shared generator for
+ * 4 B + 2 indices in and nothing out per edge.  No backward exists for it: the training step keeps conan_filter_fwd + conan_cfconv_fwd, whose
+ * saved W / h1 the backward kernels read.  `out` [num_atoms, F] is cleared by the call.  num_filters == 128, num_gaussians <= 64
+ * (conan_filter_cfconv_fwd_supported), else CONAN_E_UNSUPPORTED.  Same arithmetic as the two kernels it replaces (two fp16 planes per operand);
+ * a target's sum is formed in edge order inside a 32-edge tile and the (at most two, at cap 32) tile partials are added to the cleared row, so
+ * results are bitwise reproducible.  Replaces CFConv.forward's edge half (PyG; reached from schnet_no_sum.py:161-164,209-212) at inference. */
+int conan_filter_cfconv_fwd_supported(int num_gaussians, int num_filters);
+int conan_filter_cfconv_fwd(const float *x, const float *dist, const int *col, const int *tgt, const int *num_edges_dev, int max_edges,
+                            const float *offset, int num_gaussians, float coeff, float cutoff, int num_filters, const float *w1,
+                            const float *b1, const float *w2, const float *b2, int num_atoms, float *out, void *stream);
+
 /* CFConv message + aggregation (the HBM-bound kernel of the path): out[i,:] = sum_{e in row i} x[col[e],:] * W[e,:].
  * Replaces index_select + mul + scatter-add inside CFConv.propagate (PyG; schnet_no_sum.py:163-164,211-212).
  * CSR segment sum, one wavefront per target, no atomics.  pid (nullable): row of W used by edge e (conan_edge_pairs);

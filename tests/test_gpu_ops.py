@@ -189,6 +189,47 @@ def test_fused_filter_matches_oracle_fwd_bwd(F_, Gs, wmag):
     assert rel(W[:E].detach().cpu(), W2[:E].cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("shape,B,K,Gs", [("esol", 6, 5, 50), ("lipo", 3, 3, 50), ("esol", 3, 2, 10)])
+def test_filter_fused_into_the_gather_matches_the_two_kernels_and_fp64(shape, B, K, Gs):
+    """conan_filter_cfconv_fwd (forward only): the filter rows are generated per directed edge and consumed from the accumulators — against
+    (i) filter_generate (one row per pair) + cfconv, the training path's two kernels: same arithmetic, other summation order (1e-6), and
+    (ii) the fp64 formula out[i] = sum_j x_j * mlp(rbf(d_ij)) * C(d_ij).  Lipophilicity-sized conformers have truncated rows (33 edges: two
+    tiles per target).  Bitwise repeatable; refuses to run where a gradient is required."""
+    F_ = 128
+    assert ops.filter_cfconv_supported(Gs, F_) and not ops.filter_cfconv_supported(Gs, 64)
+    b = make_batch(shape, B, K, seed=33)
+    g = _edges(b)
+    E, n = g.num_edges, g.num_atoms
+    torch.manual_seed(Gs)
+    gs = ps.GaussianSmearing(0.0, 10.0, Gs)
+    mlp = torch.nn.Sequential(torch.nn.Linear(Gs, F_), ps.ShiftedSoftplus(), torch.nn.Linear(F_, F_))
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    prm = [p.detach().to(dev) for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
+    x = torch.randn(n, F_, device=dev)
+    off = gs.offset.to(dev)
+    with torch.no_grad():
+        out = ops.filter_cfconv(x, g, off, gs.coeff, *prm)
+        out2 = ops.filter_cfconv(x, g, off, gs.coeff, *prm)
+        W = ops.filter_generate(g, off, gs.coeff, *prm)
+        two = ops.cfconv(x, W, g, pre_cutoff_grad=True, use_pairs=True)
+    assert torch.equal(out, out2)                                              # a target's row is 0 + a (+ b): order-independent
+    assert rel(out.cpu(), two.cpu()) < 1e-6
+    ei = g.edge_index().cpu()
+    d = g.edge_weight().cpu().double()
+    Wd = mlp.double()(gs(d)) * (0.5 * (torch.cos(d * math.pi / 10.0) + 1.0))[:, None]
+    ref = torch.zeros(n, F_, dtype=torch.float64).index_add_(0, ei[1], x.cpu().double()[ei[0]] * Wd.detach())
+    assert rel(out.cpu(), ref) < TOL
+    deg = torch.bincount(ei[1], minlength=n)
+    assert bool((out[(deg == 0).to(dev)] == 0).all())                          # targets without edges: cleared rows
+    if shape == "lipo":
+        assert int(deg.max()) == 33                                             # the two-tile case is in the test
+    xr = x.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        ops.filter_cfconv(xr, g, off, gs.coeff, *prm)
+
+
 def test_filter_gradient_maximum_travels_with_the_tensor_and_is_dropped_when_the_gradient_was_touched():
     """The fp16-plane filter backward scales g from max|g|, which the pair-gradient kernel tracks (ops._tag_gmax / _take_gmax).  (i) One
     consumer per filter (every model): the tag survives the hop through the autograd engine, the fast kernels run.  (ii) ONE filter feeding
