@@ -301,7 +301,10 @@ __device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__re
 // pipe alone.  Work items: the 2 x 2 blocks that fill whole rounds of the NW wavefronts first, then the remaining tiles one by
 // one (so that no wavefront ends up with a whole block more than the others).  Same lane <-> k permutation as mm_f64_glb
 // (four consecutive k per lane and trip); one accumulator per tile (four independent chains per wavefront).
-template <int NW, bool WT, typename TX, typename TW, class FS, int KT = 2>      // KT consecutive k per lane and trip (a trip = 4 KT k)
+#ifndef CONAN_FGW_KT
+#define CONAN_FGW_KT 2      // (A/B switch: 1 and 4 measured in round 5, profiles/r5_ab_fgw_large_kt.txt)
+#endif
+template <int NW, bool WT, typename TX, typename TW, class FS, int KT = CONAN_FGW_KT>      // KT consecutive k per lane and trip (a trip = 4 KT k)
 __device__ __forceinline__ void mm_f64_glb22(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
                                              const int tid = threadIdx.x) {
     const int lane = tid & 63, wave = tid >> 6;

@@ -301,9 +301,12 @@ __global__ void __launch_bounds__(NT) k_filter_fused(
                     {
                         const int c = lane & 31, r0 = 16 * h;
                         float *ocol = Wout + 32 * (n0 + nb) + c;           // (Wout = out [n, F] in this mode)
-                        const bool joined = __shfl(trg, 15, 64) == __shfl(trg, 16, 64);      // wave-uniform
+                        // (every cross-lane read below is executed by ALL lanes and selected afterwards: a shuffle inside an arm of `h ? ... : ...`
+                        // runs under half an EXEC mask and reads an inactive lane — undefined; it returned 0 and every upper half began on target 0)
+                        const int t0 = __shfl(trg, 0, 64), t15 = __shfl(trg, 15, 64), t16 = __shfl(trg, 16, 64);
+                        const bool joined = t15 == t16;                                      // wave-uniform
                         float accs = 0.f, carry = 0.f;
-                        int cur = h ? __shfl(trg, 16, 64) : __shfl(trg, 0, 64);            // uniform per half: the branches below diverge by half only
+                        int cur = h ? t16 : t0;                                              // uniform per half: the branches below diverge by half only
                         bool first = true;                                                   // still inside the half's first segment
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {

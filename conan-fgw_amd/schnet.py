@@ -77,9 +77,9 @@ FUSE_MIN_FILTER_BYTES = 192 << 20   # fuse when the pair-shared filter tensor wo
 
 
 def _filter_tensor_outgrows_cache(graph: "ops.RadiusGraph", num_filters: int) -> bool:
-    """Measured (profiles/r5_filter_cfconv_fused_v2.txt): the fused forward generates one filter row per DIRECTED edge (twice the matrix work of the
+    """Measured (profiles/r5_filter_cfconv_fused_v3.txt): the fused forward generates one filter row per DIRECTED edge (twice the matrix work of the
     pair-shared generator), which pays once the [pairs, F] tensor the two-kernel form writes and re-reads no longer fits the Infinity Cache —
-    Lipophilicity-sized batches: stage-2 forward 3.99 -> 3.80 ms — and does not below that (cfg2: 132 MB, 1.32 ms either way).  The edge count is
+    Lipophilicity-sized batches: stage-2 forward 4.03 -> 3.78 ms — and does not below that (cfg2: 132 MB, 1.31-1.32 ms either way).  The edge count is
     device-side; the host-known estimate is atoms x min(cap, atoms per conformer - 1), no sync."""
     n, G = graph.num_atoms, max(1, graph.num_graphs)
     est_pairs = 0.5 * n * min(float(graph.cap), max(0.0, n / G - 1.0))

@@ -73,7 +73,19 @@ def test_full_size_invariants(tag, model_name, shape, B, K):
         h3s, hbs = m.forward_w_barycenter(zb, pb, K, bb, num_graphs=len(keep) * K, max_nodes=b.max_nodes)
         rows_full = np.concatenate([np.arange(mm * K, (mm + 1) * K) for mm in keep])
         if model_name == "schnet":
-            assert torch.equal(h3s, h3[rows_full])                                            # bitwise: per-graph work, fixed reduction orders
-            assert torch.equal(hbs, hb[rows_full])
+            # At inference a batch whose filter tensor outgrows the Infinity Cache takes the fused generator + gather, a small one the two
+            # kernels (schnet._filter_tensor_outgrows_cache): the same sums in another order.  Bitwise equality of a molecule's outputs across
+            # batch compositions holds per path (per-graph work, fixed reduction orders) and is checked with the path pinned.
+            from conan_fgw_amd import schnet as _sn
+            assert rel(h3s, h3[rows_full]) < 1e-6 and rel(hbs, hb[rows_full]) < 1e-5
+            keep_flag = _sn.FUSE_FILTER_INTO_GATHER
+            try:
+                _sn.FUSE_FILTER_INTO_GATHER = False
+                h3_2k, hb_2k = m.forward_w_barycenter(z, pos, K, batch, num_graphs=b.num_graphs, max_nodes=b.max_nodes)
+                h3s_2k, hbs_2k = m.forward_w_barycenter(zb, pb, K, bb, num_graphs=len(keep) * K, max_nodes=b.max_nodes)
+            finally:
+                _sn.FUSE_FILTER_INTO_GATHER = keep_flag
+            assert torch.equal(h3s_2k, h3_2k[rows_full]) and torch.equal(hbs_2k, hb_2k[rows_full])      # bitwise
+            assert rel(h3, h3_2k) < 1e-6 and rel(hb, hb_2k) < 1e-5                                      # the two paths agree
         else:                                                                                 # ViSNet's Linear layers pick their kernel by row count
             assert rel(h3s, h3[rows_full]) < 1e-6 and rel(hbs, hb[rows_full]) < 1e-5
