@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="BASELINE.json configs by name (per-GPU share): cfg2 = ESOL + SchNet, K=5, 256 molecules (the default workload); cfg3 = Lipophilicity + SchNet, "
                          "K=5, 128 per GPU (1024 over 8 GPUs); cfg4 = BACE + ViSNet, K=5, 64; cfg5 = FreeSolv + SchNet, K=20, 64.  Overrides --shape/--batch/--conformers/--model")
+    ap.add_argument("--torch-adam", action="store_true", help="optimizer step on torch.optim.Adam(fused=True, capturable=True) instead of the one-launch FlatAdam")
     ap.add_argument("--no-pack8", action="store_true", help="skip the eight-concurrent-packer-processes leg of with_input_pipeline (it is skipped anyway under a profiler preload)")
     a = ap.parse_args(argv)
     if a.config:
@@ -310,7 +311,13 @@ def run_rank(args):
         model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=args.model).to(dev)
     cidx = model.create_aggregation_index(b.num_graphs, dev)
     flat = FlatGradients(model.parameters())
-    opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True, capturable=True)
+    # Adam over the flat parameter / gradient / moment buffers in ONE launch (parallel.FlatAdam, checked against torch.optim.Adam step by step in
+    # tests/test_gpu_stage2.py); --torch-adam keeps torch's multi-tensor kernels for the A/B
+    if args.torch_adam:
+        opt = torch.optim.Adam(flat.params, lr=1e-4, fused=True, capturable=True)
+    else:
+        from conan_fgw_amd.parallel import FlatAdam
+        opt = FlatAdam(flat, lr=1e-4)
     loss_box = [torch.zeros((), device=dev)]      # the step's loss tensor itself (no copy kernel in the step): the eager step's, or the captured graph's fixed output
     train = args.mode == "train"
     inv_world = 1.0 / world
@@ -808,7 +815,8 @@ def run_rank(args):
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
                                    + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
-                       "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core"},
+                       "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core",
+                       "optimizer": "torch.optim.Adam(fused, capturable)" if args.torch_adam else "Adam in one launch over flat buffers (parallel.FlatAdam: torch.optim.Adam's update)"},
             "rccl_ranks": dist.get_world_size() if use_dist and args.backend == "nccl" else 0,
             "dist": {"backend": ("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo (host memory; ranks may share a GPU: a functional run of the world > 1 step, not a rate)") if use_dist else None,
                      "ranks": world, "distinct_gpus": min(world, torch.cuda.device_count()) if args.backend == "gloo" else world, "per_rank": per_rank},

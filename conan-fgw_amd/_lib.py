@@ -90,6 +90,7 @@ SIGNATURES = {
     "conan_mse_loss_fwd": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "conan_stage2_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "conan_stage2_head_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "conan_adam_flat_step": (c_int, [_P, _P, _P, _P, _P, _P, c_ll] + [ctypes.c_double] * 5 + [_P]),
     "conan_mlp2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "conan_mlp2_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_mlp2_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -136,9 +136,71 @@ __global__ void __launch_bounds__(256) k_mse_loss(const float *__restrict__ pred
     if (tid == 0) loss[0] = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
 }
 
+
+// Adam (torch.optim.Adam, no amsgrad / maximize) over ONE flat parameter buffer and its flat gradient, moment and step buffers (round 5): the step of
+// the reference's optimiser (train_val.py) for the whole model in one launch instead of torch's multi-tensor kernels (a step-counter foreach add
+// + two fused-Adam launches over 100 parameter tensors: 5.7 + 15.8 + 7.0 us at cfg2 for 1.09 MB of parameters).  `step` lives on the device
+// (captured graphs replay the launch): every workgroup reads it first, the workgroup that finishes last advances it.
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)      (+ weight_decay * p added to g first)
+__global__ void __launch_bounds__(256) k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                                   float *__restrict__ step, unsigned *__restrict__ ticket, long long n, double lr_d, double b1_d, double b2_d,
+                                                   float eps, float wd) {
+    // the bias corrections 1 - b^t cancel badly in fp32 for the first steps (1 - 0.999^2 keeps three digits), and 0.999 itself is 1.3e-5 of
+    // (1 - b2) away from its fp32 rounding: they are formed in fp64 from the fp64 hyper-parameters, like torch's host-side (non-capturable) path
+    __shared__ float sh[4];
+    const float t = *step + 1.0f;
+    if (threadIdx.x == 0) {
+        const double bc1d = 1.0 - pow(b1_d, (double)t), bc2d = 1.0 - pow(b2_d, (double)t);
+        sh[0] = (float)(lr_d / bc1d); sh[1] = (float)sqrt(bc2d); sh[2] = (float)(1.0 - b1_d); sh[3] = (float)(1.0 - b2_d);
+    }
+    __syncthreads();
+    const float step_size = sh[0], sqrt_bc2 = sh[1], omb1 = sh[2], omb2 = sh[3];
+    const float b2 = (float)b2_d;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4 *>(p)[i];
+        const float4 gv = reinterpret_cast<const float4 *>(g)[i];
+        float4 mv = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        float *pp = &pv.x, *mp = &mv.x, *vp = &vv.x;
+        const float *gp = &gv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gp[e] + wd * pp[e];
+            mp[e] = mp[e] + omb1 * (gg - mp[e]);                         // lerp(m, g, 1 - b1), as torch's kernels form it
+            vp[e] = b2 * vp[e] + omb2 * gg * gg;
+            pp[e] -= step_size * mp[e] / (sqrtf(vp[e]) / sqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4 *>(p)[i] = pv; reinterpret_cast<float4 *>(m)[i] = mv; reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {      // tail (n not a multiple of 4)
+            const float gg = g[i] + wd * p[i];
+            const float mm = m[i] + omb1 * (gg - m[i]), vv = b2 * v[i] + omb2 * gg * gg;
+            m[i] = mm; v[i] = vv; p[i] -= step_size * mm / (sqrtf(vv) / sqrt_bc2 + eps);
+        }
+    __syncthreads();                                                    // every thread of this workgroup has read *step
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(ticket, 1u);
+        if (done == gridDim.x - 1) { *step = t; *ticket = 0u; }         // the last workgroup to finish: everyone has read the old value
+    }
+}
 }  // namespace
 
 extern "C" {
+
+int conan_adam_flat_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *step_dev, unsigned *ticket_dev, long long n,
+                         double lr, double beta1, double beta2, double eps, double weight_decay, void *stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !step_dev || !ticket_dev || n < 0) return CONAN_E_BADARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return CONAN_E_BADARG;      // float4 access
+    if (n == 0) return CONAN_OK;
+    long long blocks = ((n >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    k_adam_flat<<<(int)blocks, 256, 0, as_stream(stream)>>>(params, grads, exp_avg, exp_avg_sq, step_dev, ticket_dev, n, lr, beta1, beta2, (float)eps, (float)weight_decay);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
 
 int conan_mse_loss_fwd(const float *pred, const float *target, int n, float *loss, float *dpred, void *stream) {
     if (!pred || !target || !loss || !dpred || n <= 0) return CONAN_E_BADARG;

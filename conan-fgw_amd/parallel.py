@@ -272,3 +272,62 @@ class FlatGradients:
             self.last_allreduce_launches = 1
             if not prescaled:
                 self.flat.mul_(1.0 / world)
+
+
+class FlatAdam:
+    """torch.optim.Adam (defaults: no amsgrad, no maximize) for the parameters of a `FlatGradients`, as ONE launch per step
+    (conan_adam_flat_step) instead of torch's multi-tensor kernels over ~100 parameter tensors.
+
+    The parameters are moved into one flat fp32 buffer in the gradient buffer's order and every `Parameter.data` is re-pointed at its slice
+    (the module keeps working unchanged: `state_dict`, `load_state_dict` and the kernels see the same tensors), the two moments are flat
+    buffers of the same layout, the step counter lives on the device so that a captured HIP graph replays the launch.  `step()` expects the
+    gradients in `flat.flat` — i.e. after `FlatGradients.pack()` / `all_reduce_mean()`.  GPU only (there is no CPU path in this package)."""
+
+    def __init__(self, flat: "FlatGradients", lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if not flat.flat.is_cuda:
+            raise RuntimeError("FlatAdam runs on the GPU only")
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        dev = flat.flat.device
+        n = flat.flat.numel()
+        self.params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._order = None
+        self._adopt()
+
+    def _adopt(self):
+        """(Re-)lay the parameters and moments out in the gradient buffer's current order (it changes once, when the overlapped all-reduce
+        calibrates its buckets) and point every Parameter at its slice."""
+        order = list(self.flat._order_idx)
+        if order == self._order:
+            return
+        old = None if self._order is None else (self._order, self.exp_avg.clone(), self.exp_avg_sq.clone())
+        new_p = torch.empty_like(self.params)
+        off, offs = 0, {}
+        with torch.no_grad():
+            for i in order:
+                p = self.flat.params[i]
+                offs[i] = off
+                new_p[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                off += p.numel()
+            if old is not None:                                   # carry the moments over to the new layout
+                o_off, oo = {}, 0
+                for i in old[0]:
+                    o_off[i] = oo; oo += self.flat.params[i].numel()
+                for i in order:
+                    k = self.flat.params[i].numel()
+                    self.exp_avg[offs[i]:offs[i] + k].copy_(old[1][o_off[i]:o_off[i] + k])
+                    self.exp_avg_sq[offs[i]:offs[i] + k].copy_(old[2][o_off[i]:o_off[i] + k])
+            self.params = new_p
+            for i in order:
+                p = self.flat.params[i]
+                p.data = self.params[offs[i]:offs[i] + p.numel()].view_as(p)
+        self._order = order
+
+    def step(self):
+        from ._lib import call, ptr, stream_ptr
+        self._adopt()
+        call("conan_adam_flat_step", ptr(self.params), ptr(self.flat.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.step_dev),
+             ptr(self._ticket), self.params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, stream_ptr())

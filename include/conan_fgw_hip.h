@@ -273,6 +273,14 @@ int conan_stage2_head_bwd(const float *dout, const float *W3, const float *Wb, c
  * small launches on the critical path between the forward and the backward of a step.  Fixed summation order. */
 int conan_mse_loss_fwd(const float *pred, const float *target, int n, float *loss, float *dpred, void *stream);
 
+/* torch.optim.Adam's step (the reference's optimiser, train_val.py; no amsgrad, no maximize) for a WHOLE model in one launch (round 5): parameters,
+ * gradients and both moments are flat fp32 buffers of n elements in one common order (16-byte aligned; conan_fgw_amd.parallel.FlatAdam lays the
+ * parameters out in FlatGradients' order and re-points every Parameter at its slice).  step_dev: one device float holding the number of steps
+ * taken so far (0 at the start), advanced by the call — device-side so that a captured graph replays it; ticket_dev: one zeroed device word of
+ * workspace.  Hyper-parameters are doubles: the bias corrections 1 - b^t are formed in fp64 (they cancel in fp32).   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), g += weight_decay * p first. */
+int conan_adam_flat_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *step_dev, unsigned *ticket_dev, long long n,
+                         double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
+
 /* Two chained node-level Linear layers in one launch (mlp2.hip):
  *   forward : mid = ssp(x w1^T + b1) [M,N1];  y = mid w2^T + b2 (+ residual) [M,N2]
  *             = InteractionBlock's  conv.lin2 -> act -> lin (+ x)  (schnet_no_sum.py:164 with PyG's InteractionBlock.forward)

@@ -307,3 +307,39 @@ def test_training_steps_on_ragged_batches_follow_the_oracle():
         d_ref = rp[k].detach() - p0[k]
         err = float((gp[k].detach().cpu().double() - rp[k].detach()).norm())
         assert err <= 5e-3 * float(d_ref.norm()) + 1e-9, (k, err, float(d_ref.norm()))
+
+
+def test_flat_adam_follows_torch_adam_step_by_step():
+    """parallel.FlatAdam (conan_adam_flat_step: one launch over flat parameter / gradient / moment buffers, device-side step counter) against
+    torch.optim.Adam on a copy of the same stage-2 model: the same gradients go into both, parameters must agree after every one of six steps
+    (1e-6 relative: the two differ only in how b^t is evaluated), with and without weight decay; the re-pointed parameters still drive the model
+    and round-trip through state_dict."""
+    import copy
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from conan_fgw_amd.parallel import FlatAdam, FlatGradients
+    dev = torch.device("cuda:0")
+    for wd in (0.0, 1e-2):
+        torch.manual_seed(11)
+        ma = EmbeddingsWithGATAggregationBaryCenter(3, dev).to(dev)
+        mb = copy.deepcopy(ma)
+        fa = FlatGradients(ma.parameters())
+        oa = FlatAdam(fa, lr=3e-3, weight_decay=wd)
+        pb = [p for p in mb.parameters() if p.requires_grad]
+        ob = torch.optim.Adam(pb, lr=3e-3, weight_decay=wd)
+        assert all(p.data_ptr() >= oa.params.data_ptr() and p.data_ptr() < oa.params.data_ptr() + 4 * oa.params.numel() for p in fa.params)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        for step in range(6):
+            grads = [torch.randn(p.shape, generator=g).to(dev) * (10.0 ** (step - 3)) for p in fa.params]      # magnitudes over six decades
+            fa.zero()
+            for p, q, gr in zip(fa.params, pb, grads):
+                p.grad = gr.clone(); q.grad = gr.clone()
+            fa.pack()
+            oa.step(); ob.step()
+            torch.cuda.synchronize()
+            for p, q in zip(fa.params, pb):
+                assert rel(p.detach().cpu(), q.detach().cpu()) < 1e-6, (wd, step)
+        assert float(oa.step_dev) == 6.0
+        sd = ma.state_dict()
+        mc = EmbeddingsWithGATAggregationBaryCenter(3, dev).to(dev)
+        mc.load_state_dict(sd, strict=True)
+        assert all(torch.equal(a, c) for a, c in zip(ma.parameters(), mc.parameters()))
