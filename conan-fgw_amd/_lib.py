@@ -51,6 +51,7 @@ SIGNATURES = {
     "conan_edge_pairs": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "conan_edge_index_i64": (c_int, [_P, _P, c_int, _P, _P]),
     "conan_embedding_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "conan_onehot_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "conan_embedding_bwd_ws": (c_ll, [c_int, c_int, c_int]),
     "conan_embedding_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

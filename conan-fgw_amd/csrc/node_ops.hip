@@ -18,65 +18,49 @@ __global__ void k_embedding_fwd(const int64_t *__restrict__ z, const float *__re
     }
 }
 
-// Deterministic embedding gradient, two stages.  Stage 1 (round 5): one workgroup per (chunk of EMB_CHUNK atoms, 128-column tile), thread c owns
-// column c.  The chunk's atoms are put in row order first (a stable rank from an all-pairs count in LDS: EMB_CHUNK^2 / 128 comparisons per
-// thread), so a thread sums every row's atoms in a REGISTER, in ascending atom order, and writes each of the `rows` table rows exactly once,
-// straight to its slab in global memory (zeros for rows the chunk does not contain).  The round-1 form kept a [rows x 128] table in LDS and
-// added atom by atom through it — a chain of 128 dependent LDS read-modify-writes, 100 zeroing stores and 100 dump stores per thread, 198
-// tables of 51 KB: 22.7 + 11.6 us per step at cfg2 for a [100, 128] gradient.  Stage 2 sums the per-chunk slabs in chunk order.
-constexpr int EMB_CHUNK = 256;        // atoms per workgroup (99 workgroups at 25 k atoms)
+// Deterministic embedding gradient, two stages.  Stage 1: one workgroup per (chunk of EMB_CHUNK atoms, 128-column tile) keeps a
+// [num_embeddings x 128] partial table in LDS; thread c owns column c, walks the chunk's atoms in order and adds
+// dout[a][c] into row z[a] (no atomics, fixed order).  Stage 2 sums the per-chunk tables in chunk order.
+constexpr int EMB_CHUNK = 128;      // atoms per workgroup: the chunk is walked serially (4 batches of 32 loads), 198 workgroups at 25 k atoms
 constexpr int EMB_ROWS_MAX = 100;     // torch.nn.Embedding(100, H): atomic numbers
 __global__ void __launch_bounds__(128) k_embedding_bwd_partial(const int64_t *__restrict__ z, const float *__restrict__ dout, int n, int H,
                                                               int rows, float *__restrict__ slabs) {
-    __shared__ int zs[EMB_CHUNK];          // row of every atom of the chunk (rows = invalid: sorts last, never summed)
-    __shared__ int ord[EMB_CHUNK];         // atoms in (row, atom) order
-    __shared__ int srow[EMB_CHUNK + 1];    // their rows (+ a sentinel)
-    const int chunk = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x, tid = threadIdx.x;
-    const int a0 = chunk * EMB_CHUNK, cnt = min(n, a0 + EMB_CHUNK) - a0;
-    for (int t = tid; t < cnt; t += 128) {                     // out-of-range indices (NaN rows in the forward) add nothing
+    __shared__ float acc[EMB_ROWS_MAX * 128];
+    __shared__ int zs[EMB_CHUNK];
+    const int chunk = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
+    const int a0 = chunk * EMB_CHUNK, a1 = min(n, a0 + EMB_CHUNK);
+    for (int t = threadIdx.x; t < rows * 128; t += 128) acc[t] = 0.f;
+    for (int t = threadIdx.x; t < a1 - a0; t += 128) {          // out-of-range indices (NaN rows in the forward) add nothing
         const long long r = z[a0 + t];
-        zs[t] = (r >= 0 && r < rows) ? (int)r : rows;
+        zs[t] = (r >= 0 && r < rows) ? (int)r : -1;
     }
     __syncthreads();
-    for (int t = tid; t < cnt; t += 128) {                     // stable rank: atoms of smaller rows first, equal rows in atom order
-        const int key = zs[t];
-        int rank = 0;
-        for (int j = 0; j < cnt; ++j) { const int kj = zs[j]; rank += (kj < key || (kj == key && j < t)) ? 1 : 0; }
-        ord[rank] = t; srow[rank] = key;
-    }
-    if (tid == 0) srow[cnt] = rows;
-    __syncthreads();
-    float *slab = slabs + (size_t)chunk * rows * H;
-    const bool live = c < H;
-    const int cc = live ? c : 0;
-    int next_row = 0;                                           // first table row not written yet
-    int i = 0;
-    while (i < cnt) {
-        const int r = __builtin_amdgcn_readfirstlane(srow[i]);  // (the walk is the same for every thread: scalar control flow)
-        if (r >= rows) break;                                   // the invalid atoms sort last
-        int e = i + 1;
-        while (e < cnt && __builtin_amdgcn_readfirstlane(srow[e]) == r) ++e;
-        float acc = 0.f;
-        constexpr int U = 16;                                   // loads issued 16 deep, added in atom order
-        int a = i;
-        for (; a + U <= e; a += U) {
+    if (c < H) {                            // loads issued 32 deep (a batch costs one memory round trip), then the order-preserving LDS accumulation
+        constexpr int U = 32;
+        int a = a0;
+        for (; a + U <= a1; a += U) {
             float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = dout[(size_t)(a0 + __builtin_amdgcn_readfirstlane(ord[a + u])) * H + cc];
+            for (int u = 0; u < U; ++u) v[u] = dout[(size_t)(a + u) * H + c];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc += v[u];
+            for (int u = 0; u < U; ++u) { const int r = zs[a + u - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += v[u]; }
         }
-        for (; a < e; ++a) acc += dout[(size_t)(a0 + __builtin_amdgcn_readfirstlane(ord[a])) * H + cc];
-        if (live) {
-            for (int q = next_row; q < r; ++q) slab[(size_t)q * H + c] = 0.f;
-            slab[(size_t)r * H + c] = acc;
-        }
-        next_row = r + 1;
-        i = e;
+        for (; a < a1; ++a) { const int r = zs[a - a0]; if (r >= 0) acc[r * 128 + threadIdx.x] += dout[(size_t)a * H + c]; }
     }
-    if (live)
-        for (int q = next_row; q < rows; ++q) slab[(size_t)q * H + c] = 0.f;
+    __syncthreads();
+    if (c < H)
+        for (int r = 0; r < rows; ++r) slabs[((size_t)chunk * rows + r) * H + c] = acc[r * 128 + threadIdx.x];
 }
+// out[a, r] = 1 if z[a] == r (and r is not the padding row), else 0: the embedding gradient dW = onehot(z)^T dout then is an ordinary weight
+// gradient and joins the batched node-level launch of a backward pass (ops._EmbeddingFn; exact: 0 / 1 split into bf16 planes without error)
+__global__ void __launch_bounds__(256) k_onehot_rows(const int64_t *__restrict__ z, int n, int rows, int padding_idx, float *__restrict__ out) {
+    const long long total = (long long)n * rows, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int a = (int)(i / rows), r = (int)(i - (long long)a * rows);
+        out[i] = (z[a] == (long long)r && r != padding_idx) ? 1.0f : 0.0f;
+    }
+}
+
 __global__ void k_embedding_bwd_reduce(const float *__restrict__ slabs, int chunks, int rows, int H, int padding_idx,
                                        float *__restrict__ dweight) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +142,16 @@ int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, in
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     k_embedding_fwd<<<blocks, 256, 0, as_stream(stream)>>>(z, weight, num_atoms, hidden >> 2, num_embeddings, out);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_onehot_rows(const int64_t *z, int num_atoms, int num_embeddings, int padding_idx, float *out, void *stream) {
+    if (!z || !out || num_atoms < 0 || num_embeddings <= 0) return CONAN_E_BADARG;
+    if (num_atoms == 0) return CONAN_OK;
+    const long long total = (long long)num_atoms * num_embeddings;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    k_onehot_rows<<<blocks, 256, 0, as_stream(stream)>>>(z, num_atoms, num_embeddings, padding_idx, out);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

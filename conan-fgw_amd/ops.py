@@ -571,13 +571,22 @@ class _EmbeddingFn(torch.autograd.Function):
         z, weight = _c(z), _c(weight)
         out = torch.empty(z.shape[0], weight.shape[1], dtype=f32, device=weight.device)
         call("conan_embedding_fwd", ptr(z, i64), ptr(weight, f32), z.shape[0], weight.shape[1], weight.shape[0], ptr(out), stream_ptr())
-        ctx.save_for_backward(z)
+        ctx.save_for_backward(z, weight)
         ctx.shape, ctx.padding_idx = weight.shape, padding_idx
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (z,) = ctx.saved_tensors
+        z, weight = ctx.saved_tensors
+        rows, H = ctx.shape
+        if _pending is not None and rows <= 128 and lib().conan_wgrad_batchable(H, rows) and not any(j["weight_ptr"] == weight.data_ptr() for j in _pending):
+            # inside a deferred backward pass (FlatGradients.backward): dW = onehot(z)^T dout is one more job of the batched node-level weight-gradient
+            # launch (≈ 16 us at cfg2 for the one-hot build and its share of the batch, against 34 us for the two kernels of conan_embedding_bwd)
+            dout = _c(dout)
+            onehot = torch.empty(z.shape[0], rows, dtype=f32, device=dout.device)
+            call("conan_onehot_rows", ptr(z), z.shape[0], rows, -1 if ctx.padding_idx is None else ctx.padding_idx, ptr(onehot), stream_ptr())
+            dw, _ = _wgrad(onehot, dout, z.shape[0], H, rows, None, weight, False)
+            return None, dw, None
         dw = torch.empty(ctx.shape, dtype=f32, device=dout.device)
         ws = torch.empty(int(lib().conan_embedding_bwd_ws(z.shape[0], ctx.shape[1], ctx.shape[0])), dtype=f32, device=dout.device)
         call("conan_embedding_bwd", ptr(z), ptr(_c(dout)), z.shape[0], ctx.shape[1], ctx.shape[0],

@@ -128,6 +128,9 @@ int conan_embedding_fwd(const int64_t *z, const float *weight, int num_atoms, in
                         void *stream);
 /* dweight[r, :] = sum_{a: z[a]==r} dout[a, :] (row padding_idx = 0), deterministic two-stage reduction;
  * ws holds conan_embedding_bwd_ws(...) floats; num_embeddings <= 100. */
+/* out[a, r] = 1 if z[a] == r and r != padding_idx, else 0 (fp32 [num_atoms, num_embeddings]): with it the embedding gradient is the weight gradient
+ * onehot(z)^T dout and can join the batched slab launch of a backward pass (conan_linear_wgrad_slabs_batch) instead of running its own two kernels. */
+int conan_onehot_rows(const int64_t *z, int num_atoms, int num_embeddings, int padding_idx, float *out, void *stream);
 long long conan_embedding_bwd_ws(int num_atoms, int hidden, int num_embeddings);
 int conan_embedding_bwd(const int64_t *z, const float *dout, int num_atoms, int hidden, int num_embeddings,
                         int padding_idx, float *dweight, float *ws, void *stream);
