@@ -57,7 +57,8 @@ __device__ __forceinline__ float block_absmax(float v, float *red) {      // red
 
 constexpr int GP = 64;        // gaussians padded to four MFMA k-steps of 16 (zero weights beyond num_gaussians)
 constexpr int W1S = GP + 8;   // LDS pitch of a W1 row in the split images (16-bit elements: 144 B, 16-B slots of 8 consecutive rows stay distinct)
-constexpr int FF_THREADS = 512;      // eight wavefronts per workgroup (training form); the inference form (no h1 output) runs twelve: FF_THREADS_INFER
+constexpr int FF_THREADS = 512;      // eight wavefronts per workgroup.  (Twelve — three per SIMD, 154 KB of LDS, 160 registers — measured the same in an in-process A/B:
+                                     // with h1 67-68 us both, W only 58-61 us both; tools/ab_inproc_filter.py, profiles/r5_ab_filter_fwd_768_threads.txt)
 
 constexpr int FF_NPL = 2;                                    // operand planes: two fp16 planes (the round-2 three-plane bf16 form measured 28 % slower: DESIGN 3.1)
 constexpr int FF_OP = 36;                                    // pitch of the per-wave output slab (floats): 32 channels + 4
@@ -67,8 +68,6 @@ constexpr int FF_OP = 36;                                    // pitch of the per
 // target (CFConv.propagate: out[i] = sum_{e in row i} x[col[e]] * W[e]) through the per-wave slab: lane <-> channel walks the 32 rows in edge
 // order and adds each finished target segment to `out` (pre-zeroed by the entry point).  A target with <= 33 edges spans at most two tiles, so
 // its row of `out` is 0 + a (+ b): the result does not depend on which tile's add lands first (bitwise reproducible at cap 32).
-constexpr int FF_THREADS_INFER = 768; // three wavefronts per SIMD: 154 KB of LDS, <= 168 registers.  W-only 74-76 -> 67-69 us at cfg2 (profiles/r5_ab_filter_fwd_768_threads.txt);
-                                      // with the h1 stream the kernel sits on its stores either way (67-69 us both), so training keeps eight
 template <int F, bool CF = false, int NT = FF_THREADS>
 __global__ void __launch_bounds__(NT) k_filter_fused(
     const float *__restrict__ dist, const int *__restrict__ num_edges_dev, int max_edges, const float *__restrict__ offset,
@@ -354,7 +353,6 @@ template <int F>
 int launch(const float *dist, const int *num_edges_dev, int max_edges, const float *offset, int Gs, float coeff,
            float cutoff, const float *w1, const float *b1, const float *w2, const float *b2, float *W, float *h1,
            hipStream_t s) {
-    if (F == 128 && !h1) return launch_nt<F, FF_THREADS_INFER>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, s);
     return launch_nt<F, FF_THREADS>(dist, num_edges_dev, max_edges, offset, Gs, coeff, cutoff, w1, b1, w2, b2, W, h1, s);
 }
 
