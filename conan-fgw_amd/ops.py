@@ -120,7 +120,8 @@ def graph_ptr_from_batch(batch: Tensor, num_graphs: int) -> Tensor:
 # (conan_wgrad_reduce_batch) by `flush_weight_gradients()` — FlatGradients.pack() calls it — instead of 24 launches of ~6 us each.
 # The returned dW / db tensors are only valid after the flush; a weight that appears twice in one backward (autograd would add
 # the two results right away) flushes on the spot and takes the immediate path.  Node-level layers postpone their slab kernel as well
-# (one batched launch, same slices): results never depend on the mode, bit for bit.
+# (one batched launch).  With the library's slice count (LATE_SLICES_AUTO = False) results do not depend on the mode, bit for bit; by default the batch
+# cuts every job into fewer, longer slices (_late_slices): the same sums in another fixed order (1e-7 relative), 15-18 % less time for the pair of launches.
 _pending = None            # None: immediate mode; list of pending jobs (dicts) while deferring
 
 
@@ -161,7 +162,10 @@ def flush_weight_gradients():
         for q, j in enumerate(late):
             g, x, md = j["operands"]
             sj[q].g, sj[q].x, sj[q].m_dev, sj[q].ws = ptr(g), ptr(x), ptr(md), ptr(j["ws"])
-            sj[q].M, sj[q].K, sj[q].N, sj[q].slices = j["M"], j["K"], j["N"], 0      # default slice count: same slabs, same bits as the immediate form (256- and 512-row slices measured no faster)
+            sl = _late_slices(len(late), j["M"])
+            sj[q].M, sj[q].K, sj[q].N, sj[q].slices = j["M"], j["K"], j["N"], sl      # 0: the library's default slice count
+            if sl:
+                j["slices"] = sl
         call("conan_linear_wgrad_slabs_batch", sj, len(late), stream_ptr())
         for j in late:
             for t in j.pop("operands"):
@@ -180,6 +184,22 @@ def flush_weight_gradients():
 
 
 _LATE_STAGE1_ROWS = 65536   # below this row count a weight gradient's slab kernel is postponed to the batched launch
+LATE_SLICES = 0             # row slices per postponed job, forced (0 = automatic, below): tools/probe_wgrad_batch.py sweeps it
+LATE_SLICES_AUTO = True     # False: the library's default (one slice per 128 rows), i.e. the same slabs — and bits — as the immediate form
+
+
+def _late_slices(n_jobs: int, M: int) -> int:
+    """Row slices per postponed node-level job.  The library's default (one per 128 rows: 198 at cfg2) gives a 22-job batch 4 356 workgroups, each
+    writing a 64 KB slab for 8 stages of work; measured in one process (tools/probe_wgrad_batch.py, profiles/r5_wgrad_batch_slices.txt): 198 slices
+    249-261 us, 128: 218-227, 96: 212-219, 80: 217, 64: 207-209, 48: 238, 24: 270 — best where a launch (<= 24 jobs) holds ~1 400 workgroups, a
+    multiple of 8 per job (the XCD grouping of jobs that share x).  Fixed order of summation either way; not the same order as the default's."""
+    if LATE_SLICES:
+        return LATE_SLICES
+    if not LATE_SLICES_AUTO:
+        return 0
+    dflt = max(1, (M + 127) // 128)
+    s = 8 * max(1, round(1400 / max(1, min(n_jobs, 24)) / 8))
+    return s if s < dflt else 0
 _flushed = {}              # weight data_ptr -> (dW data_ptr, db data_ptr | None) of the last flushes (cleared by whoever verifies them)
 
 
