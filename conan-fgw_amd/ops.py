@@ -193,11 +193,11 @@ def _late_slices(n_jobs: int, M: int) -> int:
     writing a 64 KB slab for 8 stages of work; measured in one process (tools/probe_wgrad_batch.py, profiles/r5_wgrad_batch_slices.txt): 198 slices
     249-261 us, 128: 218-227, 96: 212-219, 80: 217, 64: 207-209, 48: 238, 24: 270 — best where a launch (<= 24 jobs) holds ~1 400 workgroups, a
     multiple of 8 per job (the XCD grouping of jobs that share x).  Fixed order of summation either way; not the same order as the default's."""
+    dflt = max(1, (M + 127) // 128)
     if LATE_SLICES:
-        return LATE_SLICES
+        return LATE_SLICES if LATE_SLICES < dflt else 0           # (never more than the default: the workspace and the reducer are sized by it)
     if not LATE_SLICES_AUTO:
         return 0
-    dflt = max(1, (M + 127) // 128)
     s = 8 * max(1, round(1400 / max(1, min(n_jobs, 24)) / 8))
     return s if s < dflt else 0
 _flushed = {}              # weight data_ptr -> (dW data_ptr, db data_ptr | None) of the last flushes (cleared by whoever verifies them)
