@@ -43,6 +43,9 @@ def get_model(name: str, device, **kwargs):
     return EquivModelsHolder.get_model(name, device, **kwargs)
 
 
+GAT_ON_SIDE_STREAM = True      # stage-2 regression model: the covalent branch beside the backbone (tools/ab_step_switch.py compares)
+
+
 class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
     """The stage-2 regression model of the reference without its Lightning shell
     (`EmbeddingsWithGATAggregationBaryCenter`, conan_fgw/src/model/schnet_based_models.py:83-173 on top of `EquivAggregation`,
@@ -106,7 +109,7 @@ class EmbeddingsWithGATAggregationBaryCenter(torch.nn.Module):
         # and the FGW solve (whose last wave of workgroups leaves two thirds of the CUs idle).  autograd replays each op's
         # backward on the stream of its forward, so the overlap carries over to the backward pass.
         main = torch.cuda.current_stream()
-        side = self._side_stream(main.device)
+        side = self._side_stream(main.device) if GAT_ON_SIDE_STREAM else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             x_cov = self.gat_embeddings_model(batch.x, batch.edge_index, batch.edge_attr, batch.batch,
