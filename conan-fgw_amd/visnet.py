@@ -58,6 +58,10 @@ class EdgeEmbedding(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.edge_proj.weight); self.edge_proj.bias.data.zero_()
 
 
+NODE_LEVEL_ON_SIDE_STREAM = 3         # 3 = also the 3-D output head beside the barycenter head; ViS_MP: 1 = the atom-level head of a layer beside the edge-level projections of f; 2 = also o_proj / node_update beside
+                                      # s_proj + vec_aggregate / edge_update; 0 = one stream (tools/ab_step_switch.py compares)
+
+
 class ViS_MP(torch.nn.Module):
     def __init__(self, num_heads: int, hidden: int, cutoff: float, last_layer: bool = False):
         super().__init__()
@@ -119,9 +123,35 @@ class ViSNetBlock(torch.nn.Module):
         """ViS_MP.forward / message / aggregate / edge_update, torch_geometric_visnet.py:579-673."""
         H, n = self.hidden_channels, x.shape[0]
         md = g.num_edges_dev
-        xl = vo.layernorm(x, L.layernorm)
-        vl = vo.scale_channels(vec, L.vec_layernorm.weight)
-        q, k, v = vo.multi_lin(xl, [L.q_proj, L.k_proj, L.v_proj])
+        wt = ws = None
+
+        def node_level():
+            """Everything of the layer's head that lives on the atoms (a chain of small launches: LayerNorm, the q / k / v and vec / w_trg / w_src
+            projections, vec_dot) — independent of the edge-level projections of f below."""
+            nonlocal wt, ws
+            xl_ = vo.layernorm(x, L.layernorm)
+            vl_ = vo.scale_channels(vec, L.vec_layernorm.weight)
+            q_, k_, v_ = vo.multi_lin(xl_, [L.q_proj, L.k_proj, L.v_proj])
+            if L.last_layer:
+                vp_ = vo.lin(vl_.view(3 * n, H), L.vec_proj)                       # [3n, 3H] = [vec1|vec2|vec3]
+            else:                                                                  # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node
+                vp_, wt, ws = vo.multi_lin(vl_.view(3 * n, H), [L.vec_proj, L.w_trg_proj, L.w_src_proj])
+            return vl_, q_, k_, v_, vp_, vo.vecdot(vp_, n, H)
+
+        side = None
+        if NODE_LEVEL_ON_SIDE_STREAM:
+            # The atom-level chain (~100 us of small launches at BACE B = 64) runs on a second HIP stream under the edge-level projection of f
+            # (218 us, fills the chip); autograd replays each op's backward on the stream of its forward, so the backward overlaps the same way.
+            main = torch.cuda.current_stream()
+            side = getattr(self, "_node_stream", None)
+            if side is None or side.device != main.device:
+                side = torch.cuda.Stream(device=main.device)
+                object.__setattr__(self, "_node_stream", side)                     # (not module state)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                vl, q, k, v, vp, vdot = node_level()
+        else:
+            vl, q, k, v, vp, vdot = node_level()
         # dk / dv / f_proj read the same f: one autograd node, so that the three input gradients are summed inside the backward GEMMs
         # dk / dv stay PRE-activations: act (SiLU) is applied inside the attention kernels as they load them
         if L.last_layer:
@@ -129,14 +159,28 @@ class ViSNetBlock(torch.nn.Module):
         else:
             # (t too: act applied inside edge_update; f itself is handed through for edge_update's residual, see _MultiLinear)
             dk, dv, t, f = vo.multi_lin(f, [L.dk_proj, L.dv_proj, L.f_proj], False, md, tap=True)
-        if L.last_layer:
-            vp = vo.lin(vl.view(3 * n, H), L.vec_proj)                             # [3n, 3H] = [vec1|vec2|vec3]
-        else:                                                                      # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node
-            vp, wt, ws = vo.multi_lin(vl.view(3 * n, H), [L.vec_proj, L.w_trg_proj, L.w_src_proj])
-        vdot = vo.vecdot(vp, n, H)
+        if side is not None:
+            main.wait_stream(side)
+            for tt in (vl, q, k, v, vp, vdot, wt, ws):
+                if tt is not None:
+                    tt.record_stream(main)
         vmsg, xagg = vo.attn_message(q, k, v, dk, dv, g, L.cutoff, L.num_heads, pre_act=True)
+        tail_on_side = side is not None and NODE_LEVEL_ON_SIDE_STREAM >= 2
+        if tail_on_side:                                                           # o_proj (atoms) under s_proj + the vector aggregation (edges)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                o = vo.lin(xagg, L.o_proj)
         sact = vo.lin(vmsg, L.s_proj, False, md)                                   # [E, 2H] = pre-activation of [s1|s2]; act applied inside vec_aggregate
         vagg = vo.vec_aggregate(vl, sact, dvec, g, pre_act=True)
+        if tail_on_side:                                                           # the residual node update (atoms) under the edge update (edges)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
+            fo = f if L.last_layer else vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True)
+            main.wait_stream(side)
+            for tt in (o, xo, veco):
+                tt.record_stream(main)
+            return xo, veco, fo
         o = vo.lin(xagg, L.o_proj)
         xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
         if L.last_layer:
@@ -234,6 +278,19 @@ class ViSNet(torch.nn.Module):
         """visnet.py:124-158: two per-atom heads from the shared representation."""
         batch, gp, G = self._prep(z, batch, num_graphs)
         xs, vs = self.representation_model(z, pos, gp, G)
+        if NODE_LEVEL_ON_SIDE_STREAM >= 3:
+            # the two heads are independent chains of ~10 atom-level launches each: one of them on the second stream (forward and, through
+            # autograd's stream rule, backward)
+            main = torch.cuda.current_stream()
+            side = getattr(self.representation_model, "_node_stream", None) or torch.cuda.Stream(device=main.device)
+            object.__setattr__(self.representation_model, "_node_stream", side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                h = self._head(xs, vs, z, self.output_model, self.prior_model)
+            hb = self._head(xs, vs, z, self.output_model_bary, self.prior_model_bary)
+            main.wait_stream(side)
+            h.record_stream(main)
+            return h, hb
         return self._head(xs, vs, z, self.output_model, self.prior_model), self._head(xs, vs, z, self.output_model_bary, self.prior_model_bary)
 
     def _compute_barycenter(self, node_feature: Tensor, edge_index, batch: Tensor, batch_size: int, num_conformers: int,

@@ -2,7 +2,7 @@
 into HIP graphs once per setting of `module.ATTRIBUTE`, and the two sets of graphs are replayed alternately in the same process (blocks of
 20 steps, order reversed every round) — no first-process bias, no box-to-box spread.
 
-    python tools/ab_step_switch.py schnet.HEADS_ON_TWO_STREAMS=True,False [shape batch conformers [rounds]]"""
+    python tools/ab_step_switch.py schnet.HEADS_ON_TWO_STREAMS=True,False [shape batch conformers [rounds [schnet|visnet]]]"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,7 @@ shape = sys.argv[2] if len(sys.argv) > 2 else "esol"
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 K = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+model_name = sys.argv[6] if len(sys.argv) > 6 else "schnet"
 from conan_fgw_amd import ops
 from conan_fgw_amd.collate import DeviceCollator, molecules_from_synthetic
 from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
@@ -26,7 +27,7 @@ b = make_batch(shape, B, K, seed=1236); bg = make_bond_graph(b, seed=2236)
 data = DeviceCollator(dev, K, depth=2, static=True)(molecules_from_synthetic(b, bg)).wait()
 y = torch.from_numpy(b.y).to(dev)[:, None]
 torch.manual_seed(5)
-model = EmbeddingsWithGATAggregationBaryCenter(K, dev).to(dev)
+model = EmbeddingsWithGATAggregationBaryCenter(K, dev, model_name=model_name).to(dev)
 cidx = model.create_aggregation_index(b.num_graphs, dev)
 flat = FlatGradients(model.parameters())
 opt = FlatAdam(flat, lr=1e-4)
