@@ -416,8 +416,10 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 #define FGW_MMG mm_f64_glb22
 // C2U8: the adjacency of the input graph is staged ONCE into LDS as bytes (caller's promise cs_small_int: integers in [0, 255]) and both
 // products that contract with it read it there instead of fetching fp32 from L2 in every projected-gradient iteration.
-template <int NW, bool C2U8>
-__global__ void __launch_bounds__(64 * NW, (NW * 3 + 3) / 4) k_fgw_coupling_big(
+// WPC: workgroups per CU the register budget is cut for — 3 (80 registers: a 640-coupling shard is resident in one round, with ~80 B / lane of
+// scratch) or 2 (128 registers, no scratch): the launcher takes 2 when the batch has at most 512 couplings anyway (BACE B = 64: 320).
+template <int NW, bool C2U8, int WPC = 3>
+__global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
     const int *__restrict__ active, float *__restrict__ Tw, int *__restrict__ info, char *__restrict__ scratch,
@@ -857,6 +859,10 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
 
 inline int pitch_of(int N) { return fgw_pitch(N); }
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+#ifndef CONAN_FGW_BIG_WPC2
+#define CONAN_FGW_BIG_WPC2 1
+#endif
+constexpr bool BIG_WPC2 = CONAN_FGW_BIG_WPC2 != 0;      // (A/B switch: 0 = always the three-per-CU build)
 constexpr int GEN_NW = 8;                   // wavefronts per workgroup of the large-N coupling kernel (16 measured no faster: 453 vs 443 us per workgroup and launch)
 inline size_t coupling_lds(int N) { return (size_t)((6 + 2 * GEN_NW) * N + 16) * 8 + (size_t)N * pitch_of(N) * 28; }
 inline size_t big_lds(int N, bool c2_bytes) {
@@ -956,15 +962,17 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         const int *only = nullptr;
         if (big) {
-#define CONAN_BIG(U8)                                                                                                               \
+#define CONAN_BIG(U8, WPC)                                                                                                          \
     do {                                                                                                                            \
         if (lb > 64 * 1024)                                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW, U8>),                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW, U8, WPC>),                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);                                         \
-        k_fgw_coupling_big<GEN_NW, U8><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
-                                                                       Ypart, Cpart, redo, adj);                                     \
+        k_fgw_coupling_big<GEN_NW, U8, WPC><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
+                                                                            Ypart, Cpart, redo, adj);                                \
     } while (0)
-            if (c2b) CONAN_BIG(true); else CONAN_BIG(false);
+            const bool two_per_cu = BIG_WPC2 && B * K <= 512;      // every coupling resident at two workgroups per CU: take the 128-register build
+            if (c2b) { if (two_per_cu) CONAN_BIG(true, 2); else CONAN_BIG(true, 3); }
+            else { if (two_per_cu) CONAN_BIG(false, 2); else CONAN_BIG(false, 3); }
 #undef CONAN_BIG
             only = redo;
         }
