@@ -105,3 +105,62 @@ def test_get_model_mirrors_the_reference_factory():
     idx = model.create_aggregation_index(batch)                                      # the reference's argument: the collated batch
     assert idx.tolist() == [0] * 5 + [1] * 5 and idx.dtype == torch.long
     assert model.forward_dummy(batch, idx, batch.batch) is None
+
+
+def test_bench_config_shorthand_and_explicit_flags():
+    """bench.py --config names BASELINE.json's configurations as the per-GPU workload; a flag given beside it wins (the 8-rank dry run of cfg3 uses
+    --batch 16)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    a = bench.parse(["--config", "cfg3"])
+    assert (a.shape, a.batch, a.conformers, a.model) == ("lipo", 128, 5, "schnet")
+    a = bench.parse(["--config", "cfg3", "--batch", "16"])
+    assert (a.shape, a.batch) == ("lipo", 16)
+    a = bench.parse(["--config", "cfg4"])
+    assert (a.shape, a.batch, a.model) == ("bace", 64, "visnet")
+    a = bench.parse(["--config", "cfg5"])
+    assert (a.shape, a.batch, a.conformers) == ("freesolv", 64, 20)
+    a = bench.parse([])
+    assert (a.shape, a.batch, a.conformers, a.model, a.gpus) == ("esol", 256, 5, "schnet", 1)          # BASELINE configs[1] on one GPU
+
+
+def test_slice_rule_of_the_batched_weight_gradients():
+    """ops._late_slices: ~1 400 workgroups per launch of <= 24 jobs, a multiple of 8 per job, never more than the library's default (one per 128
+    rows: the workspace and the reducer are sized by it); the forced knob obeys the same cap."""
+    from conan_fgw_amd import ops
+    assert ops._late_slices(22, 25275) == 64                     # cfg2's backward pass
+    assert ops._late_slices(40, 15000) == 56                     # more than 24 jobs: the launch is cut at 24
+    assert ops._late_slices(22, 1280) == 0                       # graph-level layers (default 10 slices): the default stays
+    assert ops._late_slices(1, 25275) == 0                       # a lone job: 1 400 > its default 198
+    keep = ops.LATE_SLICES
+    try:
+        ops.LATE_SLICES = 96
+        assert ops._late_slices(22, 25275) == 96 and ops._late_slices(22, 1280) == 0
+    finally:
+        ops.LATE_SLICES = keep
+    ops.LATE_SLICES_AUTO = False
+    try:
+        assert ops._late_slices(22, 25275) == 0
+    finally:
+        ops.LATE_SLICES_AUTO = True
+
+
+def test_fused_gather_is_chosen_by_the_estimated_filter_tensor_size():
+    """schnet._filter_tensor_outgrows_cache: host-side estimate atoms x min(cap, atoms per conformer - 1) / 2 pair rows of 4F bytes against 192 MiB —
+    cfg2 (25 k atoms in 1 280 conformers: 123 MB) keeps the two kernels, a Lipophilicity shard (29.6 k atoms in 640: 242 MB) takes the fused one."""
+    import types
+    from conan_fgw_amd import schnet
+    cfg2 = types.SimpleNamespace(num_atoms=25275, num_graphs=1280, cap=32)
+    lipo = types.SimpleNamespace(num_atoms=29600, num_graphs=640, cap=32)
+    assert not schnet._filter_tensor_outgrows_cache(cfg2, 128)
+    assert schnet._filter_tensor_outgrows_cache(lipo, 128)
+    assert not schnet._filter_tensor_outgrows_cache(types.SimpleNamespace(num_atoms=0, num_graphs=0, cap=32), 128)
+
+
+def test_batch_hints_are_absent_on_foreign_tensors():
+    from conan_fgw_amd import ops
+    t = torch.zeros(5, dtype=torch.int64)
+    assert ops.batch_hints(t) == (None, None) and ops.batch_hints(None) == (None, None)
+    t._conan_hints = (3, 7)
+    assert ops.batch_hints(t) == (3, 7) and ops.batch_hints(t.clone()) == (None, None)      # the tag does not travel with copies
