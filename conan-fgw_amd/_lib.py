@@ -56,6 +56,7 @@ SIGNATURES = {
     "conan_embedding_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_linear_multi_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "conan_linear_sum_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
     "conan_ssp_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "conan_linear_wgrad_ws": (c_ll, [c_int, c_int, c_int]),
     "conan_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

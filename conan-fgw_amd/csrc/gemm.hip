@@ -664,6 +664,8 @@ int conan_linear_t_try(const float *x, const float *w, const float *bias, const 
                        int act, float *y, const int *m_dev, hipStream_t s, int *rc, float *pre_out);      // gemm_t.hip
 int conan_linear_t_multi(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int njobs, int act, float *const *y,
                          float *const *pre, const int *m_dev, hipStream_t s, int *rc);                    // gemm_t.hip
+int conan_linear_t_sum(const float *const *x, const int *ldx, const float *const *w, int nsrc, int w_kn, int ldw, const float *bias,
+                       const float *residual, int M, int N, float *y, const int *m_dev, hipStream_t s, int *rc);   // gemm_t.hip
 
 extern "C" {
 
@@ -726,6 +728,17 @@ int conan_linear_multi_fwd(const float *x, const float *const *w, const float *c
         if (rc != CONAN_OK) return rc;
     }
     return CONAN_OK;
+}
+
+int conan_linear_sum_fwd(const float *const *x, const int *ldx, const float *const *w, int num_inputs, int w_kn, const float *bias,
+                         const float *residual, int M, int N, const int *m_dev, float *y, void *stream) {
+    if (!x || !ldx || !w || !y || M < 0 || N <= 0 || num_inputs < 1) return CONAN_E_BADARG;
+    for (int c = 0; c < num_inputs; ++c)
+        if (!x[c] || !w[c] || ldx[c] < 128 || (ldx[c] & 3)) return CONAN_E_BADARG;
+    if (M == 0) return CONAN_OK;
+    int rc = CONAN_OK;
+    if (conan_linear_t_sum(x, ldx, w, num_inputs, w_kn, w_kn ? N : 128, bias, residual, M, N, y, m_dev, as_stream(stream), &rc)) return rc;
+    return CONAN_E_UNSUPPORTED;
 }
 
 int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream) {

@@ -328,6 +328,241 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
+
+// ---- y = sum_c x_c W_c^T (+ bias) (+ residual): up to three 128-wide contractions of DIFFERENT inputs in one launch -------------------------
+// The input gradient of several Linear layers of one input (ViS_MP's dk / dv / f_proj of f: dx = sum_c g_c W_c) and of a layer wider than one
+// 128-chunk (s_proj: g [E,256]) was a chain of launches that carried the running sum through HBM: read g_c, read the sum, write the sum, per
+// chunk — 9 and 5 [E,128] tensors where 5 and 3 have to move.  Here the sum stays in the accumulators: a wavefront streams its 32 rows of
+// chunk 0, 1, 2 one after the other (the next chunk's rows fly during this chunk's MFMA loop).  All chunks' weight planes have to stay in
+// LDS for the whole persistent loop, which is why a workgroup owns 64 of the 128 outputs (3 x 34 KB instead of 3 x 68 KB) and the two halves of
+// a tile slot run as two workgroups of the same XCD that find each other's rows in that XCD's L2.
+// Row scales: chunk c of a row has its own power-of-two scale; the accumulators live in units of 2^r with r the largest unit so far — when a
+// chunk raises r the accumulators are multiplied by the (exact) ratio, a chunk below it is scaled by 2^-r' >= its own unit instead, which is
+// what one scale for the concatenated row would do to it.
+struct LtSrcs {
+    const float *x[3], *w[3];
+    int ldx[3];
+};
+__device__ __forceinline__ float pow2i(int e) { return e < -126 ? 0.f : __uint_as_float((unsigned)(min(e, 127) + 127) << 23); }
+constexpr int LT_NOEXP = -100000;                              // "no unit": a zero / subnormal / non-finite maximum
+__device__ __forceinline__ int pow2_exp(float amax) {          // e with amax * 2^-e in [256, 512) (pow2_scale's un = 2^e), or LT_NOEXP
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    return (e >= 9 && e <= 254) ? e - 135 : LT_NOEXP;
+}
+// the two fp16 planes of one [N][K] weight image (k_linear_t16's staging as a function); returns the image's unit exponent
+template <int K, int N, int NT>
+__device__ __forceinline__ int lt_stage_planes(const float *__restrict__ w, int w_kn, int ldw, _Float16 *WB, float *wred) {
+    constexpr int WS = K + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ew;
+    if (!w_kn) {
+        constexpr int V4 = N * K / 4, PER = (V4 + NT - 1) / NT;
+        float4 wv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + u * NT;
+            const int n = (4 * q) / K, k = 4 * q - n * K;
+            wv[u] = q < V4 ? *reinterpret_cast<const float4 *>(w + (size_t)n * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float am = 0.f;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u].x), fabsf(wv[u].y)), fmaxf(fabsf(wv[u].z), fabsf(wv[u].w))));
+        ew = pow2_exp(lt_block_absmax<NT>(am, wred));
+        const float wsc = ew == LT_NOEXP ? 1.0f : pow2i(-ew);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = tid + u * NT;
+            if (q >= V4) continue;
+            const float v4[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+            const int n = (4 * q) / K, k = 4 * q - n * K;
+            lt_store4(WB, N, WS, n, k, v4, wsc);
+        }
+    } else {
+        constexpr int PATCHES = (K / 16) * (N / 64), PERW = (PATCHES + NT / 64 - 1) / (NT / 64);
+        float4 wv[PERW][4];
+        const int n4l = (lane & 3) | ((lane >> 4) << 2), k4l = (lane >> 2) & 3;
+#pragma unroll
+        for (int u = 0; u < PERW; ++u) {
+            const int pt = wave + u * (NT / 64);
+            const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wv[u][j] = pt < PATCHES ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + j) * ldw + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float am = 0.f;
+#pragma unroll
+        for (int u = 0; u < PERW; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(wv[u][j].x), fabsf(wv[u][j].y)), fmaxf(fabsf(wv[u][j].z), fabsf(wv[u][j].w))));
+        ew = pow2_exp(lt_block_absmax<NT>(am, wred));
+        const float wsc = ew == LT_NOEXP ? 1.0f : pow2i(-ew);
+#pragma unroll
+        for (int u = 0; u < PERW; ++u) {
+            const int pt = wave + u * (NT / 64);
+            if (pt >= PATCHES) continue;
+            const int k0 = (pt / (N / 64)) * 16 + 4 * k4l, n0 = (pt % (N / 64)) * 64 + 4 * n4l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v4[4] = {e == 0 ? wv[u][0].x : e == 1 ? wv[u][0].y : e == 2 ? wv[u][0].z : wv[u][0].w,
+                                     e == 0 ? wv[u][1].x : e == 1 ? wv[u][1].y : e == 2 ? wv[u][1].z : wv[u][1].w,
+                                     e == 0 ? wv[u][2].x : e == 1 ? wv[u][2].y : e == 2 ? wv[u][2].z : wv[u][2].w,
+                                     e == 0 ? wv[u][3].x : e == 1 ? wv[u][3].y : e == 2 ? wv[u][3].z : wv[u][3].w};
+                lt_store4(WB, N, WS, n0 + e, k0, v4, wsc);
+            }
+        }
+    }
+    __syncthreads();                                           // wred is reused by the next image
+    return ew == LT_NOEXP ? 0 : ew;                            // (an all-zero image: unit 1, planes 0)
+}
+
+constexpr int LS_OP = 36;                                      // pitch of the per-wave output slab: 32 channels + 4
+#ifndef CONAN_LSUM_PAIR_XCD
+#define CONAN_LSUM_PAIR_XCD 1                                  // the two output halves of a tile slot on ONE XCD (blocks b and b + 8); 0: blocks b, b + 1
+#endif
+template <int NCH, int NT>
+__global__ void __launch_bounds__(NT) k_linear_sum16(const LtSrcs Sx, const float *__restrict__ bias, const float *__restrict__ residual, int M,
+                                                     int w_kn, float *y, const int *__restrict__ m_dev, int ldw, int ldy) {
+    constexpr int K = 128, N = 64, NB = N / 32, S = K / 16, WS = K + 8, PL = LT_NPL * N * WS;      // PL: 16-bit elements of one chunk's planes
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    _Float16 *WH = reinterpret_cast<_Float16 *>(lds);          // [NCH][planes][N][WS]
+    float *BL = lds + (NCH * PL) / 2;                          // [N]
+    float *OT = BL + N + (threadIdx.x >> 6) * (32 * LS_OP);    // this wave's [32][LS_OP] output slab
+    __shared__ float wred[NT / 64];
+    if (m_dev) M = min(M, *m_dev);
+    const int tiles = (M + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x;
+#if CONAN_LSUM_PAIR_XCD
+    const int half = (b >> 3) & 1, slot = ((b >> 4) << 3) | (b & 7);        // gridDim.x is a multiple of 16
+#else
+    const int half = b & 1, slot = b >> 1;
+#endif
+    const int nslots = (int)gridDim.x >> 1;
+    const int n0 = half * N;
+    if (slot * (NT / 64) >= tiles) return;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_stride = nslots * (NT / 64);
+    float4 xa[S], xb[S];
+    auto load_x = [&](int t, int c) {
+        const int mr = min((t << 5) + l31, M - 1);
+        const float *xr = Sx.x[c] + (size_t)mr * Sx.ldx[c] + 8 * h;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
+            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
+        }
+    };
+    if (slot * (NT / 64) + wave < tiles) load_x(slot * (NT / 64) + wave, 0);
+    int ew[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        ew[c] = lt_stage_planes<K, N, NT>(Sx.w[c] + (w_kn ? (size_t)n0 : (size_t)n0 * ldw), w_kn, ldw, WH + c * PL, wred);
+    for (int t = tid; t < N; t += NT) BL[t] = bias ? bias[n0 + t] : 0.f;
+    __syncthreads();
+
+    for (int tile = slot * (NT / 64) + wave; tile < tiles; tile += wave_stride) {
+        const int m = (tile << 5) + l31;
+        const bool valid = m < M;
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        int r = LT_NOEXP;                                      // unit exponent of the accumulators
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float am = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(xa[s].x), fabsf(xa[s].y)), fmaxf(fabsf(xa[s].z), fabsf(xa[s].w))));
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(xb[s].x), fabsf(xb[s].y)), fmaxf(fabsf(xb[s].z), fabsf(xb[s].w))));
+            }
+            am = fmaxf(am, __shfl_xor(am, 32));
+            const int ex = pow2_exp(am);
+            const int u = ex == LT_NOEXP ? LT_NOEXP : ex + ew[c];
+            const int rn = max(r, u);
+            if (c > 0) {
+                const float fac = pow2i(r - rn);               // 1 unless this chunk raises the unit (0 when r was "no unit": nothing summed yet)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[nb][q] *= fac;
+            }
+            r = rn;
+            const float xsc = r == LT_NOEXP ? 1.0f : pow2i(ew[c] - r);
+            f16x8 q1[S], q2[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+                split2h(xv, xsc, q1[s], q2[s]);
+            }
+            if (c + 1 < NCH) load_x(tile, c + 1);
+            else if (tile + wave_stride < tiles) load_x(tile + wave_stride, 0);
+            const _Float16 *Wc = WH + c * PL;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int colp = 16 * s + 8 * h;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = 32 * nb + l31;
+                    const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&Wc[(0 * N + row) * WS + colp]);
+                    const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&Wc[(1 * N + row) * WS + colp]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1[s], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2[s], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1[s], acc[nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const float xun = r == LT_NOEXP ? 0.f : pow2i(r / 2) * pow2i(r - r / 2);
+        const int mc = valid ? m : M - 1;
+        const float *rr = residual ? residual + (size_t)mc * ldy + n0 + 4 * h : nullptr;
+        float4 rv[NB][4];
+        if (rr) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
+                float4 v = make_float4(fmaf(acc[nb][4 * q], xun, bb.x), fmaf(acc[nb][4 * q + 1], xun, bb.y), fmaf(acc[nb][4 * q + 2], xun, bb.z),
+                                       fmaf(acc[nb][4 * q + 3], xun, bb.w));
+                if (rr) { v.x += rv[nb][q].x; v.y += rv[nb][q].y; v.z += rv[nb][q].z; v.w += rv[nb][q].w; }
+                *reinterpret_cast<float4 *>(&OT[l31 * LS_OP + 8 * q + 4 * h]) = v;
+            }
+            // through the wave's slab: a store instruction then writes 8 rows x 128 contiguous bytes (whole lines) instead of 32 rows x 32 bytes
+            const int rbase = tile << 5;
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = 8 * i + (lane >> 3), cc = 4 * (lane & 7);
+                const float4 o = *reinterpret_cast<const float4 *>(&OT[rw * LS_OP + cc]);
+                if (rbase + rw < M) *reinterpret_cast<float4 *>(y + (size_t)(rbase + rw) * ldy + n0 + 32 * nb + cc) = o;
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+template <int NCH>
+int launch_sum(const LtSrcs &Sx, const float *bias, const float *residual, int M, int w_kn, float *y, const int *m_dev, int ldw, int ldy,
+               hipStream_t s) {
+    constexpr int NT = LT_THREADS;
+    const size_t lds = ((size_t)NCH * LT_NPL * 64 * (128 + 8) / 2 + 64 + (size_t)(NT / 64) * 32 * LS_OP) * 4;
+    const int tiles = (M + 31) / 32;
+    int slots = (tiles + NT / 64 - 1) / (NT / 64);
+    if (slots > 128) slots = 128;
+    slots = (slots + 7) & ~7;                                  // (the XCD pairing wants 8 slots per group of 16 blocks; surplus workgroups return at once)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sum16<NCH, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_linear_sum16<NCH, NT><<<2 * slots, NT, lds, s>>>(Sx, bias, residual, M, w_kn, y, m_dev, ldw, ldy);
+    return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
+}
+
 }  // namespace
 
 // Returns 1 and launches when the layer can be tiled into register-streamed (K, N) chunks of 64 / 128, 0 otherwise (caller
@@ -361,9 +596,31 @@ int conan_linear_t_multi(const float *x, const float *const *w, const float *con
     return 1;
 }
 
+// y [M,128] = sum_c x_c [M,128 | ldx_c] W_c^T (+ bias) (+ residual), nsrc = 2 or 3, in one launch; returns 0 when the shape is not covered
+int conan_linear_t_sum(const float *const *x, const int *ldx, const float *const *w, int nsrc, int w_kn, int ldw, const float *bias,
+                       const float *residual, int M, int N, float *y, const int *m_dev, hipStream_t s, int *rc) {
+    if (N != 128 || nsrc < 2 || nsrc > 3 || M < 1) return 0;
+    LtSrcs Sx{};
+    for (int c = 0; c < nsrc; ++c) { Sx.x[c] = x[c]; Sx.w[c] = w[c]; Sx.ldx[c] = ldx[c]; }
+    *rc = nsrc == 2 ? launch_sum<2>(Sx, bias, residual, M, w_kn, y, m_dev, ldw, N, s) : launch_sum<3>(Sx, bias, residual, M, w_kn, y, m_dev, ldw, N, s);
+    return 1;
+}
+
+#ifndef CONAN_LINEAR_NO_KSUM
+#define CONAN_LINEAR_KSUM 1
+#else
+#define CONAN_LINEAR_KSUM 0
+#endif
 int conan_linear_t_try(const float *x, const float *w, const float *bias, const float *residual, int M, int K, int N, int w_kn,
                        int act, float *y, const int *m_dev, hipStream_t s, int *rc, float *pre_out) {
     if (M < 1) return 0;
+    if (CONAN_LINEAR_KSUM && N == 128 && (K == 256 || K == 384) && act == 0 && !pre_out) {
+        // a contraction of two or three 128-chunks: the chunks of one x, summed in the accumulators instead of through y (k_linear_sum16)
+        const float *xs[3], *wc[3];
+        int ldx[3];
+        for (int c = 0; c < K / 128; ++c) { xs[c] = x + 128 * c; ldx[c] = K; wc[c] = w_kn ? w + (size_t)128 * c * N : w + 128 * c; }
+        if (conan_linear_t_sum(xs, ldx, wc, K / 128, w_kn, w_kn ? N : K, bias, residual, M, N, y, m_dev, s, rc)) return 1;
+    }
     if (K == 128 && N == 128) { *rc = launch_t<128, 128>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 128, 0, 128, nullptr, pre_out); return 1; }
     if (K == 128 && N == 64) { *rc = launch_t<128, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 128, 0, 64, nullptr, pre_out); return 1; }
     if (K == 64 && N == 64) { *rc = launch_t<64, 64>(x, w, bias, residual, M, w_kn, act, y, m_dev, s, 64, 0, 64, nullptr, pre_out); return 1; }

@@ -12,6 +12,9 @@ f32 = torch.float32
 _c = ops._c
 
 
+SUM_INPUT_GRADIENTS = True       # _MultiLinear.backward: the input gradients of the layers summed in one launch (False: a chain of launches)
+
+
 def _new(like: Tensor, *shape):
     return torch.empty(*shape, dtype=f32, device=like.device)
 
@@ -139,12 +142,26 @@ class _MultiLinear(torch.autograd.Function):
         for i in range(n):
             if dys[i] is None:
                 continue
-            w, N = ws[i], ws[i].shape[0]
+            N = ws[i].shape[0]
             if ctx.act:
-                g = _tail0(pres[i], md)
-                call("conan_silu_bwd", ptr(pres[i]), ptr(_c(dys[i])), M, N, ptr(md), ptr(g), stream_ptr())
+                gs[i] = _tail0(pres[i], md)
+                call("conan_silu_bwd", ptr(pres[i]), ptr(_c(dys[i])), M, N, ptr(md), ptr(gs[i]), stream_ptr())
             else:
-                g = _c(dys[i])
+                gs[i] = _c(dys[i])
+        live = [i for i in range(n) if gs[i] is not None]
+        # dx = sum_i g_i W_i (+ seed) in ONE launch with the sum in the accumulators (conan_linear_sum_fwd) where the shapes allow; otherwise
+        # a chain of GEMMs that carries the running sum through dx (each launch adds it in its epilogue)
+        one_launch = (SUM_INPUT_GRADIENTS and ctx.needs_input_grad[0] and K == 128 and 2 <= len(live) <= 3
+                      and all(ws[i].shape[0] == 128 for i in live))
+        if one_launch:
+            import ctypes
+            m = len(live)
+            dx = _tail0_shape(M, K, x.device, md)
+            call("conan_linear_sum_fwd", (ctypes.c_void_p * m)(*[gs[i].data_ptr() for i in live]), (ctypes.c_int * m)(*([128] * m)),
+                 (ctypes.c_void_p * m)(*[ws[i].data_ptr() for i in live]), m, 1, None, ptr(seed), M, K, ptr(md), ptr(dx), stream_ptr())
+            seed = None
+        for i in ([] if one_launch else live):
+            w, N, g = ws[i], ws[i].shape[0], gs[i]
             if ctx.needs_input_grad[0]:
                 if dx is None:
                     dx, res = _tail0_shape(M, K, x.device, md), seed
@@ -157,8 +174,6 @@ class _MultiLinear(torch.autograd.Function):
                     tmp = _tail0_shape(M, K, x.device, md)
                     call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(tmp), stream_ptr())
                     dx = res + tmp
-            gs[i] = g
-        live = [i for i in range(n) if gs[i] is not None]
         if len(live) > 1 and len({ws[i].shape[0] for i in live}) == 1:      # same input, same width: one batched slab launch (x streamed once)
             for i, (dw, db) in zip(live, ops._wgrad_shared_x([gs[i] for i in live], x, M, K, ws[live[0]].shape[0], md, [ws[i] for i in live],
                                                                [ctx.has_b[i] for i in live])):

@@ -164,6 +164,14 @@ int conan_linear_act_fwd(const float *x, const float *w, const float *bias, int 
  * 623-640), which the reference evaluates as separate nn.Linear calls on one tensor.  The pointer arrays are host arrays. */
 int conan_linear_multi_fwd(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int num_layers, int act,
                            const int *m_dev, float *const *y, float *const *pre, void *stream);
+/* y [M,N] = sum_c x[c] W[c]^T (+ bias) (+ residual): num_inputs (2 or 3) contractions of 128 columns each — x[c] [M,128] with row pitch ldx[c],
+ * W[c] torch.nn.Linear's [N,128] (w_kn == 0) or a [128,N] matrix (w_kn == 1: the backward's dx = sum_c g_c W_c) — in ONE launch, the sum kept in
+ * the accumulators.  N = 128 (else CONAN_E_UNSUPPORTED: chain conan_linear_fwd through `residual`).  residual may be y.  Same two-plane fp16
+ * arithmetic as conan_linear_fwd; a row's chunks share one power-of-two unit (the largest of their own), i.e. what one scale for the
+ * concatenated row [x_0 | x_1 | x_2] gives.  Replaces the autograd sum of the input gradients of ViS_MP's dk / dv / f_proj projections of one
+ * f_ij (torch_geometric_visnet.py:600-604,637-640 through aten addmm + add).  The pointer arrays are host arrays. */
+int conan_linear_sum_fwd(const float *const *x, const int *ldx, const float *const *w, int num_inputs, int w_kn, const float *bias,
+                         const float *residual, int M, int N, const int *m_dev, float *y, void *stream);
 /* g[rows,width] = dy * ssp'(v) computed from the layer OUTPUT y (ssp'(v) = sigmoid(v) = 1 - 0.5*exp(-y)). In place allowed. */
 int conan_ssp_bwd(const float *dy, const float *y, int rows, int width, const int *m_dev, float *g, void *stream);
 /* dW[N,K] = g^T @ x and dbias[N] = column sums of g (dbias nullable), deterministic two-stage reduction (no float

@@ -639,6 +639,49 @@ def test_linear_wide_layers_are_tiled_into_strided_chunks(M, K, N, act, w_kn):
     assert torch.isnan(y[M:]).all()                                 # rows beyond the device-side count are not touched
 
 
+@pytest.mark.parametrize("M,nsrc,w_kn,mags", [(1, 2, 1, (1.0, 1.0)), (33, 3, 1, (1.0, 1.0, 1.0)), (5000, 3, 1, (1.0e-6, 3.0, 1.0e-3)), (2049, 2, 0, (1.0e4, 1.0e-4)),
+                                              (70000, 3, 1, (1.0, 0.0, 1.0e-9)), (300, 3, 0, (0.0, 0.0, 0.0))])
+def test_sum_of_contractions_in_one_launch_matches_fp64_chunk_by_chunk(M, nsrc, w_kn, mags):
+    """conan_linear_sum_fwd: y = sum_c x_c W_c^T + b + residual with the sum kept in the accumulators (the input gradient of ViS_MP's dk / dv /
+    f_proj projections of one f_ij, torch_geometric_visnet.py:600-604,637-640).  The chunks of a row share one power-of-two unit, so the bound
+    is the one a single scale for the concatenated row gives: every chunk's own product to 2e-6 of the LARGEST chunk's, and the sum to 2e-6 of
+    itself for ordinary data.  Inputs with their own row pitch (columns of a wider tensor), rows beyond the device-side count untouched,
+    residual aliasing y, all-zero chunks."""
+    import ctypes
+    from conan_fgw_amd._lib import call, ptr, stream_ptr
+    gen = torch.Generator().manual_seed(M + nsrc)
+    wide = torch.randn(M + 5, 128 * nsrc + 64, generator=gen).to(dev)                   # chunk c = columns [32 + 128 c, 32 + 128 (c + 1)) — 128-byte aligned, pitch != 128
+    rowmag = torch.exp(4.0 * torch.randn(M + 5, 1, generator=gen)).to(dev)              # rows of very different size
+    xs = []
+    for c in range(nsrc):
+        v = wide[:, 32 + 128 * c: 32 + 128 * (c + 1)]
+        v.mul_(mags[c] * rowmag)
+        xs.append(v)
+    ws = [(torch.randn(128, 128, generator=gen) * (0.1 * 3.0 ** c)).to(dev) for c in range(nsrc)]
+    b = torch.randn(128, generator=gen).to(dev)
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    for with_extras in (False, True):
+        y = torch.full((M + 5, 128), float("nan"), device=dev)
+        res0 = torch.randn(M + 5, 128, generator=gen).to(dev)
+        if with_extras:
+            y.copy_(res0)                                                                   # residual == y
+        call("conan_linear_sum_fwd", (ctypes.c_void_p * nsrc)(*[v.data_ptr() for v in xs]), (ctypes.c_int * nsrc)(*[wide.stride(0)] * nsrc),
+             (ctypes.c_void_p * nsrc)(*[w.data_ptr() for w in ws]), nsrc, w_kn, ptr(b) if with_extras else None, ptr(y) if with_extras else None,
+             M + 5, 128, ptr(md), ptr(y), stream_ptr())
+        parts = [xs[c][:M].double() @ (ws[c].double() if w_kn else ws[c].double().T) for c in range(nsrc)]
+        ref = sum(parts)
+        if with_extras:
+            ref = ref + b.double() + res0[:M].double()
+            assert torch.equal(y[M:], res0[M:])                                             # rows beyond the device-side count are not touched
+        else:
+            assert torch.isnan(y[M:]).all()
+        got = y[:M].double()
+        scale = sum(p.abs() for p in parts).max(dim=1, keepdim=True).values + ((res0[:M].abs().double() + b.abs().double()) if with_extras else 0.0) + 1e-300
+        assert float(((got - ref).abs() / scale).max()) < 2e-6                              # row by row: relative to the row's largest term
+        if all(m == 1.0 for m in mags):
+            assert rel(got.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+
+
 @pytest.mark.parametrize("n", [1, 256, 1000])
 def test_mse_loss_and_its_gradient_in_one_launch(n):
     g = torch.Generator().manual_seed(n)
