@@ -2,12 +2,16 @@
 forward projections of f (dk / dv / f_proj in one launch), s_proj, their input-gradient GEMMs (today: a chain of launches that carries the
 running sum through HBM) and their weight-gradient slab launches — each against the bytes it has to move (U = one [E,128] tensor).
 
-    python tools/probe_edge_linears.py [E]"""
+    python tools/probe_edge_linears.py [library ("" = in-tree) [tag [E]]]        (tools/ab.py's probe convention)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from conan_fgw_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1]:
+    _lib._SO = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else ""
 from conan_fgw_amd._lib import call, lib, ptr, stream_ptr, WgradSlabJob
-E = int(sys.argv[1]) if len(sys.argv) > 1 else 482_000
+E = int(sys.argv[3]) if len(sys.argv) > 3 else 482_000
 H = 128
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -91,7 +95,7 @@ rows = [("forward dk / dv / f_proj of f (1 launch)", multi_fwd, 4), ("input grad
         ("forward s_proj 128 -> 256", sproj_fwd, 3), ("input gradient of s_proj 256 -> 128 (one launch since round 5; two chained before: 280 us)", sproj_dx, 3),
         ("weight-gradient slabs, three layers of one x (1 launch)", wgrad_shared, 4), ("weight-gradient slabs, one layer", wgrad_one, 2),
         ("weight-gradient slabs, s_proj (N = 256)", wgrad_sproj, 3)]
-print(f"E = {E}, H = {H}: U = one [E,H] fp32 tensor = {U:.0f} MB")
+print(f"{tag} E = {E}, H = {H}: U = one [E,H] fp32 tensor = {U:.0f} MB")
 for name, fn, u in rows:
     if fn is None:
         print(f"{name:62s} {'':8s}   {u} U = {u * U:6.0f} MB")
