@@ -534,6 +534,186 @@ __global__ void __launch_bounds__(256, KT == 128 ? 2 : 3) k_wgrad_lds_batch(cons
                               J.slices[j], tile_n, tile_k);
 }
 
+// Several 128 x 128 weight gradients over the SAME x in one workgroup (round 5): dW_j = g_j^T x for j < NJ, K = 128, N_j = 128 — ViS_MP's
+// dk / dv / f_proj of one f_ij (three [E,128] gradients, one x) and the two n tiles of s_proj (g [E,256]).  k_wgrad_lds_batch ran them as NJ
+// workgroups side by side on one XCD, each staging x again (from L2) and each paying the full round trip per 16-row stage: 391 us for the 4
+// tensors of a run of three against 135 us for the 2 of a single job — the kernel is bound by the bytes a CU keeps in flight (two stages of
+// loads per workgroup), not by the bytes it moves, so a stage that feeds NJ products costs what a stage that feeds one does.  Here a stage
+// is 16 rows of x and of all NJ gradients, x is split into its planes once, and every wave holds NJ sets of accumulators (NJ = 3: one
+// workgroup per CU, ~350 registers).  Slices, stage order, the six partial products per block and the slab layout are those of
+// wgrad_lds_body: the slabs are bit for bit what NJ separate launches write.
+template <int NJ>
+struct WgShared {
+    const float *g[NJ];          // gradient of job j, row pitch ldg
+    float *slab[NJ], *bslab[NJ]; // slab / bias slab of slice 0 for job j (n offset included), slice pitches slab_pitch / bias_pitch
+    const float *x;
+    const int *m_dev;
+    int M, ldg, slices;
+    long long slab_pitch;
+    int bias_pitch;
+};
+// NW = 4: 2 x 2 waves of 64 x 64 per job (NJ = 2: two workgroups per CU); NW = 8: 4 x 2 waves of 32(n) x 64(k) per job — NJ = 3 then needs ~200
+// registers instead of 344, two waves per SIMD cover each other's split / MFMA / wait phases (with one, a stage was the SUM of its phases).
+template <int NJ, int D, int NW>
+__global__ void __launch_bounds__(64 * NW, (NJ == 2 && NW == 4) ? 2 : 1) k_wgrad_lds_shared(const WgShared<NJ> P) {
+    constexpr int K = 128, ROWS = 16, RG = 2, W = 128 * (NJ + 1), FRAGS = RG * W, NT = 64 * NW, NF = FRAGS / NT, TNB = NW == 8 ? 1 : 2;
+    static_assert(FRAGS % NT == 0, "whole fragments per thread");
+    extern __shared__ __attribute__((aligned(16))) uint4 frag_sh[];          // [2][3][RG][W]
+    auto frag = [&](int buf, int pl, int rg, int col) -> uint4 & { return frag_sh[((buf * 3 + pl) * RG + rg) * W + col]; };
+    int M = P.M;
+    if (P.m_dev) M = min(M, *P.m_dev);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = (wave >> 1) * (32 * TNB), k0 = (wave & 1) * 64;
+    const int slice = blockIdx.x, num_slices = P.slices;
+    const int r_begin = slice * ROWS, r_end = M, STEP = num_slices * ROWS;
+    f32x16 acc[NJ][TNB][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int a = 0; a < TNB; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][a][b][r] = 0.f;
+    // producer roles: fragment f = 64 wave + NT i + lane -> (row group, operand, column); wave-uniform row group and operand
+    int f_rg[NF], f_col[NF], f_op[NF];
+    float bsum[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int fb = 64 * wave + NT * i;
+        f_rg[i] = fb / W;
+        const int cb = fb - f_rg[i] * W;
+        f_op[i] = cb >> 7;                            // 0 .. NJ - 1: gradient of job op; NJ: x
+        f_col[i] = cb + lane;                         // column inside [0, W)
+        bsum[i] = 0.f;
+    }
+    float st[D][NF][8];
+    auto fetch = [&](float (&sr)[NF][8], int m0) {
+        const bool full = m0 + ROWS <= r_end;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int mr = m0 + 8 * f_rg[i];
+            const bool isg = f_op[i] < NJ;
+            const float *src = P.x;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) src = f_op[i] == j ? P.g[j] : src;
+            const int ld = isg ? P.ldg : K;
+            const unsigned cc = (unsigned)(f_col[i] & 127);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = full ? mr + j : min(mr + j, r_end - 1);
+                sr[i][j] = (src + (size_t)m * ld)[cc];
+            }
+        }
+    };
+    auto stash = [&](int buf, float (&sr)[NF][8], int m0) {
+        const bool full = m0 + ROWS <= r_end;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if (!full) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sr[i][j] = (m0 + 8 * f_rg[i] + j < r_end) ? sr[i][j] : 0.f;
+            }
+            if (f_op[i] < NJ) bsum[i] += ((sr[i][0] + sr[i][1]) + (sr[i][2] + sr[i][3])) + ((sr[i][4] + sr[i][5]) + (sr[i][6] + sr[i][7]));
+            bf16x8 p1, p2, p3;
+            wg_split3(sr[i], p1, p2, p3);
+            frag(buf, 0, f_rg[i], f_col[i]) = __builtin_bit_cast(uint4, p1);
+            frag(buf, 1, f_rg[i], f_col[i]) = __builtin_bit_cast(uint4, p2);
+            frag(buf, 2, f_rg[i], f_col[i]) = __builtin_bit_cast(uint4, p3);
+        }
+    };
+    auto compute = [&](int buf) {
+        bf16x8 q[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) q[b][pl] = __builtin_bit_cast(bf16x8, frag(buf, pl, h, 128 * NJ + k0 + 32 * b + l31));
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bf16x8 p[TNB][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int a = 0; a < TNB; ++a) p[a][pl] = __builtin_bit_cast(bf16x8, frag(buf, pl, h, 128 * j + n0 + 32 * a + l31));
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < TNB; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[j][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p[a][PA[t]], q[b][PB[t]], acc[j][a][b], 0, 0, 0);
+        }
+    };
+    if (r_begin < r_end) {
+        int m = r_begin;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (m + d * STEP < r_end) fetch(st[d], m + d * STEP);
+        stash(0, st[0], m);
+        if (m + D * STEP < r_end) fetch(st[0], m + D * STEP);
+        __syncthreads();
+        constexpr int U = D == 2 ? 2 : 6;             // stage i: LDS buffer i & 1, register set (i + 1) % D for the stage after it
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!more) break;
+                const int buf = u & 1, rs = (u + 1) % D;
+                compute(buf);
+                if (m + STEP < r_end) stash(buf ^ 1, st[rs], m + STEP);
+                if (m + (D + 1) * STEP < r_end) fetch(st[rs], m + (D + 1) * STEP);
+                __syncthreads();
+                m += STEP;
+                more = m < r_end;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float *slab = P.slab[j] + (size_t)slice * P.slab_pitch;
+#pragma unroll
+        for (int a = 0; a < TNB; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int k = k0 + b * 32 + l31;
+                    slab[(size_t)n * K + k] = acc[j][a][b][r];
+                }
+    }
+    float *bp = reinterpret_cast<float *>(frag_sh);    // [RG][128 NJ]; the stages are idle by now
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+        if (f_op[i] < NJ) bp[f_rg[i] * (128 * NJ) + f_col[i]] = bsum[i];
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) t += bp[r * (128 * NJ) + 128 * j + tid];
+            P.bslab[j][(size_t)slice * P.bias_pitch + tid] = t;
+        }
+    }
+}
+#ifndef CONAN_WGRAD_SHARED_CFG
+#define CONAN_WGRAD_SHARED_CFG 2248                  // digits: stages of loads in flight (three jobs, two jobs), waves per workgroup (two jobs, three jobs)
+#endif
+#ifndef CONAN_WGRAD_SHARED_MIN_ROWS
+#define CONAN_WGRAD_SHARED_MIN_ROWS 65536            // (= the row count from which a job has all 512 slices; 0x7fffffff switches the kernel off)
+#endif
+template <int NJ>
+static void launch_wgrad_shared(const WgShared<NJ> &P, hipStream_t s) {
+    constexpr int CFG = CONAN_WGRAD_SHARED_CFG;
+    constexpr int D = NJ == 3 ? CFG / 1000 : (CFG / 100) % 10, NW = NJ == 3 ? CFG % 10 : (CFG / 10) % 10;
+    const size_t lds = (size_t)2 * 3 * 2 * 128 * (NJ + 1) * sizeof(uint4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_lds_shared<NJ, D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_wgrad_lds_shared<NJ, D, NW><<<P.slices, 64 * NW, lds, s>>>(P);
+}
+
 // slabs [slices][NK] (+ bias_slabs [slices][N]) -> out[g][NK] (+ bout[g][N]) for slice group g = blockIdx.y; fixed order.
 __global__ void k_wgrad_reduce(const float *__restrict__ slabs, const float *__restrict__ bias_slabs, int slices, int per_group,
                                int NK, int N, float *__restrict__ out, float *__restrict__ bout) {
@@ -766,6 +946,13 @@ static int wgrad_launch(const float *g, const float *x, int M, int K, int N, con
         dim3 grid(slices, (N + 127) / 128, (K + KT - 1) / KT);
         int tn_remap = 0;
         if (grid.y > 1 && grid.z == 1 && (slices & 7) == 0 && !gmax) { tn_remap = (int)grid.y; grid = dim3(slices * tn_remap, 1, 1); }
+        if (!rbf && !gmax && K == 128 && N == 256 && M >= CONAN_WGRAD_SHARED_MIN_ROWS) {
+            // the two n tiles of one [M,256] gradient over one x: one workgroup per slice stages x once (k_wgrad_lds_shared)
+            WgShared<2> P;
+            for (int j = 0; j < 2; ++j) { P.g[j] = g + 128 * j; P.slab[j] = slabs + (size_t)128 * j * K; P.bslab[j] = bias_slabs + 128 * j; }
+            P.x = x; P.m_dev = m_dev; P.M = M; P.ldg = N; P.slices = slices; P.slab_pitch = (long long)N * K; P.bias_pitch = N;
+            launch_wgrad_shared<2>(P, s);
+        } else
         if (gmax) {
             if (rbf || KT != 128) return CONAN_E_UNSUPPORTED;
             k_wgrad_lds_h16<<<grid, 256, 0, s>>>(g, x, M, K, N, slabs, bias_slabs, m_dev, gmax);
@@ -871,6 +1058,17 @@ int conan_linear_wgrad_slabs_batch(const conan_wgrad_slab_job *jobs, int num_job
                 while (j + run < num_jobs && run < 4 && jobs[j + run].x == b.x && jobs[j + run].M == b.M && jobs[j + run].K == b.K && jobs[j + run].N == b.N &&
                        jobs[j + run].m_dev == b.m_dev && jobs[j + run].slices == b.slices)
                     ++run;
+            if ((run == 2 || run == 3) && wide && b.K == 128 && b.N == 128 && b.M >= CONAN_WGRAD_SHARED_MIN_ROWS) {
+                // an edge-level run over one x: one workgroup per slice for all of its jobs (k_wgrad_lds_shared; same slabs bit for bit)
+                auto fill = [&](auto &P) {
+                    for (int r = 0; r < run; ++r) { P.g[r] = jobs[j + r].g; P.slab[r] = jobs[j + r].ws; P.bslab[r] = jobs[j + r].ws + (size_t)slices * b.N * b.K; }
+                    P.x = b.x; P.m_dev = b.m_dev; P.M = b.M; P.ldg = b.N; P.slices = slices; P.slab_pitch = (long long)b.N * b.K; P.bias_pitch = b.N;
+                };
+                if (run == 2) { WgShared<2> P; fill(P); launch_wgrad_shared<2>(P, s); }
+                else { WgShared<3> P; fill(P); launch_wgrad_shared<3>(P, s); }
+                j += run - 1;
+                continue;
+            }
             if (J.count + run > WGS_BATCH) flush();
             for (int r = 0; r < run; ++r) {
                 const conan_wgrad_slab_job &c = jobs[j + r];

@@ -470,6 +470,56 @@ def test_wgrad_slabs_batch_equals_the_per_job_launches():
         assert rel(long_slices[q][1].double().cpu().numpy(), gs[q][:rows[q]].double().sum(0).cpu().numpy()) < 1e-5, shapes[q]
 
 
+@pytest.mark.parametrize("M,run", [(65536, 3), (70001, 3), (131075, 2)])
+def test_edge_level_weight_gradients_over_one_x_share_its_staging_bit_for_bit(M, run):
+    """From 65 536 rows on (a job then has all 512 slices) a run of two or three 128 x 128 weight gradients over the same x — ViS_MP's dk / dv /
+    f_proj of one f_ij, torch_geometric_visnet.py:600-604,637-640 — and the two n tiles of a [M,256] gradient (s_proj, :615) run with ONE
+    workgroup per row slice that stages x once for all of them (k_wgrad_lds_shared).  Slices, stage order and the order of the partial
+    products are those of the single-job kernel: dW and db are bit for bit what separate launches give (for N = 256: what two launches on the
+    two halves of g give), a device-side row count masks the tail, and both agree with the fp64 product."""
+    from conan_fgw_amd._lib import WgradJob, WgradSlabJob, call, lib, ptr, stream_ptr
+    gen = torch.Generator().manual_seed(M + run)
+    x = torch.randn(M + 9, 128, generator=gen).to(dev)
+    gs = [torch.randn(M + 9, 128, generator=gen).to(dev) * (10.0 ** q) for q in range(run)]
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+
+    def reduce(wss):
+        jobs = (WgradJob * run)()
+        out = []
+        for q in range(run):
+            dW, db = torch.empty(128, 128, device=dev), torch.empty(128, device=dev)
+            jobs[q].ws, jobs[q].dW, jobs[q].dbias = wss[q].data_ptr(), dW.data_ptr(), db.data_ptr()
+            jobs[q].M, jobs[q].K, jobs[q].N, jobs[q].slices = M + 9, 128, 128, 0
+            out.append((dW, db))
+        call("conan_wgrad_reduce_batch", jobs, run, stream_ptr())
+        return out
+
+    wsz = int(lib().conan_linear_wgrad_ws(M + 9, 128, 128))
+    wss = [torch.empty(wsz, device=dev) for _ in range(run)]
+    for q in range(run):
+        call("conan_linear_wgrad_slabs", ptr(gs[q]), ptr(x), M + 9, 128, 128, ptr(md), ptr(wss[q]), stream_ptr())
+    one_by_one = reduce(wss)
+    wss2 = [torch.full((wsz,), float("nan"), device=dev) for _ in range(run)]
+    sj = (WgradSlabJob * run)()
+    for q in range(run):
+        sj[q].g, sj[q].x, sj[q].m_dev, sj[q].ws = gs[q].data_ptr(), x.data_ptr(), md.data_ptr(), wss2[q].data_ptr()
+        sj[q].M, sj[q].K, sj[q].N, sj[q].slices = M + 9, 128, 128, 0
+    call("conan_linear_wgrad_slabs_batch", sj, run, stream_ptr())
+    shared = reduce(wss2)
+    for q in range(run):
+        assert torch.equal(shared[q][0], one_by_one[q][0]) and torch.equal(shared[q][1], one_by_one[q][1]), q
+        ref = gs[q][:M].double().T @ x[:M].double()
+        assert rel(shared[q][0].double().cpu().numpy(), ref.cpu().numpy()) < 2e-6
+        assert rel(shared[q][1].double().cpu().numpy(), gs[q][:M].double().sum(0).cpu().numpy()) < 2e-6
+    if run == 2:                                                         # the [M,256] gradient of one layer: its two n tiles
+        gw = torch.cat(gs, dim=1).contiguous()
+        dW, db = torch.empty(256, 128, device=dev), torch.empty(256, device=dev)
+        ws = torch.empty(int(lib().conan_linear_wgrad_ws(M + 9, 128, 256)), device=dev)
+        call("conan_linear_wgrad", ptr(gw), ptr(x), M + 9, 128, 256, ptr(md), ptr(dW), ptr(db), ptr(ws), stream_ptr())
+        for q in range(2):
+            assert torch.equal(dW[128 * q: 128 * (q + 1)], one_by_one[q][0]) and torch.equal(db[128 * q: 128 * (q + 1)], one_by_one[q][1])
+
+
 @pytest.mark.parametrize("gscale", [None, 1.0, 3e-7, 4e4], ids=["bf16x3", "f16x2", "f16x2_tiny_grad", "f16x2_huge_grad"])
 @pytest.mark.parametrize("M,Gs", [(1, 50), (31, 50), (4133, 50), (40000, 50), (3000, 20), (2500, 63)])
 def test_filter_bwd_fused_matches_fp64_and_the_composed_kernels(M, Gs, gscale):
