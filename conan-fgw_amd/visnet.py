@@ -58,8 +58,9 @@ class EdgeEmbedding(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.edge_proj.weight); self.edge_proj.bias.data.zero_()
 
 
-NODE_LEVEL_ON_SIDE_STREAM = 3         # 3 = also the 3-D output head beside the barycenter head; ViS_MP: 1 = the atom-level head of a layer beside the edge-level projections of f; 2 = also o_proj / node_update beside
-                                      # s_proj + vec_aggregate / edge_update; 0 = one stream (tools/ab_step_switch.py compares)
+NODE_LEVEL_ON_SIDE_STREAM = 4         # 3 = also the 3-D output head beside the barycenter head; ViS_MP: 1 = the atom-level head of a layer beside the edge-level projections of f; 2 = also o_proj / node_update beside
+                                      # s_proj + vec_aggregate / edge_update; 4 = a layer's atom-level head no longer waits for the previous layer's edge update (its inputs come
+                                      # from node_update on the second stream itself); 0 = one stream (tools/ab_step_switch.py compares)
 
 
 class ViS_MP(torch.nn.Module):
@@ -115,11 +116,12 @@ class ViSNetBlock(torch.nn.Module):
         x = vo.lin(vo.concat2(x, xn), ne.combine)
         vec = torch.zeros(n, 3, H, dtype=f32, device=dev)                                                    # :868-870
         f = vo.edge_embed(x, vo.lin(rbf, self.edge_embedding.edge_proj, False, md), g)                       # EdgeEmbedding, :463-465
+        on_side = False                      # x, vec were produced on the second stream (by the previous layer's node_update)
         for layer in self.vis_mp_layers:
-            x, vec, f = self._vis_mp(layer, x, vec, f, g, dvec)
+            x, vec, f, on_side = self._vis_mp(layer, x, vec, f, g, dvec, on_side)
         return vo.layernorm(x, self.out_norm), vo.scale_channels(vec, self.vec_out_norm.weight)
 
-    def _vis_mp(self, L: ViS_MP, x, vec, f, g, dvec):
+    def _vis_mp(self, L: ViS_MP, x, vec, f, g, dvec, inputs_on_side: bool = False):
         """ViS_MP.forward / message / aggregate / edge_update, torch_geometric_visnet.py:579-673."""
         H, n = self.hidden_channels, x.shape[0]
         md = g.num_edges_dev
@@ -147,7 +149,12 @@ class ViSNetBlock(torch.nn.Module):
             if side is None or side.device != main.device:
                 side = torch.cuda.Stream(device=main.device)
                 object.__setattr__(self, "_node_stream", side)                     # (not module state)
-            side.wait_stream(main)
+            # (level 4) x and vec come from node_update on the second stream: the chain then starts under the previous layer's edge update (a
+            # gather kernel of small workgroups that shares the CUs) instead of queueing behind it — and then behind this layer's projection of
+            # f, a persistent kernel with one 137 KB workgroup per CU beside which nothing else becomes resident: the timeline had the chain
+            # run AFTER it (layernorm "228 us"), on the critical path of the forward pass
+            if not (inputs_on_side and NODE_LEVEL_ON_SIDE_STREAM >= 4):
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 vl, q, k, v, vp, vdot = node_level()
         else:
@@ -180,13 +187,13 @@ class ViSNetBlock(torch.nn.Module):
             main.wait_stream(side)
             for tt in (o, xo, veco):
                 tt.record_stream(main)
-            return xo, veco, fo
+            return xo, veco, fo, True
         o = vo.lin(xagg, L.o_proj)
         xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
         if L.last_layer:
-            return xo, veco, f
+            return xo, veco, f, False
         # (wt, ws: node-level — Linear commutes with the gather)
-        return xo, veco, vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True)
+        return xo, veco, vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True), False
 
 
 def ne_cutoff(block: ViSNetBlock) -> float:
