@@ -14,6 +14,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LT_THREADS = 512;
+#ifndef CONAN_LINEAR_MAX_WGS
+#define CONAN_LINEAR_MAX_WGS 256                    // persistent workgroups of an edge-level launch (one per CU: 137-141 KB of LDS each); a multiple of 16
+#endif
 
 
 // Two-plane fp16 form (default; see filter_fused.hip): v = h1 + h2 with the three products p1q1, p1q2, p2q1 on v_mfma_f32_32x32x16_f16 —
@@ -303,7 +306,7 @@ int launch_t(const float *x, const float *w, const float *bias, const float *res
     const size_t lds16 = lds_w + (size_t)(narrow ? 4 : 8) * 32 * LT_OP * 4;
     const int per = narrow ? 4 : 8;
     int grid16 = (tiles16 + per - 1) / per;
-    if (grid16 > 256 / nc) grid16 = 256 / nc;          // (nc chunks: 256 / nc tile slots x nc)
+    if (grid16 > CONAN_LINEAR_MAX_WGS / nc) grid16 = CONAN_LINEAR_MAX_WGS / nc;          // (nc chunks: MAX_WGS / nc tile slots x nc)
     grid16 *= nc;
 #define LAUNCH16(A)                                                                                                              \
     do {                                                                                                                         \
@@ -416,7 +419,30 @@ __device__ __forceinline__ int lt_stage_planes(const float *__restrict__ w, int 
     return ew == LT_NOEXP ? 0 : ew;                            // (an all-zero image: unit 1, planes 0)
 }
 
-constexpr int LS_OP = 36;                                      // pitch of the per-wave output slab: 32 channels + 4
+constexpr int LS_OP = 36;                                      // the per-wave output slab is 32 x LS_OP floats, used as [16][LT_OP]
+// The 64 outputs x 32 rows a wave holds after its epilogue (vv[nb][q] = features 32 nb + 8 q + 4 h .. + 3 of row l31) to y: through the wave's
+// slab as two half tiles of [16 rows][64 + 4], so that a store instruction writes 4 rows x 256 contiguous bytes (as [32][32 + 4], 8 rows x 128 bytes per instruction, it measured the same).
+__device__ __forceinline__ void ls_store64(float *OT, const float4 (&vv)[2][4], float *yb, int ldy, int rbase, int M, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if ((l31 >> 4) == half) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&OT[(l31 & 15) * LT_OP + 32 * nb + 8 * q + 4 * h]) = vv[nb][q];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rw = 4 * i + (lane >> 4), cc = 4 * (lane & 15);
+            const float4 o = *reinterpret_cast<const float4 *>(&OT[rw * LT_OP + cc]);
+            const int r = rbase + 16 * half + rw;
+            if (r < M) *reinterpret_cast<float4 *>(yb + (size_t)r * ldy + cc) = o;
+        }
+        wave_lds_fence();
+    }
+}
 #ifndef CONAN_LSUM_PAIR_XCD
 #define CONAN_LSUM_PAIR_XCD 1                                  // the two output halves of a tile slot on ONE XCD (blocks b and b + 8); 0: blocks b, b + 1
 #endif
@@ -525,28 +551,129 @@ __global__ void __launch_bounds__(NT) k_linear_sum16(const LtSrcs Sx, const floa
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rv[nb][q] = *reinterpret_cast<const float4 *>(rr + 32 * nb + 8 * q);
         }
+        float4 vv[2][4];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bb = *reinterpret_cast<const float4 *>(&BL[32 * nb + 8 * q + 4 * h]);
                 float4 v = make_float4(fmaf(acc[nb][4 * q], xun, bb.x), fmaf(acc[nb][4 * q + 1], xun, bb.y), fmaf(acc[nb][4 * q + 2], xun, bb.z),
                                        fmaf(acc[nb][4 * q + 3], xun, bb.w));
                 if (rr) { v.x += rv[nb][q].x; v.y += rv[nb][q].y; v.z += rv[nb][q].z; v.w += rv[nb][q].w; }
-                *reinterpret_cast<float4 *>(&OT[l31 * LS_OP + 8 * q + 4 * h]) = v;
+                vv[nb][q] = v;
             }
-            // through the wave's slab: a store instruction then writes 8 rows x 128 contiguous bytes (whole lines) instead of 32 rows x 32 bytes
-            const int rbase = tile << 5;
-            wave_lds_fence();
+        ls_store64(OT, vv, y + n0, ldy, tile << 5, M, lane);
+    }
+}
+
+// ---- y_l = x W_l^T + b_l for up to three 128 -> 128 layers of ONE input in one workgroup per tile (round 5) -------------------------------
+// The side-by-side form above (nc = 3) gives every layer its own workgroup: x is fetched and split into its planes three times and a launch
+// is 3 x tiles / 8 workgroup iterations of one tile per wave — 290 us for ViS_MP's dk / dv / f_proj at BACE B = 64, three times the single
+// layer.  Here a workgroup owns 64 of the 128 outputs of ALL layers (the planes of 3 x 64 x 128 weights: 104 KB, as k_linear_sum16), a wave
+// splits its 32 rows once and runs the layers one after the other on the same planes; the two output halves of a tile slot are the
+// workgroups b and b + 8 of one XCD.
+template <int NL, int NT>
+__global__ void __launch_bounds__(NT) k_linear_fan16(const float *__restrict__ x, const LtJobs J, int M, const int *__restrict__ m_dev, int ldx, int ldw,
+                                                     int ldy) {
+    constexpr int K = 128, N = 64, NB = N / 32, S = K / 16, WS = K + 8, PL = LT_NPL * N * WS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    _Float16 *WH = reinterpret_cast<_Float16 *>(lds);          // [NL][planes][N][WS]
+    float *BL = lds + (NL * PL) / 2;                           // [NL][N]
+    float *OT = BL + NL * N + (threadIdx.x >> 6) * (32 * LS_OP);
+    __shared__ float wred[NT / 64];
+    if (m_dev) M = min(M, *m_dev);
+    const int tiles = (M + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x;
+    const int half = (b >> 3) & 1, slot = ((b >> 4) << 3) | (b & 7);        // gridDim.x is a multiple of 16
+    const int nslots = (int)gridDim.x >> 1;
+    const int n0 = half * N;
+    if (slot * (NT / 64) >= tiles) return;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_stride = nslots * (NT / 64);
+    float4 xa[S], xb[S];
+    auto load_x = [&](int t) {
+        const int mr = min((t << 5) + l31, M - 1);
+        const float *xr = x + (size_t)mr * ldx + 8 * h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rw = 8 * i + (lane >> 3), cc = 4 * (lane & 7);
-                const float4 o = *reinterpret_cast<const float4 *>(&OT[rw * LS_OP + cc]);
-                if (rbase + rw < M) *reinterpret_cast<float4 *>(y + (size_t)(rbase + rw) * ldy + n0 + 32 * nb + cc) = o;
+        for (int s = 0; s < S; ++s) {
+            xa[s] = *reinterpret_cast<const float4 *>(xr + 16 * s);
+            xb[s] = *reinterpret_cast<const float4 *>(xr + 16 * s + 4);
+        }
+    };
+    if (slot * (NT / 64) + wave < tiles) load_x(slot * (NT / 64) + wave);
+    int ew[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ew[l] = lt_stage_planes<K, N, NT>(J.w[l] + (size_t)n0 * ldw, 0, ldw, WH + l * PL, wred);
+    for (int t = tid; t < NL * N; t += NT) BL[t] = J.bias[t / N] ? J.bias[t / N][n0 + (t % N)] : 0.f;
+    __syncthreads();
+
+    for (int tile = slot * (NT / 64) + wave; tile < tiles; tile += wave_stride) {
+        float am = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(xa[s].x), fabsf(xa[s].y)), fmaxf(fabsf(xa[s].z), fabsf(xa[s].w))));
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(xb[s].x), fabsf(xb[s].y)), fmaxf(fabsf(xb[s].z), fabsf(xb[s].w))));
+        }
+        am = fmaxf(am, __shfl_xor(am, 32));
+        float xsc, xu;
+        pow2_scale(am, xsc, xu);
+        f16x8 q1[S], q2[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float xv[8] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w, xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+            split2h(xv, xsc, q1[s], q2[s]);
+        }
+        if (tile + wave_stride < tiles) load_x(tile + wave_stride);
+        const int rbase = tile << 5;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            f32x16 acc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+            const _Float16 *Wl = WH + l * PL;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int colp = 16 * s + 8 * h;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = 32 * nb + l31;
+                    const f16x8 p1 = *reinterpret_cast<const f16x8 *>(&Wl[(0 * N + row) * WS + colp]);
+                    const f16x8 p2 = *reinterpret_cast<const f16x8 *>(&Wl[(1 * N + row) * WS + colp]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, q1[s], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q2[s], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, q1[s], acc[nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            wave_lds_fence();
+            const float xun = xu * pow2i(ew[l]);               // (pow2_scale's inverse row scale x the layer's weight unit)
+            float4 vv[2][4];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(&BL[l * N + 32 * nb + 8 * q + 4 * h]);
+                    vv[nb][q] = make_float4(fmaf(acc[nb][4 * q], xun, bb.x), fmaf(acc[nb][4 * q + 1], xun, bb.y), fmaf(acc[nb][4 * q + 2], xun, bb.z),
+                                            fmaf(acc[nb][4 * q + 3], xun, bb.w));
+                }
+            ls_store64(OT, vv, J.y[l] + n0, ldy, rbase, M, lane);
         }
     }
+}
+
+template <int NL>
+int launch_fan(const float *x, const LtJobs &J, int M, const int *m_dev, hipStream_t s) {
+    constexpr int NT = LT_THREADS;
+    const size_t lds = ((size_t)NL * LT_NPL * 64 * (128 + 8) / 2 + NL * 64 + (size_t)(NT / 64) * 32 * LS_OP) * 4;
+    const int tiles = (M + 31) / 32;
+    int slots = (tiles + NT / 64 - 1) / (NT / 64);
+    if (slots > CONAN_LINEAR_MAX_WGS / 2) slots = CONAN_LINEAR_MAX_WGS / 2;
+    slots = (slots + 7) & ~7;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_fan16<NL, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_linear_fan16<NL, NT><<<2 * slots, NT, lds, s>>>(x, J, M, m_dev, 128, 128, 128);
+    return hipGetLastError() == hipSuccess ? CONAN_OK : CONAN_E_LAUNCH;
 }
 
 template <int NCH>
@@ -556,7 +683,7 @@ int launch_sum(const LtSrcs &Sx, const float *bias, const float *residual, int M
     const size_t lds = ((size_t)NCH * LT_NPL * 64 * (128 + 8) / 2 + 64 + (size_t)(NT / 64) * 32 * LS_OP) * 4;
     const int tiles = (M + 31) / 32;
     int slots = (tiles + NT / 64 - 1) / (NT / 64);
-    if (slots > 128) slots = 128;
+    if (slots > CONAN_LINEAR_MAX_WGS / 2) slots = CONAN_LINEAR_MAX_WGS / 2;
     slots = (slots + 7) & ~7;                                  // (the XCD pairing wants 8 slots per group of 16 blocks; surplus workgroups return at once)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_sum16<NCH, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     k_linear_sum16<NCH, NT><<<2 * slots, NT, lds, s>>>(Sx, bias, residual, M, w_kn, y, m_dev, ldw, ldy);
@@ -586,12 +713,22 @@ static int chunk_launch(const float *x, const float *w, const float *bias, const
     return CONAN_OK;
 }
 
+#ifndef CONAN_LINEAR_FAN
+#define CONAN_LINEAR_FAN 1
+#endif
+#ifndef CONAN_LINEAR_FAN_MIN_ROWS
+#define CONAN_LINEAR_FAN_MIN_ROWS 65536              // edge level; a node-level run (q / k / v of 17 k atoms) keeps one workgroup per layer and tile: more workgroups in flight
+#endif
 // njobs (2..4) Linear layers K = 128 -> N = 128 of the same x in one launch; returns 0 when the shape is not covered (caller: one call per layer)
 int conan_linear_t_multi(const float *x, const float *const *w, const float *const *bias, int M, int K, int N, int njobs, int act, float *const *y,
                          float *const *pre, const int *m_dev, hipStream_t s, int *rc) {
     if (K != 128 || N != 128 || njobs < 2 || njobs > 4 || M < 1) return 0;
     LtJobs J{};
     for (int q = 0; q < njobs; ++q) { J.w[q] = w[q]; J.bias[q] = bias ? bias[q] : nullptr; J.y[q] = y[q]; J.pre[q] = pre ? pre[q] : nullptr; }
+    if (CONAN_LINEAR_FAN && act == 0 && !pre && njobs <= 3 && M >= CONAN_LINEAR_FAN_MIN_ROWS) {
+        *rc = njobs == 2 ? launch_fan<2>(x, J, M, m_dev, s) : launch_fan<3>(x, J, M, m_dev, s);
+        return 1;
+    }
     *rc = launch_t<128, 128>(x, w[0], nullptr, nullptr, M, 0, act, y[0], m_dev, s, 128, 0, 128, nullptr, nullptr, njobs, &J);
     return 1;
 }

@@ -127,3 +127,39 @@ def test_edge_buffer_tails_are_never_read():
     for u, v in zip(a, c):
         assert torch.isfinite(v).all()
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("M,n,tap,bias", [(3000, 3, True, True), (70001, 3, True, False), (66000, 2, False, True), (70001, 3, False, True)])
+def test_layers_of_one_input_forward_and_backward_match_fp64(M, n, tap, bias):
+    """visnet_ops.multi_lin — ViS_MP's dk / dv / f_proj of one f_ij (torch_geometric_visnet.py:600-604,637-640) and q / k / v of one x (:596-598):
+    outputs, the summed input gradient (with the gradient of the handed-through x as its seed), weight and bias gradients against fp64 autograd.
+    From 65 536 rows on the three of them run through the round-5 kernels — all layers of a tile in one workgroup (k_linear_fan16), the input
+    gradients summed in the accumulators (k_linear_sum16), the weight gradients over one staging of x (k_wgrad_lds_shared); below that through
+    the side-by-side and chained forms.  A device-side row count masks the tail of worst-case-sized edge buffers."""
+    from conan_fgw_amd import visnet_ops as vo
+    gen = torch.Generator().manual_seed(M + n)
+    x = (torch.randn(M + 7, 128, generator=gen) * torch.exp(2.0 * torch.randn(M + 7, 1, generator=gen))).to(dev).requires_grad_(True)
+    mods = [torch.nn.Linear(128, 128, bias=bias).to(dev) for _ in range(n)]
+    md = torch.tensor([M], dtype=torch.int32, device=dev)
+    gys = [torch.randn(M + 7, 128, generator=gen).to(dev) * (3.0 ** q) for q in range(n)]
+    gtap = torch.randn(M + 7, 128, generator=gen).to(dev)
+    outs = vo.multi_lin(x, mods, False, md, tap=tap)
+    loss = sum((o[:M] * g[:M]).sum() for o, g in zip(outs[:n], gys))
+    if tap:
+        loss = loss + (outs[n][:M] * gtap[:M]).sum()
+    loss.backward()
+    xd = x.detach()[:M].double().requires_grad_(True)
+    wd = [m.weight.detach().double().requires_grad_(True) for m in mods]
+    bd = [m.bias.detach().double().requires_grad_(True) if bias else None for m in mods]
+    refs = [xd @ w.T + (b if b is not None else 0.0) for w, b in zip(wd, bd)]
+    lref = sum((o * g[:M].double()).sum() for o, g in zip(refs, gys))
+    if tap:
+        lref = lref + (xd * gtap[:M].double()).sum()
+    lref.backward()
+    for o, r in zip(outs[:n], refs):
+        assert rel(o[:M].detach().double().cpu().numpy(), r.detach().cpu().numpy()) < 2e-6
+    assert rel(x.grad[:M].double().cpu().numpy(), xd.grad.cpu().numpy()) < 2e-6
+    for m, w, b in zip(mods, wd, bd):
+        assert rel(m.weight.grad.double().cpu().numpy(), w.grad.cpu().numpy()) < 2e-6
+        if bias:
+            assert rel(m.bias.grad.double().cpu().numpy(), b.grad.cpu().numpy()) < 2e-6
