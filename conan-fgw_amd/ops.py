@@ -354,14 +354,14 @@ def _filter_bwd2(g, h1, dist, offset, coeff, w1, w2, M, md, gmax):
 # ------------------------------------------------------------------------------------------------ linear / activation
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, m_dev):
+    def forward(ctx, x, w, b, residual, act, m_dev, grad_tail_unread=False):
         x, w = _c(x), _c(w)
         M, K = x.shape
         N = w.shape[0]
         y = torch.empty(M, N, dtype=f32, device=x.device)
         call("conan_linear_fwd", ptr(x, f32), ptr(w, f32), ptr(b), ptr(_c(residual)) if residual is not None else None,
              M, K, N, 0, act, ptr(m_dev), ptr(y), stream_ptr())
-        ctx.act, ctx.m_dev, ctx.has_b, ctx.has_res = act, m_dev, b is not None, residual is not None
+        ctx.act, ctx.m_dev, ctx.has_b, ctx.has_res, ctx.grad_tail_unread = act, m_dev, b is not None, residual is not None, grad_tail_unread
         ctx.save_for_backward(x, w, y if act else None)
         return y
 
@@ -381,11 +381,14 @@ class _LinearFn(torch.autograd.Function):
             g = dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = empty_rows(x.shape[0], x.shape[1], x.device, md)
+            if ctx.grad_tail_unread:       # the caller's promise: whatever consumes dx takes md or walks the CSR (ViS_MP's s_proj: 22 us per layer for a tail nobody reads)
+                dx = torch.empty(x.shape[0], x.shape[1], dtype=f32, device=x.device)
+            else:
+                dx = empty_rows(x.shape[0], x.shape[1], x.device, md)
             call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             dw, db = _wgrad(g, x, M, K, N, md, w, ctx.has_b)
-        return dx, dw, db, (dy if ctx.has_res else None), None, None
+        return dx, dw, db, (dy if ctx.has_res else None), None, None, None
 
 
 class _LinearTapFn(torch.autograd.Function):
@@ -428,9 +431,10 @@ def linear_tap(x: Tensor, weight: Tensor):
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: bool = False, residual: Optional[Tensor] = None,
-           m_dev: Optional[Tensor] = None) -> Tensor:
-    """act(x @ weight.T + bias) (+ residual) with act = shifted softplus.  `m_dev`: device int32 row count (edge-level)."""
-    return _LinearFn.apply(x, weight, bias, residual, 1 if act else 0, m_dev)
+           m_dev: Optional[Tensor] = None, grad_tail_unread: bool = False) -> Tensor:
+    """act(x @ weight.T + bias) (+ residual) with act = shifted softplus.  `m_dev`: device int32 row count (edge-level); the rows of the input
+    gradient beyond it are zero unless `grad_tail_unread` (then undefined: for callers whose consumers never read them)."""
+    return _LinearFn.apply(x, weight, bias, residual, 1 if act else 0, m_dev, grad_tail_unread)
 
 
 class _Mlp2Fn(torch.autograd.Function):

@@ -197,7 +197,7 @@ def multi_lin(x: Tensor, mods, act_silu: bool = False, m_dev=None, tap: bool = F
 def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Tensor:
     if act_silu and x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0:
         return _LinearSilu.apply(x, m.weight, m.bias, m_dev)
-    y = ops.linear(x, m.weight, m.bias, m_dev=m_dev)
+    y = ops.linear(x, m.weight, m.bias, m_dev=m_dev, grad_tail_unread=True)      # (edge-level gradients here are consumed by CSR walks or with the same m_dev)
     return silu(y, m_dev) if act_silu else y
 
 
