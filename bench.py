@@ -589,6 +589,8 @@ def run_rank(args):
                 return name + (":edge" if edge_rows(a[4]) else ":node")
             if name == "conan_linear_multi_fwd":
                 return name + (":edge" if edge_rows(a[3]) else ":node")
+            if name == "conan_linear_sum_fwd":
+                return name + (":edge" if edge_rows(a[7]) else ":node")
             return name
 
         def tracer(name, fn, a):
@@ -747,14 +749,26 @@ def run_rank(args):
                       "note": "event bracket around kernel + slab write (the slab reduction is batched elsewhere); two fp16 planes per operand with the gradient scaled "
                               "from its device-side maximum; eight wavefronts per 32-row tile (DESIGN 3.1b: bound by its staging instructions, 61 us stream floor at cfg2)"})
     if ev_all.get("conan_linear_multi_fwd:edge") or ev_all.get("conan_linear_fwd:edge"):
-        # edge-level Linear (ViSNet: dk / dv / f_proj of one f in one launch; s_proj): k_linear_t16<128,128,...>, two fp16 planes per operand
-        for key, lay in (("conan_linear_multi_fwd:edge", None), ("conan_linear_fwd:edge", 1)):
+        # edge-level Linear work of ViSNet (two fp16 planes per operand): the projections of one f in one launch (k_linear_fan16), their input gradients
+        # summed in the accumulators (k_linear_sum16), s_proj and its 256-wide contraction (k_linear_t16 / k_linear_sum16<2> behind conan_linear_fwd)
+        U = E * 128 * 4                                                     # one [E,128] fp32 tensor
+        for key, kern, units in (("conan_linear_multi_fwd:edge", "k_linear_fan16<NL> (the 128 -> 128 layers of one input, one workgroup per tile and output half)",
+                                  lambda n: 4 * (n - 1) + 3),               # per step: n - 1 launches of three layers (1 U in, 3 U out), the last layer's two (1 + 2)
+                                 ("conan_linear_sum_fwd:edge", "k_linear_sum16<NCH> (sum of the input gradients of those layers + the handed-through gradient, in the accumulators)",
+                                  lambda n: 5 * (n - 1) + 3),               # 3 U in + seed + 1 U out; last layer: 2 in, no seed, 1 out
+                                 ("conan_linear_fwd:edge", "k_linear_t16<128,128> / k_linear_sum16<2> (s_proj forward 128 -> 256, its input gradient 256 -> 128, the rbf projections)", None)):
             if not ev_all.get(key):
                 continue
             t_ms = mean_ms(ev_all[key])
-            other.append({"kernel": "k_linear_t16<128,128,...> (edge-level Linear on two fp16 planes; multi = the layers of one input in one launch)", "entry_point": key,
-                          "bound": "hbm", "avg_launch_ms": round(t_ms, 5), "launches_timed": len(ev_all[key]),
-                          "note": "mixed shapes under one entry point: avg_launch_ms is the mean over the step's edge-level calls; per-shape figures: profiles/r5_visnet_kernels.txt"})
+            n_step = len(ev_all[key]) / n_trace
+            ent = {"kernel": kern, "entry_point": key, "bound": "hbm", "avg_launch_ms": round(t_ms, 5), "launches_per_step": round(n_step, 1), "launches_timed": len(ev_all[key])}
+            if units is not None and n_step >= 2:
+                byts = units(int(round(n_step))) * U
+                ent.update({"algorithmic_bytes_per_step": byts, "achieved": round(byts / (t_ms * n_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(byts / (t_ms * n_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            else:
+                ent["note"] = "mixed shapes under one entry point: avg_launch_ms is the mean over the step's edge-level calls; per-launch figures: profiles/r5_visnet_edge_linears.txt"
+            other.append(ent)
     if ev_all.get(fgw_entry):
         t_ms = mean_ms(ev_all[fgw_entry])
         N_, d_ = b.max_nodes, 64
@@ -788,9 +802,10 @@ def run_rank(args):
     # the covalent branch (a second stream) overlap the main stream's, so the shares are of the SUM of all brackets, not of the wall time.
     KERNELS = {"conan_fgw_barycenter_fwd_ragged": "k_fgw_small_vectors + 5 x (k_fgw_coupling_fast | k_fgw_coupling_big, second pass, k_fgw_update_parts)",
                "conan_filter_fwd": "k_filter_fused", "conan_filter_cfconv_fwd": "k_filter_fused<128, true> (generator + gather)", "conan_filter_bwd2": "k_filter_bwd2", "conan_cfconv_fwd": "k_cfconv_fwd", "conan_cfconv_bwd_x": "k_cfconv_bwd_x128",
-               "conan_cfconv_bwd_w_pairs": "k_cfconv_bwd_wp128", "conan_linear_wgrad_slabs_batch": "k_wgrad_lds_batch", "conan_wgrad_reduce_batch": "k_wgrad_reduce4_batch",
+               "conan_cfconv_bwd_w_pairs": "k_cfconv_bwd_wp128", "conan_linear_wgrad_slabs_batch": "k_wgrad_lds_batch / k_wgrad_lds_shared<3>", "conan_wgrad_reduce_batch": "k_wgrad_reduce4_batch",
                "conan_mlp2_fwd": "k_mlp2", "conan_mlp2_bwd": "k_mlp2", "conan_linear_fwd:node": "k_linear_t16 (node level)", "conan_linear_fwd:edge": "k_linear_t16 (edge level)",
-               "conan_linear_multi_fwd:edge": "k_linear_t16 (edge level, layers of one input)", "conan_visnet_attn_message": "k_attn_msg",
+               "conan_linear_multi_fwd:edge": "k_linear_fan16 (edge level, layers of one input)", "conan_linear_sum_fwd:edge": "k_linear_sum16 (edge level, summed input gradients)",
+               "conan_linear_sum_fwd:node": "k_linear_sum16 (node level)", "conan_linear_wgrad_slabs": "k_wgrad_lds / k_wgrad_lds_shared<2>", "conan_visnet_attn_message": "k_attn_msg",
                "conan_visnet_attn_message_bwd": "k_attn_bwd_target + k_attn_bwd_source", "conan_visnet_vec_aggregate": "k_vec_aggregate",
                "conan_visnet_vec_aggregate_bwd": "k_vec_aggregate_bwd_s + _v", "conan_visnet_edge_update": "k_edge_update", "conan_visnet_edge_update_bwd": "k_edge_update_bwd_t + _s",
                "conan_radius_graph_csr": "k_radius + k_exclusive_scan", "conan_linear_wgrad_scaled": "k_wgrad_lds_h16"}

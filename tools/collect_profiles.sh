@@ -18,6 +18,7 @@ python3 $R/tools/probe_filter_bwd2.py 2>/dev/null | grep -v amdgpu > $O/filter_b
 python3 $R/tools/probe_filter_cfconv.py "" cfg2 2>/dev/null | grep -v amdgpu > $O/filter_cfconv.txt
 python3 $R/tools/probe_filter_cfconv.py "" lipo lipo 128 2>/dev/null | grep -v amdgpu >> $O/filter_cfconv.txt
 python3 $R/tools/probe_fgw_large.py "" final 2>/dev/null | grep -v amdgpu > $O/fgw_large.txt
+python3 $R/tools/probe_edge_linears.py "" final 2>/dev/null | grep -v amdgpu > $O/visnet_edge_linears.txt
 python3 $R/tools/probe_fgw_small.py "" final 2>/dev/null | grep -v amdgpu > $O/fgw_small.txt
 for cfg in "train:" "lipo:--shape lipo --batch 128" "visnet_bace:--model visnet --shape bace --batch 64" "freesolv_k20:--shape freesolv --conformers 20 --batch 64"; do
   name=${cfg%%:*}; fl=${cfg#*:}
@@ -26,6 +27,8 @@ done
 # graph-replay timeline of the cfg2 step (tools/trace_timeline.py)
 rocprofv3 --kernel-trace -d $O/tl -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/trace_timeline.py $O/tl > $O/step_timeline.txt 2>&1
+rocprofv3 --kernel-trace -d $O/tlv -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline --model visnet --shape bace --batch 64 > /dev/null 2>&1
+python3 $R/tools/trace_timeline.py $O/tlv 0 > $O/visnet_step_timeline.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $O/pmc_sq -o s -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > $O/pmc_sq.log 2>&1

@@ -13,6 +13,8 @@ cp $O/filter_bwd2_vs_pair.txt $P/r5_filter_bwd2_vs_pair.txt
 cp $O/fb2_phases.txt $P/r5_filter_bwd2_phases.txt
 cp $O/fb2_pmc/summary.txt $P/r5_filter_bwd2_pmc.txt
 cp $O/step_timeline.txt $P/r5_step_timeline.txt
+cp $O/visnet_step_timeline.txt $P/r5_visnet_step_timeline.txt
+cp $O/visnet_edge_linears.txt $P/r5_visnet_edge_linears.txt
 cp $O/r5_pmc_hbm.json $O/r5_pmc_mfma.json $P/
 cp $O/fgw_pmc/summary.txt $P/r5_fgw_pmc_counters.txt
 cp $O/fgw_pmc/fgw_pmc_sq.json $P/r5_fgw_pmc_sq.json
