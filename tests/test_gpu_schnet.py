@@ -53,6 +53,23 @@ def test_against_reference_class(path):
     if "r64_grad:lin1_bary.weight" in g.files:
         for name, p in m.named_parameters():
             assert rel(p.grad.cpu().numpy(), g["r64_grad:" + name]) < 1e-4, name
+    else:
+        # the wider goldens carry the reference's fp32 gradients only (its own fp32 FGW loop sits 1e-3 from fp64: hence 2e-3 above); the 1e-4 bar
+        # is held against the fp64 oracle with the same weights, run here (the oracle's wiring is pinned by the r64 forward fields of this file)
+        H = int(g["hidden"])
+        ref = SchNetNoSumOracle(H, H, 3)
+        ref.load_state_dict(golden_state_dict(g), strict=True)
+        ref = ref.double()
+        r3, rb = ref.forward_w_barycenter(torch.from_numpy(g["z"]), torch.from_numpy(g["pos"]).double(), K, torch.from_numpy(g["batch"]))
+        ((r3 * torch.from_numpy(g["gw_h3d"]).double()).sum() + (rb * torch.from_numpy(g["gw_hbary"]).double()).sum()).backward()
+        refg = dict(ref.named_parameters())
+        checked = 0
+        for name, p in m.named_parameters():
+            if p.grad is None or refg[name].grad is None:
+                continue
+            assert rel(p.grad.cpu().numpy(), refg[name].grad.numpy()) < 1e-4, name
+            checked += 1
+        assert checked >= 20
 
 
 def test_hints_avoid_host_sync_and_match():
