@@ -42,4 +42,4 @@ def test_other_reference_shapes(shape, B, K, H, F, Gs):
         q = refp[name]
         if q.grad is None:
             continue
-        assert rel(p.grad.cpu().numpy(), q.grad.numpy()) < 2e-3, name
+        assert rel(p.grad.cpu().numpy(), q.grad.numpy()) < 1e-4, name

@@ -97,7 +97,7 @@ def test_backward_matches_oracle_autograd(H, shape, B, K):
         if gn == 0.0:
             assert float(p.grad.abs().max()) < 1e-6, name
             continue
-        assert rel(p.grad.detach().cpu().numpy(), q.grad.numpy()) < 2e-3, name
+        assert rel(p.grad.detach().cpu().numpy(), q.grad.numpy()) < 1e-4, name      # north_star's bar (measured: 3e-6 .. 8e-6 over the five widths)
         checked += 1
     assert checked > 100
 
