@@ -206,10 +206,12 @@ def test_full_size_properties():
     assert rel(Y.double().sum(1).cpu(), ro.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("small_int", [False, True], ids=["cs_f32", "cs_u8"])
 @pytest.mark.parametrize("N,K,d", [(70, 3, 64), (110, 2, 32), (40, 5, 64), (64, 2, 16)])
-def test_large_graphs_vs_oracle(N, K, d):
+def test_large_graphs_vs_oracle(N, K, d, small_int):
     """N > 64 takes the generic kernels (LDS- or global-resident matrices), 33 < N <= 64 the register path with R=12/16:
-    compare with the fp64 C oracle (Lipophilicity / BACE-sized conformers, BASELINE.json configs[2], [3])."""
+    compare with the fp64 C oracle (Lipophilicity / BACE-sized conformers, BASELINE.json configs[2], [3]), in the fp32 layout of the structure
+    matrices and in the byte layout the models request (staged once into LDS)."""
     rng = np.random.RandomState(N)
     n_real = N - 5
     Ys = np.full((K, N, d), 0.0, np.float32)
@@ -219,13 +221,38 @@ def test_large_graphs_vs_oracle(N, K, d):
     Cs = np.triu(A, 1); Cs = (Cs | Cs.transpose(0, 2, 1)).astype(np.float32)
     ref = ofgw.fgw_barycenter(Ys, Cs, dtype=np.float64)
     r32 = ofgw.fgw_barycenter(Ys, Cs, dtype=np.float32)
-    Y, C, T, info, errs = _run(Ys, Cs)
+    Y, C, T, info, errs = _run(Ys, Cs, cs_small_int=small_int)
     assert int(info[0, 0]) == ref["outer"] and int(info[0, 1]) == int(ref["pgd"].sum()) and int(info[0, 2]) == int(ref["sinkhorn"].sum())
     # Appendix-F protocol.  These random sparse structures are far more chaotic than molecular graphs: the fp32 and fp64
     # CPU runs differ by 1e-3..1e-1 here (yard-stick), the GPU must be within 1e-4 of fp64 or at least 100x closer than fp32.
     for key, val in (("Y", Y), ("C", C), ("T", T)):
         yard = rel(r32[key], ref[key])
         e64 = rel(val[0].cpu().numpy(), ref[key])
+        assert e64 <= 1e-4 or e64 <= 1e-2 * yard, (key, e64, yard)
+
+
+@pytest.mark.parametrize("cmax", [1, 3, 127, 200])
+def test_integer_structure_matrices_in_the_byte_layout(cmax):
+    """cs_small_int promises integers in [0, 255] (adjacency counts, bond orders): the large-N kernel keeps them as bytes in LDS.  The byte layout
+    must give what the fp32 layout of the same matrices gives — equal iteration counts and flags, couplings to rounding — and meet the fp64
+    oracle's bars, up to the largest byte values."""
+    N, K, d = 83, 3, 32
+    rng = np.random.RandomState(cmax)
+    Ys = rng.uniform(0.1, 2.0, size=(2, K, N, d)).astype(np.float32)
+    W = rng.randint(1, cmax + 1, size=(2, K, N, N)) * (rng.uniform(size=(2, K, N, N)) < 0.15)
+    Cs = np.triu(W, 1); Cs = (Cs + Cs.transpose(0, 1, 3, 2)).astype(np.float32)
+    assert Cs.max() == cmax
+    kw = dict(alpha=0.1 if cmax <= 3 else 1.0e-3)          # (weights in the hundreds at alpha = 0.1 put every cost beyond exp's range: the structure term is scaled to stay a term)
+    Yb, Cb, Tb, ib, _ = _run(Ys, Cs, cs_small_int=True, **kw)
+    Yf, Cf, Tf, if_, _ = _run(Ys, Cs, cs_small_int=False, **kw)
+    assert torch.equal(ib, if_)                                # iteration counts and flags (cmax = 200: a coupling takes the exact second pass in both layouts)
+    tol = 2e-6 if cmax <= 3 else 5e-5                          # the layouts differ in rounding only (the fp32 layout reads its structure sums from fp32)
+    assert rel(Tb.cpu().numpy(), Tf.cpu().numpy()) < tol and rel(Yb.cpu().numpy(), Yf.cpu().numpy()) < tol and rel(Cb.cpu().numpy(), Cf.cpu().numpy()) < tol
+    ref = ofgw.fgw_barycenter(Ys[0], Cs[0], dtype=np.float64, **kw)
+    r32 = ofgw.fgw_barycenter(Ys[0], Cs[0], dtype=np.float32, **kw)
+    assert int(ib[0, 0]) == ref["outer"] and int(ib[0, 1]) == int(ref["pgd"].sum()) and int(ib[0, 2]) == int(ref["sinkhorn"].sum())
+    for key, val in (("Y", Yb), ("C", Cb), ("T", Tb)):
+        e64, yard = rel(val[0].cpu().numpy(), ref[key]), rel(r32[key], ref[key])
         assert e64 <= 1e-4 or e64 <= 1e-2 * yard, (key, e64, yard)
 
 

@@ -9,7 +9,7 @@ src = os.path.join(tmp, "csrc"); shutil.copytree(os.path.join(ROOT, "conan-fgw_a
 os.makedirs(os.path.join(tmp, "include")); shutil.copy(os.path.join(ROOT, "include", "conan_fgw_hip.h"), os.path.join(tmp, "include"))
 # csrc/common.h includes ../../include/...: recreate that relative layout
 os.makedirs(os.path.join(tmp, "pkg")); shutil.move(src, os.path.join(tmp, "pkg", "csrc")); src = os.path.join(tmp, "pkg", "csrc")
-subprocess.check_call(["make", "-C", src, "-s", "-j16", "CXXFLAGS=-O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DCONAN_FGW_PROFILE"])
+subprocess.check_call(["make", "-C", src, "-s", "-j16", "CXXFLAGS=-O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function -DCONAN_FGW_PROFILE " + os.environ.get("PROF_DEFS", "")])      # PROF_DEFS: extra -D switches (A/B of a phase)
 import torch
 from conan_fgw_amd import _lib
 _lib._SO = os.path.join(tmp, "pkg", "libconan_fgw_hip.so")
