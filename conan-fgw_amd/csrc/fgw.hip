@@ -414,6 +414,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 // form — whole tiles + v_mfma_f64_4x4x4_4b_f64 strips for the ragged edge (N = 85: 25 tiles + strips instead of 36 padded tiles) — twice and
 // measured it slower both times (profiles/r5_ab_fgw_large_strips_v1.txt, _v2.txt; DESIGN 3.3 has the numbers and why): removed again.
 #define FGW_MMG mm_f64_glb22
+#ifndef CONAN_FGW_ADJ_I8
+#define CONAN_FGW_ADJ_I8 1      // G = A C2^T against the byte adjacency on the integer matrix pipe, exact digits (mm_adj_i8); 0: the fp64 product
+#endif
 // C2U8: the adjacency of the input graph is staged ONCE into LDS as bytes (caller's promise cs_small_int: integers in [0, 255]) and both
 // products that contract with it read it there instead of fetching fp32 from L2 in every projected-gradient iteration.
 // WPC: workgroups per CU the register budget is cut for — 3 (80 registers: a 640-coupling shard is resident in one round, with ~80 B / lane of
@@ -467,11 +470,20 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     const bool massless = __syncthreads_or(zero_mass) != 0;
     const bool ragged = C2U8 && adj.rowptr != nullptr;
     // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
+    constexpr bool ADJ_I8 = C2U8 && CONAN_FGW_ADJ_I8 != 0;
+    int c2_wide = 0;                                                      // an adjacency byte above 127: the signed-byte product below does not apply
     for (int t = tid; t < NN; t += NT) {
         const int i = t / N, j = t - i * N;
         Kf[i * P + j] = warm ? Tg[t] : (float)(pa[i] * qb[j]);
-        if constexpr (C2U8) C2b[i * P + j] = ragged ? (unsigned char)0 : (unsigned char)C2[t];
+        if constexpr (C2U8) {
+            const unsigned char cb = ragged ? (unsigned char)0 : (unsigned char)C2[t];
+            C2b[i * P + j] = cb;
+            c2_wide |= cb > 127 ? 1 : 0;
+        }
     }
+    // (ragged: the bytes are neighbour-list counts, at most the graph's cap)
+    const bool adj_i8 = ADJ_I8 && __syncthreads_or(c2_wide) == 0;
+    uint4 *Adig = reinterpret_cast<uint4 *>(gs);                         // digit records of A: the first N P doubles of the coupling's scratch (the exact kernel's Mr: unused here)
     if constexpr (C2U8) {
         if (ragged) {                                                     // the graph's adjacency counts straight from its neighbour lists (FgwAdj)
             __syncthreads();
@@ -545,14 +557,32 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
         const int lane = tq & 63, wave = tq >> 6;
         const int tid = tq;
         // ---- A = C1 @ T                                                        (utils.py:48-53)
-        FGW_MMG<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) { Al[i * P + j] = v; }, tq);
+        double amax = 0.0;                                              // max |A| (integer form of the next product: its fixed-point unit)
+        FGW_MMG<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) {
+            Al[i * P + j] = v;
+            if constexpr (ADJ_I8) { const double av = fabs(v); amax = av > amax ? av : amax; }
+        }, tq);
+        int aexp = 0;
+        if constexpr (ADJ_I8) {
+            if (adj_i8) {
+                amax = block_max_d<NW>(amax, red);                      // (its barriers also publish A)
+                if (!(amax < 1.0e300)) { if (tid == 0) *bad_flag = 1.0; }   // a non-finite A must reach the range guard: the integer digits would hide it
+                const int e = (int)((__double_as_longlong(amax) >> 52) & 0x7ff);
+                aexp = e == 0 ? -1022 : e - 1021;                       // amax < 2^(aexp - 1): the 32-bit fixed-point image stays below 2^30, no digit overflows
+                aexp = aexp < -900 ? -900 : (aexp > 900 ? 900 : aexp);
+                fgw_digits_from_f64<NT>(N, N, Al, P, aexp, Adig, tid);
+            }
+        }
         __syncthreads();
         FGW_PROF(3);  // A = C1 @ T
         // ---- G = A @ (2 C2)^T ; K_ij = exp(Mr_ij - ref_j), Mr = -(base - 2 alpha G) / eps   (utils.py:62-64, sinkhorn.py:388)
         auto k_entry = [&](int i, int j, double v) {
             Kf[i * P + j] = (float)exp_fast(fma(v, fc.four_alpha_inv_eps, (refb[j] - base[i * P + j]) * fc.inv_eps));
         };
-        if constexpr (C2U8) FGW_MMG<NW, true>(N, N, N, Al, P, C2b, P, k_entry, tq);
+        if constexpr (ADJ_I8) {
+            if (adj_i8) mm_adj_i8<NW>(N, N, N, Adig, C2b, P, aexp, k_entry, tq);
+            else FGW_MMG<NW, true>(N, N, N, Al, P, C2b, P, k_entry, tq);
+        } else if constexpr (C2U8) FGW_MMG<NW, true>(N, N, N, Al, P, C2b, P, k_entry, tq);
         else FGW_MMG<NW, true>(N, N, N, Al, P, C2, N, k_entry, tq);
         for (int i = tid; i < N; i += NT) gv[i] = 1.0;                  // u = 0
         __syncthreads();

@@ -390,6 +390,138 @@ __device__ __forceinline__ void mm_f64_glb22(int M, int Nn, int Kd, const TX *__
     }
 }
 
+// ---- G = X Wb^T on the INTEGER matrix pipe, exact (round 5) ---------------------------------------------------------------------------------
+// X fp64 (the large-N coupling kernel's A = C1 T), Wb small integers <= 127 (the input graph's adjacency bytes, in LDS).  The consumer of G needs an
+// ABSOLUTE accuracy — G enters exp(4 alpha G / eps + ...), stored as fp32 — so X is cut ONCE per element (fgw_digits_from_f64: a pass of N^2 / 512
+// elements per thread after the product that forms X, whose epilogue collects max |X|) into a 32-bit fixed-point number q against a block-wide
+// power of two, and q into four balanced base-256 digits in [-128, 127]: (q + 0x00808080) ^ 0x00808080 holds them as its four signed bytes, two 4 x 4
+// byte transposes turn 8 consecutive elements of a row into the four 8-byte digit planes = the A operands of v_mfma_i32_16x16x32_i8, stored as one
+// 32-byte record (plane p at byte 8 p).  The product then runs on int32 accumulators — no rounding anywhere — with ONE 32-byte load per lane and
+// k-step for X (half the bytes of the fp64 operand) and no vector arithmetic on it:  G = 2^(xexp - 31) (2^24 S3 + 2^16 S2 + 2^8 S1 + S0), off the exact
+// product by the fixed-point cut alone (<= 2^-30 of max |X| per unit of Wb).  A first form that cut the digits inside the product loop (every element
+// three times, ~40 or ~15 vector instructions each on bf16 / int8 digits) measured 248 / 136 us per launch against the fp64 product's 131
+// (profiles/r5_ab_fgw_adj_i8.txt): the phase is bound by vector issue and trips, not by MFMA cycles on either pipe.
+// Lane layout of the 16x16x32 form: A lane (row = lane & 15, k = 8 (lane >> 4) .. + 7 = the 8 bytes of the operand), B lane (column = lane & 15, same
+// k), D lane (column = lane & 15, rows 4 (lane >> 4) + r).  Digit records: row i, block kb (k = 8 kb .. + 7) at D + (i * KB + kb) * 32 bytes, KB =
+// 4 ceil(Kd / 32) blocks per row (blocks beyond Kd hold zeros).
+typedef int fgw_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fgw_digit_planes4(const double (&v)[4], double scale, unsigned (&pl)[4]) {
+    unsigned r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = ((unsigned)__double2int_rn(v[u] * scale) + 0x00808080u) ^ 0x00808080u;      // bytes = balanced digits, least significant first
+    // 4 x 4 byte transpose: pl[p] = {r0.byte p, r1.byte p, r2.byte p, r3.byte p}   (v_perm_b32: selector 0-3 = bytes of the SECOND source, 4-7 = of the first)
+    const unsigned t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+    const unsigned t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    pl[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); pl[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    pl[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); pl[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+// X [M x Kd] (pitch pX) -> digit records; |X| < 2^(xexp - 1) everywhere.  All NT threads; the caller's barriers order it against producer and consumer.
+template <int NT>
+__device__ __forceinline__ void fgw_digits_from_f64(int M, int Kd, const double *__restrict__ X, int pX, int xexp, uint4 *__restrict__ D, const int tid = threadIdx.x) {
+    const int KB = ((Kd + 31) >> 5) << 2;
+    const double scale = __longlong_as_double((long long)(1023 + 31 - xexp) << 52);       // 2^(31 - xexp)
+    constexpr int R = 2;                                                  // records per thread and round: their 16 loads are in flight together (X was just written: L2)
+    for (int base = 0; base < M * KB; base += R * NT) {
+        double v[R][8];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int idx = base + q * NT + tid;
+            const int ic = idx < M * KB ? idx : M * KB - 1;
+            const int i = ic / KB, kb = ic - i * KB;
+            const double *xr = X + (size_t)i * pX;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = 8 * kb + u; v[q][u] = xr[k < Kd ? k : Kd - 1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int idx = base + q * NT + tid;
+            if (idx >= M * KB) continue;
+            const int kb = idx % KB;
+            double v0[4], v1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v0[u] = 8 * kb + u < Kd ? v[q][u] : 0.0; v1[u] = 8 * kb + 4 + u < Kd ? v[q][4 + u] : 0.0; }
+            unsigned lo[4], hi[4];
+            fgw_digit_planes4(v0, scale, lo); fgw_digit_planes4(v1, scale, hi);
+            D[2 * idx] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+            D[2 * idx + 1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+        }
+    }
+}
+__device__ __forceinline__ long fgw_bytes8(const unsigned char *__restrict__ w, int kb, int Kd) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k0 = kb + u, k1 = kb + 4 + u;
+        lo |= (unsigned)w[k0 < Kd ? k0 : Kd - 1] << (8 * u);                   // (k >= Kd: the digits there are 0, any byte will do)
+        hi |= (unsigned)w[k1 < Kd ? k1 : Kd - 1] << (8 * u);
+    }
+    return (long)(((unsigned long long)hi << 32) | lo);
+}
+template <int NW, class FS>
+__device__ __forceinline__ void mm_adj_i8(int M, int Nn, int Kd, const uint4 *__restrict__ D, const unsigned char *__restrict__ Wb, int pW, int xexp, FS st,
+                                          const int tid = threadIdx.x) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int Mq = (M + 15) >> 4, Nh = (Nn + 31) >> 5, KB = ((Kd + 31) >> 5) << 2;
+    const double unscale = __longlong_as_double((long long)(1023 + xexp - 31) << 52);      // 2^(xexp - 31)
+    for (int t = wave; t < Mq * Nh; t += NW) {
+        const int i0 = (t / Nh) << 4, j0 = (t % Nh) << 5;
+        const uint4 *dr = D + (size_t)min(i0 + li, M - 1) * KB * 2;
+        const unsigned char *w0 = Wb + (size_t)min(j0 + li, Nn - 1) * pW, *w1 = Wb + (size_t)min(j0 + 16 + li, Nn - 1) * pW;
+        fgw_i32x4 acc[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[c][d] = fgw_i32x4{0, 0, 0, 0};
+        for (int k0 = 0; k0 < Kd; k0 += 128) {                          // chunks of four k-steps: their records are in flight together (one L2 round trip per chunk)
+            uint4 da[4], db[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb8 = min(((k0 + 32 * q) >> 3) + lg, KB - 1);
+                da[q] = dr[2 * kb8]; db[q] = dr[2 * kb8 + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (k0 + 32 * q >= Kd) break;                           // (uniform)
+                const int kb8 = ((k0 + 32 * q) >> 3) + lg;
+                const long b0 = fgw_bytes8(w0, 8 * kb8, Kd), b1 = fgw_bytes8(w1, 8 * kb8, Kd);
+                const long a[4] = {(long)(((unsigned long long)da[q].y << 32) | da[q].x), (long)(((unsigned long long)da[q].w << 32) | da[q].z),
+                                   (long)(((unsigned long long)db[q].y << 32) | db[q].x), (long)(((unsigned long long)db[q].w << 32) | db[q].z)};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    acc[0][d] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a[d], b0, acc[0][d], 0, 0, 0);
+                    acc[1][d] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a[d], b1, acc[1][d], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int jb = j0 + 16 * c + li;
+            if (jb >= Nn) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * lg + r;
+                if (i >= M) continue;
+                const double g = (((double)acc[c][3][r] * 256.0 + (double)acc[c][2][r]) * 256.0 + (double)acc[c][1][r]) * 256.0 + (double)acc[c][0][r];
+                st(i, jb, g * unscale);
+            }
+        }
+    }
+}
+// block-wide maximum of one non-negative double per thread; red[] as block_sum_d
+template <int NW = FGW_WAVES>
+__device__ __forceinline__ double block_max_d(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = red[w] > m ? red[w] : m;
+    return m;
+}
+
 // Variant for thin ragged borders: MFMA on the 16-aligned core, plain FMA loops for the few border rows/columns.
 // The border output owned by a thread (two passes of 64 outputs at most) depends only on (M, Nn): it is computed once per
 // kernel (two integer divisions per pass) and reused by every product of that shape.
