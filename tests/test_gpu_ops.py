@@ -659,7 +659,8 @@ def test_global_gradient_scale_has_the_documented_floor_under_an_outlier():
 
 
 @pytest.mark.parametrize("M,K,N,act,w_kn", [(3000, 128, 384, 0, 0), (3000, 384, 128, 0, 1), (1777, 128, 256, 3, 0), (2048, 256, 128, 1, 1),
-                                            (999, 512, 256, 1, 0), (640, 192, 320, 0, 0), (1500, 256, 256, 2, 1)])
+                                            (999, 512, 256, 1, 0), (640, 192, 320, 0, 0), (1500, 256, 256, 2, 1),
+                                            (1500, 256, 128, 0, 0), (901, 384, 128, 0, 0), (70001, 256, 128, 0, 1), (1, 384, 128, 0, 1)])      # (the contractions k_linear_sum16 takes)
 def test_linear_wide_layers_are_tiled_into_strided_chunks(M, K, N, act, w_kn):
     """Layers wider than 128 (ViSNet's 128->256/384 projections and their transposes, the 512/256 classification SchNet) run as
     (n chunk, k chunk) launches of the register-streamed kernel: bias with the first k chunk, activation / residual with the last,
