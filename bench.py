@@ -169,7 +169,7 @@ def cpu_baseline(args, gpu_model=None):
     default_threads = torch.get_num_threads()
     # "All cores": this path is op-dispatch bound (the reference's FGW loop does not scale at all) and torch's
     # intra-op pool collapses when oversubscribed (256 threads on the 256-CPU GPU host: 0.5 molecules/s against 55 at 1
-    # thread, profiles/r2_cpu_baseline_full.json), so the default run times 1 thread and one 16-thread NUMA-local pool;
+    # thread, measured in round 2 with --cpu-full), so the default run times 1 thread and one 16-thread NUMA-local pool;
     # --cpu-full times 1 thread and literally all cores.  `value` is the best of the measured thread counts.
     many = all_cores if args.cpu_full else min(16, all_cores)
     configs = [1] + ([many] if many > 1 else [])
