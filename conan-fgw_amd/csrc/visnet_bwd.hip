@@ -477,6 +477,9 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__rest
 // ---------------------------------------------------------------------------------------------- node update backward
 // forward: xo = x + vdot*o2 + o3 ; veco[sp] = vec[sp] + vec3[sp]*o1 + vagg[sp]      (dx = dxo, dvec = dveco, dvagg = dveco: aliases)
 // outputs: dvdot[n,H], do[n,3H] = [sum_sp dveco*vec3 | dxo*vdot | dxo], dvp[3n,3H] = [0 | 0 | dveco*o1]
+// dvdot == nullptr (round 5): vdot = sum_sp vec1 * vec2 is a function of the same vp, and its gradient g = dx_out * o2 is formed right here — the vec1 / vec2
+// columns of dvp take g * vec2 / g * vec1 instead of zeros, so that no separate vecdot backward writes a second [3n,3H] tensor (zero in the vec3 columns) for
+// autograd to add to this one (zero in the other two): per layer one launch and a 240 MB element-wise add less.
 __global__ void k_node_update_bwd(const float *__restrict__ dxo, const float *__restrict__ dveco, const float *__restrict__ vdot, const float *__restrict__ o,
                                   const float *__restrict__ vp, int n, int H, float *__restrict__ dvdot, float *__restrict__ dout_o, float *__restrict__ dvp) {
     const long long tot = (long long)n * H, stride = (long long)gridDim.x * blockDim.x;
@@ -484,13 +487,16 @@ __global__ void k_node_update_bwd(const float *__restrict__ dxo, const float *__
         const int a = (int)(t / H), c = (int)(t - (long long)a * H);
         const float gx = dxo[t];
         const float o1 = o[(size_t)a * 3 * H + c], o2 = o[(size_t)a * 3 * H + H + c];
-        dvdot[t] = gx * o2;
+        const float gd = gx * o2;
+        if (dvdot) dvdot[t] = gd;
         float g1 = 0.f;
         for (int sp = 0; sp < 3; ++sp) {
             const size_t vi = ((size_t)a * 3 + sp) * H + c, pi = ((size_t)a * 3 + sp) * 3 * H;
             const float gv = dveco[vi];
             g1 += gv * vp[pi + 2 * H + c];
-            dvp[pi + c] = 0.f; dvp[pi + H + c] = 0.f; dvp[pi + 2 * H + c] = gv * o1;
+            dvp[pi + c] = dvdot ? 0.f : gd * vp[pi + H + c];
+            dvp[pi + H + c] = dvdot ? 0.f : gd * vp[pi + c];
+            dvp[pi + 2 * H + c] = gv * o1;
         }
         dout_o[(size_t)a * 3 * H + c] = g1;
         dout_o[(size_t)a * 3 * H + H + c] = gx * vdot[t];
@@ -760,7 +766,7 @@ int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float
 }
 int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp, int n, int H,
                                  float *dvdot, float *dout_o, float *dvp, void *stream) {
-    VB_CHECK(dxo && dveco && vdot && o && vp && dvdot && dout_o && dvp && n >= 0 && H > 0);
+    VB_CHECK(dxo && dveco && vdot && o && vp && dout_o && dvp && n >= 0 && H > 0);
     k_node_update_bwd<<<nblk((long long)n * H), 256, 0, as_stream(stream)>>>(dxo, dveco, vdot, o, vp, n, H, dvdot, dout_o, dvp);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }

@@ -63,6 +63,9 @@ NODE_LEVEL_ON_SIDE_STREAM = 4         # 3 = also the 3-D output head beside the 
                                       # from node_update on the second stream itself); 0 = one stream (tools/ab_step_switch.py compares)
 
 
+FOLD_VECDOT_BACKWARD = True           # vec_dot's backward inside node_update's (one [3n,3H] gradient instead of two and their autograd sum); False: separate nodes (tools/ab_step_switch.py)
+
+
 class ViS_MP(torch.nn.Module):
     def __init__(self, num_heads: int, hidden: int, cutoff: float, last_layer: bool = False):
         super().__init__()
@@ -138,7 +141,7 @@ class ViSNetBlock(torch.nn.Module):
                 vp_ = vo.lin(vl_.view(3 * n, H), L.vec_proj)                       # [3n, 3H] = [vec1|vec2|vec3]
             else:                                                                  # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node
                 vp_, wt, ws = vo.multi_lin(vl_.view(3 * n, H), [L.vec_proj, L.w_trg_proj, L.w_src_proj])
-            return vl_, q_, k_, v_, vp_, vo.vecdot(vp_, n, H)
+            return vl_, q_, k_, v_, vp_, (vo.vecdot_detached(vp_, n, H) if FOLD_VECDOT_BACKWARD else vo.vecdot(vp_, n, H))
 
         side = None
         if NODE_LEVEL_ON_SIDE_STREAM:
@@ -182,14 +185,14 @@ class ViSNetBlock(torch.nn.Module):
         if tail_on_side:                                                           # the residual node update (atoms) under the edge update (edges)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
+                xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
             fo = f if L.last_layer else vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True)
             main.wait_stream(side)
             for tt in (o, xo, veco):
                 tt.record_stream(main)
             return xo, veco, fo, True
         o = vo.lin(xagg, L.o_proj)
-        xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg)
+        xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
         if L.last_layer:
             return xo, veco, f, False
         # (wt, ws: node-level — Linear commutes with the gather)

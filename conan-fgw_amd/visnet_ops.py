@@ -408,12 +408,13 @@ def vec_aggregate(vec, s, dvec3, graph, pre_act=False):
 
 class _NodeUpdate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, vec, vdot, o, vp, vagg):
+    def forward(ctx, x, vec, vdot, o, vp, vagg, vdot_of_vp):
         x, vec, vdot, o, vp, vagg = (_c(t) for t in (x, vec, vdot, o, vp, vagg))
         n, H = x.shape
         xo, veco = torch.empty_like(x), torch.empty_like(vec)
         call("conan_visnet_node_update", ptr(x, f32), ptr(vec), ptr(vdot), ptr(o), ptr(vp), ptr(vagg), n, H, ptr(xo), ptr(veco), stream_ptr())
         ctx.save_for_backward(vdot, o, vp)
+        ctx.vdot_of_vp = bool(vdot_of_vp)
         return xo, veco
 
     @staticmethod
@@ -421,13 +422,23 @@ class _NodeUpdate(torch.autograd.Function):
         vdot, o, vp = ctx.saved_tensors
         n, H = vdot.shape
         dxo, dveco = _c(dxo), _c(dveco)
-        dvdot, do, dvp = torch.empty_like(vdot), torch.empty_like(o), torch.empty_like(vp)
+        do, dvp = torch.empty_like(o), torch.empty_like(vp)
+        dvdot = None if ctx.vdot_of_vp else torch.empty_like(vdot)     # vdot = vecdot_detached(vp): its gradient is folded into dvp by the kernel
         call("conan_visnet_node_update_bwd", ptr(dxo), ptr(dveco), ptr(vdot), ptr(o), ptr(vp), n, H, ptr(dvdot), ptr(do), ptr(dvp), stream_ptr())
-        return dxo, dveco, dvdot, do, dvp, dveco
+        return dxo, dveco, dvdot, do, dvp, dveco, None
 
 
-def node_update(x, vec, vdot, o, vp, vagg):
-    return _NodeUpdate.apply(x, vec, vdot, o, vp, vagg)
+def vecdot_detached(vp, n, H):
+    """vecdot(vp) outside autograd — for node_update(..., vdot_of_vp=True), whose backward carries the gradient through it."""
+    out = _new(vp, n, H)
+    call("conan_visnet_vecdot", ptr(_c(vp).detach(), f32), n, H, ptr(out), stream_ptr())
+    return out
+
+
+def node_update(x, vec, vdot, o, vp, vagg, vdot_of_vp=False):
+    """vdot_of_vp=True: vdot is vecdot_detached(vp) — the kernel's backward then also writes the vec1 / vec2 columns of dvp (the gradient through vdot)
+    instead of leaving a second [3n,3H] tensor to a vecdot backward and their sum to autograd."""
+    return _NodeUpdate.apply(x, vec, vdot, o, vp, vagg, vdot_of_vp)
 
 
 class _EdgeUpdate(torch.autograd.Function):

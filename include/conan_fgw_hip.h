@@ -458,7 +458,8 @@ int conan_visnet_vec_aggregate_bwd(const float *vec, const float *s, const float
                                    const int *col, const int *tgt, const int *t_rowptr, const int *t_eid,
                                    const int *num_edges_dev, int max_edges, int n, int H, int pre_act, float *ds,
                                    float *dvec, void *stream);
-/* Node update: dvdot [n,H], do [n,3H], dvp [n,3,3H] = [0|0|dvec_out*o1] (dx = dx_out, dvec = dvagg = dvec_out). */
+/* Node update: dvdot [n,H], do [n,3H], dvp [n,3,3H] = [0|0|dvec_out*o1] (dx = dx_out, dvec = dvagg = dvec_out).  dvdot == NULL: vdot was formed from this vp
+ * (conan_visnet_vecdot) and its backward is folded in: dvp = [g*vec2 | g*vec1 | dvec_out*o1] with g = dx_out*o2, nothing else to add to it. */
 int conan_visnet_node_update_bwd(const float *dxo, const float *dveco, const float *vdot, const float *o, const float *vp,
                                  int n, int H, float *dvdot, float *dout_o, float *dvp, void *stream);
 /* Edge update: dwt, dws [n,3,H] and dt [E,H] from df_out (df = df_out). */
