@@ -117,6 +117,7 @@ SIGNATURES = {
     "conan_visnet_edge_embed": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "conan_layernorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "conan_scale_channels": (c_int, [_P, _P, c_ll, c_int, _P, _P]),
+    "conan_scale_channels_add": (c_int, [_P, _P, _P, c_ll, c_int, _P, _P]),
     "conan_visnet_vecdot": (c_int, [_P, c_int, c_int, _P, _P]),
     "conan_visnet_attn_message": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_visnet_vec_aggregate": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),

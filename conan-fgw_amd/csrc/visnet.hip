@@ -172,9 +172,24 @@ __global__ void __launch_bounds__(256) k_layernorm(const float *__restrict__ x, 
     }
 }
 
-__global__ void k_scale_channels(const float *__restrict__ v, const float *__restrict__ w, long long rows, int H, float *__restrict__ out) {
+// out = v * w[channel] (+ add): `add` (nullable) is a second gradient of the same tensor (the residual use of vec next to VecLayerNorm, :587,:660) that autograd
+// would otherwise sum in a launch of its own.  H % 4 == 0: float4 per thread, the channel index from 32-bit arithmetic (the scalar form paid a 64-bit modulo per element).
+__global__ void k_scale_channels(const float *__restrict__ v, const float *__restrict__ w, const float *__restrict__ add, long long rows, int H, float *__restrict__ out) {
     const long long n = rows * H, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = v[t] * w[t % H];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = v[t] * w[t % H] + (add ? add[t] : 0.f);
+}
+__global__ void k_scale_channels4(const float4 *__restrict__ v, const float4 *__restrict__ w, const float4 *__restrict__ add, long long rows, int H4,
+                                  float4 *__restrict__ out) {
+    const int stride = (int)(gridDim.x * blockDim.x);                   // (a multiple of H4 is not needed: the channel is recomputed per element)
+    for (long long r0 = 0; r0 < rows * H4; r0 += stride) {
+        const long long t = r0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= rows * H4) break;
+        const int c = (int)(t % H4);
+        const float4 a = v[t], b = w[c];
+        float4 o = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+        if (add) { const float4 d = add[t]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+        out[t] = o;
+    }
 }
 
 // vec_dot[a,c] = sum_sp vp[a,sp,c] * vp[a,sp,H+c]   with vp = vec_proj(vec) [n,3,3H]    (:606-607)
@@ -479,10 +494,22 @@ int conan_layernorm_fwd(const float *x, const float *gamma, const float *beta, i
     k_layernorm<<<nblk((long long)rows * 64), 256, 0, as_stream(stream)>>>(x, gamma, beta, rows, H, eps, out);
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
+static int scale_channels_launch(const float *v, const float *w, const float *add, long long rows, int H, float *out, void *stream) {
+    if (rows == 0) return CONAN_OK;
+    const bool al = ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(add)) & 15) == 0;
+    if ((H & 3) == 0 && al)
+        k_scale_channels4<<<nblk(rows * (H / 4)), 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(v), reinterpret_cast<const float4 *>(w),
+                                                                                 reinterpret_cast<const float4 *>(add), rows, H / 4, reinterpret_cast<float4 *>(out));
+    else k_scale_channels<<<nblk(rows * H), 256, 0, as_stream(stream)>>>(v, w, add, rows, H, out);
+    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+}
 int conan_scale_channels(const float *v, const float *w, long long rows, int H, float *out, void *stream) {
     VN_CHECK(v && w && out && rows >= 0 && H > 0);
-    k_scale_channels<<<nblk(rows * H), 256, 0, as_stream(stream)>>>(v, w, rows, H, out);
-    CONAN_LAUNCH_CHECK(); return CONAN_OK;
+    return scale_channels_launch(v, w, nullptr, rows, H, out, stream);
+}
+int conan_scale_channels_add(const float *v, const float *w, const float *add, long long rows, int H, float *out, void *stream) {
+    VN_CHECK(v && w && add && out && rows >= 0 && H > 0);
+    return scale_channels_launch(v, w, add, rows, H, out, stream);
 }
 int conan_visnet_vecdot(const float *vp, int n, int H, float *out, void *stream) {
     VN_CHECK(vp && out && n >= 0 && H > 0);

@@ -63,6 +63,8 @@ NODE_LEVEL_ON_SIDE_STREAM = 4         # 3 = also the 3-D output head beside the 
                                       # from node_update on the second stream itself); 0 = one stream (tools/ab_step_switch.py compares)
 
 
+TAP_VEC_RESIDUAL = True               # vec handed through VecLayerNorm's autograd node to node_update's residual: the two gradients of vec are summed by the scaling's backward kernel
+TAP_VEC_INTO_PROJECTIONS = True       # vl handed through vec_proj / w_trg / w_src's autograd node to the vector aggregation (its gradient seeds their input-gradient sum); False: autograd adds
 FOLD_VECDOT_BACKWARD = True           # vec_dot's backward inside node_update's (one [3n,3H] gradient instead of two and their autograd sum); False: separate nodes (tools/ab_step_switch.py)
 
 
@@ -129,18 +131,30 @@ class ViSNetBlock(torch.nn.Module):
         H, n = self.hidden_channels, x.shape[0]
         md = g.num_edges_dev
         wt = ws = None
+        vec_res = vec                        # the tensor node_update takes as its residual (handed through VecLayerNorm's node when TAP_VEC_RESIDUAL)
 
         def node_level():
             """Everything of the layer's head that lives on the atoms (a chain of small launches: LayerNorm, the q / k / v and vec / w_trg / w_src
             projections, vec_dot) — independent of the edge-level projections of f below."""
-            nonlocal wt, ws
+            nonlocal wt, ws, vec_res
             xl_ = vo.layernorm(x, L.layernorm)
-            vl_ = vo.scale_channels(vec, L.vec_layernorm.weight)
+            if TAP_VEC_RESIDUAL:                                                   # vec is also node_update's residual: its gradient joins VecLayerNorm's in one pass
+                vl_, vec_res = vo.scale_channels(vec, L.vec_layernorm.weight, tap=True)
+            else:
+                vl_ = vo.scale_channels(vec, L.vec_layernorm.weight)
             q_, k_, v_ = vo.multi_lin(xl_, [L.q_proj, L.k_proj, L.v_proj])
-            if L.last_layer:
-                vp_ = vo.lin(vl_.view(3 * n, H), L.vec_proj)                       # [3n, 3H] = [vec1|vec2|vec3]
-            else:                                                                  # vec_proj, w_trg_proj, w_src_proj read the same vl: one autograd node
-                vp_, wt, ws = vo.multi_lin(vl_.view(3 * n, H), [L.vec_proj, L.w_trg_proj, L.w_src_proj])
+            mods = [L.vec_proj] if L.last_layer else [L.vec_proj, L.w_trg_proj, L.w_src_proj]      # they read the same vl: one autograd node
+            if TAP_VEC_INTO_PROJECTIONS:
+                # vl is also what the vector aggregation gathers: handed through the projections' node, so that the aggregation's gradient seeds the
+                # running sum of their input-gradient GEMMs instead of being added to it by autograd afterwards (a [3n,H] element-wise add per layer)
+                outs = vo.multi_lin(vl_.view(3 * n, H), mods, tap=True)
+                vl_ = outs[-1].view(n, 3, H)
+                outs = outs[:-1]
+            else:
+                outs = vo.multi_lin(vl_.view(3 * n, H), mods) if not L.last_layer else (vo.lin(vl_.view(3 * n, H), L.vec_proj),)
+            vp_ = outs[0]                                                          # [3n, 3H] = [vec1|vec2|vec3]
+            if not L.last_layer:
+                wt, ws = outs[1], outs[2]
             return vl_, q_, k_, v_, vp_, (vo.vecdot_detached(vp_, n, H) if FOLD_VECDOT_BACKWARD else vo.vecdot(vp_, n, H))
 
         side = None
@@ -185,14 +199,14 @@ class ViSNetBlock(torch.nn.Module):
         if tail_on_side:                                                           # the residual node update (atoms) under the edge update (edges)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
+                xo, veco = vo.node_update(x, vec_res, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
             fo = f if L.last_layer else vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True)
             main.wait_stream(side)
             for tt in (o, xo, veco):
                 tt.record_stream(main)
             return xo, veco, fo, True
         o = vo.lin(xagg, L.o_proj)
-        xo, veco = vo.node_update(x, vec, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
+        xo, veco = vo.node_update(x, vec_res, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
         if L.last_layer:
             return xo, veco, f, False
         # (wt, ws: node-level — Linear commutes with the gather)

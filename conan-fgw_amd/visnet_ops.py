@@ -298,27 +298,35 @@ def layernorm(x, m: torch.nn.LayerNorm):
 
 
 class _ScaleChannels(torch.autograd.Function):
+    """v * w[channel].  tap=True also hands v through (a second output) for a residual use of the same tensor: that use's gradient then arrives here and
+    is added by the backward kernel itself (conan_scale_channels_add) instead of by autograd in a launch of its own."""
+
     @staticmethod
-    def forward(ctx, v, w):
+    def forward(ctx, v, w, tap):
         v = _c(v)
         out = torch.empty_like(v)
         H = v.shape[-1]
         call("conan_scale_channels", ptr(v, f32), ptr(w, f32), v.numel() // H, H, ptr(out), stream_ptr())
         ctx.save_for_backward(w)
-        return out
+        return (out, v.view_as(v)) if tap else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dtap=None):
         (w,) = ctx.saved_tensors
+        if dout is None:
+            return dtap, None, None
         dout = _c(dout)
         dv = torch.empty_like(dout)
         H = dout.shape[-1]
-        call("conan_scale_channels", ptr(dout), ptr(w), dout.numel() // H, H, ptr(dv), stream_ptr())
-        return dv, None
+        if dtap is not None:
+            call("conan_scale_channels_add", ptr(dout), ptr(w), ptr(_c(dtap)), dout.numel() // H, H, ptr(dv), stream_ptr())
+        else:
+            call("conan_scale_channels", ptr(dout), ptr(w), dout.numel() // H, H, ptr(dv), stream_ptr())
+        return dv, None, None
 
 
-def scale_channels(v, w):
-    return _ScaleChannels.apply(v, w)
+def scale_channels(v, w, tap=False):
+    return _ScaleChannels.apply(v, w, bool(tap))
 
 
 class _VecDot(torch.autograd.Function):

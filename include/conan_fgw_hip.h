@@ -397,6 +397,9 @@ int conan_layernorm_fwd(const float *x, const float *gamma, const float *beta, i
                         void *stream);
 /* out[r,c] = v[r,c] * w[c]   (VecLayerNorm with norm_type=None, :262-268). */
 int conan_scale_channels(const float *v, const float *w, long long rows, int H, float *out, void *stream);
+/* out = v * w[channel] + add (all [rows,H]): the backward of a channel scaling whose input is also used as a residual — the residual's gradient `add`
+ * joins in the same pass instead of an autograd sum (VecLayerNorm's weight next to ViS_MP's vec + dvec, torch_geometric_visnet.py:587,660). */
+int conan_scale_channels_add(const float *v, const float *w, const float *add, long long rows, int H, float *out, void *stream);
 /* vec_dot[a,c] = sum_sp vp[a,sp,c] * vp[a,sp,H+c], vp = vec_proj(vec) [n,3,3H] (:605-607). */
 int conan_visnet_vecdot(const float *vp, int n, int H, float *out, void *stream);
 /* ViS_MP.message (scalar half) + aggregate (:632-645, :671): attn_h = SiLU(sum_{c in head} q_i k_j dk_e) * C(r_e);
