@@ -168,7 +168,7 @@ class _MultiLinear(torch.autograd.Function):
                     seed = None
                 else:
                     res = dx
-                if res is None or N <= 128:
+                if res is None or N <= 128 or (K == 128 and N in (256, 384)):      # (256 / 384-wide contractions into 128 outputs are ONE launch that takes a residual: k_linear_sum16)
                     call("conan_linear_fwd", ptr(g), ptr(w), None, ptr(res), M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())      # dx = g W (+ running sum)
                 else:           # a contraction wider than one 128-chunk accumulates in place over several launches: it cannot also read dx as its residual
                     tmp = _tail0_shape(M, K, x.device, md)
