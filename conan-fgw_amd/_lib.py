@@ -134,6 +134,7 @@ SIGNATURES = {
     "conan_visnet_edge_embed_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "conan_layernorm_bwd_ws": (c_ll, [c_int, c_int]),
     "conan_layernorm_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
+    "conan_layernorm_bwd_res": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "conan_visnet_vecdot_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "conan_visnet_attn_message_bwd": (c_int, [_P] * 13 + [c_float, c_int, c_int, c_int, c_int] + [_P] * 6),
     "conan_visnet_vec_aggregate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -170,8 +170,10 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd_x(const float *__restric
 
 // ---------------------------------------------------------------------------------------------- LayerNorm backward
 // dx per row (one wavefront per row); stats[r] = (mean, rstd) saved for the parameter-gradient pass
+// dres (nullable): a second gradient of x (its residual use next to the LayerNorm, :583,:659) added here instead of by autograd
 __global__ void __launch_bounds__(256) k_layernorm_bwd_x(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ dy,
-                                                         int rows, int H, float eps, float *__restrict__ dx, float *__restrict__ stats) {
+                                                         const float *__restrict__ dres, int rows, int H, float eps, float *__restrict__ dx,
+                                                         float *__restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int r = wave; r < rows; r += nw) {
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_x(const float *__restrict
         s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
         for (int c = lane; c < H; c += 64) {
             const float dxh = gr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
-            dx[(size_t)r * H + c] = rstd * (dxh - s1 - xh * s2);
+            dx[(size_t)r * H + c] = rstd * (dxh - s1 - xh * s2) + (dres ? dres[(size_t)r * H + c] : 0.f);
         }
         if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
     }
@@ -704,14 +706,25 @@ int conan_visnet_edge_embed_bwd(const float *x, const float *p, const float *df,
     CONAN_LAUNCH_CHECK(); return CONAN_OK;
 }
 long long conan_layernorm_bwd_ws(int rows, int H) { return 2LL * rows + 2LL * ((rows + LN_CHUNK - 1) / LN_CHUNK) * H; }
+static int layernorm_bwd_launch(const float *x, const float *gamma, const float *dy, const float *dres, int rows, int H, float eps, float *dx, float *dgamma,
+                                float *dbeta, float *ws, void *stream);
 int conan_layernorm_bwd(const float *x, const float *gamma, const float *dy, int rows, int H, float eps, float *dx, float *dgamma,
                         float *dbeta, float *ws, void *stream) {
     VB_CHECK(x && gamma && dy && dx && dgamma && dbeta && ws && rows >= 0 && H > 0);
+    return layernorm_bwd_launch(x, gamma, dy, nullptr, rows, H, eps, dx, dgamma, dbeta, ws, stream);
+}
+int conan_layernorm_bwd_res(const float *x, const float *gamma, const float *dy, const float *dres, int rows, int H, float eps, float *dx, float *dgamma,
+                            float *dbeta, float *ws, void *stream) {
+    VB_CHECK(x && gamma && dy && dres && dx && dgamma && dbeta && ws && rows >= 0 && H > 0);
+    return layernorm_bwd_launch(x, gamma, dy, dres, rows, H, eps, dx, dgamma, dbeta, ws, stream);
+}
+static int layernorm_bwd_launch(const float *x, const float *gamma, const float *dy, const float *dres, int rows, int H, float eps, float *dx, float *dgamma,
+                                float *dbeta, float *ws, void *stream) {
     hipStream_t s = as_stream(stream);
     float *stats = ws, *slabs = ws + 2 * (size_t)rows;
     const int chunks = (rows + LN_CHUNK - 1) / LN_CHUNK;
     if (rows > 0) {
-        k_layernorm_bwd_x<<<nblk((long long)rows * 64), 256, 0, s>>>(x, gamma, dy, rows, H, eps, dx, stats);
+        k_layernorm_bwd_x<<<nblk((long long)rows * 64), 256, 0, s>>>(x, gamma, dy, dres, rows, H, eps, dx, stats);
         k_layernorm_bwd_p<<<dim3(chunks, (H + 127) / 128), 128 * LN_RL, 0, s>>>(x, dy, stats, rows, H, slabs);
     }
     k_layernorm_bwd_reduce<<<(H + 255) / 256, 256, 0, s>>>(slabs, chunks, H, dgamma, dbeta);

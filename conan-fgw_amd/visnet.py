@@ -63,6 +63,7 @@ NODE_LEVEL_ON_SIDE_STREAM = 4         # 3 = also the 3-D output head beside the 
                                       # from node_update on the second stream itself); 0 = one stream (tools/ab_step_switch.py compares)
 
 
+TAP_X_RESIDUAL = True                 # x handed through the LayerNorm's autograd node to node_update's residual (conan_layernorm_bwd_res adds the residual's gradient)
 TAP_VEC_RESIDUAL = True               # vec handed through VecLayerNorm's autograd node to node_update's residual: the two gradients of vec are summed by the scaling's backward kernel
 TAP_VEC_INTO_PROJECTIONS = True       # vl handed through vec_proj / w_trg / w_src's autograd node to the vector aggregation (its gradient seeds their input-gradient sum); False: autograd adds
 FOLD_VECDOT_BACKWARD = True           # vec_dot's backward inside node_update's (one [3n,3H] gradient instead of two and their autograd sum); False: separate nodes (tools/ab_step_switch.py)
@@ -131,13 +132,17 @@ class ViSNetBlock(torch.nn.Module):
         H, n = self.hidden_channels, x.shape[0]
         md = g.num_edges_dev
         wt = ws = None
-        vec_res = vec                        # the tensor node_update takes as its residual (handed through VecLayerNorm's node when TAP_VEC_RESIDUAL)
+        x_res = x
+        vec_res = vec                        # the tensors node_update takes as its residuals (handed through VecLayerNorm's node when TAP_VEC_RESIDUAL)
 
         def node_level():
             """Everything of the layer's head that lives on the atoms (a chain of small launches: LayerNorm, the q / k / v and vec / w_trg / w_src
             projections, vec_dot) — independent of the edge-level projections of f below."""
-            nonlocal wt, ws, vec_res
-            xl_ = vo.layernorm(x, L.layernorm)
+            nonlocal wt, ws, vec_res, x_res
+            if TAP_X_RESIDUAL:                                                     # x is also node_update's residual: its gradient joins the LayerNorm's in one pass
+                xl_, x_res = vo.layernorm(x, L.layernorm, tap=True)
+            else:
+                xl_ = vo.layernorm(x, L.layernorm)
             if TAP_VEC_RESIDUAL:                                                   # vec is also node_update's residual: its gradient joins VecLayerNorm's in one pass
                 vl_, vec_res = vo.scale_channels(vec, L.vec_layernorm.weight, tap=True)
             else:
@@ -199,14 +204,14 @@ class ViSNetBlock(torch.nn.Module):
         if tail_on_side:                                                           # the residual node update (atoms) under the edge update (edges)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xo, veco = vo.node_update(x, vec_res, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
+                xo, veco = vo.node_update(x_res, vec_res, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
             fo = f if L.last_layer else vo.edge_update(wt, ws, t, dvec, f, g, pre_act=True)
             main.wait_stream(side)
             for tt in (o, xo, veco):
                 tt.record_stream(main)
             return xo, veco, fo, True
         o = vo.lin(xagg, L.o_proj)
-        xo, veco = vo.node_update(x, vec_res, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
+        xo, veco = vo.node_update(x_res, vec_res, vdot, o, vp, vagg, FOLD_VECDOT_BACKWARD)
         if L.last_layer:
             return xo, veco, f, False
         # (wt, ws: node-level — Linear commutes with the gather)

@@ -274,27 +274,34 @@ def edge_embed(x, p, graph):
 
 
 class _LayerNorm(torch.autograd.Function):
+    """tap=True also hands x through (second output) for a residual use of the same tensor: its gradient is added to dx by the backward kernel."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, tap):
         x = _c(x)
         out = torch.empty_like(x)
         call("conan_layernorm_fwd", ptr(x, f32), ptr(_c(gamma)), ptr(_c(beta)), x.shape[0], x.shape[1], float(eps), ptr(out), stream_ptr())
         ctx.save_for_backward(x, gamma)
         ctx.eps = float(eps)
-        return out
+        return (out, x.view_as(x)) if tap else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dtap, None, None, None, None
         n, H = x.shape
         dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(int(lib().conan_layernorm_bwd_ws(n, H)), dtype=f32, device=x.device)
-        call("conan_layernorm_bwd", ptr(x), ptr(_c(gamma)), ptr(_c(dy)), n, H, ctx.eps, ptr(dx), ptr(dg), ptr(db), ptr(ws), stream_ptr())
-        return dx, dg, db, None
+        if dtap is not None:
+            call("conan_layernorm_bwd_res", ptr(x), ptr(_c(gamma)), ptr(_c(dy)), ptr(_c(dtap)), n, H, ctx.eps, ptr(dx), ptr(dg), ptr(db), ptr(ws), stream_ptr())
+        else:
+            call("conan_layernorm_bwd", ptr(x), ptr(_c(gamma)), ptr(_c(dy)), n, H, ctx.eps, ptr(dx), ptr(dg), ptr(db), ptr(ws), stream_ptr())
+        return dx, dg, db, None, None
 
 
-def layernorm(x, m: torch.nn.LayerNorm):
-    return _LayerNorm.apply(x, m.weight, m.bias, m.eps)
+def layernorm(x, m: torch.nn.LayerNorm, tap: bool = False):
+    return _LayerNorm.apply(x, m.weight, m.bias, m.eps, bool(tap))
 
 
 class _ScaleChannels(torch.autograd.Function):

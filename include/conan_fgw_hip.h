@@ -448,6 +448,9 @@ int conan_visnet_edge_embed_bwd(const float *x, const float *p, const float *df,
 long long conan_layernorm_bwd_ws(int rows, int H);
 int conan_layernorm_bwd(const float *x, const float *gamma, const float *dy, int rows, int H, float eps, float *dx,
                         float *dgamma, float *dbeta, float *ws, void *stream);
+/* ... with a second gradient of x (`dres` [rows,H]: x's residual use next to the LayerNorm, torch_geometric_visnet.py:583,659) added to dx in the same pass. */
+int conan_layernorm_bwd_res(const float *x, const float *gamma, const float *dy, const float *dres, int rows, int H, float eps, float *dx,
+                            float *dgamma, float *dbeta, float *ws, void *stream);
 /* dvp [n,3,3H] = [dout*vec2 | dout*vec1 | 0]. */
 int conan_visnet_vecdot_bwd(const float *vp, const float *dout, int n, int H, float *dvp, void *stream);
 /* Attention message: given dvmsg [E,H] and dxagg [n,H] returns dq, dk, dv [n,H] and d(dk), d(dv) [E,H]. */
