@@ -66,12 +66,17 @@ def parse(argv=None):
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="BASELINE.json configs by name (per-GPU share): cfg2 = ESOL + SchNet, K=5, 256 molecules (the default workload); cfg3 = Lipophilicity + SchNet, "
                          "K=5, 128 per GPU (1024 over 8 GPUs); cfg4 = BACE + ViSNet, K=5, 64; cfg5 = FreeSolv + SchNet, K=20, 64.  Overrides --shape/--batch/--conformers/--model")
+    ap.add_argument("--no-clip", action="store_true", help="leave out the global-norm gradient clipping (Trainer(gradient_clip_val=1.0), trainer.py:177) between all-reduce and Adam")
     ap.add_argument("--torch-adam", action="store_true", help="optimizer step on torch.optim.Adam(fused=True, capturable=True) instead of the one-launch FlatAdam")
     ap.add_argument("--no-pack8", action="store_true", help="skip the eight-concurrent-packer-processes leg of with_input_pipeline (it is skipped anyway under a profiler preload)")
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = ap.parse_args(argv)
     if a.config:
+        # an explicit flag beside --config wins (e.g. --config cfg3 --batch 16 for a dry run) — told from the command line itself, so that a flag
+        # that happens to equal the parser's default (--config cfg3 --batch 256) is still honoured
+        given = {k for k in CONFIGS[a.config] if any(t == "--" + k or t.startswith("--" + k + "=") for t in argv)}
         for k, v in CONFIGS[a.config].items():
-            if getattr(a, k) == ap.get_default(k):               # an explicit flag beside --config wins (e.g. --config cfg3 --batch 16 for a dry run)
+            if k not in given:
                 setattr(a, k, v)
     return a
 
@@ -320,6 +325,7 @@ def run_rank(args):
         opt = FlatAdam(flat, lr=1e-4)
     loss_box = [torch.zeros((), device=dev)]      # the step's loss tensor itself (no copy kernel in the step): the eager step's, or the captured graph's fixed output
     train = args.mode == "train"
+    clip = train and not args.no_clip
     inv_world = 1.0 / world
     collective = train and use_dist and (world > 1 or args.force_collective)      # the step contains the RCCL all-reduce
 
@@ -336,6 +342,8 @@ def run_rank(args):
         if train:
             fwd_bwd()
             flat.all_reduce_mean(force=args.force_collective, prescaled=collective)      # pack + (world > 1 or forced) RCCL all-reduce(s); the mean comes from the seed
+            if clip:
+                flat.clip_grad_norm_(1.0)                   # Lightning's gradient_clip_val=1.0 of the reference's Trainer (trainer.py:177): norm over the flat buffer, scaled in place
             opt.step()
         else:
             with torch.no_grad():
@@ -411,6 +419,8 @@ def run_rank(args):
                 if train:
                     gB = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gB, stream=side, pool=gA.pool(), capture_error_mode=cmode):
+                        if clip:
+                            flat.clip_grad_norm_(1.0)
                         opt.step()                                   # (the gradients were seeded with 1 / world: the summed buffer is the mean)
                 captured = True
             except Exception as e:                                   # capture is an optimisation of the launch path, never a requirement
@@ -581,8 +591,10 @@ def run_rank(args):
         from conan_fgw_amd import _lib as _cl
         n_trace = 10
 
+        n_atoms_rows = int(z.shape[0])
+
         def edge_rows(m):
-            return m >= 65536                                            # node-level calls see a few ten thousand rows, edge-level ones hundreds of thousands
+            return m > 3 * n_atoms_rows                                       # node-level calls see n or (ViSNet's vector channels) 3 n rows, edge-level ones one row per edge
 
         def trace_key(name, a):
             if name == "conan_linear_fwd":
@@ -818,7 +830,7 @@ def run_rank(args):
                             for k, t in sorted(tot.items(), key=lambda kv: -kv[1])[:8]]}
     if rank == 0:
         mol = args.batch * world * steps
-        exe = ("HIP-graph replay (fwd+bwd+pack | RCCL all-reduce | Adam)" if train else "HIP-graph replay") if use_graph else "eager"
+        exe = (("HIP-graph replay (fwd+bwd+pack | RCCL all-reduce | clip + Adam)" if clip else "HIP-graph replay (fwd+bwd+pack | RCCL all-reduce | Adam)") if train else "HIP-graph replay") if use_graph else "eager"
         out = {
             "metric": "molecules/s (K=5 conformers)", "value": round(mol / dt, 1), "unit": "molecules/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / steps, 4),
@@ -828,10 +840,11 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
-                                   + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
+                                   + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce" + (" + global-norm clip 1.0" if clip else "") + " + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
                        "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core",
-                       "optimizer": "torch.optim.Adam(fused, capturable)" if args.torch_adam else "Adam in one launch over flat buffers (parallel.FlatAdam: torch.optim.Adam's update)"},
+                       "optimizer": "torch.optim.Adam(fused, capturable)" if args.torch_adam else "Adam in one launch over flat buffers (parallel.FlatAdam: torch.optim.Adam's update)",
+                       "grad_clip": "global L2 norm 1.0 on the flat buffer (conan_grad_clip_flat; Trainer(gradient_clip_val=1.0), trainer.py:177)" if clip else None},
             "rccl_ranks": dist.get_world_size() if use_dist and args.backend == "nccl" else 0,
             "dist": {"backend": ("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo (host memory; ranks may share a GPU: a functional run of the world > 1 step, not a rate)") if use_dist else None,
                      "ranks": world, "distinct_gpus": min(world, torch.cuda.device_count()) if args.backend == "gloo" else world, "per_rank": per_rank},

@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libconan_fgw_hip.so")
 _LIB = None
-ABI_VERSION = 4            # == CONAN_FGW_ABI_VERSION of include/conan_fgw_hip.h (tests/test_abi.py compares the two)
+ABI_VERSION = 5            # == CONAN_FGW_ABI_VERSION of include/conan_fgw_hip.h (tests/test_abi.py compares the two)
 
 c_int, c_float, c_void_p, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 
@@ -92,7 +92,8 @@ SIGNATURES = {
     "conan_mse_loss_fwd": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "conan_stage2_head_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "conan_stage2_head_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "conan_adam_flat_step": (c_int, [_P, _P, _P, _P, _P, _P, c_ll] + [ctypes.c_double] * 5 + [_P]),
+    "conan_adam_flat_step": (c_int, [_P, _P, _P, _P, _P, _P, c_ll] + [ctypes.c_double] * 5 + [_P, _P]),
+    "conan_grad_clip_flat": (c_int, [_P, c_ll, ctypes.c_double, _P, _P, _P, _P]),
     "conan_mlp2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "conan_mlp2_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "conan_mlp2_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -76,6 +76,10 @@ class DeviceBatch(types.SimpleNamespace):
             collator._consumed = ev
             collator._landing_busy = False
             self._static_pair = None
+            # The fixed views are ONE set of tensor objects for every batch: the host-known sizes are attached here, on the consumer's thread,
+            # at the moment this batch becomes their content — not at enqueue time, where a worker thread assembling batch i + 1 would
+            # overwrite what a size-less call on batch i is about to read (a smaller max_nodes under-sizes the dense barycenter padding).
+            self.batch._conan_hints = (int(self.num_graphs), int(self.max_nodes))
             if collator._landing_released is not None:
                 collator._landing_released.release()          # CollatePipeline's worker may assemble the next batch
         return self
@@ -120,8 +124,14 @@ class DeviceCollator:
     what a captured HIP graph needs: fixed input addresses.  The kernel then expands into a landing copy and `DeviceBatch.wait()` moves
     it to the fixed addresses with one device-to-device transfer, so the expansion of batch i+1 overlaps the step on batch i."""
 
-    def __init__(self, device, num_conformers: int, depth: int = 2, static: bool = False):
+    def __init__(self, device, num_conformers: int, depth: int = 2, static: bool = False, strict_max_nodes: bool = True):
+        """`strict_max_nodes` (static collators): reject a batch whose largest conformer differs from the first batch's — the padded size N of
+        the dense FGW problem is a launch parameter of the step, so a captured graph replayed on such a batch would run with the wrong N
+        (and N is part of the result: SURVEY.md Appendix D.1).  False: only the addresses are fixed (eager consumers); the sizes of every
+        batch ride on its index tensor from `wait()` on."""
         self.device = torch.device(device)
+        self.strict_max_nodes = bool(strict_max_nodes)
+        self._static_max_nodes = None
         if self.device.type != "cuda":
             raise RuntimeError("DeviceCollator assembles batches for the GPU path; there is no CPU fallback")
         self.K = int(num_conformers)
@@ -229,6 +239,11 @@ class DeviceCollator:
                 if self._landing_busy:
                     raise RuntimeError("static DeviceCollator: call .wait() on the previous batch before assembling the next one "
                                        "(there is one landing copy)")
+                if self._static_max_nodes is None:
+                    self._static_max_nodes = int(L.max_nodes)
+                elif self.strict_max_nodes and int(L.max_nodes) != self._static_max_nodes:
+                    raise RuntimeError(f"static DeviceCollator: the largest conformer of this batch has {int(L.max_nodes)} atoms, the first batch's "
+                                       f"had {self._static_max_nodes}; a captured step was sized for the latter (strict_max_nodes=False for eager consumers)")
                 if self._consumed is not None:
                     if host_wait:
                         self._consumed.synchronize()
@@ -249,10 +264,10 @@ class DeviceCollator:
                         num_molecules=int(L.B), num_conformers=int(L.K), ready=ev)
         # The reference's call shape is forward(batch, conformers_index, node_index) with no size arguments (schnet_based_models.py:135-173):
         # the host-known sizes ride on the index tensors themselves, so that an unchanged harness reaches the sync-free path (ops.batch_hints).
-        ops_tag = (int(L.num_graphs), int(L.max_nodes))
-        o["batch"]._conan_hints = ops_tag
         if self.static:
-            b._static_pair = (self, fixed, landing)
+            b._static_pair = (self, fixed, landing)               # (shared fixed views: DeviceBatch.wait attaches the sizes)
+        else:
+            o["batch"]._conan_hints = (int(L.num_graphs), int(L.max_nodes))
         return b
 
 

@@ -557,17 +557,21 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
         const int lane = tq & 63, wave = tq >> 6;
         const int tid = tq;
         // ---- A = C1 @ T                                                        (utils.py:48-53)
-        double amax = 0.0;                                              // max |A| (integer form of the next product: its fixed-point unit)
+        // max |A| as a bit pattern (integer form of the next product: its fixed-point unit); compared as integers so that a NaN or an infinity in A
+        // ends up as the maximum instead of being dropped by a floating-point comparison (block_max_bits)
+        unsigned long long amax = 0ull;
         FGW_MMG<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) {
             Al[i * P + j] = v;
-            if constexpr (ADJ_I8) { const double av = fabs(v); amax = av > amax ? av : amax; }
+            if constexpr (ADJ_I8) { const unsigned long long ab = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull; amax = ab > amax ? ab : amax; }
         }, tq);
         int aexp = 0;
         if constexpr (ADJ_I8) {
             if (adj_i8) {
-                amax = block_max_d<NW>(amax, red);                      // (its barriers also publish A)
-                if (!(amax < 1.0e300)) { if (tid == 0) *bad_flag = 1.0; }   // a non-finite A must reach the range guard: the integer digits would hide it
-                const int e = (int)((__double_as_longlong(amax) >> 52) & 0x7ff);
+                amax = block_max_bits<NW>(amax, red);                   // (its barriers also publish A)
+                const int e = (int)(amax >> 52);                        // biased exponent of max |A|; 0x7ff = an infinity or a NaN somewhere in A
+                // max |A| >= 2^899 (e - 1023 >= 899), non-finite included, must reach the range guard: the integer digits would turn a NaN into a
+                // finite G (__double2int_rn(NaN) = 0) and saturate beyond the unit's clamp below
+                if (e >= 1922) { if (tid == 0) *bad_flag = 1.0; }
                 aexp = e == 0 ? -1022 : e - 1021;                       // amax < 2^(aexp - 1): the 32-bit fixed-point image stays below 2^30, no digit overflows
                 aexp = aexp < -900 ? -900 : (aexp > 900 ? 900 : aexp);
                 fgw_digits_from_f64<NT>(N, N, Al, P, aexp, Adig, tid);

@@ -521,6 +521,21 @@ __device__ __forceinline__ double block_max_d(double v, double *red) {
     for (int w = 1; w < NW; ++w) m = red[w] > m ? red[w] : m;
     return m;
 }
+// The same on the BIT PATTERNS of non-negative doubles (sign bit cleared by the caller): integer order is numeric order there, and an infinity or
+// a NaN sorts above every finite value — a floating-point maximum drops NaN (every comparison with it is false), this one carries it to the caller.
+template <int NW>
+__device__ __forceinline__ unsigned long long block_max_bits(unsigned long long v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    unsigned long long *r = reinterpret_cast<unsigned long long *>(red);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long m = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = r[w] > m ? r[w] : m;
+    return m;
+}
 
 // Variant for thin ragged borders: MFMA on the 16-aligned core, plain FMA loops for the few border rows/columns.
 // The border output owned by a thread (two passes of 64 outputs at most) depends only on (M, Nn): it is computed once per

@@ -144,12 +144,14 @@ __global__ void __launch_bounds__(256) k_mse_loss(const float *__restrict__ pred
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)      (+ weight_decay * p added to g first)
 __global__ void __launch_bounds__(256) k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                                                    float *__restrict__ step, unsigned *__restrict__ ticket, long long n, double lr_d, double b1_d, double b2_d,
-                                                   float eps, float wd) {
+                                                   float eps, float wd, const double *__restrict__ lr_dev) {
     // the bias corrections 1 - b^t cancel badly in fp32 for the first steps (1 - 0.999^2 keeps three digits), and 0.999 itself is 1.3e-5 of
     // (1 - b2) away from its fp32 rounding: they are formed in fp64 from the fp64 hyper-parameters, like torch's host-side (non-capturable) path
     __shared__ float sh[4];
     const float t = *step + 1.0f;
     if (threadIdx.x == 0) {
+        // the learning rate of a captured launch is read where a scheduler can change it between replays (a by-value argument is baked into the graph)
+        if (lr_dev) lr_d = *lr_dev;
         const double bc1d = 1.0 - pow(b1_d, (double)t), bc2d = 1.0 - pow(b2_d, (double)t);
         sh[0] = (float)(lr_d / bc1d); sh[1] = (float)sqrt(bc2d); sh[2] = (float)(1.0 - b1_d); sh[3] = (float)(1.0 - b2_d);
     }
@@ -185,19 +187,83 @@ __global__ void __launch_bounds__(256) k_adam_flat(float *__restrict__ p, const 
         if (done == gridDim.x - 1) { *step = t; *ticket = 0u; }         // the last workgroup to finish: everyone has read the old value
     }
 }
+// Global-norm gradient clipping over the flat gradient buffer (torch.nn.utils.clip_grad_norm_, which Lightning runs for the reference's
+// Trainer(gradient_clip_val=1.0), trainer.py:177): squared sums per workgroup in fp64 into fixed slots, the last workgroup to arrive adds the slots in
+// index order (same result on every run), writes total_norm and the coefficient min(1, max_norm / (total_norm + 1e-6)); a second launch scales in place.
+__global__ void __launch_bounds__(256) k_grad_sqnorm(const float *__restrict__ g, long long n, double max_norm, double *__restrict__ part,
+                                                     unsigned *__restrict__ ticket, float *__restrict__ out2) {
+    __shared__ double red[4];
+    __shared__ bool last;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(g)[i];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += (double)g[i] * g[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&part[blockIdx.x], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double s = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double nrm = sqrt(s);
+        double c = max_norm / (nrm + 1e-6);
+        if (!(c < 1.0)) c = 1.0;                    // clamp(max=1)
+        if (nrm != nrm) c = nrm;                    // torch with error_if_nonfinite=False: a NaN norm gives a NaN coefficient (an infinite one gives 0)
+        out2[0] = (float)nrm; out2[1] = (float)c;
+        *ticket = 0u;
+    }
+}
+__global__ void __launch_bounds__(256) k_grad_scale_dev(float *__restrict__ g, long long n, const float *__restrict__ out2) {
+    const float c = out2[1];
+    if (c == 1.0f) return;
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4 *>(g)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        reinterpret_cast<float4 *>(g)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] *= c;
+}
 }  // namespace
 
 extern "C" {
 
+int conan_grad_clip_flat(float *grads, long long n, double max_norm, float *norm_coef_dev, double *partials_dev, unsigned *ticket_dev, void *stream) {
+    if (!grads || !norm_coef_dev || !partials_dev || !ticket_dev || n < 0 || !(max_norm > 0.0)) return CONAN_E_BADARG;
+    if ((uintptr_t)grads & 15) return CONAN_E_BADARG;
+    long long blocks = ((n >> 2) + 1023) / 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks > CONAN_GRAD_CLIP_MAX_BLOCKS) blocks = CONAN_GRAD_CLIP_MAX_BLOCKS;
+    k_grad_sqnorm<<<(int)blocks, 256, 0, as_stream(stream)>>>(grads, n, max_norm, partials_dev, ticket_dev, norm_coef_dev);
+    CONAN_LAUNCH_CHECK();
+    k_grad_scale_dev<<<(int)blocks, 256, 0, as_stream(stream)>>>(grads, n, norm_coef_dev);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
 int conan_adam_flat_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *step_dev, unsigned *ticket_dev, long long n,
-                         double lr, double beta1, double beta2, double eps, double weight_decay, void *stream) {
+                         double lr, double beta1, double beta2, double eps, double weight_decay, const double *lr_dev, void *stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !step_dev || !ticket_dev || n < 0) return CONAN_E_BADARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return CONAN_E_BADARG;      // float4 access
     if (n == 0) return CONAN_OK;
     long long blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
-    k_adam_flat<<<(int)blocks, 256, 0, as_stream(stream)>>>(params, grads, exp_avg, exp_avg_sq, step_dev, ticket_dev, n, lr, beta1, beta2, (float)eps, (float)weight_decay);
+    k_adam_flat<<<(int)blocks, 256, 0, as_stream(stream)>>>(params, grads, exp_avg, exp_avg_sq, step_dev, ticket_dev, n, lr, beta1, beta2, (float)eps, (float)weight_decay, lr_dev);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

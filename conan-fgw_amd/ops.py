@@ -100,6 +100,21 @@ def empty_rows(rows: int, width: int, device, m_dev: Optional[Tensor]) -> Tensor
     return t
 
 
+# Debug switch for the "rows beyond the device-side count are never read" contract of the worst-case-sized edge buffers (unread_rows): when set,
+# those buffers start as NaN instead of whatever the allocator hands out, so that a consumer that does read the tail shows up as non-finite
+# results (tests/test_gpu_visnet.py runs a whole training step both ways and demands identical bits).
+POISON_UNREAD_TAILS = False
+
+
+def unread_rows(rows: int, width: int, device) -> Tensor:
+    """[rows, width] fp32 buffer of which the caller's kernel writes the first m_dev rows and NOBODY reads the rest (every consumer walks the CSR
+    or takes the same device-side count): no clear at all."""
+    t = torch.empty(rows, width, dtype=f32, device=device)
+    if POISON_UNREAD_TAILS:
+        t.fill_(float("nan"))
+    return t
+
+
 def batch_hints(batch: Optional[Tensor]):
     """(num_graphs, max_nodes) that DeviceCollator attached to the node -> graph index tensor it produced (host-known from the item sizes), or
     (None, None): a caller that passes no size arguments — the reference's call shape — then needs no device -> host read to size anything."""
@@ -382,7 +397,7 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if ctx.grad_tail_unread:       # the caller's promise: whatever consumes dx takes md or walks the CSR (ViS_MP's s_proj: 22 us per layer for a tail nobody reads)
-                dx = torch.empty(x.shape[0], x.shape[1], dtype=f32, device=x.device)
+                dx = unread_rows(x.shape[0], x.shape[1], x.device)
             else:
                 dx = empty_rows(x.shape[0], x.shape[1], x.device, md)
             call("conan_linear_fwd", ptr(g), ptr(w), None, None, M, N, K, 1, 0, ptr(md), ptr(dx), stream_ptr())

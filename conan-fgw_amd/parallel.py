@@ -274,41 +274,123 @@ class FlatGradients:
                 self.flat.mul_(1.0 / world)
 
 
-class FlatAdam:
+    # ------------------------------------------------------------------------------------------------ clip
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_(params, max_norm) on the packed buffer (call after pack() / all_reduce_mean(): the .grad tensors alias
+        it), without the host round trip and the ~100-tensor foreach kernels: what Lightning runs for the reference's
+        Trainer(gradient_clip_val=1.0) (trainer.py:177) between backward and the optimiser step.  Returns the total norm (0-dim, on the device)."""
+        if not self.flat.is_cuda:
+            return _clip_cpu(self.flat, max_norm)
+        from ._lib import call, ptr, stream_ptr
+        if getattr(self, "_clip_ws", None) is None:
+            dev = self.flat.device
+            self._clip_ws = (torch.zeros(2, dtype=torch.float32, device=dev), torch.zeros(256, dtype=torch.float64, device=dev),
+                             torch.zeros(1, dtype=torch.int32, device=dev))
+        out, part, ticket = self._clip_ws
+        call("conan_grad_clip_flat", ptr(self.flat), self.flat.numel(), float(max_norm), ptr(out), ptr(part), ptr(ticket), stream_ptr())
+        return out[0]
+
+
+def _clip_cpu(flat: torch.Tensor, max_norm: float) -> torch.Tensor:
+    """The same rule on a CPU buffer (gloo tests of the step's host logic)."""
+    nrm = flat.double().norm()
+    coef = torch.clamp(max_norm / (nrm + 1e-6), max=1.0)
+    flat.mul_(coef.to(flat.dtype))
+    return nrm.to(torch.float32)
+
+
+class _LiveGroup(dict):
+    """The param_group of FlatAdam: `group["lr"] = x` (what a scheduler or user code does with a plain float) lands in the device scalar the
+    kernel reads, so that a captured launch follows it; the entry itself stays the device tensor (torch's own idiom for capturable optimisers:
+    schedulers `fill_` a tensor lr in place)."""
+
+    def __init__(self, owner, *a, **kw):
+        super().__init__(*a, **kw)
+        self._owner = owner
+
+    def __setitem__(self, key, value):
+        if key == "lr" and "lr" in self and isinstance(self["lr"], torch.Tensor) and value is not self["lr"]:
+            self["lr"].fill_(float(value))
+            return
+        super().__setitem__(key, value)
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+
+class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam (defaults: no amsgrad, no maximize) for the parameters of a `FlatGradients`, as ONE launch per step
     (conan_adam_flat_step) instead of torch's multi-tensor kernels over ~100 parameter tensors.
 
     The parameters are moved into one flat fp32 buffer in the gradient buffer's order and every `Parameter.data` is re-pointed at its slice
     (the module keeps working unchanged: `state_dict`, `load_state_dict` and the kernels see the same tensors), the two moments are flat
     buffers of the same layout, the step counter lives on the device so that a captured HIP graph replays the launch.  `step()` expects the
-    gradients in `flat.flat` — i.e. after `FlatGradients.pack()` / `all_reduce_mean()`.  GPU only (there is no CPU path in this package)."""
+    gradients in `flat.flat` — i.e. after `FlatGradients.pack()` / `all_reduce_mean()`.  GPU only (there is no CPU path in this package).
 
-    def __init__(self, flat: "FlatGradients", lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    It is a `torch.optim.Optimizer` as far as the reference's training loop needs one (common.py:253-262: Adam + ReduceLROnPlateau; Lightning's
+    checkpoint of `optimizer_states`):
+    * `param_groups[0]["lr"]` is a 0-dim fp64 tensor ON THE DEVICE which the kernel reads (never a by-value argument): schedulers `fill_` it, a plain
+      `group["lr"] = 1e-4` is routed into it — a captured HIP graph follows both between replays;
+    * `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (per-parameter `step`, `exp_avg`, `exp_avg_sq`; parameters numbered in
+      the order of `flat.params`), so the moments and the step count resume from a checkpoint written by either optimiser;
+    * every `step()` verifies on the host that each Parameter still aliases its slice of the flat buffer (`p.data = ...`, `module.to(dtype)`,
+      `load_state_dict(assign=True)` break that silently: the kernel would update a buffer the model no longer reads) and re-adopts the parameters'
+      current values when it does not; with `module=` it also verifies that the module still holds the very Parameter objects (assign=True
+      replaces them — those cannot be re-adopted, the gradient hooks sit on the old ones: RuntimeError).  A replayed graph does not run this
+      check: call `check_aliasing()` where parameters may have been replaced (after loading a checkpoint)."""
+
+    def __init__(self, flat: "FlatGradients", lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, module=None):
         if not flat.flat.is_cuda:
             raise RuntimeError("FlatAdam runs on the GPU only")
-        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        if not 0.0 <= float(lr) or not 0.0 <= float(eps) or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or not 0.0 <= float(weight_decay):
+            raise ValueError("FlatAdam: invalid hyper-parameter")          # torch.optim.Adam's own checks
+        self.flat = flat
+        self._module = module
         dev = flat.flat.device
         n = flat.flat.numel()
+        self._lr_dev = torch.full((), float(lr), dtype=torch.float64, device=dev)
+        super().__init__(flat.params, dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay),
+                                           amsgrad=False, maximize=False, foreach=None, capturable=True, differentiable=False, fused=None))
+        g = _LiveGroup(self, self.param_groups[0])
+        dict.__setitem__(g, "lr", self._lr_dev)
+        self.param_groups = [g]
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._order = None
+        self._offs: dict = {}
         self._adopt()
 
-    def _adopt(self):
+    # hyper-parameters as attributes (the round-5 interface)
+    lr = property(lambda self: float(self._lr_dev))
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
+    def add_param_group(self, param_group):
+        if getattr(self, "flat", None) is not None and self.param_groups:
+            raise RuntimeError("FlatAdam has exactly one parameter group: the parameters of its FlatGradients")
+        super().add_param_group(param_group)
+
+    def _adopt(self, force: bool = False):
         """(Re-)lay the parameters and moments out in the gradient buffer's current order (it changes once, when the overlapped all-reduce
-        calibrates its buckets) and point every Parameter at its slice."""
+        calibrates its buckets) and point every Parameter at its slice.  `force`: the order is unchanged but a Parameter no longer aliases its
+        slice — its current value is taken over (the model's tensors are the truth) and it is re-pointed."""
         order = list(self.flat._order_idx)
-        if order == self._order:
+        if order == self._order and not force:
             return
-        old = None if self._order is None else (self._order, self.exp_avg.clone(), self.exp_avg_sq.clone())
+        old = None if self._order is None or order == self._order else (self._order, self.exp_avg.clone(), self.exp_avg_sq.clone())
         new_p = torch.empty_like(self.params)
         off, offs = 0, {}
         with torch.no_grad():
             for i in order:
                 p = self.flat.params[i]
+                if p.dtype != torch.float32 or p.device != self.params.device:
+                    raise RuntimeError(f"FlatAdam: parameter {i} is now {p.dtype} on {p.device}; the flat buffers are fp32 on {self.params.device} "
+                                       "(module.to(dtype / device) after the optimiser was built is not supported)")
                 offs[i] = off
                 new_p[off:off + p.numel()].copy_(p.detach().reshape(-1))
                 off += p.numel()
@@ -320,14 +402,105 @@ class FlatAdam:
                     k = self.flat.params[i].numel()
                     self.exp_avg[offs[i]:offs[i] + k].copy_(old[1][o_off[i]:o_off[i] + k])
                     self.exp_avg_sq[offs[i]:offs[i] + k].copy_(old[2][o_off[i]:o_off[i] + k])
-            self.params = new_p
+            if self._order is None or old is not None:
+                self.params = new_p
+            else:
+                self.params.copy_(new_p)                          # same layout: keep the buffer's address (a captured graph holds it)
             for i in order:
                 p = self.flat.params[i]
                 p.data = self.params[offs[i]:offs[i] + p.numel()].view_as(p)
-        self._order = order
+        self._order, self._offs = order, offs
 
-    def step(self):
+    def check_aliasing(self, repair: bool = True) -> bool:
+        """True when every Parameter still aliases its slice of the flat parameter buffer.  Otherwise: with `repair` the parameters' current
+        values are copied into the buffer and the Parameters re-pointed (returns False once, True afterwards); without it RuntimeError."""
+        if self._module is not None:
+            seen, cur = set(), []
+            for p in self._module.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p)); cur.append(p)
+            if len(cur) != len(self.flat.params) or any(a is not b for a, b in zip(cur, self.flat.params)):
+                raise RuntimeError("FlatAdam: the module no longer holds the Parameter objects this optimiser (and its FlatGradients) were built on "
+                                   "(load_state_dict(assign=True) / parameter re-registration): rebuild FlatGradients and FlatAdam, or load "
+                                   "with assign=False, which copies into the aliased tensors")
+        base = self.params.data_ptr()
+        ok = all(self.flat.params[i].data_ptr() == base + 4 * off and self.flat.params[i].dtype == torch.float32 for i, off in self._offs.items())
+        if ok:
+            return True
+        if not repair:
+            raise RuntimeError("FlatAdam: a Parameter no longer aliases the flat parameter buffer (p.data was replaced): the step would update a "
+                               "buffer the model does not read")
+        self._adopt(force=True)
+        return False
+
+    @torch.no_grad()
+    def step(self, closure=None):
         from ._lib import call, ptr, stream_ptr
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self._adopt()
+        self.check_aliasing(repair=True)
+        g = self.param_groups[0]
+        if g["lr"] is not self._lr_dev:                              # someone replaced the entry around _LiveGroup (dict.update on a copy, ...)
+            self._lr_dev.fill_(float(g["lr"]))
+            dict.__setitem__(g, "lr", self._lr_dev)
         call("conan_adam_flat_step", ptr(self.params), ptr(self.flat.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.step_dev),
-             ptr(self._ticket), self.params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, stream_ptr())
+             ptr(self._ticket), self.params.numel(), 0.0, g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], ptr(self._lr_dev), stream_ptr())
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.flat.zero()
+
+    # ------------------------------------------------------------------------------------------------ checkpoint (torch.optim.Adam's format)
+    def state_dict(self):
+        self._adopt()
+        state = {}
+        steps = float(self.step_dev)
+        if steps > 0:                                               # (torch's Adam has no state before its first step)
+            for i, p in enumerate(self.flat.params):
+                off, k = self._offs[i], p.numel()
+                # `step` as torch's default (non-capturable) Adam keeps it: a CPU fp32 scalar — the checkpoint then loads into either optimiser
+                state[i] = {"step": torch.tensor(steps, dtype=torch.float32), "exp_avg": self.exp_avg[off:off + k].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p).clone()}
+        grp = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        grp["lr"] = float(self._lr_dev)
+        grp["capturable"] = False                                   # (a statement about torch's kernels, for a torch.optim.Adam that loads this)
+        grp["params"] = list(range(len(self.flat.params)))
+        return {"state": state, "param_groups": [grp]}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one parameter group of %d parameters" % len(self.flat.params))
+        if groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise ValueError("FlatAdam.load_state_dict: amsgrad / maximize are not implemented")
+        self._adopt()
+        g = self.param_groups[0]
+        for k in ("betas", "eps", "weight_decay"):
+            if k in groups[0]:
+                v = groups[0][k]
+                dict.__setitem__(g, k, (float(v[0]), float(v[1])) if k == "betas" else float(v))
+        self._lr_dev.fill_(float(groups[0]["lr"]))
+        dict.__setitem__(g, "lr", self._lr_dev)
+        ids = list(groups[0]["params"])
+        state = state_dict["state"]
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_dev.zero_()
+        steps = set()
+        for pos, key in enumerate(ids):
+            st = state.get(key, state.get(str(key)))
+            if not st:
+                continue
+            p = self.flat.params[pos]
+            off, k = self._offs[pos], p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdam.load_state_dict: moment of parameter {pos} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+            self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1).to(self.exp_avg))
+            self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1).to(self.exp_avg_sq))
+            steps.add(float(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam.load_state_dict: the parameters carry different step counts {sorted(steps)}; one counter serves them all")
+        if steps:
+            self.step_dev.fill_(steps.pop())

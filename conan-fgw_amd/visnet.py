@@ -199,7 +199,8 @@ class ViSNetBlock(torch.nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 o = vo.lin(xagg, L.o_proj)
-        sact = vo.lin(vmsg, L.s_proj, False, md)                                   # [E, 2H] = pre-activation of [s1|s2]; act applied inside vec_aggregate
+        # [E, 2H] = pre-activation of [s1|s2] (act applied inside vec_aggregate); vmsg's gradient is consumed by the attention backward's CSR walk
+        sact = vo.lin(vmsg, L.s_proj, False, md, grad_tail_unread=True)
         vagg = vo.vec_aggregate(vl, sact, dvec, g, pre_act=True)
         if tail_on_side:                                                           # the residual node update (atoms) under the edge update (edges)
             side.wait_stream(main)

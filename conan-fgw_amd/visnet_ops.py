@@ -23,7 +23,7 @@ def _tail0_shape(rows: int, width: int, device, m_dev):
     """Worst-case-sized edge buffer.  The rows beyond the device-side edge count are never read: every HIP consumer walks the CSR rows or
     takes the same device-side count, and the torch element-wise ops in between only carry the tail along (round 1 cleared it with a
     kernel per buffer: 93 launches = 1.6 ms of a BACE step)."""
-    return torch.empty(rows, width, dtype=f32, device=device)
+    return ops.unread_rows(rows, width, device)
 
 
 def _tail0(like: Tensor, m_dev):
@@ -194,10 +194,13 @@ def multi_lin(x: Tensor, mods, act_silu: bool = False, m_dev=None, tap: bool = F
     return tuple(lin(x, m, act_silu, m_dev) for m in mods) + ((x,) if tap else ())
 
 
-def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None) -> Tensor:
+def lin(x: Tensor, m: torch.nn.Linear, act_silu: bool = False, m_dev=None, grad_tail_unread: bool = False) -> Tensor:
+    """`grad_tail_unread`: the caller's promise, per call site, that whatever consumes the INPUT gradient of this edge-level layer walks the CSR or
+    takes the same m_dev (then its rows beyond m_dev are left as allocated instead of cleared: ViS_MP's s_proj, 22 us per layer); the default
+    keeps them zero, which is what an arbitrary consumer (an element-wise torch op, a second use summed by autograd) needs."""
     if act_silu and x.shape[1] % 64 == 0 and m.weight.shape[0] % 64 == 0:
         return _LinearSilu.apply(x, m.weight, m.bias, m_dev)
-    y = ops.linear(x, m.weight, m.bias, m_dev=m_dev, grad_tail_unread=True)      # (edge-level gradients here are consumed by CSR walks or with the same m_dev)
+    y = ops.linear(x, m.weight, m.bias, m_dev=m_dev, grad_tail_unread=grad_tail_unread and m_dev is not None)
     return silu(y, m_dev) if act_silu else y
 
 

@@ -37,7 +37,7 @@ extern "C" {
 /* Library / device probe.  Returns CONAN_FGW_ABI_VERSION of the build.  The version changes whenever an existing export changes its
  * signature or meaning (v2: num_embeddings / pre_act arguments of round 2; v3: round-3 signatures), so a consumer compiled against
  * this header can detect a stale library: compare the return value with the macro. */
-#define CONAN_FGW_ABI_VERSION 4
+#define CONAN_FGW_ABI_VERSION 5
 int conan_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------- batch assembly */
@@ -288,9 +288,19 @@ int conan_mse_loss_fwd(const float *pred, const float *target, int n, float *los
  * gradients and both moments are flat fp32 buffers of n elements in one common order (16-byte aligned; conan_fgw_amd.parallel.FlatAdam lays the
  * parameters out in FlatGradients' order and re-points every Parameter at its slice).  step_dev: one device float holding the number of steps
  * taken so far (0 at the start), advanced by the call — device-side so that a captured graph replays it; ticket_dev: one zeroed device word of
- * workspace.  Hyper-parameters are doubles: the bias corrections 1 - b^t are formed in fp64 (they cancel in fp32).   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), g += weight_decay * p first. */
+ * workspace.  Hyper-parameters are doubles: the bias corrections 1 - b^t are formed in fp64 (they cancel in fp32).   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), g += weight_decay * p first.
+ * lr_dev (nullable, ABI 5): one device double that overrides `lr` — a launch captured in a HIP graph then follows a learning-rate scheduler
+ * (the reference's ReduceLROnPlateau, common.py:253-262) between replays; the by-value `lr` would be baked into the graph. */
 int conan_adam_flat_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *step_dev, unsigned *ticket_dev, long long n,
-                         double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
+                         double lr, double beta1, double beta2, double eps, double weight_decay, const double *lr_dev, void *stream);
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (norm type 2; what Lightning runs for the reference's Trainer(gradient_clip_val=1.0),
+ * trainer.py:177) on the flat gradient buffer, without a host round trip: norm_coef_dev[0] = total L2 norm, norm_coef_dev[1] = min(1, max_norm /
+ * (norm + 1e-6)), then grads *= coefficient in place (skipped when it is 1).  Squares are summed in fp64, per workgroup into partials_dev
+ * (CONAN_GRAD_CLIP_MAX_BLOCKS doubles of workspace) and from there in index order: the same bits on every run.  ticket_dev: one zeroed device word.
+ * Two launches on `stream`; graph-capturable. */
+#define CONAN_GRAD_CLIP_MAX_BLOCKS 256
+int conan_grad_clip_flat(float *grads, long long n, double max_norm, float *norm_coef_dev, double *partials_dev, unsigned *ticket_dev, void *stream);
 
 /* Two chained node-level Linear layers in one launch (mlp2.hip):
  *   forward : mid = ssp(x w1^T + b1) [M,N1];  y = mid w2^T + b2 (+ residual) [M,N2]

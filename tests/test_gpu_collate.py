@@ -109,6 +109,40 @@ def test_static_collator_keeps_addresses_and_rejects_shape_changes():
         coll(molecules_from_synthetic(cb2, bg2))
 
 
+def _plain_molecule(n, K, seed):
+    from conan_fgw_amd.collate import ConformerMolecule
+    rng = np.random.default_rng(seed)
+    return ConformerMolecule(z=rng.integers(1, 9, n).astype(np.int64), pos=rng.normal(size=(K, n, 3)).astype(np.float32),
+                             x=rng.normal(size=(n, 4)).astype(np.float32), edge_index=np.array([[0, 1], [1, 0]], dtype=np.int64),
+                             edge_attr=rng.normal(size=(2, 3)).astype(np.float32), y=float(seed))
+
+
+def test_static_collator_sizes_follow_the_batch_being_consumed():
+    """Two batches of EQUAL shape (atoms, bond edges, graphs) and different largest conformer through one static collator: the fixed views
+    are one set of tensor objects, so the host-known sizes a size-less call reads (ops.batch_hints) must change when a batch is taken over by
+    wait(), not when the next one is enqueued (a worker thread does that while the consumer still runs the previous batch: a smaller
+    max_nodes would under-size the dense barycenter padding).  By default a changed largest conformer is rejected (a captured step was sized
+    for the first)."""
+    from conan_fgw_amd import ops
+    K = 2
+    big, even = [_plain_molecule(3, K, 1), _plain_molecule(5, K, 2)], [_plain_molecule(4, K, 3), _plain_molecule(4, K, 4)]
+    coll = DeviceCollator(dev, K, depth=2, static=True, strict_max_nodes=False)
+    a = coll(big).wait()
+    assert ops.batch_hints(a.batch) == (4, 5) and a.max_nodes == 5
+    b = coll(even)                                          # assembled (here: by the same thread), not yet taken over
+    assert b.batch is a.batch                               # the shared fixed view
+    assert ops.batch_hints(a.batch) == (4, 5)               # ... still describes the batch being consumed
+    b.wait()
+    assert ops.batch_hints(b.batch) == (4, 4) and b.max_nodes == 4
+    torch.cuda.synchronize()
+    assert b.graph_ptr.tolist() == [0, 4, 8, 12, 16]
+    strict = DeviceCollator(dev, K, depth=2, static=True)
+    strict(big).wait()
+    with pytest.raises(RuntimeError, match="largest conformer"):
+        strict(even)
+    strict(big).wait()                                      # the same size again is fine
+
+
 def test_pipeline_on_a_worker_thread_yields_the_same_batches_in_order():
     """CollatePipeline: the host half runs on a worker thread `prefetch` batches ahead; the batches arrive in source order and equal what the
     collator produces when called directly (item records are cached on the items: the second epoch takes the cached path)."""

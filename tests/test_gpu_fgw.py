@@ -231,6 +231,28 @@ def test_large_graphs_vs_oracle(N, K, d, small_int):
         assert e64 <= 1e-4 or e64 <= 1e-2 * yard, (key, e64, yard)
 
 
+@pytest.mark.parametrize("poison", [float("nan"), float("inf"), 1.0e290], ids=["nan", "inf", "1e290"])
+def test_non_finite_structure_in_the_byte_layout_stays_non_finite(poison):
+    """N > 64, byte layout: G = A C2^T runs on integer digits of A = C1 T, and __double2int_rn(NaN) = 0 — a NaN (or an entry beyond the
+    fixed-point unit's clamp) in the barycenter's structure matrix must reach the range guard (max |A| is compared as a bit pattern, which
+    keeps NaN / Inf as the maximum) instead of being turned into finite digits.  One molecule of two starts from a poisoned init_C: its
+    results must not be finite numbers, the other molecule's must be bitwise what it gets alone."""
+    N, K, d = 83, 3, 32
+    rng = np.random.RandomState(7)
+    Ys = rng.uniform(0.1, 2.0, size=(2, K, N, d)).astype(np.float32)
+    W = (rng.uniform(size=(2, K, N, N)) < 0.15).astype(np.float32)
+    Cs = np.triu(W, 1); Cs = (Cs + Cs.transpose(0, 1, 3, 2)).astype(np.float32)
+    init_C = Cs[:, 0].copy()
+    init_C[0, 5, 9] = init_C[0, 9, 5] = poison
+    Yt, Ct, It = (torch.from_numpy(a).to(dev) for a in (Ys, Cs, init_C))
+    Y, C, T, info, _ = ops.fgw_barycenter_batched(Yt, Ct, init_C=It, cs_small_int=True)
+    Y1, C1, T1, info1, _ = ops.fgw_barycenter_batched(Yt[1:], Ct[1:], init_C=It[1:], cs_small_int=True)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(C[0]).all() or not torch.isfinite(Y[0]).all() or not torch.isfinite(T[0]).all()
+    assert torch.isfinite(Y[1]).all() and torch.isfinite(C[1]).all()
+    assert torch.equal(Y[1], Y1[0]) and torch.equal(C[1], C1[0]) and torch.equal(T[1], T1[0]) and torch.equal(info[1], info1[0])
+
+
 @pytest.mark.parametrize("cmax", [1, 3, 127, 200])
 def test_integer_structure_matrices_in_the_byte_layout(cmax):
     """cs_small_int promises integers in [0, 255] (adjacency counts, bond orders): the large-N kernel keeps them as bytes in LDS.  The byte layout

@@ -355,3 +355,140 @@ def test_flat_adam_follows_torch_adam_step_by_step():
         mc = EmbeddingsWithGATAggregationBaryCenter(3, dev).to(dev)
         mc.load_state_dict(sd, strict=True)
         assert all(torch.equal(a, c) for a, c in zip(ma.parameters(), mc.parameters()))
+
+
+def test_flat_adam_is_an_optimizer_the_reference_loop_can_use():
+    """What the reference's training loop does with its optimiser (common.py:253-262: Adam + ReduceLROnPlateau; Lightning checkpoints
+    `optimizer.state_dict()`), on parallel.FlatAdam: the learning rate lives on the device (a scheduler's change reaches a CAPTURED launch),
+    the state round-trips in torch.optim.Adam's format in both directions, a Parameter whose .data was replaced is taken over again instead of
+    training a buffer the model no longer reads, and replaced Parameter OBJECTS are reported."""
+    import copy
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from conan_fgw_amd.parallel import FlatAdam, FlatGradients
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    ma = EmbeddingsWithGATAggregationBaryCenter(3, dev).to(dev)
+    mb = copy.deepcopy(ma)
+    fa = FlatGradients(ma.parameters())
+    oa = FlatAdam(fa, lr=3e-3, module=ma)
+    pb = [p for p in mb.parameters() if p.requires_grad]
+    ob = torch.optim.Adam(pb, lr=3e-3)
+    assert isinstance(oa, torch.optim.Optimizer) and len(oa.param_groups) == 1 and oa.param_groups[0]["lr"].is_cuda
+    sa = torch.optim.lr_scheduler.ReduceLROnPlateau(oa, mode="min", patience=0, factor=0.8)          # common.py:258-262
+    sb = torch.optim.lr_scheduler.ReduceLROnPlateau(ob, mode="min", patience=0, factor=0.8)
+    g = torch.Generator(device="cpu").manual_seed(6)
+
+    def feed(n):
+        for _ in range(n):
+            grads = [torch.randn(p.shape, generator=g).to(dev) for p in fa.params]
+            fa.zero()
+            for p, q, gr in zip(fa.params, pb, grads):
+                p.grad = gr.clone(); q.grad = gr.clone()
+            fa.pack()
+            oa.step(); ob.step()
+
+    def same(tol=1e-6):
+        torch.cuda.synchronize()
+        for p, q in zip(fa.params, pb):
+            assert rel(p.detach().cpu(), q.detach().cpu()) < tol
+
+    feed(2); same()
+    for metric in (1.0, 2.0, 3.0):                           # no improvement twice: both schedulers cut the rate twice
+        sa.step(metric); sb.step(metric)
+    assert abs(oa.lr - ob.param_groups[0]["lr"]) < 1e-12 and abs(oa.lr - 3e-3 * 0.64) < 1e-12
+    feed(2); same()
+    oa.param_groups[0]["lr"] = 1e-3; ob.param_groups[0]["lr"] = 1e-3                                  # plain assignment (user code, other schedulers)
+    assert oa.param_groups[0]["lr"].is_cuda and abs(oa.lr - 1e-3) < 1e-15
+    feed(1); same()
+
+    # a captured launch follows the device-side rate between replays
+    grads = [torch.randn(p.shape, generator=g).to(dev) for p in fa.params]
+    fa.zero()
+    for p, q, gr in zip(fa.params, pb, grads):
+        p.grad = gr.clone(); q.grad = gr.clone()
+    fa.pack()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            oa.step()
+    torch.cuda.current_stream().wait_stream(side)
+    for lr in (1e-3, 5e-4):
+        oa.param_groups[0]["lr"] = lr; ob.param_groups[0]["lr"] = lr
+        graph.replay(); ob.step()
+        same()
+
+    # checkpoint: torch's format, both directions
+    sd_a, sd_b = oa.state_dict(), ob.state_dict()
+    assert set(sd_a) == {"state", "param_groups"} and sorted(sd_a["state"]) == sorted(sd_b["state"]) and sd_a["param_groups"][0]["params"] == sd_b["param_groups"][0]["params"]
+    for k in sd_b["state"]:
+        assert float(sd_a["state"][k]["step"]) == float(sd_b["state"][k]["step"]) == 7.0
+        assert rel(sd_a["state"][k]["exp_avg"].cpu(), sd_b["state"][k]["exp_avg"].cpu()) < 1e-5
+        assert rel(sd_a["state"][k]["exp_avg_sq"].cpu(), sd_b["state"][k]["exp_avg_sq"].cpu()) < 1e-5
+    mc, md = copy.deepcopy(mb), copy.deepcopy(mb)
+    fc = FlatGradients(mc.parameters()); oc = FlatAdam(fc, lr=1.0)
+    oc.load_state_dict(copy.deepcopy(sd_b))                                                      # resume FlatAdam from torch.optim.Adam's checkpoint
+    od = torch.optim.Adam([p for p in md.parameters() if p.requires_grad], lr=1.0)
+    od.load_state_dict(copy.deepcopy(sd_a))                                                      # ... and torch.optim.Adam from FlatAdam's
+    assert abs(oc.lr - 5e-4) < 1e-15 and od.param_groups[0]["lr"] == 5e-4 and float(oc.step_dev) == 7.0
+    grads = [torch.randn(p.shape, generator=g).to(dev) for p in fa.params]
+    fa.zero(); fc.zero()
+    pd = [p for p in md.parameters() if p.requires_grad]
+    for o, p, q, r_, gr in zip(fa.params, fc.params, pb, pd, grads):
+        o.grad = gr.clone(); p.grad = gr.clone(); q.grad = gr.clone(); r_.grad = gr.clone()
+    fa.pack(); fc.pack()
+    oa.step(); oc.step(); ob.step(); od.step()                                                   # (the two originals step too: they stay in step for the checks below)
+    same()
+    for p, q, r_ in zip(fc.params, pb, pd):
+        assert rel(p.detach().cpu(), q.detach().cpu()) < 1e-6 and rel(r_.detach().cpu(), q.detach().cpu()) < 1e-6
+
+    # a replaced .data is taken over (the model's tensors are the truth), not silently left behind
+    w = fa.params[0]
+    with torch.no_grad():
+        w.data = (w.detach() * 0.5).clone()
+        pb[0].mul_(0.5)
+    with pytest.raises(RuntimeError, match="alias"):
+        oa.check_aliasing(repair=False)
+    feed(1); same()
+    assert oa.check_aliasing() and w.data_ptr() >= oa.params.data_ptr() and w.data_ptr() < oa.params.data_ptr() + 4 * oa.params.numel()
+    # replaced Parameter objects (load_state_dict(assign=True)) cannot be re-adopted: reported
+    ma.load_state_dict({k: v.clone() for k, v in ma.state_dict().items()}, assign=True)
+    with pytest.raises(RuntimeError, match="Parameter objects"):
+        oa.step()
+
+
+def test_clip_grad_norm_on_the_flat_buffer_matches_torch():
+    """FlatGradients.clip_grad_norm_ (conan_grad_clip_flat: fp64 sum of squares in a fixed order, coefficient and scaling on the device) against
+    torch.nn.utils.clip_grad_norm_ — Lightning's gradient_clip_val=1.0 of the reference's Trainer (trainer.py:177) — for a norm above and below
+    the threshold; repeated calls give the same bits."""
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from conan_fgw_amd.parallel import FlatGradients
+    dev = torch.device("cuda:0")
+    torch.manual_seed(13)
+    m = EmbeddingsWithGATAggregationBaryCenter(3, dev).to(dev)
+    fa = FlatGradients(m.parameters())
+    g = torch.Generator(device="cpu").manual_seed(8)
+    for scale in (10.0, 1e-4):
+        grads = [torch.randn(p.shape, generator=g).to(dev) * scale for p in fa.params]
+        outs = []
+        for _ in range(2):
+            fa.zero()
+            for p, gr in zip(fa.params, grads):
+                p.grad = gr.clone()
+            fa.pack()
+            nrm = fa.clip_grad_norm_(1.0)
+            outs.append((nrm.clone(), fa.flat.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        ref = [gr.clone().requires_grad_(False) for gr in grads]
+        holders = [torch.nn.Parameter(torch.zeros_like(r)) for r in ref]
+        for h, r in zip(holders, ref):
+            h.grad = r
+        ref_norm = torch.nn.utils.clip_grad_norm_(holders, 1.0)
+        assert abs(float(nrm) - float(ref_norm)) <= 2e-6 * float(ref_norm)
+        for p, h in zip(fa.params, holders):
+            assert p.grad.data_ptr() >= fa.flat.data_ptr()                                       # still the aliased view: clipped in place
+            assert rel(p.grad.cpu(), h.grad.cpu()) < 2e-6
+        if scale < 1:
+            assert all(torch.equal(p.grad, gr) for p, gr in zip(fa.params, grads))                    # below the threshold nothing is touched

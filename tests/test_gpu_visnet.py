@@ -129,6 +129,41 @@ def test_edge_buffer_tails_are_never_read():
         assert torch.equal(u, v)
 
 
+def test_unread_tails_poisoned_with_nan_change_nothing():
+    """The deterministic form of the test above: ops.POISON_UNREAD_TAILS makes every buffer handed out under the "rows beyond the device-side
+    count are never read" contract (ops.unread_rows: the edge-level activations of visnet_ops and the input gradient of s_proj, the one
+    `lin()` call site that opts in) start as NaN.  A whole stage-2 training step on the ViSNet backbone — forward, loss, backward, every
+    parameter gradient — must give the same bits with and without the poison."""
+    import types
+    from conan_fgw_amd import ops
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from conan_fgw_amd.synthetic import make_bond_graph
+    b = make_batch("bace", 3, 3, seed=33)
+    bg = make_bond_graph(b, seed=34)
+    torch.manual_seed(10)
+    m = EmbeddingsWithGATAggregationBaryCenter(3, dev, model_name="visnet").to(dev)
+    data = types.SimpleNamespace(z=torch.from_numpy(b.z).to(dev), pos=torch.from_numpy(b.pos).to(dev), batch=torch.from_numpy(b.batch).to(dev),
+                                 x=torch.from_numpy(bg.x).to(dev), edge_index=torch.from_numpy(bg.edge_index).to(dev), edge_attr=torch.from_numpy(bg.edge_attr).to(dev))
+    cidx = m.create_aggregation_index(b.num_graphs, dev)
+
+    def run(poison):
+        ops.POISON_UNREAD_TAILS = poison
+        try:
+            for p in m.parameters():
+                p.grad = None
+            y = m(data, cidx, data.batch)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.POISON_UNREAD_TAILS = False
+        return [y.detach().clone()] + [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]
+
+    a, c = run(False), run(True)
+    assert len(a) == len(c) and len(a) > 100
+    for u, v in zip(a, c):
+        assert torch.isfinite(v).all() and torch.equal(u, v)
+
+
 @pytest.mark.parametrize("M,n,tap,bias", [(3000, 3, True, True), (70001, 3, True, False), (66000, 2, False, True), (70001, 3, False, True)])
 def test_layers_of_one_input_forward_and_backward_match_fp64(M, n, tap, bias):
     """visnet_ops.multi_lin — ViS_MP's dk / dv / f_proj of one f_ij (torch_geometric_visnet.py:600-604,637-640) and q / k / v of one x (:596-598):

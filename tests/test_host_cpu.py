@@ -121,6 +121,10 @@ def test_bench_config_shorthand_and_explicit_flags():
     assert (a.shape, a.batch, a.model) == ("bace", 64, "visnet")
     a = bench.parse(["--config", "cfg5"])
     assert (a.shape, a.batch, a.conformers) == ("freesolv", 64, 20)
+    a = bench.parse(["--config", "cfg3", "--batch", "256"])                                             # an explicit flag that equals the parser's default still wins
+    assert (a.shape, a.batch) == ("lipo", 256)
+    a = bench.parse(["--config", "cfg4", "--model=schnet", "--conformers", "5"])
+    assert (a.shape, a.batch, a.model, a.conformers) == ("bace", 64, "schnet", 5)
     a = bench.parse([])
     assert (a.shape, a.batch, a.conformers, a.model, a.gpus) == ("esol", 256, 5, "schnet", 1)          # BASELINE configs[1] on one GPU
 

@@ -110,3 +110,22 @@ def test_overlap_falls_back_to_one_allreduce_when_single_process():
     for p, gg in zip(flat.params, g):
         assert torch.equal(p.grad, gg)
     assert flat.last_allreduce_launches == 0
+
+
+def test_clip_grad_norm_on_a_cpu_flat_buffer_follows_torch():
+    """FlatGradients.clip_grad_norm_ on a CPU buffer (the gloo tests' host logic; on the GPU it is conan_grad_clip_flat): the same rule as
+    torch.nn.utils.clip_grad_norm_ — coefficient min(1, max_norm / (norm + 1e-6)) applied in place to the aliased .grad views."""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(11))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    for scale in (3.0, 1e-3):
+        fg = FlatGradients(ps)
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p) * scale
+            p.grad, q.grad = g.clone(), g.clone()
+        fg.pack()
+        n1 = fg.clip_grad_norm_(1.0)
+        n2 = torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        assert abs(float(n1) - float(n2)) < 1e-5 * float(n2)
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-8)
