@@ -447,7 +447,7 @@ constexpr int FAST_SK_DOUBLES = 2 * 256 + 2 * 64;                    // column /
 
 struct FastLds {
     int npa;                 // doubles per fp64 matrix slot (N * P rounded up to even: 16-byte aligned slots)
-    size_t off_t, off_c2, off_red, off_vec, off_sk, bytes;
+    size_t off_t, off_c2, off_red, off_vec, off_sk, off_rs, bytes;
     bool vec_alias, sk_alias;
 };
 template <typename C2T>
@@ -463,6 +463,9 @@ __host__ __device__ inline FastLds fast_lds(int N) {
     L.sk_alias = L.npa >= FAST_SK_DOUBLES;                           // Sinkhorn scratch overlays AK once K sits in registers
     L.off_vec = L.vec_alias ? L.off_t : o; if (!L.vec_alias) o += FAST_VEC_DOUBLES * 8;
     L.off_sk = L.sk_alias ? (size_t)L.npa * 8 : o; if (!L.sk_alias) o += FAST_SK_DOUBLES * 8;
+    // [4][N] doubles: per-wavefront row sums of the complete-graph form (the input graph's structure matrix is not read on that path: they overlay it)
+    const bool rs_alias = (size_t)NP * sizeof(C2T) >= (size_t)4 * N * 8;
+    L.off_rs = rs_alias ? L.off_c2 : o; if (!rs_alias) o += (size_t)4 * N * 8;
     L.bytes = o;
     return L;
 }
@@ -571,6 +574,29 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         }
     }
     __syncthreads();
+    // ---- A COMPLETE input graph (every pair of its n real nodes adjacent, weight 1; padded nodes isolated — what a conformer of an ESOL- /
+    // FreeSolv-sized molecule is under the 10 A cutoff, schnet_no_sum.py:94-100) has C2 = 1 1^T - I on the real block, so the two products against it are
+    //     (A C2^T)_ij = [j < n] (sum_{k<n} A_ik - A_ij)          T C2 T^T = t t^T - T_r T_r^T,  t = T 1_r
+    // row sums and one product over the n real columns instead of three N^3 products (utils.py:62-64, :67-73).  Detected from the staged matrix itself
+    // (dense and ragged inputs alike): n = 1 + the non-zeros of row 0, then every entry is compared with the pattern.  Workgroup-uniform.
+    int n_real;
+    {
+        const bool nz = lane < N && C2l[lane] != (C2T)0;
+        n_real = 1 + __popcll(__ballot(nz));
+    }
+    bool complete;
+    {
+        bool ok = true;
+        int i = e_i0, j = e_j0;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            if (tid + u * FGW_THREADS < NN) ok = ok && (C2l[i * P + j] == (C2T)((i != j && i < n_real && j < n_real) ? 1 : 0));
+            j += e_dr; i += e_dq;
+            if (j >= N) { j -= N; ++i; }
+        }
+        complete = __syncthreads_and(ok) != 0 && n_real >= 2;
+    }
+    double *rsum = reinterpret_cast<double *>(smem + L.off_rs);      // [4][N] (complete graphs only; may overlay C2, which that path never reads again)
     FGW_PROF(0);      // staging
     const double qj = pq[64 + lane];                                    // b_j with j = lane (layout A)
     const double pi_l = pq[lane];                                       // a_i with i = lane (layout B)
@@ -632,10 +658,42 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         FGW_PROF(3);  // A = C1 @ T
         // ---- G = A @ (2 C2)^T, Mr = -(base - 2 alpha G) / eps (utils.py:62-64, sinkhorn.py:388), K = exp(Mr - ref_j) with the column
         // reference ref_j = -base_jj / eps: formed where the product leaves its result, written over A once every wavefront has read A.
-        mm_lds2<FGW_WAVES, MAXT, 0, true, true>(N, N, N, AKl, P, C2l, P, [&]() { __syncthreads(); }, [&](int i, int j, double v) {
-            const double x = fma(v, fc.four_alpha_inv_eps, (Bl[j * P + j] - Bl[i * P + j]) * fc.inv_eps);      // Mr_ij - ref_j, G = 2 v
-            AKl[i * P + j] = exp_fast(x);
-        }, tq);
+        int nr = n_real;
+        asm volatile("" : "+s"(nr));
+        if (complete) {
+            // (A C2^T)_ij = [j < n] (a_i - A_ij), a_i = sum_{k<n} A_ik: lane <-> row, wavefront <-> columns k = w, w + 4, ...; the four partial sums
+            // of a row meet through `rsum`, K is formed in place (an entry is read and written by the same thread)
+            {
+                const int lc = lq_ok ? lq : N - 1;
+                const double *ar = AKl + lc * P + wq;
+                double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int q = wq + 4 * r;
+                    if (q < nr) { if (r & 1) p1 += ar[4 * r]; else p0 += ar[4 * r]; }      // (wavefront-uniform)
+                }
+                if (lq_ok) rsum[wq * N + lq] = p0 + p1;
+            }
+            __syncthreads();
+            {
+                int i = tq / N, j = tq - i * N;
+                const int dq = FGW_THREADS / N, dr = FGW_THREADS - dq * N;
+                for (int t = tq; t < N * N; t += FGW_THREADS) {
+                    const int o = i * P + j;
+                    const double ai = ((rsum[i] + rsum[N + i]) + rsum[2 * N + i]) + rsum[3 * N + i];
+                    const double v = j < nr ? ai - AKl[o] : 0.0;
+                    const double x = fma(v, fc.four_alpha_inv_eps, (Bl[j * P + j] - Bl[o]) * fc.inv_eps);
+                    AKl[o] = exp_fast(x);
+                    j += dr; i += dq;
+                    if (j >= N) { j -= N; ++i; }
+                }
+            }
+        } else {
+            mm_lds2<FGW_WAVES, MAXT, 0, true, true>(N, N, N, AKl, P, C2l, P, [&]() { __syncthreads(); }, [&](int i, int j, double v) {
+                const double x = fma(v, fc.four_alpha_inv_eps, (Bl[j * P + j] - Bl[i * P + j]) * fc.inv_eps);      // Mr_ij - ref_j, G = 2 v
+                AKl[i * P + j] = exp_fast(x);
+            }, tq);
+        }
         __syncthreads();
         FGW_PROF(4);  // G, K
         // ---- K into registers in both layouts: kA[r] = K[w + 4r][lane] (lane <-> column), kB[r] = K[lane][w + 4r] (lane <-> row)
@@ -768,9 +826,29 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        mm_lds2<FGW_WAVES, 1, 0, false, false>(N, N, N, Tl, P, C2l, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; });
-        __syncthreads();
-        mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, N, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
+        if (complete) {                                                 // t t^T - T_r T_r^T (see the detection above)
+            {
+                const int lc = lane_ok ? lane : N - 1;
+                const float *tr = Tl + lc * P + w;
+                double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int q = w + 4 * r;
+                    if (q < n_real) { if (r & 1) p1 += (double)tr[4 * r]; else p0 += (double)tr[4 * r]; }
+                }
+                if (lane_ok) rsum[w * N + lane] = p0 + p1;
+            }
+            __syncthreads();
+            mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, n_real, Tl, P, Tl, P, [] {}, [&](int i, int j, double v) {
+                const double ti = ((rsum[i] + rsum[N + i]) + rsum[2 * N + i]) + rsum[3 * N + i];
+                const double tj = ((rsum[j] + rsum[N + j]) + rsum[2 * N + j]) + rsum[3 * N + j];
+                Cp[i * N + j] = (fgw_part_t)(ti * tj - v);
+            });
+        } else {
+            mm_lds2<FGW_WAVES, 1, 0, false, false>(N, N, N, Tl, P, C2l, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; });
+            __syncthreads();
+            mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, N, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
+        }
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;

@@ -231,6 +231,43 @@ def test_large_graphs_vs_oracle(N, K, d, small_int):
         assert e64 <= 1e-4 or e64 <= 1e-2 * yard, (key, e64, yard)
 
 
+@pytest.mark.parametrize("small_int", [False, True], ids=["cs_f32", "cs_u8"])
+@pytest.mark.parametrize("N,sizes", [(20, (20, 13, 2, 7)), (33, (33, 21, 32, 6)), (40, (40, 17, 39, 3))], ids=["n20", "n33", "n40"])
+def test_complete_input_graphs_take_the_row_sum_form(N, sizes, small_int):
+    """A conformer graph in which every pair of real atoms is adjacent (what the 10 A cutoff makes of an ESOL- / FreeSolv-sized molecule) has
+    C2 = 1 1^T - I on its real block: k_fgw_coupling_fast detects that from the staged matrix and replaces the products against C2 by row sums
+    (G = A C2^T per projected-gradient iteration, T C2 T^T in the epilogue).  Checked against the fp64 oracle — which multiplies the dense matrices —
+    for real-node counts from 2 to N (no padding at all), in both layouts of the structure matrices: equal iteration counts, Y / C / T on the
+    Appendix-F bars; a molecule's result is bitwise what it gets alone and next to a molecule whose graphs miss one edge (general path)."""
+    K, d = 3, 16
+    rng = np.random.RandomState(N)
+    B = len(sizes)
+    Ys = np.full((B, K, N, d), 0.5, np.float32)
+    Cs = np.zeros((B, K, N, N), np.float32)
+    for b, n in enumerate(sizes):
+        Ys[b, :, :n] = rng.uniform(0.1, 2.0, size=(K, n, d))
+        Cs[b, :, :n, :n] = 1.0 - np.eye(n, dtype=np.float32)
+    Y, C, T, info, _ = _run(Ys, Cs, cs_small_int=small_int)
+    for b in range(B):
+        ref = ofgw.fgw_barycenter(Ys[b], Cs[b], dtype=np.float64)
+        r32 = ofgw.fgw_barycenter(Ys[b], Cs[b], dtype=np.float32)
+        assert int(info[b, 0]) == ref["outer"] and int(info[b, 1]) == int(ref["pgd"].sum()) and int(info[b, 2]) == int(ref["sinkhorn"].sum()), b
+        assert int(info[b, 3]) == 0                                              # no coupling left the scaling form
+        for key, val in (("Y", Y), ("C", C), ("T", T)):
+            e64, yard = rel(val[b].cpu().numpy(), ref[key]), rel(r32[key], ref[key])
+            assert e64 <= 1e-4 or e64 <= 1e-2 * yard, (b, key, e64, yard)
+    # batch composition: alone, and next to a molecule on the general path (one edge of every graph removed)
+    Ys2, Cs2 = Ys[:2].copy(), Cs[:2].copy()
+    Cs2[1, :, 0, 1] = Cs2[1, :, 1, 0] = 0.0
+    Ya, Ca, Ta, ia, _ = _run(Ys[:1], Cs[:1], cs_small_int=small_int)
+    Ym, Cm, Tm, im, _ = _run(Ys2, Cs2, cs_small_int=small_int)
+    for got in ((Ya, Ca, Ta, ia), (Ym, Cm, Tm, im)):
+        assert torch.equal(got[0][0], Y[0]) and torch.equal(got[1][0], C[0]) and torch.equal(got[2][0], T[0]) and torch.equal(got[3][0], info[0])
+    ref = ofgw.fgw_barycenter(Ys2[1], Cs2[1], dtype=np.float64)
+    assert int(im[1, 0]) == ref["outer"] and int(im[1, 1]) == int(ref["pgd"].sum()) and int(im[1, 2]) == int(ref["sinkhorn"].sum())
+    assert rel(Ym[1].cpu().numpy(), ref["Y"]) <= 1e-4 and rel(Cm[1].cpu().numpy(), ref["C"]) <= 1e-4
+
+
 @pytest.mark.parametrize("poison", [float("nan"), float("inf"), 1.0e290], ids=["nan", "inf", "1e290"])
 def test_non_finite_structure_in_the_byte_layout_stays_non_finite(poison):
     """N > 64, byte layout: G = A C2^T runs on integer digits of A = C1 T, and __double2int_rn(NaN) = 0 — a NaN (or an entry beyond the

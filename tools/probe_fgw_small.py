@@ -14,7 +14,13 @@ out = []
 for (B, K, N, d) in ((256, 5, 33, 64), (64, 20, 33, 64), (256, 5, 26, 64)):
     g = torch.Generator().manual_seed(0)
     Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
-    A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
+    if os.environ.get("PROBE_COMPLETE"):      # complete graphs on n real nodes (n as in the ESOL-shaped batches), padded nodes isolated, the K graphs of a molecule alike
+        n = torch.randint(6, N + 1, (B,), generator=g); n[0] = N
+        idx = torch.arange(N)
+        real = (idx[None, :] < n[:, None]).float()
+        Cs = (real[:, :, None] * real[:, None, :] * (1.0 - torch.eye(N)))[:, None].expand(B, K, N, N).contiguous().to(dev)
+    else:
+        A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
     for _ in range(3): r = ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=True)
     torch.cuda.synchronize()
     ts = []
