@@ -642,7 +642,7 @@ def run_rank(args):
                     big.fill_(1.0)
                     s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s_.record()
-                    ops.call("conan_cfconv_fwd", ops.ptr(xc), ops.ptr(Wc), ops.ptr(_g.rowptr), ops.ptr(_g.col), ops.ptr(_g.pid), int(z.shape[0]), 128, ops.ptr(oc), ops.stream_ptr())
+                    ops.call("conan_cfconv_fwd", ops.ptr(xc), ops.ptr(Wc), ops.ptr(_g.rowptr), ops.ptr(_g.col), ops.ptr(_g.pid), int(z.shape[0]), 128, ops.ptr(oc), None, ops.stream_ptr())
                     e_.record(); torch.cuda.synchronize()
                     ts.append(s_.elapsed_time(e_))
                 cold_ms = float(np.median(ts[2:]))
@@ -814,7 +814,7 @@ def run_rank(args):
     # the covalent branch (a second stream) overlap the main stream's, so the shares are of the SUM of all brackets, not of the wall time.
     KERNELS = {"conan_fgw_barycenter_fwd_ragged": "k_fgw_small_vectors + 5 x (k_fgw_coupling_fast | k_fgw_coupling_big, second pass, k_fgw_update_parts)",
                "conan_filter_fwd": "k_filter_fused", "conan_filter_cfconv_fwd": "k_filter_fused<128, true> (generator + gather)", "conan_filter_bwd2": "k_filter_bwd2", "conan_cfconv_fwd": "k_cfconv_fwd", "conan_cfconv_bwd_x": "k_cfconv_bwd_x128",
-               "conan_cfconv_bwd_w_pairs": "k_cfconv_bwd_wp128", "conan_linear_wgrad_slabs_batch": "k_wgrad_lds_batch / k_wgrad_lds_shared<3>", "conan_wgrad_reduce_batch": "k_wgrad_reduce4_batch",
+               "conan_cfconv_bwd_w_pairs": "k_cfconv_bwd_wp128", "conan_cfconv_bwd_xw_pairs": "k_cfconv_bwd_xw128 (dx + pair gradient in one launch)", "conan_linear_wgrad_slabs_batch": "k_wgrad_lds_batch / k_wgrad_lds_shared<3>", "conan_wgrad_reduce_batch": "k_wgrad_reduce4_batch",
                "conan_mlp2_fwd": "k_mlp2", "conan_mlp2_bwd": "k_mlp2", "conan_linear_fwd:node": "k_linear_t16 (node level)", "conan_linear_fwd:edge": "k_linear_t16 (edge level)",
                "conan_linear_multi_fwd:edge": "k_linear_fan16 (edge level, layers of one input)", "conan_linear_sum_fwd:edge": "k_linear_sum16 (edge level, summed input gradients)",
                "conan_linear_sum_fwd:node": "k_linear_sum16 (node level)", "conan_linear_wgrad_slabs": "k_wgrad_lds / k_wgrad_lds_shared<2>", "conan_visnet_attn_message": "k_attn_msg",

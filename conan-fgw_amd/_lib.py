@@ -104,7 +104,9 @@ SIGNATURES = {
     "conan_filter_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "conan_filter_cfconv_fwd_supported": (c_int, [c_int, c_int]),
     "conan_filter_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int, c_float, c_float, c_int, _P, _P, _P, _P, c_int, _P, _P]),
-    "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "conan_cfconv_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    "conan_cfconv_bwd_xw_pairs_supported": (c_int, [c_int]),
+    "conan_cfconv_bwd_xw_pairs": (c_int, [_P] * 10 + [ctypes.c_float, c_int, c_int, _P, _P, _P, _P]),
     "conan_cfconv_bwd_x": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     "conan_cfconv_bwd_w_pairs": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, c_float, _P, _P, _P]),
     "conan_cfconv_bwd_w": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_float, _P, _P]),

@@ -13,8 +13,11 @@ namespace {
 template <int VEC>   // VEC = F / 32 / 4  (number of float4 per lane per row): F=128 -> 1, F=256 -> 2
 __global__ void __launch_bounds__(256) k_cfconv_fwd(const float *__restrict__ x, const float *__restrict__ W,
                                                     const int *__restrict__ rowptr, const int *__restrict__ col, int num_atoms,
-                                                    float *__restrict__ out, const int *__restrict__ pid) {
+                                                    float *__restrict__ out, const int *__restrict__ pid, float *__restrict__ zero_slot) {
     constexpr int F = 128 * VEC;
+    // zero_slot: the max |g| word that the backward of THIS gather raises with atomicMax (k_cfconv_bwd_xw128: dx and the pair gradient in one
+    // launch, so no kernel of the backward pass runs in front of it) — cleared here, by a kernel of the forward pass that is launched anyway
+    if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
@@ -68,7 +71,8 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd(const float *__restrict__ x,
 // generic width (F % 4 == 0, any size): one wavefront per target, lanes stride over float4 columns
 __global__ void __launch_bounds__(256) k_cfconv_fwd_generic(const float *__restrict__ x, const float *__restrict__ W,
                                                             const int *__restrict__ rowptr, const int *__restrict__ col, int num_atoms,
-                                                            int F, float *__restrict__ out, const int *__restrict__ pid) {
+                                                            int F, float *__restrict__ out, const int *__restrict__ pid, float *__restrict__ zero_slot) {
+    if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) *zero_slot = 0.f;      // see k_cfconv_fwd
     const int lane = threadIdx.x & 63;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
@@ -264,21 +268,111 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_wp128(const float *__restric
     }
 }
 
+// dx AND the pair gradient in one pass over the by-source CSR (round 6).  The two kernels above walk the same neighbourhoods: k_cfconv_bwd_x128 gathers
+// W[pair] and dout[target] for every edge of a source j, k_cfconv_bwd_wp128 gathers x and dout of both endpoints of every pair.  A pair belongs to
+// the edge that is its e0 (conan_pair_list: the direction with source <= target, or the only direction the neighbour cap left): while source j walks
+// its edges, an edge that owns its pair has x[j], dout[j] (this wavefront's own rows) and dout[target] (gathered for dx anyway) at hand — the pair
+// row g = C(d) (x[j] dout[t] + [reverse edge exists] x[t] dout[j]) needs ONE more row, x[t].  Per pair that is 1 extra row gather instead of 4 and one
+// launch less on the backward chain; the expression and its order of operations are k_cfconv_bwd_wp128's.  max |g| is raised in gmax_bits, which
+// the forward gather of the same CFConv cleared (conan_cfconv_fwd's zero_slot).
+template <int U, bool ANYX>
+__global__ void __launch_bounds__(256) k_cfconv_bwd_xw128(const float *__restrict__ W, const float *__restrict__ x, const float *__restrict__ dout,
+                                                          const int *__restrict__ t_rowptr, const int *__restrict__ t_eid,
+                                                          const int *__restrict__ tgt, const int *__restrict__ pid, const int *__restrict__ pe0,
+                                                          const int *__restrict__ pe1, const float *__restrict__ pdist, float cutoff,
+                                                          int num_atoms, float *__restrict__ dx, float *__restrict__ dWp,
+                                                          unsigned *__restrict__ gmax_bits) {
+    constexpr int F = 128;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous sources per workgroup
+    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    float amax = 0.f;
+    for (int j = a_lo; j < a_hi; j += 4) {
+        const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
+        const float4 xs = reinterpret_cast<const float4 *>(x + (size_t)j * F)[l32];          // this source's own rows
+        const float4 ds = reinterpret_cast<const float4 *>(dout + (size_t)j * F)[l32];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = s0; base < s1; base += 64) {          // indices one edge per lane, then cross-lane hand-out (see the forward)
+            const int cnt = min(64, s1 - base);
+            int my_t = 0, my_r = 0, my_own = 0;
+            float my_m1 = 0.f, my_cc = 0.f;
+            if (lane < cnt) {
+                const int e = t_eid[base + lane];
+                my_t = tgt[e];
+                my_r = pid[e];
+                my_own = pe0[my_r] == e ? 1 : 0;
+                if (my_own) {
+                    my_m1 = pe1[my_r] >= 0 ? 1.f : 0.f;
+                    my_cc = 0.5f * (cosf(__fdiv_rn(pdist[my_r] * 3.14159265358979323846f, cutoff)) + 1.0f);
+                }
+            }
+            for (int k2 = 0; k2 < cnt; k2 += 2 * U) {
+                float4 w4[U], g4[U], x4[U];
+                float m[U], mm[U], cc[U];
+                int rr[U], own[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k2 + 2 * u + half, kk = min(k, cnt - 1);
+                    const int t = __shfl(my_t, kk, 64);
+                    rr[u] = __shfl(my_r, kk, 64);
+                    w4[u] = reinterpret_cast<const float4 *>(W + (size_t)rr[u] * F)[l32];
+                    g4[u] = reinterpret_cast<const float4 *>(dout + (size_t)t * F)[l32];
+                    const int ow = __shfl(my_own, kk, 64);            // (never inside a conditional arm: a cross-lane read under half an EXEC mask sees a switched-off lane as 0)
+                    own[u] = k < cnt ? ow : 0;
+                    mm[u] = __shfl(my_m1, kk, 64); cc[u] = __shfl(my_cc, kk, 64);
+                    m[u] = k < cnt ? 1.f : 0.f;
+                    // ANYX: x[t] for every edge (its address does not wait for the pair table; an edge that does not own its pair wastes an L2 row read);
+                    // else: such an edge re-reads the row this wavefront holds
+                    x4[u] = reinterpret_cast<const float4 *>(x + (size_t)((ANYX || own[u]) ? t : j) * F)[l32];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc.x += m[u] * g4[u].x * w4[u].x; acc.y += m[u] * g4[u].y * w4[u].y;
+                    acc.z += m[u] * g4[u].z * w4[u].z; acc.w += m[u] * g4[u].w * w4[u].w;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!own[u]) continue;
+                    float4 r;
+                    r.x = (xs.x * g4[u].x + mm[u] * x4[u].x * ds.x) * cc[u];
+                    r.y = (xs.y * g4[u].y + mm[u] * x4[u].y * ds.y) * cc[u];
+                    r.z = (xs.z * g4[u].z + mm[u] * x4[u].z * ds.z) * cc[u];
+                    r.w = (xs.w * g4[u].w + mm[u] * x4[u].w * ds.w) * cc[u];
+                    reinterpret_cast<float4 *>(dWp + (size_t)rr[u] * F)[l32] = r;
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+                }
+            }
+        }
+        acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+        acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+        if (half == 0) reinterpret_cast<float4 *>(dx + (size_t)j * F)[l32] = acc;
+    }
+    if (gmax_bits) {
+        amax = wave_max(amax);
+        const unsigned bits = __float_as_uint(amax);
+        if (lane == 0 && bits > *reinterpret_cast<volatile unsigned *>(gmax_bits) && bits < 0x7f800000u) atomicMax(gmax_bits, bits);
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const int *col, const int *pid, int num_atoms,
-                     int num_filters, float *out, void *stream) {
+                     int num_filters, float *out, float *zero_slot, void *stream) {
     if (!x || !W || !rowptr || !col || !out || num_atoms < 0 || num_filters <= 0 || (num_filters & 3)) return CONAN_E_BADARG;
-    if (num_atoms == 0) return CONAN_OK;
+    if (num_atoms == 0) {
+        if (zero_slot && hipMemsetAsync(zero_slot, 0, sizeof(float), as_stream(stream)) != hipSuccess) return CONAN_E_LAUNCH;
+        return CONAN_OK;
+    }
     hipStream_t s = as_stream(stream);
     int blocks = (num_atoms + 3) / 4;                 // 4 wavefronts (targets) per 256-thread workgroup
     if (blocks > 65536) blocks = 65536;
     blocks = round_up8(blocks);
-    if (num_filters == 128) k_cfconv_fwd<1><<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, out, pid);
-    else if (num_filters == 256) k_cfconv_fwd<2><<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, out, pid);
-    else k_cfconv_fwd_generic<<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, num_filters, out, pid);
+    if (num_filters == 128) k_cfconv_fwd<1><<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, out, pid, zero_slot);
+    else if (num_filters == 256) k_cfconv_fwd<2><<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, out, pid, zero_slot);
+    else k_cfconv_fwd_generic<<<blocks, 256, 0, s>>>(x, W, rowptr, col, num_atoms, num_filters, out, pid, zero_slot);
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }
@@ -322,6 +416,25 @@ int conan_cfconv_bwd_w_pairs(const float *x, const float *dout, const int *num_p
     else
         k_cfconv_bwd_wp<<<4096, 256, 0, as_stream(stream)>>>(x, dout, num_pairs_dev, max_pairs, pair_e0, pair_e1, col, tgt, num_filters, pair_dist,
                                                               cutoff, dWp);
+    CONAN_LAUNCH_CHECK();
+    return CONAN_OK;
+}
+
+int conan_cfconv_bwd_xw_pairs_supported(int num_filters) { return num_filters == 128; }
+
+int conan_cfconv_bwd_xw_pairs(const float *W, const float *x, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt, const int *pid,
+                              const int *pair_e0, const int *pair_e1, const float *pair_dist, float cutoff, int num_atoms, int num_filters, float *dx,
+                              float *dWp, float *gmax, void *stream) {
+    if (!W || !x || !dout || !t_rowptr || !t_eid || !tgt || !pid || !pair_e0 || !pair_e1 || !pair_dist || !dx || !dWp || num_atoms < 0) return CONAN_E_BADARG;
+    if (!conan_cfconv_bwd_xw_pairs_supported(num_filters)) return CONAN_E_UNSUPPORTED;
+    if (num_atoms == 0) return CONAN_OK;
+    int blocks = (num_atoms + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    blocks = round_up8(blocks);
+    // U = 2 edge steps per trip, x[target] only for edges that own their pair: the forms U = 1 / 2 / 4 with and without the unconditional x gather measured
+    // within 4 % of each other (profiles/r6_ab_cfconv_bwd_one_launch.txt: the launch sits on its W read and g write streams, not on its occupancy)
+    k_cfconv_bwd_xw128<2, false><<<blocks, 256, 0, as_stream(stream)>>>(W, x, dout, t_rowptr, t_eid, tgt, pid, pair_e0, pair_e1, pair_dist, cutoff, num_atoms, dx, dWp,
+                                                                        reinterpret_cast<unsigned *>(gmax));
     CONAN_LAUNCH_CHECK();
     return CONAN_OK;
 }

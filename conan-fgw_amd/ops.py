@@ -744,14 +744,24 @@ def filter_cfconv(x: Tensor, graph: "RadiusGraph", offset: Tensor, coeff: float,
     return out
 
 
+FUSED_CFCONV_BACKWARD = True      # dx and the pair gradient in one launch (conan_cfconv_bwd_xw_pairs); tools / tests switch it off to compare
+
+
 class _CFConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, graph, pre_cutoff_grad=False, use_pairs=False):
         x, W = _c(x), _c(W)
         out = torch.empty_like(x)
         pid = graph.pairs().pid if use_pairs else None
-        call("conan_cfconv_fwd", ptr(x, f32), ptr(W, f32), ptr(graph.rowptr), ptr(graph.col), ptr(pid), graph.num_atoms, x.shape[1],
-             ptr(out), stream_ptr())
+        F = x.shape[1]
+        # max |dW| of the pair gradient (F = 128): one device float per CFConv, raised with atomicMax by the backward kernel that writes the pair
+        # gradient.  Something has to clear it before every backward pass without a fill launch of its own: the fused backward (dx + pair gradient in
+        # one launch) has no kernel in front of it, so this forward launch does (zero_slot) — fresh on every forward / backward pair, captured or not.
+        ctx.gmax = None
+        if use_pairs and F == 128 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and FUSED_CFCONV_BACKWARD and pre_cutoff_grad:
+            ctx.gmax = torch.empty(1, dtype=f32, device=x.device)
+        call("conan_cfconv_fwd", ptr(x, f32), ptr(W, f32), ptr(graph.rowptr), ptr(graph.col), ptr(pid), graph.num_atoms, F,
+             ptr(out), ptr(ctx.gmax), stream_ptr())
         ctx.graph, ctx.pre, ctx.pairs = graph, pre_cutoff_grad, use_pairs
         ctx.save_for_backward(x, W)
         return out
@@ -763,6 +773,15 @@ class _CFConvFn(torch.autograd.Function):
         dout = _c(dout)
         dx = dW = None
         F = x.shape[1]
+        if ctx.gmax is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # dx and the pair gradient from ONE walk of the by-source CSR (the expression and the bits of conan_cfconv_bwd_w_pairs)
+            t_rowptr, t_eid = g.transpose()
+            dx = torch.empty_like(x)
+            dW = torch.empty_like(W)
+            call("conan_cfconv_bwd_xw_pairs", ptr(W), ptr(x), ptr(dout), ptr(t_rowptr), ptr(t_eid), ptr(g.tgt), ptr(g.pid), ptr(g.pair_e0), ptr(g.pair_e1),
+                 ptr(g.pair_dist), float(g.cutoff), g.num_atoms, F, ptr(dx), ptr(dW), ptr(ctx.gmax), stream_ptr())
+            _tag_gmax(dW, ctx.gmax)
+            return dx, dW, None, None, None
         # max |dW| of the pair gradient (F = 128): one device float per CFConv backward, raised by conan_cfconv_bwd_w_pairs with atomicMax.  It is
         # cleared by the dx kernel that runs right before it on this stream (zero_slot) — fresh on every backward pass, no fill launch, and
         # nothing lives on the graph object (round 4 kept a zeroed pool there: stale once a graph object outlived one backward).

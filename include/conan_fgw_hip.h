@@ -355,9 +355,10 @@ int conan_filter_cfconv_fwd(const float *x, const float *dist, const int *col, c
 /* CFConv message + aggregation (the HBM-bound kernel of the path): out[i,:] = sum_{e in row i} x[col[e],:] * W[e,:].
  * Replaces index_select + mul + scatter-add inside CFConv.propagate (PyG; schnet_no_sum.py:163-164,211-212).
  * CSR segment sum, one wavefront per target, no atomics.  pid (nullable): row of W used by edge e (conan_edge_pairs);
- * NULL = row e. */
+ * NULL = row e.  zero_slot (nullable, ABI 5): one device float that this launch clears — the `gmax` word that conan_cfconv_bwd_xw_pairs raises in
+ * the backward pass of the same gather (no kernel of the backward pass runs in front of that launch, so the forward clears it). */
 int conan_cfconv_fwd(const float *x, const float *W, const int *rowptr, const int *col, const int *pid, int num_atoms,
-                     int num_filters, float *out, void *stream);
+                     int num_filters, float *out, float *zero_slot, void *stream);
 /* Backward: dx[j,:] = sum_{e: col[e]==j} W[e,:]*dout[tgt[e],:] (via the by-source CSR), dW[e,:] = x[col[e],:]*dout[tgt[e],:].
  * zero_slot (nullable, ABI 4): one device float that this launch clears — the `gmax` word of the conan_cfconv_bwd_w_pairs call that follows on
  * the same stream, so that no fill launch of its own is needed and the word is fresh on every backward pass (captured graphs included). */
@@ -370,6 +371,14 @@ int conan_cfconv_bwd_x(const float *W, const float *dout, const int *t_rowptr, c
 int conan_cfconv_bwd_w_pairs(const float *x, const float *dout, const int *num_pairs_dev, int max_pairs, const int *pair_e0,
                              const int *pair_e1, const int *col, const int *tgt, int num_filters, const float *pair_dist,
                              float cutoff, float *dWp, float *gmax, void *stream);
+/* conan_cfconv_bwd_x and conan_cfconv_bwd_w_pairs in ONE pass over the by-source CSR (round 6, ABI 5; num_filters = 128): while source j walks its
+ * edges for dx[j], an edge that is its pair's e0 has x[j], dout[j] and dout[target] at hand and gathers x[target] to write the pair row — one extra
+ * row gather per pair instead of four, one launch less on the backward chain; the expression is conan_cfconv_bwd_w_pairs' (same bits).  gmax (nullable):
+ * raised to max |dWp|; the caller has cleared it — conan_cfconv_fwd's zero_slot in the forward pass. */
+int conan_cfconv_bwd_xw_pairs_supported(int num_filters);
+int conan_cfconv_bwd_xw_pairs(const float *W, const float *x, const float *dout, const int *t_rowptr, const int *t_eid, const int *tgt, const int *pid,
+                              const int *pair_e0, const int *pair_e1, const float *pair_dist, float cutoff, int num_atoms, int num_filters, float *dx,
+                              float *dWp, float *gmax, void *stream);
 /* dist (nullable) + cutoff: additionally multiply row e by 0.5*(cos(dist[e]*pi/cutoff)+1), i.e. return the gradient with
  * respect to the filter BEFORE the cosine cutoff. */
 int conan_cfconv_bwd_w(const float *x, const float *dout, const int *num_edges_dev, int max_edges, const int *col,

@@ -65,5 +65,5 @@ def test_workspace_queries_need_no_gpu(built):
 
 def test_bad_arguments_are_rejected_without_launching(built):
     L = built.lib()
-    assert L.conan_cfconv_fwd(None, None, None, None, None, 10, 128, None, None) == -1
+    assert L.conan_cfconv_fwd(None, None, None, None, None, 10, 128, None, None, None) == -1
     assert L.conan_linear_fwd(None, None, None, None, 4, 4, 4, 0, 0, None, None, None) == -1

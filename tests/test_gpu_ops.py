@@ -230,6 +230,44 @@ def test_filter_fused_into_the_gather_matches_the_two_kernels_and_fp64(shape, B,
         ops.filter_cfconv(xr, g, off, gs.coeff, *prm)
 
 
+@pytest.mark.parametrize("shape,B,K", [("esol", 6, 5), ("lipo", 3, 2), ("bace", 2, 2)])
+def test_cfconv_backward_in_one_launch_equals_the_two_kernels(shape, B, K):
+    """conan_cfconv_bwd_xw_pairs (dx and the pair gradient from ONE walk of the by-source CSR: a pair row is written by the edge that is its e0,
+    from the rows the dx gather holds plus x[target]) against conan_cfconv_bwd_x + conan_cfconv_bwd_w_pairs: the same bits in dx, in every pair
+    row and in max |g| — also where the neighbour cap leaves one-directional pairs (lipo / bace: e1 = -1) — and repeated passes stay equal
+    (the forward gather clears the maximum's word every time)."""
+    b = make_batch(shape, B, K, seed=17)
+    g = _edges(b)
+    n, F_ = g.num_atoms, 128
+    P = int(g.pairs().num_pairs_dev.item())
+    if shape != "esol":
+        assert int((g.pair_e1[:P] < 0).sum()) > 0                               # one-directional pairs are in the test
+    gen = torch.Generator().manual_seed(B)
+    x0, W0, gy = torch.randn(n, F_, generator=gen), torch.randn(g.max_edges, F_, generator=gen), torch.randn(n, F_, generator=gen)
+
+    def run(fused):
+        ops.FUSED_CFCONV_BACKWARD = fused
+        try:
+            outs = []
+            for rep in range(2):
+                x = x0.to(dev).requires_grad_(True); W = W0.to(dev).requires_grad_(True)
+                out = ops.cfconv(x, W, g, pre_cutoff_grad=True, use_pairs=True)
+                (dx, dW) = torch.autograd.grad(out, (x, W), (gy * (1.0 if rep == 0 else 1e-3)).to(dev))
+                tag = getattr(dW, "_conan_gmax", None)
+                torch.cuda.synchronize()
+                outs.append((out.detach().clone(), dx.clone(), dW[:P].clone(), None if tag is None else tag[0].clone()))
+            return outs
+        finally:
+            ops.FUSED_CFCONV_BACKWARD = True
+
+    a, c = run(True), run(False)
+    for (o1, dx1, dw1, m1), (o2, dx2, dw2, m2) in zip(a, c):
+        assert torch.equal(o1, o2) and torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+        assert m1 is not None and m2 is not None and torch.equal(m1, m2)
+        assert float(m1) == float(dw1.abs().max())
+    assert float(a[1][3]) < 0.01 * float(a[0][3])                                # the second pass's (1000x smaller) maximum is not the first's
+
+
 def test_filter_gradient_maximum_travels_with_the_tensor_and_is_dropped_when_the_gradient_was_touched():
     """The fp16-plane filter backward scales g from max|g|, which the pair-gradient kernel tracks (ops._tag_gmax / _take_gmax).  (i) One
     consumer per filter (every model): the tag survives the hop through the autograd engine, the fast kernels run.  (ii) ONE filter feeding

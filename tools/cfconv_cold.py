@@ -21,7 +21,7 @@ out = torch.empty_like(x)
 alg = P * 4 * F + 2 * n * 4 * F + 4 * (2 * E + n + 1)
 
 def run():
-    ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(W), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), ops.stream_ptr())
+    ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(W), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), None, ops.stream_ptr())
 
 def timed(prep, reps=20):
     ts = []

@@ -24,7 +24,7 @@ def timed(fn, reps=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
 out = torch.empty(n, F, device=dev)
-def fwd(): ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(W), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), ops.stream_ptr())
+def fwd(): ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(W), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), None, ops.stream_ptr())
 tr, te = g.transpose(); dx = torch.empty(n, F, device=dev); dW = torch.empty(g.max_edges, F, device=dev)
 def bx(): ops.call("conan_cfconv_bwd_x", ops.ptr(W), ops.ptr(gy), ops.ptr(tr), ops.ptr(te), ops.ptr(g.tgt), ops.ptr(g.pid), n, F, ops.ptr(dx), None, ops.stream_ptr())
 def bw(): ops.call("conan_cfconv_bwd_w_pairs", ops.ptr(x), ops.ptr(gy), ops.ptr(g.num_pairs_dev), g.max_edges, ops.ptr(g.pair_e0), ops.ptr(g.pair_e1), ops.ptr(g.col), ops.ptr(g.tgt), F, ops.ptr(g.pair_dist), 10.0, ops.ptr(dW), None, ops.stream_ptr())
@@ -35,7 +35,7 @@ offset = torch.linspace(0, 10, Gs, device=dev); coeff = -0.5 / float(offset[1] -
 w1 = torch.randn(F, Gs, device=dev) / 7; b1 = torch.randn(F, device=dev) / 10; w2 = torch.randn(F, F, device=dev) / 11; b2 = torch.randn(F, device=dev) / 10
 Wm = torch.empty(g.max_edges, F, device=dev); h1 = torch.empty(g.max_edges, F, device=dev)
 def produce(): ops.call("conan_filter_fwd", ops.ptr(g.pair_dist), ops.ptr(g.num_pairs_dev), g.max_edges, ops.ptr(offset), Gs, coeff, 10.0, F, ops.ptr(w1), ops.ptr(b1), ops.ptr(w2), ops.ptr(b2), ops.ptr(Wm), (None if os.environ.get("NO_H1") else ops.ptr(h1)), ops.stream_ptr())
-def fwd_m(): ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(Wm), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), ops.stream_ptr())
+def fwd_m(): ops.call("conan_cfconv_fwd", ops.ptr(x), ops.ptr(Wm), ops.ptr(g.rowptr), ops.ptr(g.col), ops.ptr(g.pid), n, F, ops.ptr(out), None, ops.stream_ptr())
 ts = []
 for _ in range(12):
     produce()
