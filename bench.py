@@ -710,7 +710,7 @@ def run_rank(args):
                                                        "achieved_gbs": round(cfconv_algorithmic_bytes(E, P, n_atoms, F_) / (cold_ms * 1e-3) / 1e9, 1),
                                                        "frac_of_hbm_peak": round(cfconv_algorithmic_bytes(E, P, n_atoms, F_) / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     elif args.model == "schnet":
-        traffic, traffic_src = committed_pmc("k_cfconv_fwd", ("r5_pmc_hbm.json", "r4_pmc_hbm.json", "r3_pmc_hbm.json"))
+        traffic, traffic_src = committed_pmc("k_cfconv_fwd", ("r6_pmc_hbm.json", "r5_pmc_hbm.json", "r4_pmc_hbm.json", "r3_pmc_hbm.json"))
         alg = cfconv_algorithmic_bytes(E, P, n_atoms, F_)
         achieved = alg / (kdur_ms * 1e-3) / 1e9
         roofline = {"kernel": "k_cfconv_fwd (CFConv gather * filter, CSR segment-sum)", "entry_point": PRIMARY, "bound": "hbm",
@@ -760,6 +760,13 @@ def run_rank(args):
                       "avg_launch_ms": round(t_ms, 5), "issued_fp16_tflops": round(issued / (t_ms * 1e-3) / 1e12, 1), "algorithmic_bytes_per_launch": byts,
                       "note": "event bracket around kernel + slab write (the slab reduction is batched elsewhere); two fp16 planes per operand with the gradient scaled "
                               "from its device-side maximum; eight wavefronts per 32-row tile (DESIGN 3.1b: bound by its staging instructions, 61 us stream floor at cfg2)"})
+    if ev_all.get("conan_cfconv_bwd_xw_pairs"):
+        t_ms = mean_ms(ev_all["conan_cfconv_bwd_xw_pairs"])
+        byts = 2 * P * 4 * F_ + 3 * n_atoms * 4 * F_ + 4 * (3 * E + 3 * P + n_atoms + 1)      # W rows in, pair-gradient rows out, x / dout in and dx out once, indices
+        other.append({"kernel": "k_cfconv_bwd_xw128 (CFConv backward: dx and the pair gradient from one walk of the by-source CSR)", "entry_point": "conan_cfconv_bwd_xw_pairs",
+                      "bound": "hbm", "achieved": round(byts / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "avg_launch_ms": round(t_ms, 5), "algorithmic_bytes_per_launch": byts,
+                      "note": "raw HIP-event bracket; the filter tensor it reads was written a forward pass earlier (cold), the pair gradient it writes is read back by k_filter_bwd2"})
     if ev_all.get("conan_linear_multi_fwd:edge") or ev_all.get("conan_linear_fwd:edge"):
         # edge-level Linear work of ViSNet (two fp16 planes per operand): the projections of one f in one launch (k_linear_fan16), their input gradients
         # summed in the accumulators (k_linear_sum16), s_proj and its 256-wide contraction (k_linear_t16 / k_linear_sum16<2> behind conan_linear_fwd)
@@ -788,7 +795,7 @@ def run_rank(args):
         fgw_flop = 5 * K * 5 * (4 * N_ ** 3 + 5 * 12 * N_ ** 2)    # outer 5 x K x PGD 5 x (4N^3 + Sinkhorn 5 x ~12N^2), worst case
         fgw_pmc = None                                                  # counters of the coupling kernel from the committed PMC passes (profiles/)
         if default_cfg2:
-            for rr in ("r5", "r4", "r3"):
+            for rr in ("r6", "r5", "r4", "r3"):
                 try:
                     sq = json.load(open(os.path.join(ROOT, "profiles", f"{rr}_fgw_pmc_sq.json")))["kernels"]
                     hb = json.load(open(os.path.join(ROOT, "profiles", f"{rr}_fgw_pmc_hbm.json")))["kernels"]

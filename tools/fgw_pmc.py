@@ -7,7 +7,12 @@ dev = torch.device("cuda:0")
 B, K, N, d = 256, 5, 33, 64
 g = torch.Generator().manual_seed(0)
 Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
-A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
+if os.environ.get("PROBE_RANDOM"):      # random structures: the general path of k_fgw_coupling_fast
+    A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
+else:                                   # complete graphs on n real nodes, padded nodes isolated: what the ESOL-shaped batch of cfg2 is (round 6: the row-sum form)
+    n = torch.randint(6, N + 1, (B,), generator=g); n[0] = N
+    real = (torch.arange(N)[None, :] < n[:, None]).float()
+    Cs = (real[:, :, None] * real[:, None, :] * (1.0 - torch.eye(N)))[:, None].expand(B, K, N, N).contiguous().to(dev)
 for _ in range(3):
     ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=True)
 torch.cuda.synchronize()
