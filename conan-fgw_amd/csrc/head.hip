@@ -208,13 +208,14 @@ __global__ void __launch_bounds__(256) k_grad_sqnorm(const float *__restrict__ g
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
+        // hand-off of ONE 8-byte partial per workgroup to the last arriver: a write-through (sc1) store drained before the ticket add, read back with
+        // sc1 loads after the add has returned — no agent-scope release fence (an L2 write-back per workgroup: the first form of this kernel took 15 us)
         __hip_atomic_store(&part[blockIdx.x], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         double s = 0.0;
         for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double nrm = sqrt(s);
