@@ -215,15 +215,21 @@ __global__ void __launch_bounds__(256) k_grad_sqnorm(const float *__restrict__ g
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
-        double s = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double nrm = sqrt(s);
-        double c = max_norm / (nrm + 1e-6);
-        if (!(c < 1.0)) c = 1.0;                    // clamp(max=1)
-        if (nrm != nrm) c = nrm;                    // torch with error_if_nonfinite=False: a NaN norm gives a NaN coefficient (an infinite one gives 0)
-        out2[0] = (float)nrm; out2[1] = (float)c;
-        *ticket = 0u;
+    if (last) {                                     // (workgroup-uniform) the partials: one per thread, summed in a fixed tree — the same bits on every run
+        double v = threadIdx.x < gridDim.x ? __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double nrm = sqrt(((red[0] + red[1]) + red[2]) + red[3]);
+            double c = max_norm / (nrm + 1e-6);
+            if (!(c < 1.0)) c = 1.0;                    // clamp(max=1)
+            if (nrm != nrm) c = nrm;                    // torch with error_if_nonfinite=False: a NaN norm gives a NaN coefficient (an infinite one gives 0)
+            out2[0] = (float)nrm; out2[1] = (float)c;
+            *ticket = 0u;
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_grad_scale_dev(float *__restrict__ g, long long n, const float *__restrict__ out2) {
@@ -246,7 +252,7 @@ extern "C" {
 int conan_grad_clip_flat(float *grads, long long n, double max_norm, float *norm_coef_dev, double *partials_dev, unsigned *ticket_dev, void *stream) {
     if (!grads || !norm_coef_dev || !partials_dev || !ticket_dev || n < 0 || !(max_norm > 0.0)) return CONAN_E_BADARG;
     if ((uintptr_t)grads & 15) return CONAN_E_BADARG;
-    long long blocks = ((n >> 2) + 1023) / 1024;
+    long long blocks = ((n >> 2) + 255) / 256;      // one float4 per thread up to 256 workgroups (= one partial per thread of the last arriver)
     if (blocks < 1) blocks = 1;
     if (blocks > CONAN_GRAD_CLIP_MAX_BLOCKS) blocks = CONAN_GRAD_CLIP_MAX_BLOCKS;
     k_grad_sqnorm<<<(int)blocks, 256, 0, as_stream(stream)>>>(grads, n, max_norm, partials_dev, ticket_dev, norm_coef_dev);

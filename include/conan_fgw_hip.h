@@ -297,7 +297,7 @@ int conan_adam_flat_step(float *params, const float *grads, float *exp_avg, floa
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (norm type 2; what Lightning runs for the reference's Trainer(gradient_clip_val=1.0),
  * trainer.py:177) on the flat gradient buffer, without a host round trip: norm_coef_dev[0] = total L2 norm, norm_coef_dev[1] = min(1, max_norm /
  * (norm + 1e-6)), then grads *= coefficient in place (skipped when it is 1).  Squares are summed in fp64, per workgroup into partials_dev
- * (CONAN_GRAD_CLIP_MAX_BLOCKS doubles of workspace) and from there in index order: the same bits on every run.  ticket_dev: one zeroed device word.
+ * (CONAN_GRAD_CLIP_MAX_BLOCKS doubles of workspace) and from there in a fixed tree by the last workgroup to arrive: the same bits on every run.  ticket_dev: one zeroed device word.
  * Two launches on `stream`; graph-capturable. */
 #define CONAN_GRAD_CLIP_MAX_BLOCKS 256
 int conan_grad_clip_flat(float *grads, long long n, double max_norm, float *norm_coef_dev, double *partials_dev, unsigned *ticket_dev, void *stream);
