@@ -389,7 +389,9 @@ def run_rank(args):
 
         # ---- eager rate (always measured; it is `value` only with --eager)
         n_eager = args.steps if args.eager else max(3, min(args.steps, 10))
-        dt_eager_blocks = [timed(eager_step, n_eager) for _ in range(max(1, args.blocks) if args.eager else 1)]
+        # (without --eager this rate is informational: three blocks and their median as well — a single block right behind the warm-up carried the
+        # process's cold-start hiccups, 4 to 15 ms per "step" on a fresh box for a step that takes 2.7)
+        dt_eager_blocks = [timed(eager_step, n_eager) for _ in range(max(1, args.blocks) if args.eager else 3)]
         dt_eager = float(np.median(dt_eager_blocks))
         dt_blocks = dt_eager_blocks
         loss_eager = float(loss_box[0])
@@ -860,7 +862,8 @@ def run_rank(args):
             "allreduce": {"payload_bytes": int(flat.flat.numel()) * 4, "calls_per_step": (1 if collective else 0) if use_graph else flat.last_allreduce_launches,
                           "in_timed_step": bool(collective), "forced": bool(args.force_collective and world == 1),
                           "eager_overlap_buckets": list(buckets)},
-            "eager": {"molecules_per_s": round(args.batch * world * n_eager / dt_eager, 1), "ms_per_step": round(1e3 * dt_eager / n_eager, 4), "steps": n_eager},
+            "eager": {"molecules_per_s": round(args.batch * world * n_eager / dt_eager, 1), "ms_per_step": round(1e3 * dt_eager / n_eager, 4), "steps": n_eager,
+                      "blocks_ms_per_step": [round(1e3 * t / n_eager, 4) for t in dt_eager_blocks]},
             "with_input_pipeline": pipe,
             "graph_capture_error": graph_err,
             "graph_launch_host_ms": None if (args.eager or host_launch_ms is None) else round(host_launch_ms, 4),
