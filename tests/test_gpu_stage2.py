@@ -492,3 +492,76 @@ def test_clip_grad_norm_on_the_flat_buffer_matches_torch():
             assert rel(p.grad.cpu(), h.grad.cpu()) < 2e-6
         if scale < 1:
             assert all(torch.equal(p.grad, gr) for p, gr in zip(fa.params, grads))                    # below the threshold nothing is touched
+
+
+def test_checkpoint_resume_continues_the_run_bit_for_bit():
+    """The reference's optimisation loop on the product path — collate pipeline, stage-2 model, MSE, flat gradients, global-norm clipping (trainer.py:177),
+    FlatAdam under ReduceLROnPlateau (common.py:253-262) — interrupted by a checkpoint: seven steps straight through against four steps, a checkpoint of
+    model / optimiser / scheduler state (what Lightning saves), a FRESH model + optimiser + scheduler loaded from it, and the remaining three steps.
+    Every kernel of the step sums in a fixed order, so the resumed run must land on the same parameters, moments and losses bit for bit."""
+    import copy
+    import io
+    from conan_fgw_amd import ops
+    from conan_fgw_amd.collate import DeviceCollator, molecules_from_synthetic
+    from conan_fgw_amd.head import EmbeddingsWithGATAggregationBaryCenter
+    from conan_fgw_amd.parallel import FlatAdam, FlatGradients
+    dev = torch.device("cuda:0")
+    K = 3
+    sets = []
+    for B, seed in [(5, 71), (3, 72), (6, 73), (4, 74), (5, 75), (2, 76), (6, 77)]:
+        cb = make_batch("esol", B, K, seed=seed); bg = make_bond_graph(cb, seed=seed + 100)
+        sets.append(molecules_from_synthetic(cb, bg))
+    coll = DeviceCollator(dev, K, depth=2)
+
+    def build():
+        torch.manual_seed(21)
+        m = EmbeddingsWithGATAggregationBaryCenter(K, dev).to(dev)
+        flat = FlatGradients(m.parameters())
+        opt = FlatAdam(flat, lr=2e-3, module=m)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", patience=0, factor=0.5)
+        return m, flat, opt, sched
+
+    def run(m, flat, opt, sched, items_list, losses):
+        for items in items_list:
+            db = coll(items).wait()
+            data, node_index = db.as_model_input()
+            flat.zero()
+            loss = ops.mse_loss(m(data, db.conformers_index, node_index), db.y[::K][:, None].contiguous())
+            flat.backward(loss)
+            flat.all_reduce_mean()
+            flat.clip_grad_norm_(1.0)
+            opt.step()
+            losses.append(float(loss.detach()))
+            sched.step(losses[-1] if len(losses) % 2 else 1e9)          # (every second "validation" is bad: the rate is cut during the run)
+
+    # straight through
+    ma, fa, oa, sa = build()
+    la = []
+    run(ma, fa, oa, sa, sets, la)
+    # interrupted
+    mb, fb, ob, sb = build()
+    lb = []
+    run(mb, fb, ob, sb, sets[:4], lb)
+    buf = io.BytesIO()
+    torch.save({"model": mb.state_dict(), "optimizer": ob.state_dict(), "scheduler": sb.state_dict()}, buf)
+    del mb, fb, ob, sb
+    buf.seek(0)
+    ck = torch.load(buf, map_location=dev, weights_only=False)
+    torch.manual_seed(999)                                                   # (a different initialisation: everything must come from the checkpoint)
+    mc = EmbeddingsWithGATAggregationBaryCenter(K, dev).to(dev)
+    fc = FlatGradients(mc.parameters())
+    oc = FlatAdam(fc, lr=1.0, module=mc)
+    sc = torch.optim.lr_scheduler.ReduceLROnPlateau(oc, mode="min", patience=0, factor=0.5)
+    mc.load_state_dict(ck["model"], strict=True)
+    oc.load_state_dict(ck["optimizer"])
+    sc.load_state_dict(ck["scheduler"])
+    assert oc.check_aliasing()                                               # load_state_dict copied INTO the aliased tensors
+    run(mc, fc, oc, sc, sets[4:], lb)
+    torch.cuda.synchronize()
+    assert la == lb, (la, lb)
+    assert oa.lr == oc.lr and oa.lr < 2e-3 and float(oa.step_dev) == float(oc.step_dev) == 7.0
+    for (k, p), (_, q) in zip(ma.named_parameters(), mc.named_parameters()):
+        assert torch.equal(p, q), k
+    sda, sdc = oa.state_dict(), oc.state_dict()
+    for i in sda["state"]:
+        assert torch.equal(sda["state"][i]["exp_avg"], sdc["state"][i]["exp_avg"]) and torch.equal(sda["state"][i]["exp_avg_sq"], sdc["state"][i]["exp_avg_sq"])
