@@ -23,7 +23,12 @@ B, K, N, d = int(os.environ.get("PROF_B", 256)), 5, int(os.environ.get("PROF_N",
 g = torch.Generator().manual_seed(0)
 Ys = (torch.rand(B, K, N, d, generator=g) * 1.9 + 0.1).to(dev)
 print(f"B={B} K={K} N={N} d={d}  ({'register-resident kernel, N <= 64' if N <= 64 else 'large-N kernel'})")
-A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
+if os.environ.get("PROF_COMPLETE"):      # complete graphs on n real nodes (the cfg2 batch's shape: the row-sum form of k_fgw_coupling_fast)
+    n = torch.randint(6, N + 1, (B,), generator=g); n[0] = N
+    real = (torch.arange(N)[None, :] < n[:, None]).float()
+    Cs = (real[:, :, None] * real[:, None, :] * (1.0 - torch.eye(N)))[:, None].expand(B, K, N, N).contiguous().to(dev)
+else:
+    A = (torch.rand(B, K, N, N, generator=g) < 0.5).float(); Cs = torch.triu(A, 1); Cs = (Cs + Cs.transpose(-1, -2)).to(dev)
 SMALL_INT = os.environ.get("PROF_FLOAT_CS", "") == ""
 for _ in range(2): ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=SMALL_INT)
 torch.cuda.synchronize()
