@@ -940,6 +940,7 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
     double *Yw = reinterpret_cast<double *>(w); w += al256((size_t)B * N * d * 8);
     int *active = reinterpret_cast<int *>(w); w += al256((size_t)B * 16);
     char *sc_c = w; w += al256((size_t)B * K * coupling_scratch_stride(NP));
+    int *order_ws = reinterpret_cast<int *>(w);      // [B] ints at the head of the reserved region: FgwAdj.order
     w += al256((size_t)B * NP * 16);        // (reserved)
     fgw_part_t *Ypart = reinterpret_cast<fgw_part_t *>(w);
     fgw_part_t *Cpart = Ypart + (size_t)B * K * N * d;
@@ -962,6 +963,7 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
         }
     }
 
+    if (small && adj.rowptr && !kl && (B & 7) == 0 && B <= 4096) adj.order = order_ws;      // size-ordered dealing of the coupling workgroups (speed only)
     if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, init_C, init_Y, active, info, errs, Y, C, adj, s);
     else k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C, adj);
     const size_t lc = coupling_lds(N);

@@ -479,21 +479,13 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The K workgroups of a molecule read the same C (28 KB), Y and vectors: with the plain numbering they sit on K different XCDs (workgroups are
     // dealt round-robin) and each pulls its own copy through its own L2.  XCD k takes the k-th contiguous eighth of the couplings instead.
-    int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    if (adj.order && (gridDim.x & 7) == 0) {
-        // Molecules by descending size (k_fgw_small_vectors), dealt like cards: rank r goes to XCD r % 8 (blocks are dealt round-robin over the XCDs,
-        // so block b and b + 8 share one), and the blocks of an XCD walk its molecules rank by rank — the K couplings of a molecule stay on one XCD and
-        // next to each other, and the five couplings a CU receives (every 32nd block of its XCD) come from five different parts of the size range.  A
-        // coupling's work grows with its real nodes (padded nodes are solved as one node): in the order the batch was drawn the busiest CU of an
-        // ESOL-shaped batch carries 1.3 x the mean, dealt 1.1 x.  Placement is for speed only; every molecule's result is the same bits anywhere.
-        const int x = (int)blockIdx.x & 7, pblk = (int)blockIdx.x >> 3;
-        cid = adj.order[x + 8 * (pblk / D.K)] * D.K + pblk % D.K;
-    }
+    const int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int b = cid / D.K, s = cid % D.K;
     if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool lane_ok = lane < N;
     FGW_PROF_DECL;
 
     const FastLds L = fast_lds<C2T>(N);
@@ -562,29 +554,6 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         vec_own = src[i < N ? i : N - 1];
         vec_own = i < N ? vec_own : 0.0;
     }
-    // (padded nodes as one node — see the detection below: the checks of the barycenter's structure matrix read global memory; with the ragged lists the
-    // number of real nodes is known here, so those loads fly with the staging loads)
-    int nb = N;                                                         // first padded node = number of real nodes (dense structure: found below)
-    if (ragged) nb = min(adj.gptr[cid + 1] - adj.gptr[cid], N);
-    const bool pad_try = !pb && !ps && !Ypart && !prm.fixed_structure && !prm.fixed_features;
-    auto c1_block_ok = [&](int nb_) {                                   // rows nb_+1 .. N-1 of C equal to row nb_, its columns likewise, the block constant (1e-9)
-        auto near = [](double a, double b_) { return fabs(a - b_) <= 1e-9 * (fabs(b_) + 1e-30) || a == b_; };
-        bool ok = true;
-        const int lc = lane < N ? lane : N - 1;
-        const double c_nb = C1[(size_t)nb_ * N + lc];                   // row nb_ (lane <-> column)
-        const double cbb = __shfl(c_nb, nb_, 64);
-        const double want = lane < nb_ ? c_nb : cbb;
-        for (int r = nb_ + 1 + w; r < N; r += FGW_WAVES) ok = ok && (lane >= N || near(C1[(size_t)r * N + lc], want));
-        ok = ok && (lane < nb_ || lane >= N || near(c_nb, cbb));
-        const int mcol = N - nb_;                                       // columns of the block, lane <-> column nb_ + lane
-        for (int k = w; k < nb_; k += FGW_WAVES) {
-            const double v = C1[(size_t)k * N + nb_ + (lane < mcol ? lane : 0)];
-            ok = ok && near(v, __shfl(v, 0, 64));
-        }
-        return ok;
-    };
-    bool pad_ok = pad_try && ragged && N - nb >= 2 && nb >= 1;
-    if (pad_ok) pad_ok = c1_block_ok(nb);
     if (stage_yz) {
         const int Nd = N * d;
         for (int t0 = tid; t0 < Nd; t0 += 4 * FGW_THREADS) {
@@ -628,57 +597,9 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         complete = __syncthreads_and(ok) != 0 && n_real >= 2;
     }
     double *rsum = reinterpret_cast<double *>(smem + L.off_rs);      // [4][N] (complete graphs only; may overlay C2, which that path never reads again)
-    // ---- PADDED NODES AS ONE NODE.  The reference pads every conformer of a batch to N = N_max nodes (schnet_no_sum.py:242-252, 282: SURVEY.md Appendix
-    // D.1): the m = N - n padded nodes of an input graph are isolated, carry the same feature row and the same mass 1 / N — they are EXCHANGEABLE, and so
-    // are the barycenter's nodes n .. N - 1 (init_C = Cs[0] has them isolated, Y starts at zero, every update is permutation-equivariant): all iterates
-    // have identical rows / columns there, with C constant on the whole block (its diagonal included: T's rows are identical).  The solve on the
-    // (n + 1)-node problem whose last node carries the block's mass m / N is then the SAME iteration (sinkhorn.py:413-416 with the potentials of the merged
-    // row / column shifted by log m: the scaling vector g starts at m there instead of 1) and gives T'_iP = sum of the block's entries — provided the
-    // norms of the stopping rules count a merged entry m (or m^2) times at 1 / m (1 / m^2) of its value, as the full matrices do (bregman.py:144-147,
-    // sinkhorn.py:418-433).  The reduced matrices are the top-left (n + 1)^2 corners of the staged ones (node n stands for its block), so nothing moves:
-    // the loops below run to Nx = n + 1, masses and the warm-start coupling take the multiplicity, the results are expanded when they are written.
-    // Products shrink by (Nx / N)^3 — ESOL-shaped batches: n = 20 of N = 33 on average.  Checked per coupling (workgroup-uniform), against the data:
-    // uniform masses, rows n + 1 .. N - 1 of Z, Y and C equal to row n (1e-9: the update kernel sums border rows in another order), the block of C
-    // constant; anything else runs at full size.
-    if (!ragged) {                                                      // dense structure: one past the last node that has an edge
-        int mx = 1;
-        int i = e_i0, j = e_j0;
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            if (tid + u * FGW_THREADS < NN && C2l[i * P + j] != (C2T)0) mx = max(mx, max(i, j) + 1);
-            j += e_dr; i += e_dq;
-            if (j >= N) { j -= N; ++i; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-        int *ired = reinterpret_cast<int *>(red);
-        if (lane == 0) ired[w] = mx;
-        __syncthreads();
-        nb = max(max(ired[0], ired[1]), max(ired[2], ired[3]));
-        __syncthreads();
-        pad_ok = pad_try && N - nb >= 2 && nb >= 1;
-        if (pad_ok) pad_ok = c1_block_ok(nb);
-    }
-    int m_pad = 0;                                                      // multiplicity of the merged node; 0 = the problem runs at full size
-    if (pad_try && N - nb >= 2 && nb >= 1) {                            // (workgroup-uniform condition: the barrier below is taken by all or by none)
-        auto nearf = [](double a, double b_) { return fabs(a - b_) <= 1e-9 * (fabs(b_) + 1e-30) || a == b_; };
-        bool ok = pad_ok;
-        for (int r = nb + 1 + w; r < N; r += FGW_WAVES)                 // feature rows of the input graph and of the barycenter: wavefront <-> row, lane <-> column
-            for (int c = lane; c < d; c += 64) {
-                if (stage_yz) {
-                    ok = ok && nearf((double)Zl[r * d + c], (double)Zl[nb * d + c]) && nearf(Yl[r * d + c], Yl[nb * d + c]);
-                } else {
-                    ok = ok && nearf((double)Z[(size_t)r * d + c], (double)Z[(size_t)nb * d + c]);
-                    if (!y_zero) ok = ok && nearf(Y[(size_t)r * d + c], Y[(size_t)nb * d + c]);
-                }
-            }
-        if (__syncthreads_and(ok) != 0) m_pad = N - nb;
-    }
-    const int Nx = m_pad ? nb + 1 : N;                                  // logical size of the problem from here on
-    const double mult = m_pad ? (double)m_pad : 1.0;
     FGW_PROF(0);      // staging
-    const double qj = pq[64 + lane] * ((m_pad && lane == nb) ? mult : 1.0);      // b_j with j = lane (layout A); the merged node carries its block's mass
-    const double pi_l = pq[lane] * ((m_pad && lane == nb) ? mult : 1.0);         // a_i with i = lane (layout B)
+    const double qj = pq[64 + lane];                                    // b_j with j = lane (layout A)
+    const double pi_l = pq[lane];                                       // a_i with i = lane (layout B)
     const double *r1v = vec4, *r2v = vec4 + 64, *y2v = vec4 + 128, *z2v = vec4 + 192;
     auto base_of = [&](int i, int j, double dot) {                      // utils.py:39-43,154-171, bregman.py:124-125
         double m = -2.0 * dot; m += y2v[i]; m += z2v[j];
@@ -696,34 +617,24 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             if (j >= N) { j -= N; ++i; }
         }
     } else if (stage_yz) {
-        mm_lds2<FGW_WAVES, MAXT, 0, true, true>(Nx, Nx, d, Yl, d, Zl, d, [&]() { load_c1_t(); __syncthreads(); },
+        mm_lds2<FGW_WAVES, MAXT, 0, true, true>(N, N, d, Yl, d, Zl, d, [&]() { load_c1_t(); __syncthreads(); },
                                                 [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
         for_entries([&](int u, int o) { C1l[o] = c1v[u]; });            // Z is consumed (the barrier inside the product): C1 takes its place
     } else {
-        mm_f64(Nx, Nx, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
+        mm_f64(N, N, d, [&](int i, int k) { return Y[(size_t)i * d + k]; }, [&](int k, int j) { return (double)Z[(size_t)j * d + k]; },
                [&](int i, int j, double v) { Bl[i * P + j] = base_of(i, j, v); });
     }
     // ---- T0 = G0 (warm start) or p q^T (bregman.py:98-101), written over the vectors once nobody reads them any more
     __syncthreads();
     FGW_PROF(1);      // dot(Y, Z) + base
     if (warm) {
-        if (m_pad) {                                                    // the merged row / column holds the SUM of its block's entries
-            int i = e_i0, j = e_j0;
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                if (tid + u * FGW_THREADS < NN) Tl[i * P + j] = (float)((double)tv[u] * ((i == nb ? mult : 1.0) * (j == nb ? mult : 1.0)));
-                j += e_dr; i += e_dq;
-                if (j >= N) { j -= N; ++i; }
-            }
-        } else {
-            for_entries([&](int u, int o) { Tl[o] = tv[u]; });
-        }
+        for_entries([&](int u, int o) { Tl[o] = tv[u]; });
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {                                   // (first outer iteration only: p comes straight from global memory)
             const int i = w + 4 * r;
-            const double pi_r = (pb ? (double)pb[(size_t)b * N + (i < N ? i : N - 1)] : fc.inv_n) * ((m_pad && i == nb) ? mult : 1.0);
-            if (i < Nx && lane < Nx) Tl[i * P + lane] = (float)(pi_r * qj);
+            const double pi_r = pb ? (double)pb[(size_t)b * N + (i < N ? i : N - 1)] : fc.inv_n;
+            if (i < N && lane_ok) Tl[i * P + lane] = (float)(pi_r * qj);
         }
     }
     __syncthreads();
@@ -737,10 +648,8 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     while (!bail && err > fc.inner_tol && cpt < prm.max_iter) {         // bregman.py:119
         // Everything per-lane below (LDS offsets, tile indices, fragment pointers) is derived from THIS copy of the thread index, which the
         // optimiser cannot see through: left alone it hoists some sixty loop-invariant offsets out of the loop and spills them.
-        int tq = tid, N = Nx, P = D.P;                                  // (shadow the kernel-wide N, P on purpose; N = the logical size)
+        int tq = tid, N = D.N, P = D.P;                                 // (shadow the kernel-wide N, P on purpose)
         asm volatile("" : "+v"(tq), "+s"(N), "+s"(P));                  // uniform offsets (k * P, tile counts ...) are re-derived too: they spill SGPRs
-        int nbq = m_pad ? nb : -1;                                      // index of the merged node (-1: none)
-        asm volatile("" : "+s"(nbq));
         const int lq = tq & 63, wq = tq >> 6;
         const bool lq_ok = lq < N;
         // ---- A = C1 @ T                                                        (utils.py:48-53)
@@ -823,10 +732,13 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             if (!have_colp) {                                           // v update (:415): column products against the current g (1 at ii = 0)
                 double pc = 0.0;
                 if (ii == 0) {
-                    // g starts at 1 (u = 0, sinkhorn.py:396) — at the merged node's multiplicity for that row (its m rows enter a column sum)
-                    gvP[permL] = lq_ok ? (lq == nbq ? (double)m_pad : 1.0) : 0.0;
+                    double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { if (r % 3 == 0) pc += kA[r]; else if (r % 3 == 1) p1 += kA[r]; else p2 += kA[r]; }
+                    pc = (pc + p1) + p2;
+                } else {
+                    pc = dotR(kA, gw);
                 }
-                pc = dotR(kA, gw);
                 *bufCw = pc;
                 __syncthreads();
                 colp = ((bufC[lq] + bufC[64 + lq]) + bufC[128 + lq]) + bufC[192 + lq];
@@ -847,9 +759,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
                 colp = ((bufC[lq] + bufC[64 + lq]) + bufC[128 + lq]) + bufC[192 + lq];
                 have_colp = true;                                       // the next v update starts from these products
                 double df = lq_ok ? f * colp - qj : 0.0;
-                df = df * df;
-                if (lq == nbq) df /= (double)m_pad;                     // the block's m columns, each with 1 / m of the merged residual
-                df = wave_sum_d(df);                                   // identical in every wavefront: the break is workgroup-uniform
+                df = wave_sum_d(df * df);                              // identical in every wavefront: the break is workgroup-uniform
                 if (sqrt(df) < fc.stop_thr) { ++ii; break; }
             }
         }
@@ -865,13 +775,8 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
                 const bool ok = lq_ok && wq + 4 * r < N;
                 float *tp = ok ? trow + 4 * r * P : t_dummy;
                 const float tn = (float)((gw[r] * kA[r]) * f);
-                double df = ok ? (double)tn - (double)*tp : 0.0;
-                df *= df;
-                if (nbq >= 0) {                                         // a merged entry stands for m (m^2) entries of 1 / m (1 / m^2) of its value
-                    const double im = 1.0 / (double)m_pad;
-                    df *= (lq == nbq ? im : 1.0) * (wq + 4 * r == nbq ? im : 1.0);
-                }
-                e2 += df;
+                const double df = ok ? (double)tn - (double)*tp : 0.0;
+                e2 += df * df;
                 *tp = tn;
             }
         }
@@ -890,19 +795,10 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
         asm volatile("" : "+v"(te));
         int i = te / N, j = te - i * N;
         const int dq = FGW_THREADS / N, dr = FGW_THREADS - dq * N;
-        if (m_pad) {                                                    // every entry of the block gets its share of the merged entry
-            const float im = (float)(1.0 / mult);
-            for (int t = te; t < NN; t += FGW_THREADS) {
-                Tg[t] = Tl[min(i, nb) * P + min(j, nb)] * ((i >= nb ? im : 1.0f) * (j >= nb ? im : 1.0f));
-                j += dr; i += dq;
-                if (j >= N) { j -= N; ++i; }
-            }
-        } else {
-            for (int t = te; t < NN; t += FGW_THREADS) {
-                Tg[t] = Tl[i * P + j];
-                j += dr; i += dq;
-                if (j >= N) { j -= N; ++i; }
-            }
+        for (int t = te; t < NN; t += FGW_THREADS) {
+            Tg[t] = Tl[i * P + j];
+            j += dr; i += dq;
+            if (j >= N) { j -= N; ++i; }
         }
     }
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; }
@@ -930,11 +826,9 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        // (merged problem: the product is formed at the logical size into `base`'s storage — free since the loop ended — and expanded on the way out:
-        // entry (i, j) of the block rows / columns is 1 / m (1 / m^2) of the merged entry, both indices being barycenter nodes)
         if (complete) {                                                 // t t^T - T_r T_r^T (see the detection above)
             {
-                const int lc = lane < Nx ? lane : Nx - 1;
+                const int lc = lane_ok ? lane : N - 1;
                 const float *tr = Tl + lc * P + w;
                 double p0 = 0.0, p1 = 0.0;
 #pragma unroll
@@ -942,33 +836,18 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
                     const int q = w + 4 * r;
                     if (q < n_real) { if (r & 1) p1 += (double)tr[4 * r]; else p0 += (double)tr[4 * r]; }
                 }
-                if (lane < Nx) rsum[w * N + lane] = p0 + p1;
+                if (lane_ok) rsum[w * N + lane] = p0 + p1;
             }
             __syncthreads();
-            mm_lds2<FGW_WAVES, 1, 0, true, false>(Nx, Nx, n_real, Tl, P, Tl, P, [] {}, [&](int i, int j, double v) {
+            mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, n_real, Tl, P, Tl, P, [] {}, [&](int i, int j, double v) {
                 const double ti = ((rsum[i] + rsum[N + i]) + rsum[2 * N + i]) + rsum[3 * N + i];
                 const double tj = ((rsum[j] + rsum[N + j]) + rsum[2 * N + j]) + rsum[3 * N + j];
-                if (m_pad) Bl[i * P + j] = ti * tj - v;
-                else Cp[i * N + j] = (fgw_part_t)(ti * tj - v);
+                Cp[i * N + j] = (fgw_part_t)(ti * tj - v);
             });
         } else {
-            mm_lds2<FGW_WAVES, 1, 0, false, false>(Nx, Nx, Nx, Tl, P, C2l, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; });
+            mm_lds2<FGW_WAVES, 1, 0, false, false>(N, N, N, Tl, P, C2l, P, [] {}, [&](int i, int j, double v) { AKl[i * P + j] = v; });
             __syncthreads();
-            mm_lds2<FGW_WAVES, 1, 0, true, false>(Nx, Nx, Nx, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) {
-                if (m_pad) Bl[i * P + j] = v;
-                else Cp[i * N + j] = (fgw_part_t)v;
-            });
-        }
-        if (m_pad) {
-            __syncthreads();
-            const double im = 1.0 / mult;
-            int i = tid / N, j = tid - i * N;
-            const int dq = FGW_THREADS / N, dr = FGW_THREADS - dq * N;
-            for (int t = tid; t < NN; t += FGW_THREADS) {
-                Cp[t] = (fgw_part_t)(Bl[min(i, nb) * P + min(j, nb)] * ((i >= nb ? im : 1.0) * (j >= nb ? im : 1.0)));
-                j += dr; i += dq;
-                if (j >= N) { j -= N; ++i; }
-            }
+            mm_lds2<FGW_WAVES, 1, 0, true, false>(N, N, N, AKl, P, Tl, P, [] {}, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
         }
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
@@ -1052,31 +931,6 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
     if (j < N && sub == 0) { zo[j] = z2; zo[N + j] = r2; }
     if (s == 0)
         molecule_vectors<256>(Yw + (size_t)b * N * d, Cw + (size_t)b * N * N, pb ? pb + (size_t)b * N : nullptr, N, d, kl != 0, yvec + (size_t)b * 2 * N);
-    // ---- FgwAdj.order: the molecules by descending number of real nodes (ties in index order: a stable counting sort, the same permutation on every
-    // run), for the coupling kernel's workgroup dealing.  The LAST workgroup does it (its own work above is the shortest wait for the launch).
-    if (adj.order && blockIdx.x == gridDim.x - 1) {
-        unsigned char *nsz = cm;                                        // [B] sizes, over the adjacency bytes (64 * 65 + 16 >= 4096: the launcher's bound on B)
-        __shared__ int hist[66], base[66];
-        __syncthreads();                                                // (everyone is done with cm)
-        for (int t = threadIdx.x; t < 66; t += 256) hist[t] = 0;
-        __syncthreads();
-        for (int m = threadIdx.x; m < D.B; m += 256) {
-            const int n = min(max(adj.gptr[m * D.K + 1] - adj.gptr[m * D.K], 0), 64);
-            nsz[m] = (unsigned char)n;
-            atomicAdd(&hist[n], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
-            for (int v = 64; v >= 0; --v) { base[v] = run; run += hist[v]; }
-        }
-        __syncthreads();
-        if (threadIdx.x <= 64) {
-            int pos = base[threadIdx.x];
-            for (int m = 0; m < D.B; ++m)
-                if (nsz[m] == (unsigned char)threadIdx.x) adj.order[pos++] = m;
-        }
-    }
 }
 
 // Barycenter update from the per-graph contributions (utils.py:67-95, barycenter.py:112).  TWO workgroups per molecule (round 4), because the two
