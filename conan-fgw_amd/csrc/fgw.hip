@@ -469,13 +469,11 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     // with g = 1 on every row: such couplings go to the exact pass, whose potentials start at -inf on those nodes.
     const bool massless = __syncthreads_or(zero_mass) != 0;
     const bool ragged = C2U8 && adj.rowptr != nullptr;
-    // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101)
     constexpr bool ADJ_I8 = C2U8 && CONAN_FGW_ADJ_I8 != 0;
     int c2_wide = 0;                                                      // an adjacency byte above 127: the signed-byte product below does not apply
-    for (int t = tid; t < NN; t += NT) {
-        const int i = t / N, j = t - i * N;
-        Kf[i * P + j] = warm ? Tg[t] : (float)(pa[i] * qb[j]);
-        if constexpr (C2U8) {
+    if constexpr (C2U8) {
+        for (int t = tid; t < NN; t += NT) {
+            const int i = t / N, j = t - i * N;
             const unsigned char cb = ragged ? (unsigned char)0 : (unsigned char)C2[t];
             C2b[i * P + j] = cb;
             c2_wide |= cb > 127 ? 1 : 0;
@@ -491,13 +489,61 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
             __syncthreads();
         }
     }
+    // ---- PADDED NODES AS ONE NODE (k_fgw_coupling_fast has the argument): the m = N - n padded nodes of the input graph and of the barycenter are
+    // exchangeable, the solve runs on the (n + 1)-node problem whose last node carries their mass — Lipophilicity- / BACE-shaped batches: n = 49 / 62 of
+    // N = 85 / 97 on average, the products shrink by (Nx / N)^3.  Byte layout only (the layout of the model path); checked against the data per coupling.
+    int nb = N, m_pad = 0;
+    if constexpr (C2U8) {
+        if (ragged) nb = min(adj.gptr[cid + 1] - adj.gptr[cid], N);
+        else {                                                            // dense structure: one past the last node that has an edge
+            int mx = 1;
+            for (int t = tid; t < NN; t += NT) {
+                const int i = t / N, j = t - i * N;
+                if (C2b[i * P + j]) mx = max(mx, max(i, j) + 1);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            int *ired = reinterpret_cast<int *>(red);
+            if (lane == 0) ired[wave] = mx;
+            __syncthreads();
+            nb = ired[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) nb = max(nb, ired[w]);
+            __syncthreads();
+        }
+        if (N - nb >= 2 && nb >= 1 && !pb && !ps && !massless && !prm.fixed_structure && !prm.fixed_features) {      // (workgroup-uniform)
+            auto near = [](double a, double b_) { return fabs(a - b_) <= 1e-9 * (fabs(b_) + 1e-30) || a == b_; };
+            bool ok = true;
+            const double cbb = C1[(size_t)nb * N + nb];
+            for (int r = nb + 1 + wave; r < N; r += NW) {                 // wavefront <-> row, lane <-> column
+                for (int c = lane; c < d; c += 64) {
+                    ok = ok && near((double)Z[(size_t)r * d + c], (double)Z[(size_t)nb * d + c]);
+                    if (!y_zero) ok = ok && near(Y[(size_t)r * d + c], Y[(size_t)nb * d + c]);
+                }
+                for (int k = lane; k < N; k += 64) ok = ok && near(C1[(size_t)r * N + k], k < nb ? C1[(size_t)nb * N + k] : cbb);
+            }
+            for (int k = nb + tid; k < N; k += NT) ok = ok && near(C1[(size_t)nb * N + k], cbb);
+            for (int k = wave; k < nb; k += NW)                           // columns of the block
+                for (int c = nb + 1 + lane; c < N; c += 64) ok = ok && near(C1[(size_t)k * N + c], C1[(size_t)k * N + nb]);
+            if (__syncthreads_and(ok) != 0) m_pad = N - nb;
+        }
+    }
+    const int Nx = m_pad ? nb + 1 : N;                                    // logical size of the problem from here on
+    const double mult = m_pad ? (double)m_pad : 1.0;
+    if (m_pad && tid == 0) { pa[nb] *= mult; qb[nb] *= mult; }          // the merged node carries its block's mass
+    __syncthreads();
+    // ---- T0: warm start from the previous outer iteration, else outer(p, q)      (bregman.py:98-101); the merged row / column holds its block's SUM
+    for (int t = tid; t < Nx * Nx; t += NT) {
+        const int i = t / Nx, j = t - i * Nx;
+        Kf[i * P + j] = warm ? (float)((double)Tg[i * N + j] * ((m_pad && i == nb ? mult : 1.0) * (m_pad && j == nb ? mult : 1.0))) : (float)(pa[i] * qb[j]);
+    }
     {   // init_matrix vectors (utils.py:39-43) and squared feature norms: 8 lanes per index (see k_fgw_coupling)
         constexpr int LPI = 8;
-        for (int i0 = 0; i0 < N; i0 += NT / LPI) {
+        for (int i0 = 0; i0 < Nx; i0 += NT / LPI) {
             const int i = i0 + tid / LPI, sub = tid % LPI;
             double r1 = 0.0, r2 = 0.0, y2 = 0.0, z2 = 0.0;
-            if (i < N) {
-                for (int k = sub; k < N; k += LPI) {
+            if (i < Nx) {
+                for (int k = sub; k < Nx; k += LPI) {
                     double c2;
                     if constexpr (C2U8) c2 = ragged ? (double)C2b[i * P + k] : (double)C2[i * N + k];
                     else c2 = (double)C2[i * N + k];
@@ -514,20 +560,20 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
             for (int o = 1; o < LPI; o <<= 1) {
                 r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); y2 += __shfl_xor(y2, o, 64); z2 += __shfl_xor(z2, o, 64);
             }
-            if (i < N && sub == 0) { ra[i] = r1; rb[i] = r2; y2a[i] = y2; z2a[i] = z2; }
+            if (i < Nx && sub == 0) { ra[i] = r1; rb[i] = r2; y2a[i] = y2; z2a[i] = z2; }
         }
     }
     __syncthreads();
     FGW_PROF(0);      // staging: T0, per-index vectors
     if (!y_zero)
-        FGW_MMG<NW, true>(N, N, d, Y, d, Z, d, [&](int i, int j, double v) { base[i * P + j] = v; });
+        FGW_MMG<NW, true>(Nx, Nx, d, Y, d, Z, d, [&](int i, int j, double v) { base[i * P + j] = v; });
     __syncthreads();
     FGW_PROF(1);      // dot(Y, Z)
     // ---- base = 2 alpha constC + (1 - alpha) M (utils.py:154-171, bregman.py:124-125), lane <-> column, wavefronts split the rows;
     // the column minimum of base rides along: ref_j = -min_i base_ij / eps is the stabiliser of K's column j
-    for (int j = lane; j < N; j += 64) {
+    for (int j = lane; j < Nx; j += 64) {
         double mn = 1.0e300;
-        for (int i = wave; i < N; i += NW) {
+        for (int i = wave; i < Nx; i += NW) {
             double m = -2.0 * (y_zero ? 0.0 : base[i * P + j]);
             m += y2a[i]; m += z2a[j];
             m = m > 0.0 ? m : 0.0;
@@ -538,7 +584,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
         part[wave * N + j] = mn;
     }
     __syncthreads();
-    for (int j = tid; j < N; j += NT) {
+    for (int j = tid; j < Nx; j += NT) {
         double mn = part[j];
 #pragma unroll
         for (int w = 1; w < NW; ++w) { const double o = part[w * N + j]; mn = o < mn ? o : mn; }
@@ -552,15 +598,17 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     bool bail = massless;
     while (!bail && err > fc.inner_tol && cpt < prm.max_iter) {         // bregman.py:119
         // per-lane and uniform offsets of this iteration are derived from laundered copies: hoisted out of the loop they spill
-        int tq = tid, N = D.N, P = D.P;
+        int tq = tid, N = Nx, P = D.P;                                  // (N: the logical size; D.N stays the pitch of the global matrices)
         asm volatile("" : "+v"(tq), "+s"(N), "+s"(P));
         const int lane = tq & 63, wave = tq >> 6;
         const int tid = tq;
+        int nbq = m_pad ? nb : -1;                                      // index of the merged node (-1: none)
+        asm volatile("" : "+s"(nbq));
         // ---- A = C1 @ T                                                        (utils.py:48-53)
         // max |A| as a bit pattern (integer form of the next product: its fixed-point unit); compared as integers so that a NaN or an infinity in A
         // ends up as the maximum instead of being dropped by a floating-point comparison (block_max_bits)
         unsigned long long amax = 0ull;
-        FGW_MMG<NW, false>(N, N, N, C1, N, Kf, P, [&](int i, int j, double v) {
+        FGW_MMG<NW, false>(N, N, N, C1, D.N, Kf, P, [&](int i, int j, double v) {
             Al[i * P + j] = v;
             if constexpr (ADJ_I8) { const unsigned long long ab = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull; amax = ab > amax ? ab : amax; }
         }, tq);
@@ -587,8 +635,8 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
             if (adj_i8) mm_adj_i8<NW>(N, N, N, Adig, C2b, P, aexp, k_entry, tq);
             else FGW_MMG<NW, true>(N, N, N, Al, P, C2b, P, k_entry, tq);
         } else if constexpr (C2U8) FGW_MMG<NW, true>(N, N, N, Al, P, C2b, P, k_entry, tq);
-        else FGW_MMG<NW, true>(N, N, N, Al, P, C2, N, k_entry, tq);
-        for (int i = tid; i < N; i += NT) gv[i] = 1.0;                  // u = 0
+        else FGW_MMG<NW, true>(N, N, N, Al, P, C2, D.N, k_entry, tq);
+        for (int i = tid; i < N; i += NT) gv[i] = i == nbq ? (double)m_pad : 1.0;      // u = 0 (the merged row: its m rows enter a column sum)
         __syncthreads();
         FGW_PROF(4);  // G, K
         // ---- Sinkhorn on the scaling vectors (sinkhorn.py:413-433): f_j = b_j / sum_i K_ij g_i ; g_i = a_i / sum_j K_ij f_j
@@ -649,7 +697,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
                     for (int w = 0; w < NW; ++w) c += part[w * N + j];
                     if (bad(c)) *bad_flag = 1.0;
                     const double df = fv[j] * c - qb[j];
-                    e2 += df * df;
+                    e2 += j == nbq ? df * df / (double)m_pad : df * df;      // the block's m columns, each with 1 / m of the merged residual
                     part[j] = qb[j] / c;                                // the next v update, parked in this thread's own slot of row 0 until the test below
                 }
                 const double tot = block_sum_d<NW>(e2, red);            // (its barriers publish the flag)
@@ -667,13 +715,14 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
         // cpt = 0 is T0, re-read / re-formed here (K has taken its place).
         double e2 = 0.0;
         const bool want_err = cpt % 10 == 0;
-        for (int t = tid; t < NN; t += NT) {
+        for (int t = tid; t < N * N; t += NT) {
             const int i = t / N, j = t - i * N;
             const float tn = (float)((gv[i] * (double)Kf[i * P + j]) * fv[j]);
             if (want_err) {
-                const double tp = cpt == 0 ? (warm ? (double)Tg[t] : (double)(float)(pa[i] * qb[j])) : 0.0;
+                const double mi = i == nbq ? (double)m_pad : 1.0, mj = j == nbq ? (double)m_pad : 1.0;
+                const double tp = cpt == 0 ? (warm ? (double)(float)((double)Tg[i * D.N + j] * (mi * mj)) : (double)(float)(pa[i] * qb[j])) : 0.0;
                 const double df = (double)tn - tp;
-                e2 += df * df;
+                e2 += df * df / (mi * mj);                              // a merged entry stands for m (m^2) entries of 1 / m (1 / m^2) of its value
             }
             Kf[i * P + j] = tn;
         }
@@ -687,20 +736,51 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
         return;
     }
     __syncthreads();
-    for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Kf[i * P + j]; }
+    if (m_pad) {                                                        // every entry of the block gets its share of the merged entry
+        const float im = (float)(1.0 / mult);
+        for (int t = tid; t < NN; t += NT) {
+            const int i = t / N, j = t - i * N;
+            Tg[t] = Kf[min(i, nb) * P + min(j, nb)] * ((i >= nb ? im : 1.0f) * (j >= nb ? im : 1.0f));
+        }
+    } else {
+        for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Kf[i * P + j]; }
+    }
     if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; }
     FGW_PROF(8);      // T -> global
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;
-        FGW_MMG<NW, false>(N, d, N, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
+        FGW_MMG<NW, false>(Nx, d, Nx, Kf, P, Z, d, [&](int i, int c, double v) { Yp[(size_t)i * d + c] = (fgw_part_t)v; });
+        if (m_pad) {                                                    // rows of the block: 1 / m of the merged row (this workgroup wrote it: fence + barrier)
+            __threadfence_block();
+            __syncthreads();
+            const double im = 1.0 / mult;
+            for (int t = tid; t < (N - nb) * d; t += NT) {
+                const int r = t / d, c = t - r * d;
+                const double v = (double)Yp[(size_t)nb * d + c] * im;
+                if (r > 0) Yp[(size_t)(nb + r) * d + c] = (fgw_part_t)v;
+            }
+            __syncthreads();
+            for (int c = tid; c < d; c += NT) Yp[(size_t)nb * d + c] = (fgw_part_t)((double)Yp[(size_t)nb * d + c] * im);
+        }
     }
     FGW_PROF(9);      // Ypart = T @ Z
     if (!prm.fixed_structure) {                                         // Cpart = T @ C2 @ T^T               (utils.py:67-73)
         fgw_part_t *Cp = Cpart + ((size_t)b * D.K + s) * NN;
-        if constexpr (C2U8) FGW_MMG<NW, false>(N, N, N, Kf, P, C2b, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
+        if constexpr (C2U8) FGW_MMG<NW, false>(Nx, Nx, Nx, Kf, P, C2b, P, [&](int i, int j, double v) { Al[i * P + j] = v; });
         else FGW_MMG<NW, false>(N, N, N, Kf, P, C2, N, [&](int i, int j, double v) { Al[i * P + j] = v; });
         __syncthreads();
-        FGW_MMG<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
+        if (m_pad) {                                                    // at the logical size into `base` (free since the loop ended), expanded on the way out
+            FGW_MMG<NW, true>(Nx, Nx, Nx, Al, P, Kf, P, [&](int i, int j, double v) { base[i * P + j] = v; });
+            __threadfence_block();
+            __syncthreads();
+            const double im = 1.0 / mult;
+            for (int t = tid; t < NN; t += NT) {
+                const int i = t / N, j = t - i * N;
+                Cp[t] = (fgw_part_t)(base[min(i, nb) * P + min(j, nb)] * ((i >= nb ? im : 1.0) * (j >= nb ? im : 1.0)));
+            }
+        } else {
+            FGW_MMG<NW, true>(N, N, N, Al, P, Kf, P, [&](int i, int j, double v) { Cp[i * N + j] = (fgw_part_t)v; });
+        }
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
