@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     } else {
         for (int t = tid; t < NN; t += NT) { const int i = t / N, j = t - i * N; Tg[t] = Kf[i * P + j]; }
     }
-    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; if (m_pad) atomicOr(&info[b * 4 + 3], 2); }      // (flag bit 1: solved with its padded nodes merged)
     FGW_PROF(8);      // T -> global
     if (!prm.fixed_features) {                                          // Ypart = T @ Z                      (utils.py:90-95)
         fgw_part_t *Yp = Ypart + ((size_t)b * D.K + s) * N * d;

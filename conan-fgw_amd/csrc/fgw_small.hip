@@ -905,7 +905,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
             }
         }
     }
-    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; }
+    if (tid == 0) { atomicAdd(&info[b * 4 + 1], cpt); atomicAdd(&info[b * 4 + 2], sk_total); redo[cid] = 0; if (m_pad) atomicOr(&info[b * 4 + 3], 2); }      // (flag bit 1: solved with its padded nodes merged)
     FGW_PROF(8);      // T -> global
 
     // ---- contributions to the barycenter update while T is resident

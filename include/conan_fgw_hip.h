@@ -542,7 +542,8 @@ long long conan_fgw_workspace_bytes(int B, int K, int N, int d);
  * a molecule that stopped early keeps its last couplings in the later slots),
  * info[B,4] int32 = {outer iterations, total PGD iterations, total Sinkhorn iterations, flags}; flags bit 0: at least one coupling
  * solve of the molecule left the range of the scaling-form Sinkhorn and was redone on the exact log-domain path (same result
- * contract, slower),
+ * contract, slower); bit 1 (round 6): at least one coupling solve ran with the molecule's padded nodes merged into one node (the N - n padded nodes
+ * of a conformer graph and of the barycenter are exchangeable: same iteration, same result contract, (n + 1)^3 instead of N^3 — DESIGN.md 3.3),
  * errs[B,2,max_iter] fp32 = err_feature / err_structure per outer iteration (NaN where not executed).
  * Internal arithmetic is fp64 (DESIGN.md section "FGW numerics"); I/O is fp32. */
 int conan_fgw_barycenter_fwd(const float *Ys, const float *Cs, const float *ps, const float *p, const float *lambdas,

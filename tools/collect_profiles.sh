@@ -17,7 +17,8 @@ python3 $R/tools/probe_stream_bw.py > $O/stream_bw.txt 2>/dev/null
 python3 $R/tools/probe_filter_bwd2.py 2>/dev/null | grep -v amdgpu > $O/filter_bwd2_vs_pair.txt
 python3 $R/tools/probe_filter_cfconv.py "" cfg2 2>/dev/null | grep -v amdgpu > $O/filter_cfconv.txt
 python3 $R/tools/probe_filter_cfconv.py "" lipo lipo 128 2>/dev/null | grep -v amdgpu >> $O/filter_cfconv.txt
-python3 $R/tools/probe_fgw_large.py "" final 2>/dev/null | grep -v amdgpu > $O/fgw_large.txt
+python3 $R/tools/probe_fgw_large.py "" "dense random structures, no padding  " 2>/dev/null | grep -v amdgpu > $O/fgw_large.txt
+PROBE_PADDED=1 python3 $R/tools/probe_fgw_large.py "" "sizes ~0.57 N padded to N (one at N)" 2>/dev/null | grep -v amdgpu >> $O/fgw_large.txt
 python3 $R/tools/probe_edge_linears.py "" final 2>/dev/null | grep -v amdgpu > $O/visnet_edge_linears.txt
 python3 $R/tools/probe_fgw_small.py "" "random structures (general path)" 2>/dev/null | grep -v amdgpu > $O/fgw_small.txt
 PROBE_COMPLETE=1 python3 $R/tools/probe_fgw_small.py "" "complete graphs (row-sum form)   " 2>/dev/null | grep -v amdgpu >> $O/fgw_small.txt
