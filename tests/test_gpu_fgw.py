@@ -286,7 +286,8 @@ def test_padded_nodes_are_solved_as_one_node(N, n, small_int):
     Cs = np.zeros((1, K, N, N), np.float32); Cs[0, :, :n, :n] = A
     for k in range(K):
         Cs[0, k, n - 1, 0] = Cs[0, k, 0, n - 1] = 1.0                            # the last real node has an edge in every graph (dense layouts find n from it)
-    merged_possible = small_int or N <= 64                                       # (the large kernel merges in the byte layout only)
+    # (the large kernel merges in the byte layout only; N = 64 with fp32 structure matrices outgrows the round-3 kernel's LDS and runs on the round-2 one)
+    merged_possible = small_int or N <= 48
 
     def check(Ysx, Csx, want_merged, **kw):                                     # kw: numpy arrays with the batch dimension (init_Y, ps)
         Y, C, T, info, _ = _run(Ysx, Csx, cs_small_int=small_int, **{k: torch.from_numpy(v).to(dev) for k, v in kw.items()})
@@ -294,7 +295,7 @@ def test_padded_nodes_are_solved_as_one_node(N, n, small_int):
         ref = ofgw.fgw_barycenter(Ysx[0], Csx[0], dtype=np.float64, **okw)
         r32 = ofgw.fgw_barycenter(Ysx[0], Csx[0], dtype=np.float32, **okw)
         assert int(info[0, 0]) == ref["outer"] and int(info[0, 1]) == int(ref["pgd"].sum()) and int(info[0, 2]) == int(ref["sinkhorn"].sum())
-        assert bool(int(info[0, 3]) & 2) == want_merged, (int(info[0, 3]), want_merged)
+        assert want_merged is None or bool(int(info[0, 3]) & 2) == want_merged, (int(info[0, 3]), want_merged)
         for key, val in (("Y", Y), ("C", C), ("T", T)):
             e64, yard = rel(val[0].cpu().numpy(), ref[key]), rel(r32[key], ref[key])
             assert e64 <= 1e-4 or e64 <= 1e-2 * yard, (key, e64, yard)
@@ -304,8 +305,8 @@ def test_padded_nodes_are_solved_as_one_node(N, n, small_int):
     if merged_possible:                                                          # the expansion: block rows / columns are copies of one another
         assert torch.equal(Y[0, n], Y[0, N - 1]) and torch.equal(C[0, n, :n], C[0, N - 1, :n]) and torch.equal(C[0, :n, n], C[0, :n, N - 1])
         assert torch.equal(T[0, :, n, :n], T[0, :, N - 1, :n]) and torch.equal(T[0, :, :n, n], T[0, :, :n, N - 1])
-    Yp = Ys.copy(); Yp[0, 1, N - 1, 3] += 0.05                                   # one padded feature row differs
-    check(Yp, Cs, False)
+    Yp = Ys.copy(); Yp[0, 1, N - 1, 3] += 0.05                                   # one padded feature row of ONE graph differs: that coupling runs at full size from the start,
+    check(Yp, Cs, None)                                                          # the others until the first update has made the barycenter's block rows differ
     iy = np.zeros((1, N, d), np.float32); iy[0, n + 1:] = rng.uniform(0.0, 0.2, size=(N - n - 1, d))
     check(Ys, Cs, False, init_Y=iy)
     ps = np.full((1, K, N), 1.0 / N, np.float32); ps[0, :, 0] *= 1.5; ps[0, :, 1] *= 0.5
