@@ -851,7 +851,7 @@ def run_rank(args):
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
                                    + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce" + (" + global-norm clip 1.0" if clip else "") + " + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
-                       "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core",
+                       "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core; exact reformulations of the same iteration: the exchangeable padded nodes of a conformer graph / of the barycenter solved as one node, products against a complete graph's structure matrix as row sums (DESIGN.md 3.3 round 6; iteration counts and results = the full-size solve's)",
                        "optimizer": "torch.optim.Adam(fused, capturable)" if args.torch_adam else "Adam in one launch over flat buffers (parallel.FlatAdam: torch.optim.Adam's update)",
                        "grad_clip": "global L2 norm 1.0 on the flat buffer (conan_grad_clip_flat; Trainer(gradient_clip_val=1.0), trainer.py:177)" if clip else None},
             "rccl_ranks": dist.get_world_size() if use_dist and args.backend == "nccl" else 0,
