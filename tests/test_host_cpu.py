@@ -168,3 +168,17 @@ def test_batch_hints_are_absent_on_foreign_tensors():
     assert ops.batch_hints(t) == (None, None) and ops.batch_hints(None) == (None, None)
     t._conan_hints = (3, 7)
     assert ops.batch_hints(t) == (3, 7) and ops.batch_hints(t.clone()) == (None, None)      # the tag does not travel with copies
+
+
+def test_captured_step_and_flat_adam_refuse_cpu_buffers():
+    """The graph-captured step and the one-launch Adam exist on the GPU only; on CPU buffers they fail loudly instead of falling back."""
+    import pytest
+    import torch
+    from conan_fgw_amd.capture import CapturedTrainStep
+    from conan_fgw_amd.parallel import FlatAdam, FlatGradients
+    lin = torch.nn.Linear(4, 3)
+    flat = FlatGradients(lin.parameters())
+    with pytest.raises(RuntimeError, match="GPU only"):
+        FlatAdam(flat)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        CapturedTrainStep(lambda: lin(torch.ones(2, 4)).sum(), flat, torch.optim.SGD(lin.parameters(), lr=0.1))
