@@ -37,7 +37,7 @@ BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 matrix peak (MI355X_MICROARCH.md; 2:
 
 
 CONFIGS = {"cfg2": dict(shape="esol", batch=256, conformers=5, model="schnet"), "cfg3": dict(shape="lipo", batch=128, conformers=5, model="schnet"),
-           "cfg4": dict(shape="bace", batch=64, conformers=5, model="visnet"), "cfg5": dict(shape="freesolv", batch=64, conformers=20, model="schnet")}
+           "cfg4": dict(shape="bace", batch=64, conformers=5, model="visnet", head="classification"), "cfg5": dict(shape="freesolv", batch=64, conformers=20, model="schnet")}
 
 
 def parse(argv=None):
@@ -65,7 +65,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-full", action="store_true", help="SURVEY 8(d) protocol in full: 3 warm-up + 10 timed batches per leg")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="BASELINE.json configs by name (per-GPU share): cfg2 = ESOL + SchNet, K=5, 256 molecules (the default workload); cfg3 = Lipophilicity + SchNet, "
-                         "K=5, 128 per GPU (1024 over 8 GPUs); cfg4 = BACE + ViSNet, K=5, 64; cfg5 = FreeSolv + SchNet, K=20, 64.  Overrides --shape/--batch/--conformers/--model")
+                         "K=5, 128 per GPU (1024 over 8 GPUs); cfg4 = BACE classification + ViSNet, K=5, 64 (sigmoid head, BCE); cfg5 = FreeSolv + SchNet, K=20, 64.  Overrides --shape/--batch/--conformers/--model")
     ap.add_argument("--no-clip", action="store_true", help="leave out the global-norm gradient clipping (Trainer(gradient_clip_val=1.0), trainer.py:177) between all-reduce and Adam")
     ap.add_argument("--torch-adam", action="store_true", help="optimizer step on torch.optim.Adam(fused=True, capturable=True) instead of the one-launch FlatAdam")
     ap.add_argument("--no-pack8", action="store_true", help="skip the eight-concurrent-packer-processes leg of with_input_pipeline (it is skipped anyway under a profiler preload)")
@@ -849,7 +849,7 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.shape.upper()}-shaped + " + ("ViSNet-128 (6 layers, 8 heads, 32 RBF, cutoff 5 A), " if args.model == "visnet" else "SchNet-128 (3 interactions, 50 gaussians, cutoff 10 A, cap 32), ")
                                    + f"K={K}, batch={args.batch} molecules per GPU, {args.mode} step "
-                                   + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce" + (" + global-norm clip 1.0" if clip else "") + " + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
+                                   + ("classification head (sigmoid, BCE) " if classify else "") + ("(stage-2 model incl. GAT branch: fwd + bwd + flat-gradient all-reduce" + (" + global-norm clip 1.0" if clip else "") + " + Adam)" if train else "(forward_w_barycenter + GAT branch + head)"),
                        "molecules_per_gpu": args.batch, "conformers": K, "atoms": n_atoms, "edges": E, "filter_pairs": P, "max_nodes": b.max_nodes,
                        "mode": args.mode, "parallelism": f"dp{world}", "execution": exe, "fgw": "alpha=0.1 eps=0.1 max_iter=5 numItermax=5, fp64 core; exact reformulations of the same iteration: the exchangeable padded nodes of a conformer graph / of the barycenter solved as one node, products against a complete graph's structure matrix as row sums (DESIGN.md 3.3 round 6; iteration counts and results = the full-size solve's)",
                        "optimizer": "torch.optim.Adam(fused, capturable)" if args.torch_adam else "Adam in one launch over flat buffers (parallel.FlatAdam: torch.optim.Adam's update)",

@@ -118,7 +118,7 @@ def test_bench_config_shorthand_and_explicit_flags():
     a = bench.parse(["--config", "cfg3", "--batch", "16"])
     assert (a.shape, a.batch) == ("lipo", 16)
     a = bench.parse(["--config", "cfg4"])
-    assert (a.shape, a.batch, a.model) == ("bace", 64, "visnet")
+    assert (a.shape, a.batch, a.model, a.head) == ("bace", 64, "visnet", "classification")          # BASELINE configs[3]: BACE classification + ViSNet
     a = bench.parse(["--config", "cfg5"])
     assert (a.shape, a.batch, a.conformers) == ("freesolv", 64, 20)
     a = bench.parse(["--config", "cfg3", "--batch", "256"])                                             # an explicit flag that equals the parser's default still wins

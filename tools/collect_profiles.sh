@@ -10,7 +10,7 @@ $B > $O/bench_train.json 2> $O/bench_train.err
 $B --mode fwd --no-cpu-baseline > $O/bench_fwd.json 2>/dev/null
 $B --config cfg3 --no-cpu-baseline > $O/bench_lipo.json 2>/dev/null
 $B --config cfg3 --mode fwd --no-cpu-baseline > $O/bench_lipo_fwd.json 2>/dev/null
-$B --model visnet --shape bace --batch 64 --no-cpu-baseline > $O/bench_visnet_bace.json 2>/dev/null
+$B --config cfg4 --no-cpu-baseline > $O/bench_visnet_bace.json 2>/dev/null
 $B --shape freesolv --conformers 20 --batch 64 --no-cpu-baseline > $O/bench_freesolv_k20.json 2>/dev/null
 python3 $R/tools/cfconv_cold.py > $O/cfconv_cold.json 2>/dev/null
 python3 $R/tools/probe_stream_bw.py > $O/stream_bw.txt 2>/dev/null
@@ -24,14 +24,14 @@ python3 $R/tools/probe_fgw_small.py "" "random structures (general path)" 2>/dev
 PROBE_COMPLETE=1 python3 $R/tools/probe_fgw_small.py "" "complete graphs (row-sum form)   " 2>/dev/null | grep -v amdgpu >> $O/fgw_small.txt
 python3 $R/tools/probe_cfconv_bwd.py "" final 2>/dev/null | grep -v amdgpu > $O/cfconv_bwd.txt
 python3 $R/tools/probe_cfconv_bwd.py "" final lipo 128 2>/dev/null | grep -v amdgpu >> $O/cfconv_bwd.txt
-for cfg in "train:" "lipo:--shape lipo --batch 128" "visnet_bace:--model visnet --shape bace --batch 64" "freesolv_k20:--shape freesolv --conformers 20 --batch 64"; do
+for cfg in "train:" "lipo:--shape lipo --batch 128" "visnet_bace:--config cfg4" "freesolv_k20:--shape freesolv --conformers 20 --batch 64"; do
   name=${cfg%%:*}; fl=${cfg#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o $name -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --eager $fl > /dev/null 2>&1
 done
 # graph-replay timeline of the cfg2 step (tools/trace_timeline.py)
 rocprofv3 --kernel-trace -d $O/tl -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/trace_timeline.py $O/tl > $O/step_timeline.txt 2>&1
-rocprofv3 --kernel-trace -d $O/tlv -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline --model visnet --shape bace --batch 64 > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $O/tlv -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline --config cfg4 > /dev/null 2>&1
 python3 $R/tools/trace_timeline.py $O/tlv 0 > $O/visnet_step_timeline.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --eager > /dev/null 2>&1
