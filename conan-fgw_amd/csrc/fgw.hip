@@ -19,6 +19,7 @@
 #include "fgw_common.h"
 #ifdef CONAN_FGW_PROFILE
 FGW_PROF_ACCESSOR(conan_debug_fgw_prof_large)
+FGW_PROF_TRACE_ACCESSOR(conan_debug_fgw_trace_large)
 #endif
 
 namespace {
@@ -56,6 +57,7 @@ __global__ void k_fgw_init(const float *__restrict__ Cs, const float *__restrict
     }
     if (threadIdx.x == 0) { fgw_active_init(active, D.B, b); info[b * 4 + 0] = 0; info[b * 4 + 1] = 0; info[b * 4 + 2] = 0; info[b * 4 + 3] = 0; }
     for (int t = threadIdx.x; t < 2 * max_iter; t += blockDim.x) errs[(size_t)b * 2 * max_iter + t] = __builtin_nanf("");
+    if (adj.order && blockIdx.x == gridDim.x - 1) fgw_order_by_size<256>(adj, D.B, D.K, (int)threadIdx.x);      // (launched with 256 threads)
 }
 
 // ------------------------------------------------------------------------------------------------ coupling solve
@@ -419,8 +421,11 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 #endif
 // C2U8: the adjacency of the input graph is staged ONCE into LDS as bytes (caller's promise cs_small_int: integers in [0, 255]) and both
 // products that contract with it read it there instead of fetching fp32 from L2 in every projected-gradient iteration.
-// WPC: workgroups per CU the register budget is cut for — 3 (80 registers: a 640-coupling shard is resident in one round, with ~80 B / lane of
-// scratch) or 2 (128 registers, no scratch): the launcher takes 2 when the batch has at most 512 couplings anyway (BACE B = 64: 320).
+// WPC: workgroups per CU the register budget is cut for — 3 (80 registers: a 640-coupling shard is resident in one round, with ~200 B / lane of
+// scratch) or 2 (128 registers, 12 B of scratch): the launcher takes 2 when the batch has at most 512 couplings anyway (BACE B = 64: 320) and, since
+// round 6, at ANY number of couplings when they are dealt by size (FgwAdj.order: the model's ragged layout) — the largest couplings start first and the
+// smallest wait for the first free slots: Lipophilicity B = 128 (640 couplings on 512 slots) 4.54 against 4.89 ms per step for the three-per-CU build,
+// B = 256 / 512 per GPU -1.2 / -1.6 % (profiles/r6_ab_fgw_placement.txt).
 template <int NW, bool C2U8, int WPC = 3>
 __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
@@ -430,7 +435,14 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * NW;
     // XCD k owns the k-th contiguous eighth of the couplings (see k_fgw_coupling_fast): the K workgroups of a molecule share C in one L2
-    const int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    if (adj.order && (gridDim.x & 7) == 0) {
+        // Molecules by descending size (FgwAdj.order, filled by k_fgw_init), ranks dealt round the XCDs, the blocks of an XCD in rank order: the largest
+        // couplings are dispatched first, and when the grid exceeds the resident slots (two workgroups per CU) the ones that wait are the smallest —
+        // they go to whichever CU frees a slot first, which balances the launch better than any fixed assignment tried.
+        const int x = (int)blockIdx.x & 7, pblk = (int)blockIdx.x >> 3;
+        cid = adj.order[x + 8 * (pblk / D.K)] * D.K + pblk % D.K;
+    }
     const int b = cid / D.K, s = cid % D.K;
     if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
@@ -784,6 +796,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
+    FGW_PROF_TRACE(Nx | (cpt << 8) | (sk_total << 20));
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -973,6 +986,15 @@ __global__ void __launch_bounds__(64) k_readout_bwd(const float *__restrict__ Y,
 
 inline int pitch_of(int N) { return fgw_pitch(N); }
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+#ifndef CONAN_FGW_WPC2_MAX
+#define CONAN_FGW_WPC2_MAX 512      // (A/B switch) couplings up to which the 128-register build is taken
+#endif
+#ifndef CONAN_FGW_WPC2_ORDERED
+#define CONAN_FGW_WPC2_ORDERED 1    // (A/B switch) the 128-register build at any number of couplings when they are dealt by size
+#endif
+#ifndef CONAN_FGW_BIG_ORDER
+#define CONAN_FGW_BIG_ORDER 1       // (A/B switch) size-ordered dealing on the N > 64 path
+#endif
 #ifndef CONAN_FGW_BIG_WPC2
 #define CONAN_FGW_BIG_WPC2 1
 #endif
@@ -1043,7 +1065,8 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
         }
     }
 
-    if (small && adj.rowptr && !kl && (B & 7) == 0 && B <= 4096) adj.order = order_ws;      // size-ordered dealing of the coupling workgroups (speed only)
+    // size-ordered dealing of the coupling workgroups (speed only): k_fgw_coupling_fast and k_fgw_coupling_big
+    if (adj.rowptr && !kl && (B & 7) == 0 && B <= 4096 && (small || (CONAN_FGW_BIG_ORDER && big_lds(N, true) <= LDS_LIMIT))) adj.order = order_ws;
     if (small) conan_fgw_small_prepare(Ys, Cs, ps, p, D, *params, Cw, Yw, zvec, yvec, init_C, init_Y, active, info, errs, Y, C, adj, s);
     else k_fgw_init<<<B, 256, 0, s>>>(Cs, init_C, init_Y, D, params->max_iter, Cw, Yw, active, info, errs, Y, C, adj);
     const size_t lc = coupling_lds(N);
@@ -1086,7 +1109,7 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
         k_fgw_coupling_big<GEN_NW, U8, WPC><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
                                                                             Ypart, Cpart, redo, adj);                                \
     } while (0)
-            const bool two_per_cu = BIG_WPC2 && B * K <= 512;      // every coupling resident at two workgroups per CU: take the 128-register build
+            const bool two_per_cu = BIG_WPC2 && (B * K <= CONAN_FGW_WPC2_MAX || (CONAN_FGW_WPC2_ORDERED && adj.order));      // the 128-register build (see WPC above)
             if (c2b) { if (two_per_cu) CONAN_BIG(true, 2); else CONAN_BIG(true, 3); }
             else { if (two_per_cu) CONAN_BIG(false, 2); else CONAN_BIG(false, 3); }
 #undef CONAN_BIG

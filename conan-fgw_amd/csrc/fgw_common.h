@@ -13,6 +13,28 @@ static __device__ long long g_fgw_prof[32];            // one copy per translati
         if (reset) { long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fgw_prof), z, sizeof(z)) != hipSuccess) return -2; } \
         return 0;                                                                        \
     }
+// Placement trace (tools/fgw_placement.py): one record per workgroup — block, a tag (the size its problem ran at), the HW_ID and XCC_ID registers
+// (which CU of which XCD it ran on), first and last wall-clock tick.
+static __device__ long long g_fgw_trace[2 + 6 * 8192];
+#define FGW_PROF_TRACE_ACCESSOR(name)                                                    \
+    extern "C" int name(long long *out, int reset) {                                     \
+        if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fgw_trace), sizeof(long long) * (2 + 6 * 8192)) != hipSuccess) return -2; \
+        if (reset) { long long z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fgw_trace), z, sizeof(z)) != hipSuccess) return -2; } \
+        return 0;                                                                        \
+    }
+#define FGW_PROF_TRACE(tag)                                                              \
+    do {                                                                                 \
+        if (threadIdx.x == 0) {                                                          \
+            const unsigned long long i_ = atomicAdd(reinterpret_cast<unsigned long long *>(&g_fgw_trace[0]), 1ull); \
+            if (i_ < 8192) {                                                             \
+                long long *r_ = &g_fgw_trace[2 + 6 * i_];                                \
+                r_[0] = (long long)blockIdx.x; r_[1] = (long long)(tag);                 \
+                r_[2] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));            \
+                r_[3] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));           \
+                r_[4] = prof_w0; r_[5] = wall_clock64();                                 \
+            }                                                                            \
+        }                                                                                \
+    } while (0)
 #define FGW_PROF_DECL long long prof_t = wall_clock64(); const long long prof_w0 = prof_t, prof_c0 = clock64(); long long prof_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define FGW_PROF(k)                                                                      \
     do {                                                                                 \
@@ -32,10 +54,12 @@ static __device__ long long g_fgw_prof[32];            // one copy per translati
 #define FGW_PROF_DECL
 #define FGW_PROF(k) asm volatile("; FGWMARK " #k)
 #define FGW_PROF_FLUSH
+#define FGW_PROF_TRACE(tag)
 #else
 #define FGW_PROF_DECL
 #define FGW_PROF(k)
 #define FGW_PROF_FLUSH
+#define FGW_PROF_TRACE(tag)
 #endif
 
 constexpr int FGW_THREADS = 256;
@@ -294,6 +318,33 @@ __device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__re
             const int i = i0 + lk + 4 * q;
             if (i < M && cb) st(i, jb, acc[q] + acc2[q]);
         }
+    }
+}
+
+// FgwAdj.order: the molecules by descending number of real nodes (ties in index order: a stable counting sort, the same permutation on every
+// run).  One workgroup of NT >= 256 threads, B <= 4096 (the launcher's bound); sizes above 255 share the last bin.
+template <int NT>
+__device__ __forceinline__ void fgw_order_by_size(const FgwAdj &adj, int B, int K, int tid) {
+    static_assert(NT >= 256, "one thread per size bin");
+    __shared__ unsigned char nsz[4096];
+    __shared__ int hist[256], base[256];
+    for (int t = tid; t < 256; t += NT) hist[t] = 0;
+    __syncthreads();
+    for (int m = tid; m < B; m += NT) {
+        const int n = min(max(adj.gptr[m * K + 1] - adj.gptr[m * K], 0), 255);
+        nsz[m] = (unsigned char)n;
+        atomicAdd(&hist[n], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int v = 255; v >= 0; --v) { base[v] = run; run += hist[v]; }
+    }
+    __syncthreads();
+    if (tid < 256 && hist[tid] > 0) {
+        int pos = base[tid];
+        for (int m = 0; m < B; ++m)
+            if (nsz[m] == (unsigned char)tid) adj.order[pos++] = m;
     }
 }
 

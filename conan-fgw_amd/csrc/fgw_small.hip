@@ -23,6 +23,7 @@
 
 #ifdef CONAN_FGW_PROFILE
 FGW_PROF_ACCESSOR(conan_debug_fgw_prof)
+FGW_PROF_TRACE_ACCESSOR(conan_debug_fgw_trace)
 #endif
 
 namespace {
@@ -973,6 +974,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     }
     FGW_PROF(10);     // Cpart = T @ C2 @ T^T
     FGW_PROF_FLUSH;
+    FGW_PROF_TRACE(Nx | (cpt << 8) | (sk_total << 20));
 }
 
 // Per-index vectors of the gradient's constant part (init_matrix, utils.py:39-43) and of the feature cost (utils.py:154-171).
@@ -1052,31 +1054,9 @@ __global__ void __launch_bounds__(256) k_fgw_small_vectors(const float *__restri
     if (j < N && sub == 0) { zo[j] = z2; zo[N + j] = r2; }
     if (s == 0)
         molecule_vectors<256>(Yw + (size_t)b * N * d, Cw + (size_t)b * N * N, pb ? pb + (size_t)b * N : nullptr, N, d, kl != 0, yvec + (size_t)b * 2 * N);
-    // ---- FgwAdj.order: the molecules by descending number of real nodes (ties in index order: a stable counting sort, the same permutation on every
-    // run), for the coupling kernel's workgroup dealing.  The LAST workgroup does it (its own work above is the shortest wait for the launch).
-    if (adj.order && blockIdx.x == gridDim.x - 1) {
-        unsigned char *nsz = cm;                                        // [B] sizes, over the adjacency bytes (64 * 65 + 16 >= 4096: the launcher's bound on B)
-        __shared__ int hist[66], base[66];
-        __syncthreads();                                                // (everyone is done with cm)
-        for (int t = threadIdx.x; t < 66; t += 256) hist[t] = 0;
-        __syncthreads();
-        for (int m = threadIdx.x; m < D.B; m += 256) {
-            const int n = min(max(adj.gptr[m * D.K + 1] - adj.gptr[m * D.K], 0), 64);
-            nsz[m] = (unsigned char)n;
-            atomicAdd(&hist[n], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
-            for (int v = 64; v >= 0; --v) { base[v] = run; run += hist[v]; }
-        }
-        __syncthreads();
-        if (threadIdx.x <= 64) {
-            int pos = base[threadIdx.x];
-            for (int m = 0; m < D.B; ++m)
-                if (nsz[m] == (unsigned char)threadIdx.x) adj.order[pos++] = m;
-        }
-    }
+    // ---- FgwAdj.order: the molecules by descending number of real nodes, for the coupling kernel's workgroup dealing.  The LAST workgroup does it
+    // (its own work above is the shortest wait for the launch).
+    if (adj.order && blockIdx.x == gridDim.x - 1) fgw_order_by_size<256>(adj, D.B, D.K, (int)threadIdx.x);
 }
 
 // Barycenter update from the per-graph contributions (utils.py:67-95, barycenter.py:112).  TWO workgroups per molecule (round 4), because the two

@@ -521,7 +521,10 @@ def test_massless_nodes_survive_the_exact_second_pass(N, n):
     ("esol", 3, 4, {"loss_fun": "kl_loss"}),              # a loss without a ragged load stage: graphs expanded once, dense path
     ("bace", 6, 5, {}),                                   # N > 64: k_fgw_init + k_fgw_coupling_big
     ("bace", 6, 3, {"epsilon": 2e-4}),
-], ids=["n_le_64", "n_le_64_exact_pass", "kl_dense_fallback", "n_gt_64", "n_gt_64_exact_pass"])
+    ("esol", 16, 5, {}),                                  # B a multiple of 8: the ragged solve deals its workgroups by molecule size (FgwAdj.order), the dense one
+    ("bace", 8, 5, {}),                                   # does not — placement must not change a bit; N > 64: the order comes from k_fgw_init
+    ("lipo", 104, 5, {}),                                 # 520 couplings: dealt, the large kernel's two-per-CU build with the smallest couplings waiting for a
+], ids=["n_le_64", "n_le_64_exact_pass", "kl_dense_fallback", "n_gt_64", "n_gt_64_exact_pass", "n_le_64_dealt", "n_gt_64_dealt", "n_gt_64_dealt_520"])      # slot; dense, the three-per-CU build in the drawn order
 def test_structure_read_from_the_ragged_neighbour_lists_equals_the_dense_adjacency(shape, B, K, kw):
     """The models hand the solver the radius graph itself (`adjacency=graph`): no [G,N,N] tensor is built.  The coupling
     kernels' load stage forms the same adjacency counts from the graph's CSR, so every output equals the solve on `to_dense_adj` bit for

@@ -16,6 +16,8 @@ for name, B, K, N, d in (("bace B=64", 64, 5, 97, 64), ("lipo B=128", 128, 5, 85
     if os.environ.get("PROBE_PADDED"):       # molecules of different sizes padded to N as the model's glue leaves them: n real nodes (normal around 0.57 N, one molecule with
         # n = N), isolated padded nodes with one common feature row — round 6: the coupling kernels solve them as one node
         n = (torch.randn(B, generator=g) * 0.14 * N + 0.57 * N).round().clamp(8, N).long(); n[0] = N
+        if os.environ.get("PROBE_ONLY_ABOVE"):      # diagnostic: molecules at or below that size shrink to 2 nodes (they end at once) — what the launch costs
+            n = torch.where(n <= int(os.environ["PROBE_ONLY_ABOVE"]), torch.full_like(n, 2), n)      # without them = the bound of running them elsewhere
         real = (torch.arange(N)[None, :] < n[:, None]).float()
         Cs = Cs * (real[:, None, :, None] * real[:, None, None, :])
         for b_ in range(B): Cs[b_, :, int(n[b_]) - 1, 0] = 1.0; Cs[b_, :, 0, int(n[b_]) - 1] = 1.0
