@@ -624,6 +624,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
             Al[i * P + j] = v;
             if constexpr (ADJ_I8) { const unsigned long long ab = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull; amax = ab > amax ? ab : amax; }
         }, tq);
+        FGW_PROF(3);  // A = C1 @ T (the product as wavefront 0 sees it; its stores are still in flight)
         int aexp = 0;
         if constexpr (ADJ_I8) {
             if (adj_i8) {
@@ -638,7 +639,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
             }
         }
         __syncthreads();
-        FGW_PROF(3);  // A = C1 @ T
+        FGW_PROF(5);  // max |A|, digits of A (integer path), barrier
         // ---- G = A @ (2 C2)^T ; K_ij = exp(Mr_ij - ref_j), Mr = -(base - 2 alpha G) / eps   (utils.py:62-64, sinkhorn.py:388)
         auto k_entry = [&](int i, int j, double v) {
             Kf[i * P + j] = (float)exp_fast(fma(v, fc.four_alpha_inv_eps, (refb[j] - base[i * P + j]) * fc.inv_eps));

@@ -39,7 +39,7 @@ reps = 5
 for _ in range(reps): out = ops.fgw_barycenter_batched(Ys, Cs, cs_small_int=SMALL_INT)
 torch.cuda.synchronize()
 PROF(buf, 0)
-names = ["staging", "T0 + dot(Y,Z)", "base registers", "A = C1 @ T", "G = A @ 2C2^T", "K = exp(Mr-max) + 1st column step", "Sinkhorn iterations",
+names = ["staging", "T0 + dot(Y,Z)", "base registers", "A = C1 @ T (product)", "G = A @ 2C2^T", "max |A| + digits of A + barrier (large-N kernel)", "Sinkhorn iterations",
          "T store + err", "T -> global", "Ypart = T @ Z", "Cpart = T C2 T^T"]
 if N <= 64 and not os.environ.get("PROF_OLD"):      # round-3 kernel (k_fgw_coupling_fast): its marks
     names = ["staging", "dot(Y,Z) + base", "T0", "A = C1 @ T", "G = A @ 2C2^T -> K = exp(Mr - ref)", "K -> registers", "Sinkhorn iterations",

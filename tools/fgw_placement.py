@@ -32,11 +32,14 @@ N = int(data.max_nodes)
 TRACE = L.conan_debug_fgw_trace if N <= 64 else L.conan_debug_fgw_trace_large
 TRACE.restype = ctypes.c_int; TRACE.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
 buf = (ctypes.c_longlong * (2 + 6 * 8192))()
+PROF = L.conan_debug_fgw_prof if N <= 64 else L.conan_debug_fgw_prof_large
+PROF.restype = ctypes.c_int; PROF.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+pbuf = (ctypes.c_longlong * 32)()
 with torch.no_grad():
     for _ in range(3): model(data, cidx, data.batch, num_graphs=data.num_graphs, max_nodes=data.max_nodes)
-    torch.cuda.synchronize(); TRACE(buf, 1)
+    torch.cuda.synchronize(); TRACE(buf, 1); PROF(pbuf, 1)
     model(data, cidx, data.batch, num_graphs=data.num_graphs, max_nodes=data.max_nodes)
-    torch.cuda.synchronize(); TRACE(buf, 0)
+    torch.cuda.synchronize(); TRACE(buf, 0); PROF(pbuf, 0)
 n = min(int(buf[0]), 8192)
 rec = np.array(buf[2:2 + 6 * n], dtype=np.int64).reshape(n, 6)
 rec = rec[np.argsort(rec[:, 4], kind="stable")]
@@ -48,6 +51,11 @@ for i in range(1, n):
     if rec[i, 4] >= end: launches.append(cur); cur = []
     cur.append(i); end = max(end, rec[i, 5])
 launches.append(cur)
+names = (["staging", "dot(Y,Z) + base", "T0", "A = C1 @ T", "G -> K = exp(Mr - ref)", "K -> registers", "Sinkhorn iterations", "T store + err", "T -> global", "Ypart = T @ Z", "Cpart = T C2 T^T"] if N <= 64 else
+         ["staging", "dot(Y,Z)", "base", "A = C1 @ T (product)", "G, K", "max |A| + digits + barrier", "Sinkhorn iterations", "T store + err", "T -> global", "Ypart = T @ Z", "Cpart = T C2 T^T"])
+tot = sum(pbuf[:11])
+print("phases of the coupling kernel in this forward pass, us per workgroup (mean over all workgroups of the solve): " +
+      "; ".join(f"{nm} {pbuf[k] / 100.0 / max(1, int(buf[0])):.1f}" for k, nm in enumerate(names) if pbuf[k]) + f"; total {tot / 100.0 / max(1, int(buf[0])):.1f}")
 print(f"{shape} B={B} K={K} N={N}: {n} records in {len(launches)} launches of {[len(l) for l in launches]} workgroups; sizes min/mean/max {sizes.min()}/{sizes.mean():.1f}/{sizes.max()}")
 for li in sorted({0, len(launches) - 1}):          # the first launch (every coupling active, cold start) and the last (some molecules have converged)
     r = rec[launches[li]]; it_l, sk_l = its[launches[li]], sks[launches[li]]
