@@ -426,7 +426,9 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
 // round 6, at ANY number of couplings when they are dealt by size (FgwAdj.order: the model's ragged layout) — the largest couplings start first and the
 // smallest wait for the first free slots: Lipophilicity B = 128 (640 couplings on 512 slots) 4.54 against 4.89 ms per step for the three-per-CU build,
 // B = 256 / 512 per GPU -1.2 / -1.6 % (profiles/r6_ab_fgw_placement.txt).
-template <int NW, bool C2U8, int WPC = 3>
+// ORD: the launch deals its workgroups by molecule size (FgwAdj.order).  A template parameter, not a run-time test of the pointer: launches without an
+// order (dense structure matrices: the reference-shaped call) keep exactly the code and the register allocation they had.
+template <int NW, bool C2U8, int WPC = 3, bool ORD = false>
 __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_big(
     const float *__restrict__ Ys, const float *__restrict__ Cs, const float *__restrict__ ps, const float *__restrict__ pb,
     FgwDims D, conan_fgw_params prm, FastConst fc, int outer, int y_zero, const double *__restrict__ Cw, const double *__restrict__ Yw,
@@ -436,12 +438,13 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     constexpr int NT = 64 * NW;
     // XCD k owns the k-th contiguous eighth of the couplings (see k_fgw_coupling_fast): the K workgroups of a molecule share C in one L2
     int cid = (gridDim.x & 7) == 0 ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    if (adj.order && (gridDim.x & 7) == 0) {
+    if constexpr (ORD) {
         // Molecules by descending size (FgwAdj.order, filled by k_fgw_init), ranks dealt round the XCDs, the blocks of an XCD in rank order: the largest
         // couplings are dispatched first, and when the grid exceeds the resident slots (two workgroups per CU) the ones that wait are the smallest —
         // they go to whichever CU frees a slot first, which balances the launch better than any fixed assignment tried.
         const int x = (int)blockIdx.x & 7, pblk = (int)blockIdx.x >> 3;
-        cid = adj.order[x + 8 * (pblk / D.K)] * D.K + pblk % D.K;
+        cid = __builtin_amdgcn_readfirstlane(adj.order[x + 8 * (pblk / D.K)]) * D.K + pblk % D.K;
+        asm volatile("" : "+s"(cid));      // pinned to a scalar register: without it everything derived from the LOADED index is kept per lane (128 VGPRs + scratch instead of 106)
     }
     const int b = cid / D.K, s = cid % D.K;
     if (!fgw_active(active, D.B, b, outer)) return;
@@ -1102,17 +1105,19 @@ static int fgw_fwd_impl(const float *Ys, const float *Cs, const float *ps, const
         const int y_zero = (outer == 0 && !init_Y) ? 1 : 0;
         const int *only = nullptr;
         if (big) {
-#define CONAN_BIG(U8, WPC)                                                                                                          \
+#define CONAN_BIG(U8, WPC, ORD)                                                                                                     \
     do {                                                                                                                            \
         if (lb > 64 * 1024)                                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW, U8, WPC>),                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fgw_coupling_big<GEN_NW, U8, WPC, ORD>),                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);                                         \
-        k_fgw_coupling_big<GEN_NW, U8, WPC><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
-                                                                            Ypart, Cpart, redo, adj);                                \
+        k_fgw_coupling_big<GEN_NW, U8, WPC, ORD><<<B * K, 64 * GEN_NW, lb, s>>>(Ys, Cs, ps, p, D, *params, fc, outer, y_zero, Cw, Yw, active, T, info, sc_c, \
+                                                                                 Ypart, Cpart, redo, adj);                           \
     } while (0)
             const bool two_per_cu = BIG_WPC2 && (B * K <= CONAN_FGW_WPC2_MAX || (CONAN_FGW_WPC2_ORDERED && adj.order));      // the 128-register build (see WPC above)
-            if (c2b) { if (two_per_cu) CONAN_BIG(true, 2); else CONAN_BIG(true, 3); }
-            else { if (two_per_cu) CONAN_BIG(false, 2); else CONAN_BIG(false, 3); }
+            const bool ordered = adj.order != nullptr && (B * K & 7) == 0 && two_per_cu && c2b;      // (an order implies the byte layout and the two-per-CU build)
+            if (ordered) CONAN_BIG(true, 2, true);
+            else if (c2b) { if (two_per_cu) CONAN_BIG(true, 2, false); else CONAN_BIG(true, 3, false); }
+            else { if (two_per_cu) CONAN_BIG(false, 2, false); else CONAN_BIG(false, 3, false); }
 #undef CONAN_BIG
             only = redo;
         }

@@ -96,8 +96,8 @@ __device__ __forceinline__ void fgw_active_init(int *__restrict__ active, int B,
 struct FgwAdj {
     const int *gptr, *rowptr, *col, *tgt;
     float *dense;
-    int *order;              // [B] (nullable, N <= 64 path): molecules by descending number of real nodes — k_fgw_small_vectors fills it, k_fgw_coupling_fast deals its
-                             // workgroups over the XCDs / CUs in that order (a coupling's work grows with its real nodes: padded nodes are solved as one)
+    int *order;              // [B] (nullable): molecules by descending number of real nodes — k_fgw_small_vectors / k_fgw_init fill it (fgw_order_by_size), k_fgw_coupling_fast and
+                             // k_fgw_coupling_big deal their workgroups over the XCDs / CUs in that order (a coupling's work grows with its real nodes: padded nodes are solved as one)
 };
 // to_dense_adj (schnet_no_sum.py:249; orientation of k_densify: entry [source][target] += 1) of graph g into a ZEROED LDS byte matrix with row
 // pitch P (4-byte aligned): one thread per edge, counts packed four to a word (an entry above 255 would carry: a radius graph has no repeated
