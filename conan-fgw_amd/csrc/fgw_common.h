@@ -328,6 +328,7 @@ __device__ __forceinline__ void fgw_order_by_size(const FgwAdj &adj, int B, int 
     static_assert(NT >= 256, "one thread per size bin");
     __shared__ unsigned char nsz[4096];
     __shared__ int hist[256], base[256];
+    if (B > 4096) return;                                                   // (the launcher does not hand out an order buffer beyond that; workgroup-uniform)
     for (int t = tid; t < 256; t += NT) hist[t] = 0;
     __syncthreads();
     for (int m = tid; m < B; m += NT) {
