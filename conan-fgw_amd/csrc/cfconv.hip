@@ -9,6 +9,18 @@
 #include "common.h"
 
 namespace {
+// The wavefront's index inside its workgroup, as a value the compiler KNOWS to be wave-uniform: everything derived from it (the target row, its CSR bounds,
+// the loop over its edges) then lives in scalar registers and is fetched by scalar loads — threadIdx.x >> 6 alone is a per-lane value to the compiler.
+#ifndef CONAN_CFCONV_UNIFORM
+#define CONAN_CFCONV_UNIFORM 1      // (A/B switch)
+#endif
+__device__ __forceinline__ int wave_u() {
+#if CONAN_CFCONV_UNIFORM
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    return (int)(threadIdx.x >> 6);
+#endif
+}
 
 template <int VEC>   // VEC = F / 32 / 4  (number of float4 per lane per row): F=128 -> 1, F=256 -> 2
 __global__ void __launch_bounds__(256) k_cfconv_fwd(const float *__restrict__ x, const float *__restrict__ W,
@@ -21,7 +33,7 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd(const float *__restrict__ x,
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
-    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    const int a_lo = lb * per + wave_u(), a_hi = min(num_atoms, (lb + 1) * per);
     for (int i = a_lo; i < a_hi; i += 4) {
         const int e0 = rowptr[i], e1 = rowptr[i + 1];
         float4 acc[VEC];
@@ -76,7 +88,7 @@ __global__ void __launch_bounds__(256) k_cfconv_fwd_generic(const float *__restr
     const int lane = threadIdx.x & 63;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
-    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    const int a_lo = lb * per + wave_u(), a_hi = min(num_atoms, (lb + 1) * per);
     const int F4 = F >> 2;
     for (int i = a_lo; i < a_hi; i += 4) {
         const int e0 = rowptr[i], e1 = rowptr[i + 1];
@@ -105,7 +117,7 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_x128(const float *__restrict
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
-    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    const int a_lo = lb * per + wave_u(), a_hi = min(num_atoms, (lb + 1) * per);
     for (int j = a_lo; j < a_hi; j += 4) {
         const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -147,7 +159,7 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_x(const float *__restrict__ 
     const int lane = threadIdx.x & 63;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous targets per workgroup
-    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    const int a_lo = lb * per + wave_u(), a_hi = min(num_atoms, (lb + 1) * per);
     const int F4 = F >> 2;
     for (int j = a_lo; j < a_hi; j += 4) {
         const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
@@ -222,7 +234,7 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_wp128(const float *__restric
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (P + (int)gridDim.x - 1) / (int)gridDim.x;                  // contiguous pairs per workgroup
     const int p_lo = lb * per, p_hi = min(P, (lb + 1) * per);
-    for (int base = p_lo + 64 * (threadIdx.x >> 6); base < p_hi; base += 256) {
+    for (int base = p_lo + 64 * wave_u(); base < p_hi; base += 256) {
         const int cnt = min(64, p_hi - base);
         int s0 = 0, t0 = 0, s1 = 0, t1 = 0;
         float cc = 0.f, m1 = 0.f;
@@ -286,7 +298,7 @@ __global__ void __launch_bounds__(256) k_cfconv_bwd_xw128(const float *__restric
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int per = (num_atoms + (int)gridDim.x - 1) / (int)gridDim.x;          // contiguous sources per workgroup
-    const int a_lo = lb * per + (threadIdx.x >> 6), a_hi = min(num_atoms, (lb + 1) * per);
+    const int a_lo = lb * per + wave_u(), a_hi = min(num_atoms, (lb + 1) * per);
     float amax = 0.f;
     for (int j = a_lo; j < a_hi; j += 4) {
         const int s0 = t_rowptr[j], s1 = t_rowptr[j + 1];
