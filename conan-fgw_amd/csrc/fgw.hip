@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64 * NW) k_fgw_coupling(
     if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     FGW_PROF_DECL;
 
     // ---- carve
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(64 * NW, (NW * WPC + 3) / 4) k_fgw_coupling_bi
     if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     FGW_PROF_DECL;
 
     float *Kf = reinterpret_cast<float *>(smem);                          // [N,P]  T (between iterations) / K (inside one)

@@ -228,7 +228,7 @@ __device__ __forceinline__ double exp_lse(double x) {
 // Workgroup-collective (tiles are dealt round-robin to the wavefronts); no barrier inside.
 template <int NW = FGW_WAVES, class FX, class FW, class FS>
 __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS st) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
     for (int t = wave; t < Mq * Nq; t += NW) {
@@ -276,7 +276,7 @@ __device__ __forceinline__ void mm_f64_pad(int M, int Nn, int Kd, FX X, FW W, FS
 template <int NW, bool WT, typename TX, typename TW, class FS>
 __device__ __forceinline__ void mm_f64_glb(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
                                            const int tid = threadIdx.x) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
     for (int t = wave; t < Mq * Nq; t += NW) {
@@ -361,7 +361,7 @@ __device__ __forceinline__ void fgw_order_by_size(const FgwAdj &adj, int B, int 
 template <int NW, bool WT, typename TX, typename TW, class FS, int KT = CONAN_FGW_KT>      // KT consecutive k per lane and trip (a trip = 4 KT k)
 __device__ __forceinline__ void mm_f64_glb22(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FS st,
                                              const int tid = threadIdx.x) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Mq = (M + 15) >> 4, Nq = (Nn + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
     const int Mb = Mq >> 1, Nb = Nq >> 1;                             // 2 x 2 blocks over the even part
@@ -514,7 +514,7 @@ __device__ __forceinline__ long fgw_bytes8(const unsigned char *__restrict__ w, 
 template <int NW, class FS>
 __device__ __forceinline__ void mm_adj_i8(int M, int Nn, int Kd, const uint4 *__restrict__ D, const unsigned char *__restrict__ Wb, int pW, int xexp, FS st,
                                           const int tid = threadIdx.x) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int Mq = (M + 15) >> 4, Nh = (Nn + 31) >> 5, KB = ((Kd + 31) >> 5) << 2;
     const double unscale = __longlong_as_double((long long)(1023 + xexp - 31) << 52);      // 2^(xexp - 31)
@@ -624,7 +624,7 @@ __device__ __forceinline__ bool border_path(int M, int Nn) {       // dispatch r
 
 template <int NW = FGW_WAVES, class FX, class FW, class FS>
 __device__ __forceinline__ void mm_f64_border(int M, int Nn, int Kd, FX X, FW W, FS st, const BorderIdx &bi) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Mq = M >> 4, Nq = Nn >> 4;
     const int li = lane & 15, lk = lane >> 4;
     for (int t = wave; t < Mq * Nq; t += NW) {
@@ -708,7 +708,7 @@ __device__ __forceinline__ void mm_lds(int M, int Nn, int Kd, const TX *__restri
                                        const BorderIdx &bi, const int tid = threadIdx.x) {
     // `tid`: callers inside a long loop pass a copy of threadIdx.x laundered through an empty asm, so that the per-lane pointers and
     // tile indices below are re-derived per call instead of being hoisted out of the loop and kept (spilled) across it
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const bool border = border_path<NW>(M, Nn);
     const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;
@@ -950,7 +950,7 @@ __device__ __forceinline__ double mm2_border_part(const TX *__restrict__ xp, con
 template <int NW, int MAXT, int KMAX, bool WT, bool HOLD, typename TX, typename TW, class FM, class FS>
 __device__ __forceinline__ void mm_lds2(int M, int Nn, int Kd, const TX *__restrict__ X, int pX, const TW *__restrict__ W, int pW, FM mid, FS st,
                                         const int tid = threadIdx.x) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const bool border = border_path<NW>(M, Nn);
     const int Mq = border ? M >> 4 : (M + 15) >> 4, Nq = border ? Nn >> 4 : (Nn + 15) >> 4;

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(FGW_THREADS, (SECOND || R > 9) ? 1 : 3) k_fgw_
     if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N, NP = N * P;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool lane_ok = lane < N;
     FGW_PROF_DECL;
 
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(FGW_THREADS, FastCfg<R>::OCC) k_fgw_coupling_f
     if (!fgw_active(active, D.B, b, outer)) return;
     const int N = D.N, P = D.P, d = D.d;
     const int NN = N * N;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     FGW_PROF_DECL;
 
     const FastLds L = fast_lds<C2T>(N);
@@ -1095,7 +1095,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_fgw_update_parts(
             double *Yb = Yw + (size_t)b * Nd;
             if constexpr (Y_FROM_T) {
                 float *Tl = reinterpret_cast<float *>(usmem), *Zl = Tl + (size_t)chunk * NN;
-                const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
                 const int Mq = (N + 15) >> 4, Nq = (d + 15) >> 4;
                 constexpr int NWU = UPD_THREADS / 64, TW = 2;                          // two padded 16 x 16 output tiles per wavefront and round: one round up to N = 64, d = 64
                 for (int t0 = 0; t0 < Mq * Nq; t0 += NWU * TW) {
