@@ -34,7 +34,7 @@ __global__ void k_gat_edge_vec_bwd(const float *__restrict__ w_edge, const float
 __global__ void __launch_bounds__(256) k_gat_node_alpha(const float *__restrict__ h, const float *__restrict__ att_src, const float *__restrict__ att_dst,
                                                         int n, int C, float *__restrict__ a_src, float *__restrict__ a_dst) {
     const int lane = threadIdx.x & 63;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (i >= n) return;
     float s = 0.f, t = 0.f;
     for (int c = lane; c < C; c += 64) { const float v = h[(size_t)i * C + c]; s += v * att_src[c]; t += v * att_dst[c]; }
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_gat_aggregate_fwd(const float *__restri
                                                            const float *__restrict__ bias, float slope, int n, int C, float *__restrict__ out,
                                                            float *__restrict__ alpha, float *__restrict__ alpha_self) {
     const int lane = threadIdx.x & 63;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (i >= n) return;
     const int e0 = rowptr[i], e1 = rowptr[i + 1], deg = e1 - e0;
     float vd[GAT_MAXD];
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_target(const float *__restrict_
                                                         const float *__restrict__ v, float slope, int n, int C, float *__restrict__ dpre,
                                                         float *__restrict__ dpre_self, float *__restrict__ da_dst, float *__restrict__ part, int PW) {
     const int lane = threadIdx.x & 63;
-    const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wg = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     float vd[DT], dvacc[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) { vd[d] = d < D ? v[d] : 0.f; dvacc[d] = 0.f; }
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_source(const float *__restrict_
                                                         const int *__restrict__ t_rowptr, const int *__restrict__ t_pos, const int *__restrict__ t_tgt,
                                                         int n, int C, float *__restrict__ dh, float *__restrict__ part, int PW) {
     const int lane = threadIdx.x & 63;
-    const int wg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wg = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     constexpr int MAXV = 4;                                   // C <= 256
     float p_as[MAXV], p_ad[MAXV], p_b[MAXV];
 #pragma unroll

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_ne_scale(const float *Win, float *W, co
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
         const int cnt = min(VN_RUN, E - base);
         const float my_s = (lane < cnt && col[base + lane] != tgt[base + lane]) ? cos_cutoff(dist[base + lane], cutoff) : 0.0f;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_edge_embed(const float *__restrict__ x,
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
         const int cnt = min(VN_RUN, E - base);
         const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_edge_embed(const float *__restrict__ x,
 __global__ void __launch_bounds__(256) k_layernorm(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                                                    int rows, int H, float eps, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int r = wave; r < rows; r += nw) {
         float s = 0.f;
         for (int c = lane; c < H; c += 64) s += x[(size_t)r * H + c];
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) k_attn_msg(const float *__restrict__ q, c
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = (int)blockIdx.y * (HALF ? 32 : 64) * CPL + ll * CPL;      // blockIdx.y: block of 64 CPL (HALF: 32 CPL) channels — whole heads (H > 128)
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;                                       // idle lanes (H < 64 CPL) read column 0 and store nothing
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate(const float *__restrict__
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = ll * CPL;
     for (int i = wave; i < n; i += nw) {
         float a0[CPL], a1[CPL], a2[CPL];
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_any(const float *__restri
                                                            const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int pre,
                                                            float *__restrict__ vagg) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw) {
         for (int c = lane; c < H; c += 64) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_edge_update(const float *__restrict__ w
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VN_RUN; base < E; base += nw * VN_RUN) {
         const int cnt = min(VN_RUN, E - base);
         const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd_p(const float *__restric
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VB_RUN; base < E; base += nw * VB_RUN) {
         const int cnt = min(VB_RUN, E - base);
         const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_edge_embed_bwd_x(const float *__restric
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
         for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
             const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_x(const float *__restrict
                                                          const float *__restrict__ dres, int rows, int H, float eps, float *__restrict__ dx,
                                                          float *__restrict__ stats) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int r = wave; r < rows; r += nw) {
         const float *xr = x + (size_t)r * H, *gr = dy + (size_t)r * H;
         float s = 0.f;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_target(const float *__restrict
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = (int)blockIdx.y * (HALF ? 32 : 64) * CPL + ll * CPL;      // blockIdx.y: channel block of whole heads (H > 128, visnet.hip)
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;                                       // idle lanes read column 0 and store nothing
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_source(const float *__restrict
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     const int c0 = (int)blockIdx.y * (HALF ? 32 : 64) * CPL + ll * CPL;
     const bool on = c0 < H;
     const int cl = on ? c0 : 0;
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_s(const float *__rest
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int base = wave * VB_RUN; base < E; base += nw * VB_RUN) {
         const int cnt = min(VB_RUN, E - base);
         const int my_j = lane < cnt ? col[base + lane] : 0, my_i = lane < cnt ? tgt[base + lane] : 0;
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) k_vec_aggregate_bwd_v(const float *__rest
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
         for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
             const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;                        // H = 64 CPL: one pass; every lane walks the row (idle ones: column 0, no stores)
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_t(const float *__restri
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nw)
         for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
             const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) k_edge_update_bwd_s(const float *__restri
     const int lane = threadIdx.x & 63;
     const int hf = HALF ? lane >> 5 : 0, ll = HALF ? (lane & 31) : lane;      // HALF: a half-wavefront per edge (H = 32 CPL), two edges per step
     constexpr int ES = HALF ? 2 : 1;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (gridDim.x * blockDim.x) >> 6;
     for (int j = wave; j < n; j += nw)
         for (int cp = 0; cp < H; cp += (HALF ? 32 : 64) * CPL) {
             const int c0 = cp + ll * CPL; const bool on = c0 < H; const int cl = on ? c0 : 0;
